@@ -1,0 +1,164 @@
+/* itemalign.h — C ABI of libitemalign_hip.so (MI355X / gfx950 kernels of the item-pair matching engine).
+ *
+ * The reference (sunzeyeah/item-alignment) has no native or FFI boundary: it is pure PyTorch and its
+ * arithmetic is dispatched by ATen.  This header therefore *defines* the boundary:
+ * each entry point replaces the ATen/cuBLAS work behind one reference call site, cited per function
+ * (paths relative to the reference tree).  INTEGRATION.md shows the ctypes stub a maintainer adds.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative IA_ERR_* code otherwise (ia_strerror for text);
+ *    nothing throws across the boundary.
+ *  - all pointers are borrowed DEVICE pointers (tensor.data_ptr()) of contiguous row-major tensors;
+ *    nothing is allocated or freed inside; scratch comes in through (workspace, workspace_bytes) with
+ *    an ia_*_workspace_bytes query.
+ *  - launches are asynchronous on `stream` (pass torch's current HIP stream); no device sync inside.
+ *  - "bf16" tensors are passed as void*; fp32 master weights / gradients as float*.
+ *  - dropout uses a counter-based generator keyed by (seed, stream_id, element index): forward and
+ *    backward of one op must be given the same (drop_p, seed, stream_id).
+ */
+#ifndef ITEMALIGN_H
+#define ITEMALIGN_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* ia_stream_t; /* hipStream_t */
+
+#define IA_OK 0
+#define IA_ERR_ARG (-1)
+#define IA_ERR_LAUNCH (-2)
+#define IA_ERR_WORKSPACE (-3)
+#define IA_ERR_UNSUPPORTED (-4)
+
+const char* ia_strerror(int code);
+int ia_abi_version(void);
+
+/* ---- GEMM: torch.nn.Linear forward / dgrad / wgrad (src/models/text.py:1241 -> RobertaLayer dense
+ * layers; src/models/multimodal.py:811 -> timm Block qkv/proj/fc1/fc2; patch-embed conv as GEMM).
+ * C[M,N] = A*B with A k-contiguous ([M,K], lda) or k-strided ([K,M], lda); B k-contiguous ([N,K], ldb;
+ * a Linear weight) or k-strided ([K,N], ldb).  epilogue: */
+#define IA_EPI_NONE 0
+#define IA_EPI_BIAS 1      /* + bias[N] (fp32) */
+#define IA_EPI_BIAS_GELU 2 /* C2 = bf16(acc + bias) (pre-activation), C = gelu_erf(C2) */
+#define IA_EPI_ADD 3       /* + aux[M,N] (bf16, ldaux) */
+#define IA_EPI_DGELU 4     /* * gelu'(aux[M,N]) */
+#define IA_EPI_BIAS_ADD 5  /* + bias + aux */
+int ia_gemm_bf16(const void* A, int a_kstrided, int lda, const void* B, int b_kstrided, int ldb, void* C, int c_is_f32, int ldc,
+                 int M, int N, int K, int epilogue, const float* bias, const void* aux, int ldaux, void* C2, int accumulate,
+                 ia_stream_t stream);
+
+/* ---- LayerNorm tails (RobertaSelfOutput / RobertaOutput: dense -> dropout -> +residual -> LayerNorm;
+ * timm Block norm1/norm2).  z = residual + dropout(x + bias); y = LN(z).  z_out may alias x. */
+int ia_ln_fwd(const void* x, const float* bias, const void* residual, void* z_out, void* y, float* mean, float* rstd,
+              const float* gamma, const float* beta, int M, int H, float eps, float drop_p, uint32_t seed, uint32_t stream_id,
+              ia_stream_t stream);
+size_t ia_ln_bwd_workspace_bytes(int M, int H);
+/* dz = LN'(dy) + dres; dx = dropout-masked dz (only when drop_p > 0); dgamma/dbeta/dbias (+)= column sums */
+int ia_ln_bwd(const void* dy, const void* dres, const void* z, const float* mean, const float* rstd, const float* gamma, void* dz,
+              void* dx, float* dgamma, float* dbeta, float* dbias, int M, int H, float drop_p, uint32_t seed, uint32_t stream_id,
+              void* workspace, size_t workspace_bytes, int accumulate, ia_stream_t stream);
+size_t ia_colsum_workspace_bytes(int M, int N);
+int ia_colsum(const void* x, int ld, int M, int N, float* out, int accumulate, void* workspace, size_t workspace_bytes,
+              ia_stream_t stream);
+
+/* ---- fused self-attention, head dim 64 (transformers RobertaSelfAttention eager path: QK^T/sqrt(d)
+ * + additive key mask -> softmax -> dropout -> PV; timm Attention without mask).  q/k/v point at the
+ * first column of head 0 of each operand and share row stride ld_qkv (elements); key_mask is [B,L]
+ * uint8 (1 = attend) or NULL; lse2 is [B,nh,L] fp32 (log2-domain log-sum-exp, saved for backward). */
+int ia_attn_fwd(const void* q, const void* k, const void* v, int ld_qkv, const uint8_t* key_mask, void* out, int ld_o, float* lse2,
+                int B, int nh, int L, float scale, float drop_p, uint32_t seed, ia_stream_t stream);
+int ia_attn_bwd(const void* q, const void* k, const void* v, int ld_qkv, const uint8_t* key_mask, const void* out, const void* d_out,
+                int ld_o, const float* lse2, float* delta, void* dq, void* dk, void* dv, int ld_dqkv, int B, int nh, int L,
+                float scale, float drop_p, uint32_t seed, ia_stream_t stream);
+
+/* ---- embeddings (src/models/base.py:238-279, :501-556, :394-442) */
+int ia_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const int32_t* extra_idx, const float* word,
+                    const float* type, const float* pos, const float* extra, const float* gamma, const float* beta, void* z_out,
+                    void* y, float* mean, float* rstd, int M, int H, float eps, float drop_p, uint32_t seed, uint32_t stream_id,
+                    ia_stream_t stream);
+size_t ia_embed_ln_bwd_workspace_bytes(int M, int H);
+int ia_embed_ln_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma, const int64_t* ids,
+                    const int64_t* type_ids, const int64_t* pos_ids, const int32_t* extra_idx, float* dword, float* dtype, float* dpos,
+                    float* dextra, float* dgamma, float* dbeta, int M, int H, int word_pad, int pos_pad, float drop_p, uint32_t seed,
+                    uint32_t stream_id, void* workspace, size_t workspace_bytes, ia_stream_t stream);
+
+/* ---- ViT input side (timm PatchEmbed + cls token + pos_embed; src/models/multimodal.py:811) */
+int ia_im2col_patch(const float* images, void* patches, int B, int C, int S, int P, ia_stream_t stream);
+int ia_vit_tokens_fwd(const void* patch, const float* cls, const float* pos, void* tokens, int B, int NP, int H, ia_stream_t stream);
+int ia_vit_tokens_bwd(const void* dtokens, void* dpatch, float* dcls, float* dpos, int B, int NP, int H, int accumulate,
+                      ia_stream_t stream);
+
+/* ---- CLS row pick with dropout (features[:, 0, :] -> dropout, src/models/base.py:104,140-141) */
+int ia_gather_rows_fwd(const void* src, int ld, const int32_t* rows, float* out, int B, int H, float drop_p, uint32_t seed,
+                       uint32_t stream_id, ia_stream_t stream);
+int ia_gather_rows_bwd(const float* dout, int ld, const int32_t* rows, void* dsrc, int B, int H, float drop_p, uint32_t seed,
+                       uint32_t stream_id, int accumulate, ia_stream_t stream);
+
+/* ---- heads and loss (src/models/base.py:103-117, :139-157; nn.CrossEntropyLoss text.py:1292) */
+#define IA_ACT_NONE 0
+#define IA_ACT_TANH 1
+int ia_linear_small_fwd(const float* x, int ldx, const float* W, const float* bias, float* y, int B, int N, int K, int act,
+                        ia_stream_t stream);
+int ia_linear_small_bwd(const float* dy, const float* y, const float* x, int ldx, const float* W, float* dx, int lddx, float* dW,
+                        float* db, int B, int N, int K, int act, ia_stream_t stream);
+int ia_pair_head_ce_fwd(const float* x, const float* y, const float* W, const float* bias, const int64_t* labels, float* logits,
+                        float* probs, float* loss, float* loss_per, int B, int D, int C, ia_stream_t stream);
+int ia_pair_head_ce_bwd(const float* probs, const int64_t* labels, const float* dloss, const float* x, const float* y, const float* W,
+                        float* dx, float* dy, float* dW, float* db, int B, int D, int C, ia_stream_t stream);
+
+/* ---- optimiser (torch.optim.AdamW, finetune_multimodal.py:296-308,460-468) */
+int ia_adamw_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, const void* chunk_table,
+                  int n_chunks, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                  ia_stream_t stream);
+int ia_cast_f32_to_bf16(const float* src, void* dst, size_t n, ia_stream_t stream);
+int ia_cast_bf16_to_f32(const void* src, float* dst, size_t n, ia_stream_t stream);
+
+/* ---- whole-layer drivers: one call = every launch of one encoder layer, in order, on `stream`.
+ * Weights: bf16 shadows for the GEMM operands, fp32 masters for bias / LayerNorm vectors. */
+typedef struct {
+  const void* w_qkv;   /* bf16 [3H, H]  query | key | value stacked (state_dict attention.self.{query,key,value}.weight) */
+  const float* b_qkv;  /* fp32 [3H] */
+  const void* w_o;     /* bf16 [H, H]   attention.output.dense.weight / timm attn.proj */
+  const float* b_o;
+  const float* ln1_g;  /* attention.output.LayerNorm (BERT post-LN) / norm1 (ViT pre-LN) */
+  const float* ln1_b;
+  const void* w_fc1;   /* bf16 [I, H]   intermediate.dense / mlp.fc1 */
+  const float* b_fc1;
+  const void* w_fc2;   /* bf16 [H, I]   output.dense / mlp.fc2 */
+  const float* b_fc2;
+  const float* ln2_g;  /* output.LayerNorm / norm2 */
+  const float* ln2_b;
+} ia_layer_weights;
+
+typedef struct { /* fp32 gradient arena slots, same shapes as above; all accumulate (+=) */
+  float* w_qkv; float* b_qkv; float* w_o; float* b_o; float* ln1_g; float* ln1_b;
+  float* w_fc1; float* b_fc1; float* w_fc2; float* b_fc2; float* ln2_g; float* ln2_b;
+} ia_layer_grads;
+
+typedef struct {
+  int B, L, H, I, nh;      /* tokens M = B*L; head dim = H/nh = 64 */
+  int pre_ln;              /* 0 = BERT post-LN layer (RobertaLayer), 1 = ViT pre-LN block (timm Block) */
+  float eps;               /* 1e-12 BERT / 1e-6 ViT */
+  float hidden_drop, attn_drop;
+  uint32_t seed;           /* per-step seed; the layer index is mixed in through layer_id */
+  uint32_t layer_id;
+} ia_layer_cfg;
+
+/* per-layer activation stash (saved by forward, read by backward) and shared backward scratch */
+size_t ia_layer_stash_bytes(const ia_layer_cfg* cfg);
+size_t ia_layer_bwd_scratch_bytes(const ia_layer_cfg* cfg);
+/* x [M,H] bf16 -> y [M,H] bf16.  key_mask [B,L] uint8 or NULL.  stash may be NULL for inference
+ * (then `scratch` of ia_layer_stash_bytes is used transiently and nothing is kept). */
+int ia_layer_fwd(const ia_layer_cfg* cfg, const ia_layer_weights* w, const void* x, const uint8_t* key_mask, void* y, void* stash,
+                 ia_stream_t stream);
+/* dy [M,H] bf16 -> dx [M,H] bf16 (dx may alias dy); parameter gradients accumulate into g. */
+int ia_layer_bwd(const ia_layer_cfg* cfg, const ia_layer_weights* w, const ia_layer_grads* g, const void* x, const uint8_t* key_mask,
+                 const void* y, const void* stash, const void* dy, void* dx, void* scratch, size_t scratch_bytes, ia_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ITEMALIGN_H */

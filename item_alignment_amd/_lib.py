@@ -1,0 +1,103 @@
+"""ctypes binding of libitemalign_hip.so (the C ABI declared in include/itemalign.h).
+
+The product path has no CPU or eager-PyTorch fallback: if the shared library is missing, or an entry
+point returns a non-zero code, this module raises.  Pointers are `tensor.data_ptr()` of live torch
+tensors; the stream is torch's current HIP stream.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libitemalign_hip.so")
+
+vp, i32, u32, f32, sz = C.c_void_p, C.c_int, C.c_uint32, C.c_float, C.c_size_t
+
+
+class LayerWeights(C.Structure):
+    _fields_ = [(n, vp) for n in ("w_qkv", "b_qkv", "w_o", "b_o", "ln1_g", "ln1_b", "w_fc1", "b_fc1", "w_fc2", "b_fc2",
+                                  "ln2_g", "ln2_b")]
+
+
+class LayerGrads(C.Structure):
+    _fields_ = [(n, vp) for n in ("w_qkv", "b_qkv", "w_o", "b_o", "ln1_g", "ln1_b", "w_fc1", "b_fc1", "w_fc2", "b_fc2",
+                                  "ln2_g", "ln2_b")]
+
+
+class LayerCfg(C.Structure):
+    _fields_ = [("B", i32), ("L", i32), ("H", i32), ("I", i32), ("nh", i32), ("pre_ln", i32), ("eps", f32),
+                ("hidden_drop", f32), ("attn_drop", f32), ("seed", u32), ("layer_id", u32)]
+
+
+# name -> (restype, argtypes); must list every symbol include/itemalign.h declares
+SIGNATURES = {
+    "ia_strerror": (C.c_char_p, [i32]),
+    "ia_abi_version": (i32, []),
+    "ia_gemm_bf16": (i32, [vp, i32, i32, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp]),
+    "ia_ln_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, u32, u32, vp]),
+    "ia_ln_bwd_workspace_bytes": (sz, [i32, i32]),
+    "ia_ln_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, u32, u32, vp, sz, i32, vp]),
+    "ia_colsum_workspace_bytes": (sz, [i32, i32]),
+    "ia_colsum": (i32, [vp, i32, i32, i32, vp, i32, vp, sz, vp]),
+    "ia_attn_fwd": (i32, [vp, vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, f32, f32, u32, vp]),
+    "ia_attn_bwd": (i32, [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, u32, vp]),
+    "ia_embed_ln_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, u32, u32, vp]),
+    "ia_embed_ln_bwd_workspace_bytes": (sz, [i32, i32]),
+    "ia_embed_ln_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u32, u32,
+                               vp, sz, vp]),
+    "ia_im2col_patch": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "ia_vit_tokens_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "ia_vit_tokens_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "ia_gather_rows_fwd": (i32, [vp, i32, vp, vp, i32, i32, f32, u32, u32, vp]),
+    "ia_gather_rows_bwd": (i32, [vp, i32, vp, vp, i32, i32, f32, u32, u32, i32, vp]),
+    "ia_linear_small_fwd": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "ia_linear_small_bwd": (i32, [vp, vp, vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
+    "ia_pair_head_ce_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "ia_pair_head_ce_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "ia_adamw_flat": (i32, [vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, i32, f32, vp]),
+    "ia_cast_f32_to_bf16": (i32, [vp, vp, sz, vp]),
+    "ia_cast_bf16_to_f32": (i32, [vp, vp, sz, vp]),
+    "ia_layer_stash_bytes": (sz, [C.POINTER(LayerCfg)]),
+    "ia_layer_bwd_scratch_bytes": (sz, [C.POINTER(LayerCfg)]),
+    "ia_layer_fwd": (i32, [C.POINTER(LayerCfg), C.POINTER(LayerWeights), vp, vp, vp, vp, vp]),
+    "ia_layer_bwd": (i32, [C.POINTER(LayerCfg), C.POINTER(LayerWeights), C.POINTER(LayerGrads), vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+}
+
+_lib = None
+
+
+class ItemAlignError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP extension; raise if it is absent (there is deliberately no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ItemAlignError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C item_alignment_amd/csrc`). The MI355X path has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().ia_strerror(rc).decode()
+        raise ItemAlignError(f"{what} failed: {msg} (code {rc})")
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """data_ptr of a tensor or None -> NULL."""
+    return None if t is None else t.data_ptr()

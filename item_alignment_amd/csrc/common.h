@@ -1,0 +1,70 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the item-pair matching engine.
+// Hardware facts used here were verified on an MI355X with tools/probe_layouts.hip
+// (MFMA fragment maps, ds_read_tr16_b64 gather, buffer->LDS out-of-range zero fill).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define IA_LDS(p) ((__attribute__((address_space(3))) void*)(p))
+#define IA_DEV __device__ __forceinline__
+
+// error codes of the C-ABI (ia_strerror in capi.hip)
+#define IA_OK 0
+#define IA_ERR_ARG (-1)      // bad shape / alignment / null pointer
+#define IA_ERR_LAUNCH (-2)   // hipGetLastError after a launch
+#define IA_ERR_WORKSPACE (-3)// workspace too small
+#define IA_ERR_UNSUPPORTED (-4)
+
+IA_DEV float bf2f(bf16 v) { return (float)v; }
+IA_DEV bf16 f2bf(float v) { return (bf16)v; }
+
+// buffer descriptor over [ptr, ptr+bytes): out-of-range lanes read 0 (registers and LDS-DMA alike).
+IA_DEV __amdgpu_buffer_rsrc_t ia_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
+// wave-wide reductions (64 lanes)
+IA_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+IA_DEV float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Counter-based dropout RNG: one 32-bit mix per (seed, stream, index) -> two 16-bit uniforms.
+// keep element iff u16 >= thr16 where thr16 = round(p * 65536).
+IA_DEV uint32_t ia_mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+IA_DEV uint32_t ia_rng(uint32_t seed, uint32_t stream, uint32_t idx) {
+  return ia_mix32(idx ^ ia_mix32(stream ^ (seed * 0x9E3779B9U)));
+}
+
+IA_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+IA_DEV float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+static inline int ia_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? IA_OK : IA_ERR_LAUNCH;
+}

@@ -1,0 +1,245 @@
+// bf16 MFMA GEMM for the encoder hot path (gfx950).
+//
+//   C[M,N] = A[M,K] * B[K,N]   (+ fused epilogue), fp32 accumulate in MFMA accumulators.
+//
+// Operand memory layouts (no explicit transposes anywhere on the path):
+//   A k-contiguous : A[m][k]  (activations / output-gradients, row = token)
+//   A k-strided    : At[k][m] (dW = dY^T X : the "A" of that product is dY stored [token][n])
+//   B k-contiguous : Bt[n][k] (a torch Linear weight W[N,K] used in the forward)
+//   B k-strided    : B[k][n]  (the same W used for dX = dY W, and X in dW = dY^T X)
+// k-strided operands are staged row-major into LDS exactly as they lie in HBM and are turned into
+// MFMA fragments with ds_read_b64_tr_b16 (the LDS transpose read), so the reference's three GEMM
+// flavours (y = xW^T, dx = dy W, dW = dy^T x; torch.nn.Linear under autograd, reference
+// src/models/text.py:1241 -> transformers RobertaLayer) all stream each operand from HBM once.
+//
+// Tile: 128x128x64 per 256-thread workgroup (4 waves as 2x2, 64x64 per wave, 4x4 MFMA 16x16x32
+// fragments), LDS double buffer (2 x 32 KiB) filled by buffer_load ... lds (16 B/lane, out-of-range
+// rows arrive as zeros so ragged M / K tails need no extra code), XOR-swizzled on the source side.
+// The MFMA is issued with swapped operands so each lane ends up with 4 consecutive output columns.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 16384;   // one operand tile (128 x 64 bf16)
+constexpr uint32_t OOB = 0xFFFFFFF0u;
+
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_ADD = 3, EPI_DGELU = 4, EPI_BIAS_ADD = 5 };
+
+struct GemmArgs {
+  const bf16* A; const bf16* B; void* C; bf16* C2; const float* bias; const bf16* aux;
+  int M, N, K;
+  int lda, ldb, ldc, ldaux;
+  uint32_t a_bytes, b_bytes;
+  int accumulate;
+  int tiles_m, tiles_n;
+};
+
+// 32-byte-slot swizzle of a k-strided tile row (row = k index within the 64-row tile)
+IA_DEV int ks_swz(int k) { return ((k & 3) | (((k >> 3) & 1) << 2)) << 1; }
+
+template <bool KS>
+IA_DEV void stage_tile(__amdgpu_buffer_rsrc_t rs, char* s, int kt, int x0, int ld, int K, int tid, int wave) {
+  // K-contiguous: tile [128 rows(x)][64 k] (128 B rows); k-strided: tile [64 rows(k)][128 x] (256 B rows)
+#pragma unroll
+  for (int issue = 0; issue < 4; ++issue) {
+    uint32_t off;
+    if (!KS) {
+      const int row = issue * 32 + (tid >> 3);
+      const int c = (tid & 7) ^ (row & 7);
+      const int k = kt * BK + c * 8;
+      off = (uint32_t)(((x0 + row) * ld + k) * 2);
+      if (k >= K) off = OOB;
+    } else {
+      const int row = issue * 16 + (tid >> 4);
+      const int c = (tid & 15) ^ ks_swz(row);
+      const int k = kt * BK + row;
+      off = (uint32_t)((k * ld + x0 + c * 8) * 2);
+      if (k >= K) off = OOB;
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, IA_LDS(s + issue * 4096 + wave * 1024), 16, off, 0, 0, 0);
+  }
+}
+
+IA_DEV bf16x8 lds_frag_kc(const char* s, int row, int chunk) {
+  return *reinterpret_cast<const bf16x8*>(s + row * 128 + ((chunk ^ (row & 7)) << 4));
+}
+
+IA_DEV bf16x8 lds_frag_ks(const char* s, int k, int col) {
+  // 16-lane group reads a [4 k][16 col] block twice (k, k+4); lane p supplies row k+(p>>2), 4 cols.
+  const int addr = k * 256 + ((((col >> 3) ^ ks_swz(k))) << 4) + (col & 7) * 2;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(s + addr));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(s + addr + 4 * 256));
+  s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+template <bool AKS, bool BKS, int EPI, bool OUTF32>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware tile order: the 8 XCDs each take a contiguous run of tiles (bijective for any grid).
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  // group 8 m-tiles per n sweep so one XCD re-uses the same B panel from its L2
+  const int GM = 8;
+  const int group = bid / (GM * p.tiles_n);
+  const int first_m = group * GM;
+  const int gsz = min(p.tiles_m - first_m, GM);
+  const int bm = first_m + (bid % (GM * p.tiles_n)) % gsz;
+  const int bn = (bid % (GM * p.tiles_n)) / gsz;
+  const int m0 = bm * BM, n0 = bn * BN;
+
+  const __amdgpu_buffer_rsrc_t rsA = ia_rsrc(p.A, p.a_bytes);
+  const __amdgpu_buffer_rsrc_t rsB = ia_rsrc(p.B, p.b_bytes);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.K + BK - 1) / BK;
+  stage_tile<AKS>(rsA, smem, 0, m0, p.lda, p.K, tid, wave);
+  stage_tile<BKS>(rsB, smem + TILE_BYTES, 0, n0, p.ldb, p.K, tid, wave);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int g = lane >> 4, li = lane & 15;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) {
+      char* nb = smem + (buf ^ 1) * 2 * TILE_BYTES;
+      stage_tile<AKS>(rsA, nb, kt + 1, m0, p.lda, p.K, tid, wave);
+      stage_tile<BKS>(rsB, nb + TILE_BYTES, kt + 1, n0, p.ldb, p.K, tid, wave);
+    }
+    const char* sA = smem + buf * 2 * TILE_BYTES;
+    const char* sB = sA + TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        if (!AKS) af[mi] = lds_frag_kc(sA, wm * 64 + mi * 16 + li, ks * 4 + g);
+        else      af[mi] = lds_frag_ks(sA, ks * 32 + g * 8 + (li >> 2), wm * 64 + mi * 16 + (li & 3) * 4);
+      }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        // k-contiguous B: fragment row i <-> n = (i>>2)*16 + ni*4 + (i&3), so lane group g ends up
+        // holding 16 consecutive n; k-strided B: plain n = ni*16 + i (conflict-free transpose read).
+        if (!BKS) bfr[ni] = lds_frag_kc(sB, wn * 64 + (li >> 2) * 16 + ni * 4 + (li & 3), ks * 4 + g);
+        else      bfr[ni] = lds_frag_ks(sB, ks * 32 + g * 8 + (li >> 2), wn * 64 + ni * 16 + (li & 3) * 4);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // epilogue: lane (g, li) holds C[m = ..+li][n = nb .. nb+3] in acc[mi][ni]
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = m0 + wm * 64 + mi * 16 + li;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + wn * 64 + (BKS ? ni * 16 + g * 4 : g * 16 + ni * 4);
+      if (n >= p.N) continue;
+      f32x4 v = acc[mi][ni];
+      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_ADD) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+        v += b;
+      }
+      if (EPI == EPI_BIAS_GELU) {
+        bf16x4 pre = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        *reinterpret_cast<bf16x4*>(p.C2 + (size_t)m * p.ldc + n) = pre;
+        // activation is taken on the bf16-rounded pre-activation so the backward (which only has
+        // the stored bf16 value) differentiates exactly the function the forward evaluated
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(bf2f(pre[r]));
+      }
+      if (EPI == EPI_ADD || EPI == EPI_BIAS_ADD) {
+        const bf16x4 a = *reinterpret_cast<const bf16x4*>(p.aux + (size_t)m * p.ldaux + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bf2f(a[r]);
+      }
+      if (EPI == EPI_DGELU) {
+        const bf16x4 a = *reinterpret_cast<const bf16x4*>(p.aux + (size_t)m * p.ldaux + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad(bf2f(a[r]));
+      }
+      if (OUTF32) {
+        float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+        if (p.accumulate) { const f32x4 o = *reinterpret_cast<const f32x4*>(c); v += o; }
+        *reinterpret_cast<f32x4*>(c) = v;
+      } else {
+        bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n) = o;
+      }
+    }
+  }
+}
+
+template <bool AKS, bool BKS, int EPI, bool OUTF32>
+int launch(const GemmArgs& a, hipStream_t st) {
+  const int grid = a.tiles_m * a.tiles_n;
+  hipLaunchKernelGGL((gemm_kernel<AKS, BKS, EPI, OUTF32>), dim3(grid), dim3(256), 0, st, a);
+  return ia_check_launch();
+}
+
+}  // namespace
+
+extern "C" int ia_gemm_bf16(const void* A, int a_kstrided, int lda, const void* B, int b_kstrided, int ldb,
+                            void* C, int c_is_f32, int ldc, int M, int N, int K, int epilogue,
+                            const float* bias, const void* aux, int ldaux, void* C2, int accumulate,
+                            hipStream_t stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return IA_ERR_ARG;
+  if ((lda & 7) || (ldb & 7) || (ldc & 3) || (N & 3)) return IA_ERR_ARG;
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15)) return IA_ERR_ARG;
+  GemmArgs g;
+  g.A = (const bf16*)A; g.B = (const bf16*)B; g.C = C; g.C2 = (bf16*)C2; g.bias = bias; g.aux = (const bf16*)aux;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux; g.accumulate = accumulate;
+  const uint64_t ab = a_kstrided ? ((uint64_t)(K - 1) * lda + M) * 2 : ((uint64_t)(M - 1) * lda + K) * 2;
+  const uint64_t bb = b_kstrided ? ((uint64_t)(K - 1) * ldb + N) * 2 : ((uint64_t)(N - 1) * ldb + K) * 2;
+  if (ab >= 0x7FFFFFFFull || bb >= 0x7FFFFFFFull) return IA_ERR_ARG;
+  if (!a_kstrided && (K & 7)) return IA_ERR_ARG;
+  g.a_bytes = (uint32_t)ab; g.b_bytes = (uint32_t)bb;
+  g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
+  const bool needs_bias = epilogue == EPI_BIAS || epilogue == EPI_BIAS_GELU || epilogue == EPI_BIAS_ADD;
+  const bool needs_aux = epilogue == EPI_ADD || epilogue == EPI_DGELU || epilogue == EPI_BIAS_ADD;
+  if (needs_bias && !bias) return IA_ERR_ARG;
+  if (needs_aux && (!aux || (ldaux & 3))) return IA_ERR_ARG;
+  if (epilogue == EPI_BIAS_GELU && !C2) return IA_ERR_ARG;
+
+  if (!a_kstrided && !b_kstrided && !c_is_f32) {
+    switch (epilogue) {
+      case EPI_NONE: return launch<false, false, EPI_NONE, false>(g, stream);
+      case EPI_BIAS: return launch<false, false, EPI_BIAS, false>(g, stream);
+      case EPI_BIAS_GELU: return launch<false, false, EPI_BIAS_GELU, false>(g, stream);
+      case EPI_BIAS_ADD: return launch<false, false, EPI_BIAS_ADD, false>(g, stream);
+      case EPI_ADD: return launch<false, false, EPI_ADD, false>(g, stream);
+    }
+  } else if (!a_kstrided && b_kstrided && !c_is_f32) {
+    switch (epilogue) {
+      case EPI_NONE: return launch<false, true, EPI_NONE, false>(g, stream);
+      case EPI_ADD: return launch<false, true, EPI_ADD, false>(g, stream);
+      case EPI_DGELU: return launch<false, true, EPI_DGELU, false>(g, stream);
+    }
+  } else if (a_kstrided && b_kstrided && c_is_f32) {
+    if (epilogue == EPI_NONE) return launch<true, true, EPI_NONE, true>(g, stream);
+  } else if (!a_kstrided && !b_kstrided && c_is_f32) {
+    if (epilogue == EPI_NONE) return launch<false, false, EPI_NONE, true>(g, stream);
+    if (epilogue == EPI_BIAS) return launch<false, false, EPI_BIAS, true>(g, stream);
+  }
+  return IA_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,180 @@
+// Pair heads and losses (tiny fp32 work on [B, H] CLS features), gfx950.
+//
+//   ia_linear_small_fwd/bwd : y = act(x W^T + b), act in {none, tanh}; fp32 master weights are read
+//                             directly (reference base.py:139-157 RobertaClassificationHead dense+tanh,
+//                             base.py:66-76 VecSim dense+tanh, base.py:530 img2txt)
+//   ia_pair_head_ce_fwd/bwd : logits = [x | y] W^T + b, probs = softmax(logits), loss = mean CE
+//                             (reference base.py:103-117 TwoTowerClassificationHead + nn.CrossEntropyLoss
+//                              text.py:1292,1360; with y = null it is out_proj + softmax + CE of the
+//                              one-tower head, base.py:155 + text.py:1463,1473)
+// One wave per output element; the batch is tens of rows, so these kernels are latency- not
+// bandwidth-bound and are kept simple and deterministic (no atomics).
+#include "common.h"
+
+namespace {
+
+enum { ACT_NONE = 0, ACT_TANH = 1 };
+
+// y[b,n] = act(sum_k x[b,k] W[n,k] + bias[n]); grid = ceil(B*N / 4) blocks of 4 waves
+__global__ __launch_bounds__(256) void linear_small_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ W,
+                                                               const float* __restrict__ bias, float* __restrict__ y, int B, int N,
+                                                               int K, int act) {
+  const int lane = threadIdx.x & 63;
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (o >= B * N) return;
+  const int b = o / N, n = o % N;
+  const float* xr = x + (size_t)b * ldx;
+  const float* wr = W + (size_t)n * K;
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s += xr[k] * wr[k];
+  s = wave_sum(s);
+  if (lane == 0) {
+    if (bias) s += bias[n];
+    y[(size_t)b * N + n] = act == ACT_TANH ? tanhf(s) : s;
+  }
+}
+
+// dpre[b,n] = dy[b,n] * act'(y[b,n]);  dx[b,k] = sum_n dpre[b,n] W[n,k]
+__global__ __launch_bounds__(256) void linear_small_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                  const float* __restrict__ W, float* __restrict__ dx, int lddx, int B,
+                                                                  int N, int K, int act) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= B * K) return;
+  const int b = t / K, k = t % K;
+  float s = 0.f;
+  for (int n = 0; n < N; ++n) {
+    float g = dy[(size_t)b * N + n];
+    if (act == ACT_TANH) { const float yy = y[(size_t)b * N + n]; g *= 1.f - yy * yy; }
+    s += g * W[(size_t)n * K + k];
+  }
+  dx[(size_t)b * lddx + k] = s;
+}
+
+// dW[n,k] += sum_b dpre[b,n] x[b,k];  db[n] += sum_b dpre[b,n]
+__global__ __launch_bounds__(256) void linear_small_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                  const float* __restrict__ x, int ldx, float* __restrict__ dW,
+                                                                  float* __restrict__ db, int B, int N, int K, int act) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= N * K) return;
+  const int n = t / K, k = t % K;
+  float s = 0.f, sb = 0.f;
+  for (int b = 0; b < B; ++b) {
+    float g = dy[(size_t)b * N + n];
+    if (act == ACT_TANH) { const float yy = y[(size_t)b * N + n]; g *= 1.f - yy * yy; }
+    s += g * x[(size_t)b * ldx + k];
+    sb += g;
+  }
+  dW[t] += s;
+  if (db && k == 0) db[n] += sb;
+}
+
+// one wave per sample: logits, probs, per-sample loss; then a single-wave mean
+__global__ __launch_bounds__(64) void pair_head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ yv,
+                                                           const float* __restrict__ W, const float* __restrict__ bias,
+                                                           const int64_t* __restrict__ labels, float* __restrict__ logits,
+                                                           float* __restrict__ probs, float* __restrict__ loss_per, int B, int D, int C) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int F = yv ? 2 * D : D;
+  float lg[8];
+  for (int c = 0; c < C; ++c) {
+    float s = 0.f;
+    for (int k = lane; k < D; k += 64) s += x[(size_t)b * D + k] * W[(size_t)c * F + k];
+    if (yv) for (int k = lane; k < D; k += 64) s += yv[(size_t)b * D + k] * W[(size_t)c * F + D + k];
+    s = wave_sum(s);
+    lg[c] = s + (bias ? bias[c] : 0.f);
+  }
+  if (lane == 0) {
+    float mx = lg[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, lg[c]);
+    float den = 0.f;
+    for (int c = 0; c < C; ++c) den += expf(lg[c] - mx);
+    for (int c = 0; c < C; ++c) { logits[(size_t)b * C + c] = lg[c]; probs[(size_t)b * C + c] = expf(lg[c] - mx) / den; }
+    if (labels) loss_per[b] = -(lg[labels[b]] - mx - logf(den));
+  }
+}
+
+__global__ __launch_bounds__(64) void mean_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) s += v[i];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) out[0] = s / (float)n;
+}
+
+// dlogits[b,c] = dloss * (probs - onehot) / B ; dx = dlogits W[:, :D] ; dy = dlogits W[:, D:]
+__global__ __launch_bounds__(256) void pair_head_bwd_dxy_kernel(const float* __restrict__ probs, const int64_t* __restrict__ labels,
+                                                                const float* __restrict__ dloss, const float* __restrict__ W,
+                                                                float* __restrict__ dx, float* __restrict__ dyv, int B, int D, int C,
+                                                                int two) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int F = two ? 2 * D : D;
+  if (t >= B * F) return;
+  const int b = t / F, k = t % F;
+  const float scale = dloss[0] / (float)B;
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float g = (probs[(size_t)b * C + c] - (labels[b] == c ? 1.f : 0.f)) * scale;
+    s += g * W[(size_t)c * F + k];
+  }
+  if (k < D) dx[(size_t)b * D + k] = s; else dyv[(size_t)b * D + (k - D)] = s;
+}
+
+__global__ __launch_bounds__(256) void pair_head_bwd_dw_kernel(const float* __restrict__ probs, const int64_t* __restrict__ labels,
+                                                               const float* __restrict__ dloss, const float* __restrict__ x,
+                                                               const float* __restrict__ yv, float* __restrict__ dW, float* __restrict__ db,
+                                                               int B, int D, int C, int two) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int F = two ? 2 * D : D;
+  if (t >= C * F) return;
+  const int c = t / F, k = t % F;
+  const float scale = dloss[0] / (float)B;
+  float s = 0.f, sb = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float g = (probs[(size_t)b * C + c] - (labels[b] == c ? 1.f : 0.f)) * scale;
+    const float f = k < D ? x[(size_t)b * D + k] : yv[(size_t)b * D + (k - D)];
+    s += g * f;
+    sb += g;
+  }
+  dW[t] += s;
+  if (db && k == 0) db[c] += sb;
+}
+
+}  // namespace
+
+extern "C" int ia_linear_small_fwd(const float* x, int ldx, const float* W, const float* bias, float* y, int B, int N, int K, int act,
+                                   hipStream_t stream) {
+  if (!x || !W || !y || B <= 0 || N <= 0 || K <= 0 || (act != ACT_NONE && act != ACT_TANH)) return IA_ERR_ARG;
+  hipLaunchKernelGGL(linear_small_fwd_kernel, dim3((B * N + 3) / 4), dim3(256), 0, stream, x, ldx, W, bias, y, B, N, K, act);
+  return ia_check_launch();
+}
+
+// dx may be null (input needs no gradient); dW / db accumulate (+=); y = forward output (for tanh').
+extern "C" int ia_linear_small_bwd(const float* dy, const float* y, const float* x, int ldx, const float* W, float* dx, int lddx,
+                                   float* dW, float* db, int B, int N, int K, int act, hipStream_t stream) {
+  if (!dy || !x || !W || B <= 0 || N <= 0 || K <= 0 || (act == ACT_TANH && !y)) return IA_ERR_ARG;
+  if (dx) hipLaunchKernelGGL(linear_small_bwd_dx_kernel, dim3((B * K + 255) / 256), dim3(256), 0, stream, dy, y, W, dx, lddx, B, N, K, act);
+  if (dW) hipLaunchKernelGGL(linear_small_bwd_dw_kernel, dim3((N * K + 255) / 256), dim3(256), 0, stream, dy, y, x, ldx, dW, db, B, N, K, act);
+  return ia_check_launch();
+}
+
+// x, y: [B, D] fp32 (y may be null: single-feature head); W: [C, 2D] (or [C, D]); labels may be null
+// (then loss is not written); loss_per: scratch of B floats.
+extern "C" int ia_pair_head_ce_fwd(const float* x, const float* y, const float* W, const float* bias, const int64_t* labels,
+                                   float* logits, float* probs, float* loss, float* loss_per, int B, int D, int C, hipStream_t stream) {
+  if (!x || !W || !logits || !probs || B <= 0 || D <= 0 || C <= 0 || C > 8) return IA_ERR_ARG;
+  if (labels && (!loss || !loss_per)) return IA_ERR_ARG;
+  hipLaunchKernelGGL(pair_head_fwd_kernel, dim3(B), dim3(64), 0, stream, x, y, W, bias, labels, logits, probs, loss_per, B, D, C);
+  if (labels) hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(64), 0, stream, loss_per, B, loss);
+  return ia_check_launch();
+}
+
+// dloss: device scalar (upstream gradient of the mean loss). dW/db accumulate; dx/dy are overwritten.
+extern "C" int ia_pair_head_ce_bwd(const float* probs, const int64_t* labels, const float* dloss, const float* x, const float* y,
+                                   const float* W, float* dx, float* dy, float* dW, float* db, int B, int D, int C, hipStream_t stream) {
+  if (!probs || !labels || !dloss || !x || !W || !dx || B <= 0 || D <= 0 || C <= 0 || C > 8) return IA_ERR_ARG;
+  const int two = y != nullptr;
+  if (two && !dy) return IA_ERR_ARG;
+  const int F = two ? 2 * D : D;
+  hipLaunchKernelGGL(pair_head_bwd_dxy_kernel, dim3((B * F + 255) / 256), dim3(256), 0, stream, probs, labels, dloss, W, dx, dy, B, D, C, two);
+  if (dW) hipLaunchKernelGGL(pair_head_bwd_dw_kernel, dim3((C * F + 255) / 256), dim3(256), 0, stream, probs, labels, dloss, x, y, dW, db, B, D, C, two);
+  return ia_check_launch();
+}

@@ -1,0 +1,314 @@
+// Row-wise LayerNorm family (HBM-bound tails of the encoder layer), gfx950.
+//
+//   ia_ln_fwd : z = residual + dropout(x + bias);  y = LN(z) * gamma + beta      (BERT post-LN tail,
+//               reference: transformers RobertaSelfOutput / RobertaOutput called from
+//               src/models/text.py:1241; with residual = bias = null it is the plain pre-LN of ViT)
+//   ia_ln_bwd : dz = LN'(dy) (+ optional residual-path gradient dres), per-block partial sums of
+//               dgamma / dbeta / dbias, and the dropout-masked gradient of the GEMM branch
+//   ia_colsum : column sums of a [M,N] bf16 matrix (bias gradients) as per-block partials
+//   ia_reduce_partials : deterministic second stage, accumulates into the fp32 gradient arena
+//
+// One 64-lane wave owns one row at a time and keeps it in registers (16 B loads, 8 bf16 per lane
+// per 512-column slab); statistics are fp32, two-pass (mean, then centred variance).
+#include "common.h"
+
+namespace {
+
+constexpr int MAXV = 8;  // up to 4096 columns
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ bias,
+                                                     const bf16* __restrict__ res, bf16* __restrict__ z_out,
+                                                     bf16* __restrict__ y, float* __restrict__ mean_out,
+                                                     float* __restrict__ rstd_out, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, int M, int H, float eps,
+                                                     uint32_t thr16, float inv_keep, uint32_t seed, uint32_t stream) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float v[NV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int col = i * 512 + lane * 8;
+    if (col < H) {
+      const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + (size_t)row * H + col);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = bf2f(xv[j]);
+      if (bias) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + col);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + col + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[i][j] += b0[j]; v[i][4 + j] += b1[j]; }
+      }
+      if (thr16) {
+        const uint32_t base = (uint32_t)(((size_t)row * H + col) >> 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t r = ia_rng(seed, stream, base + j);
+          v[i][2 * j] = ((r & 0xFFFFu) >= thr16) ? v[i][2 * j] * inv_keep : 0.f;
+          v[i][2 * j + 1] = ((r >> 16) >= thr16) ? v[i][2 * j + 1] * inv_keep : 0.f;
+        }
+      }
+      if (res) {
+        const bf16x8 rv = *reinterpret_cast<const bf16x8*>(res + (size_t)row * H + col);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[i][j] += bf2f(rv[j]);
+      }
+      if (z_out) {
+        bf16x8 zv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) zv[j] = f2bf(v[i][j]);
+        *reinterpret_cast<bf16x8*>(z_out + (size_t)row * H + col) = zv;
+        // statistics are taken on the stored (bf16-rounded) z so fwd and bwd see the same x-hat
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[i][j] = bf2f(zv[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[i][j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+    }
+  }
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int col = i * 512 + lane * 8;
+    if (col < H) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int col = i * 512 + lane * 8;
+    if (col < H) {
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + col), g1 = *reinterpret_cast<const f32x4*>(gamma + col + 4);
+      f32x4 b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
+      if (beta) { b0 = *reinterpret_cast<const f32x4*>(beta + col); b1 = *reinterpret_cast<const f32x4*>(beta + col + 4); }
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[j] = f2bf((v[i][j] - mean) * rstd * g0[j] + b0[j]);
+        o[4 + j] = f2bf((v[i][4 + j] - mean) * rstd * g1[j] + b1[j]);
+      }
+      *reinterpret_cast<bf16x8*>(y + (size_t)row * H + col) = o;
+    }
+  }
+}
+
+// partial layout: part[blk][3][H] : 0 = dgamma, 1 = dbeta, 2 = dbias (gradient of the GEMM branch)
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ dres,
+                                                     const bf16* __restrict__ z, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                     bf16* __restrict__ dz, bf16* __restrict__ dx, float* __restrict__ part,
+                                                     int M, int H, uint32_t thr16, float inv_keep, uint32_t seed,
+                                                     uint32_t stream) {
+  __shared__ float red[3][4][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float ag[NV][8], ab[NV][8], ax[NV][8];
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; ax[i][j] = 0.f; }
+  float gm[NV][8];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int col = i * 512 + lane * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gm[i][j] = (col < H) ? gamma[col + j] : 0.f;
+  }
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    float g[NV][8], xh[NV][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int col = i * 512 + lane * 8;
+      if (col < H) {
+        const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dy + (size_t)row * H + col);
+        const bf16x8 zv = *reinterpret_cast<const bf16x8*>(z + (size_t)row * H + col);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float d = bf2f(dv[j]);
+          const float xhat = (bf2f(zv[j]) - mu) * rs;
+          xh[i][j] = xhat;
+          ag[i][j] += d * xhat;
+          ab[i][j] += d;
+          g[i][j] = d * gm[i][j];
+          s1 += g[i][j];
+          s2 += g[i][j] * xhat;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { g[i][j] = 0.f; xh[i][j] = 0.f; }
+      }
+    }
+    s1 = wave_sum(s1) / (float)H;
+    s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int col = i * 512 + lane * 8;
+      if (col < H) {
+        float o[8];
+        bf16x8 ov;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = rs * (g[i][j] - s1 - xh[i][j] * s2);
+        if (dres) {
+          const bf16x8 rv = *reinterpret_cast<const bf16x8*>(dres + (size_t)row * H + col);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] += bf2f(rv[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ov[j] = f2bf(o[j]);
+        *reinterpret_cast<bf16x8*>(dz + (size_t)row * H + col) = ov;
+        if (thr16) {
+          const uint32_t base = (uint32_t)(((size_t)row * H + col) >> 1);
+          bf16x8 xv;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t r = ia_rng(seed, stream, base + j);
+            const float a = ((r & 0xFFFFu) >= thr16) ? o[2 * j] * inv_keep : 0.f;
+            const float b = ((r >> 16) >= thr16) ? o[2 * j + 1] * inv_keep : 0.f;
+            xv[2 * j] = f2bf(a); xv[2 * j + 1] = f2bf(b);
+            ax[i][2 * j] += a; ax[i][2 * j + 1] += b;
+          }
+          *reinterpret_cast<bf16x8*>(dx + (size_t)row * H + col) = xv;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ax[i][j] += o[j];
+        }
+      }
+    }
+  }
+  // cross-wave reduction, 512 columns at a time
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      red[0][wave][lane * 8 + j] = ag[i][j];
+      red[1][wave][lane * 8 + j] = ab[i][j];
+      red[2][wave][lane * 8 + j] = ax[i][j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 512 * 3; c += 256) {
+      const int w = c / 512, cc = c % 512;
+      const int col = i * 512 + cc;
+      if (col < H) part[((size_t)blockIdx.x * 3 + w) * H + col] = red[w][0][cc] + red[w][1][cc] + red[w][2][cc] + red[w][3][cc];
+    }
+  }
+}
+
+// column sums: block (256 threads) covers 512 columns x a strided set of rows
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, float* __restrict__ part, int M, int N, int ld) {
+  __shared__ float red[4][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 512 + lane * 8;
+  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (col < N) {
+    for (int row = blockIdx.y * 4 + wave; row < M; row += gridDim.y * 4) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (size_t)row * ld + col);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += bf2f(v[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[wave][lane * 8 + j] = a[j];
+  __syncthreads();
+  for (int c = threadIdx.x; c < 512; c += 256) {
+    const int cc = blockIdx.x * 512 + c;
+    if (cc < N) part[(size_t)blockIdx.y * N + cc] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+  }
+}
+
+// out[c] (+)= sum_b part[b*stride + c]
+__global__ void reduce_partials_kernel(const float* __restrict__ part, int nblk, size_t stride, float* __restrict__ out, int n, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += part[(size_t)b * stride + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+int ln_blocks(int M) { int b = (M + 3) / 4; return b < 1024 ? b : 1024; }
+
+}  // namespace
+
+extern "C" int ia_ln_fwd(const void* x, const float* bias, const void* residual, void* z_out, void* y, float* mean,
+                         float* rstd, const float* gamma, const float* beta, int M, int H, float eps, float drop_p,
+                         uint32_t seed, uint32_t stream_id, hipStream_t stream) {
+  if (!x || !y || !mean || !rstd || !gamma || M <= 0 || H <= 0 || (H & 7) || H > 512 * MAXV) return IA_ERR_ARG;
+  const uint32_t thr16 = drop_p > 0.f ? (uint32_t)(drop_p * 65536.f + 0.5f) : 0u;
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - (float)thr16 / 65536.f) : 1.f;
+  const int nv = (H + 511) / 512;
+  dim3 grid((M + 3) / 4), blk(256);
+#define IA_LN_FWD(NV) hipLaunchKernelGGL((ln_fwd_kernel<NV>), grid, blk, 0, stream, (const bf16*)x, bias, (const bf16*)residual, \
+    (bf16*)z_out, (bf16*)y, mean, rstd, gamma, beta, M, H, eps, thr16, inv_keep, seed, stream_id)
+  switch (nv) {
+    case 1: IA_LN_FWD(1); break;
+    case 2: IA_LN_FWD(2); break;
+    case 3: IA_LN_FWD(3); break;
+    case 4: IA_LN_FWD(4); break;
+    default: IA_LN_FWD(8); break;
+  }
+#undef IA_LN_FWD
+  return ia_check_launch();
+}
+
+extern "C" size_t ia_ln_bwd_workspace_bytes(int M, int H) { return (size_t)ln_blocks(M) * 3 * H * sizeof(float); }
+
+// dgamma/dbeta/dbias may be null (skipped); all three accumulate (+=) into fp32 when `accumulate`.
+extern "C" int ia_ln_bwd(const void* dy, const void* dres, const void* z, const float* mean, const float* rstd,
+                         const float* gamma, void* dz, void* dx, float* dgamma, float* dbeta, float* dbias, int M, int H,
+                         float drop_p, uint32_t seed, uint32_t stream_id, void* workspace, size_t workspace_bytes,
+                         int accumulate, hipStream_t stream) {
+  if (!dy || !z || !mean || !rstd || !gamma || !dz || M <= 0 || (H & 7) || H > 512 * MAXV) return IA_ERR_ARG;
+  if (workspace_bytes < ia_ln_bwd_workspace_bytes(M, H) || !workspace) return IA_ERR_WORKSPACE;
+  const uint32_t thr16 = drop_p > 0.f ? (uint32_t)(drop_p * 65536.f + 0.5f) : 0u;
+  if (thr16 && !dx) return IA_ERR_ARG;
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - (float)thr16 / 65536.f) : 1.f;
+  const int nv = (H + 511) / 512, nb = ln_blocks(M);
+  float* part = (float*)workspace;
+  dim3 grid(nb), blk(256);
+#define IA_LN_BWD(NV) hipLaunchKernelGGL((ln_bwd_kernel<NV>), grid, blk, 0, stream, (const bf16*)dy, (const bf16*)dres, (const bf16*)z, \
+    mean, rstd, gamma, (bf16*)dz, (bf16*)dx, part, M, H, thr16, inv_keep, seed, stream_id)
+  switch (nv) {
+    case 1: IA_LN_BWD(1); break;
+    case 2: IA_LN_BWD(2); break;
+    case 3: IA_LN_BWD(3); break;
+    case 4: IA_LN_BWD(4); break;
+    default: IA_LN_BWD(8); break;
+  }
+#undef IA_LN_BWD
+  int rc = ia_check_launch();
+  if (rc) return rc;
+  float* outs[3] = {dgamma, dbeta, dbias};
+  for (int w = 0; w < 3; ++w) {
+    if (!outs[w]) continue;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((H + 255) / 256), dim3(256), 0, stream, part + (size_t)w * H, nb,
+                       (size_t)3 * H, outs[w], H, accumulate);
+  }
+  return ia_check_launch();
+}
+
+extern "C" size_t ia_colsum_workspace_bytes(int M, int N) {
+  int rb = (M + 3) / 4; if (rb > 256) rb = 256;
+  return (size_t)rb * N * sizeof(float);
+}
+
+extern "C" int ia_colsum(const void* x, int ld, int M, int N, float* out, int accumulate, void* workspace,
+                         size_t workspace_bytes, hipStream_t stream) {
+  if (!x || !out || M <= 0 || N <= 0 || (N & 7) || (ld & 7)) return IA_ERR_ARG;
+  if (!workspace || workspace_bytes < ia_colsum_workspace_bytes(M, N)) return IA_ERR_WORKSPACE;
+  int rb = (M + 3) / 4; if (rb > 256) rb = 256;
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 511) / 512, rb), dim3(256), 0, stream, (const bf16*)x, (float*)workspace, M, N, ld);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, (const float*)workspace, rb,
+                     (size_t)N, out, N, accumulate);
+  return ia_check_launch();
+}
