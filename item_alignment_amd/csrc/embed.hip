@@ -179,12 +179,26 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16* __restric
   }
 }
 
-__global__ void reduce2_kernel(const float* __restrict__ part, int nblk, size_t stride, float* __restrict__ out, int n, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n) return;
+// out_w[c] += sum_b part[(b*2 + w)*H + c]; 32 columns x 32 row-slices per block
+__global__ __launch_bounds__(1024) void reduce2_kernel(const float* __restrict__ part, int nblk, int H, float* __restrict__ o0,
+                                                       float* __restrict__ o1) {
+  __shared__ float red[32][33];
+  const int cx = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += part[(size_t)b * stride + c];
-  out[c] = accumulate ? out[c] + s : s;
+  if (c < 2 * H) {
+    const int w = c / H, col = c % H;
+    for (int b = sl; b < nblk; b += 32) s += part[((size_t)b * 2 + w) * H + col];
+  }
+  red[sl][cx] = s;
+  __syncthreads();
+  if (sl == 0 && c < 2 * H) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) t += red[i][cx];
+    float* o = (c / H) ? o1 : o0;
+    if (o) o[c % H] += t;
+  }
 }
 
 // images [B, C, S, S] fp32 NCHW -> patches [B * (S/P)^2, C*P*P] bf16, column = (c, ph, pw); P = 16
@@ -290,7 +304,7 @@ __global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const float* __res
   }
 }
 
-int ln_blocks(int M) { int b = (M + 3) / 4; return b < 1024 ? b : 1024; }
+int ln_blocks(int M) { int b = (M + 3) / 4; return b < 512 ? b : 512; }
 void drop_params(float p, uint32_t& thr16, float& inv_keep) {
   thr16 = p > 0.f ? (uint32_t)(p * 65536.f + 0.5f) : 0u;
   inv_keep = p > 0.f ? 1.f / (1.f - (float)thr16 / 65536.f) : 1.f;
@@ -335,8 +349,7 @@ extern "C" int ia_embed_ln_bwd(const void* dy, const void* z, const float* mean,
     type_ids, pos_ids, extra_idx, dword, dtype, dpos, dextra, part, M, H, word_pad, pos_pad, thr16, inv_keep, seed, stream_id)
   switch (nv) { case 1: IA_E(1); break; case 2: IA_E(2); break; case 3: IA_E(3); break; case 4: IA_E(4); break; default: IA_E(8); }
 #undef IA_E
-  if (dgamma) hipLaunchKernelGGL(reduce2_kernel, dim3((H + 255) / 256), dim3(256), 0, stream, part, nb, (size_t)2 * H, dgamma, H, 1);
-  if (dbeta) hipLaunchKernelGGL(reduce2_kernel, dim3((H + 255) / 256), dim3(256), 0, stream, part + H, nb, (size_t)2 * H, dbeta, H, 1);
+  hipLaunchKernelGGL(reduce2_kernel, dim3((2 * H + 31) / 32), dim3(1024), 0, stream, part, nb, H, dgamma, dbeta);
   return ia_check_launch();
 }
 

@@ -227,16 +227,32 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x,
   }
 }
 
-// out[c] (+)= sum_b part[b*stride + c]
-__global__ void reduce_partials_kernel(const float* __restrict__ part, int nblk, size_t stride, float* __restrict__ out, int n, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n) return;
+// out_w[c] (+)= sum_b part[(b*nw + w)*H + c] for w < nw; 32 columns x 32 row-slices per block so the
+// second stage is bandwidth- not latency-bound (a column-per-thread serial sum took 0.7 ms).
+struct ReduceOuts { float* p[3]; };
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ part, int nblk, int nw, int H, ReduceOuts outs,
+                                                               int accumulate) {
+  __shared__ float red[32][33];
+  const int cx = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;          // column in [0, nw*H)
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += part[(size_t)b * stride + c];
-  out[c] = accumulate ? out[c] + s : s;
+  if (c < nw * H) {
+    const int w = c / H, col = c % H;
+    for (int b = sl; b < nblk; b += 32) s += part[((size_t)b * nw + w) * H + col];
+  }
+  red[sl][cx] = s;
+  __syncthreads();
+  if (sl == 0 && c < nw * H) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) t += red[i][cx];
+    const int w = c / H, col = c % H;
+    float* o = outs.p[w];
+    if (o) o[col] = accumulate ? o[col] + t : t;
+  }
 }
 
-int ln_blocks(int M) { int b = (M + 3) / 4; return b < 1024 ? b : 1024; }
+int ln_blocks(int M) { int b = (M + 3) / 4; return b < 512 ? b : 512; }
 
 }  // namespace
 
@@ -288,12 +304,8 @@ extern "C" int ia_ln_bwd(const void* dy, const void* dres, const void* z, const 
 #undef IA_LN_BWD
   int rc = ia_check_launch();
   if (rc) return rc;
-  float* outs[3] = {dgamma, dbeta, dbias};
-  for (int w = 0; w < 3; ++w) {
-    if (!outs[w]) continue;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((H + 255) / 256), dim3(256), 0, stream, part + (size_t)w * H, nb,
-                       (size_t)3 * H, outs[w], H, accumulate);
-  }
+  ReduceOuts outs{{dgamma, dbeta, dbias}};
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((3 * H + 31) / 32), dim3(1024), 0, stream, part, nb, 3, H, outs, accumulate);
   return ia_check_launch();
 }
 
@@ -308,7 +320,7 @@ extern "C" int ia_colsum(const void* x, int ld, int M, int N, float* out, int ac
   if (!workspace || workspace_bytes < ia_colsum_workspace_bytes(M, N)) return IA_ERR_WORKSPACE;
   int rb = (M + 3) / 4; if (rb > 256) rb = 256;
   hipLaunchKernelGGL(colsum_kernel, dim3((N + 511) / 512, rb), dim3(256), 0, stream, (const bf16*)x, (float*)workspace, M, N, ld);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, (const float*)workspace, rb,
-                     (size_t)N, out, N, accumulate);
+  ReduceOuts outs{{out, nullptr, nullptr}};
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 31) / 32), dim3(1024), 0, stream, (const float*)workspace, rb, 1, N, outs, accumulate);
   return ia_check_launch();
 }

@@ -1,0 +1,332 @@
+"""TEST INFRASTRUCTURE — captures golden vectors from the REFERENCE's own model classes.
+
+Runs only in the build container (needs /root/reference, read-only); writes tests/golden/<case>.npz:
+inputs, the state_dict spec + seed (weights are regenerated, not stored), and the reference outputs
+(loss, logits, probs, src/tgt embeds, a few hidden states and parameter gradients), eval mode, fp32.
+
+    python oracle/gen_golden.py            # regenerates every fixture
+"""
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle.ref_harness import load_reference, reference_config  # noqa: E402
+from oracle.weights import seeded_state_dict, spec_of  # noqa: E402
+from oracle import ref_models as O  # noqa: E402
+
+warnings.filterwarnings("ignore")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+TINY = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=120,
+            max_position_embeddings=96, type_vocab_size=2, pad_token_id=0, hidden_dropout_prob=0.1,
+            attention_probs_dropout_prob=0.1, layer_norm_eps=1e-12, num_labels=2)
+CFG_KEYS = ["hidden_size", "num_hidden_layers", "num_attention_heads", "intermediate_size", "vocab_size",
+            "max_position_embeddings", "type_vocab_size", "pad_token_id", "hidden_dropout_prob", "attention_probs_dropout_prob",
+            "layer_norm_eps", "num_labels", "interaction_type", "classification_method", "similarity_measure", "loss_type",
+            "max_seq_len", "max_seq_len_pv", "max_pvs", "loss_margin", "cls_layers", "cls_pool", "ensemble", "auxiliary_task",
+            "image_hidden_size", "image_size", "filter_sizes", "num_filters", "classifier_dropout", "num_entities",
+            "num_relations", "kg_embedding_dim", "entity_projection_bias", "num_hidden_layers_multimodal",
+            "num_attention_heads_multimodal", "feedforward_multiplication_multimodal"]
+
+
+def cfg_dict(cfg):
+    return {k: getattr(cfg, k) for k in CFG_KEYS if hasattr(cfg, k)}
+
+
+def text_batch(rs, B, L, vocab, ragged=True):
+    ids = rs.randint(3, vocab, size=(B, L)).astype(np.int64)
+    mask = np.ones((B, L), dtype=np.int64)
+    if ragged:
+        for b in range(B):
+            n = L - 2 - 3 * b
+            ids[b, n:] = 0
+            mask[b, n:] = 0
+    ids[:, 0] = 1
+    tt = np.zeros((B, L), dtype=np.int64)
+    tt[:, L // 2:] = 1
+    tt = tt * mask
+    return ids, mask, tt
+
+
+def save(name, cfg, seed, spec, inputs, out, grads, extra=None):
+    arrays = {}
+    for k, v in inputs.items():
+        if v is not None:
+            arrays["in_" + k] = np.asarray(v)
+    for k in ("loss", "logits", "probs", "src_embeds", "tgt_embeds"):
+        v = getattr(out, k, None)
+        if v is not None:
+            arrays["out_" + k] = v.detach().numpy()
+    for k, v in (grads or {}).items():
+        arrays["grad_" + k] = v.detach().numpy()
+    for k, v in (extra or {}).items():
+        arrays["extra_" + k] = v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)
+    meta = dict(case=name, seed=seed, config=cfg_dict(cfg), spec=[[k, list(s)] for k, s in spec])
+    arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **arrays)
+    print(f"wrote {name}.npz  loss={arrays.get('out_loss')}")
+
+
+def load_weights(model, seed):
+    spec = spec_of(model.state_dict())
+    sd = seeded_state_dict(spec, seed)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(("position_ids" in k or "token_type_ids" in k or "inv_freq" in k or k.endswith(".mask") or k.endswith("pos_emb"))
+               for k in missing), missing
+    return spec
+
+
+def grads_of(model, names):
+    p = dict(model.named_parameters())
+    return {n: p[n].grad for n in names if n in p and p[n].grad is not None}
+
+
+def t(x):
+    return None if x is None else torch.from_numpy(np.asarray(x))
+
+
+def main():
+    os.makedirs(GOLDEN, exist_ok=True)
+    M = load_reference()
+    rs = np.random.RandomState(2345)
+    B = 3
+
+    # ---- RobertaOneTower: cls/ce ; cls layers 1,2 cat ; vec_sim cosine
+    for name, over in [("roberta_one_tower_cls_ce", {}),
+                       ("roberta_one_tower_cls12_cat", dict(cls_layers="1,2")),
+                       ("roberta_one_tower_cls12_avg", dict(cls_layers="1,2", cls_pool="avg")),
+                       ("roberta_one_tower_vecsim_cosine", dict(classification_method="vec_sim", similarity_measure="cosine", loss_type="cosine")),
+                       ("roberta_one_tower_vecsim_l2_bce", dict(classification_method="vec_sim", similarity_measure="l2", loss_type="bce")),
+                       ("roberta_one_tower_vecsim_ip_hinge", dict(classification_method="vec_sim", similarity_measure="inner_product", loss_type="hinge")),
+                       ]:
+        cfg = reference_config(**TINY, interaction_type="one_tower", max_seq_len=8, max_seq_len_pv=12, **over)
+        model = M.RobertaOneTower(cfg).eval()
+        seed = 11
+        spec = load_weights(model, seed)
+        ids, mask, tt = text_batch(rs, B, 40, cfg.vocab_size)
+        labels = np.array([0, 1, 1], dtype=np.int64)
+        lab = t(labels).float() if over.get("loss_type") == "bce" else t(labels)
+        out = model(input_ids=t(ids), attention_mask=t(mask), token_type_ids=t(tt), position_ids=None, labels=lab,
+                    output_hidden_states=True)
+        out.loss.backward()
+        hs = model.roberta(t(ids), attention_mask=t(mask), token_type_ids=t(tt), output_hidden_states=True).hidden_states
+        save(name, cfg, seed, spec, dict(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels), out,
+             grads_of(model, ["classifier.out_proj.weight", "classifier.dense.weight", "roberta.encoder.layer.0.attention.self.query.weight",
+                              "roberta.encoder.layer.1.output.LayerNorm.weight", "roberta.embeddings.word_embeddings.weight",
+                              "roberta.embeddings.position_embeddings.weight", "roberta.encoder.layer.0.intermediate.dense.bias"]),
+             extra=dict(hidden0=hs[0], hidden1=hs[1], hidden_last=hs[-1]))
+
+    # ---- RobertaTwoTower with each loss
+    for lt in ["ce", "cosine", "hinge", "euclidean"]:
+        cfg = reference_config(**TINY, interaction_type="two_tower", max_seq_len=8, max_seq_len_pv=12, loss_type=lt)
+        if lt in ("hinge", "euclidean"):
+            cfg.num_labels = 1
+        model = M.RobertaTwoTower(cfg).eval()
+        seed = 12
+        spec = load_weights(model, seed)
+        ids1, mask1, tt1 = text_batch(rs, B, 20, cfg.vocab_size)
+        ids2, mask2, tt2 = text_batch(rs, B, 20, cfg.vocab_size)
+        tt1[:] = 0; tt2[:] = 0
+        labels = np.array([1, 0, 1], dtype=np.int64)
+        out = model(input_ids_1=t(ids1), attention_mask_1=t(mask1), token_type_ids_1=t(tt1), input_ids_2=t(ids2),
+                    attention_mask_2=t(mask2), token_type_ids_2=t(tt2), labels=t(labels))
+        out.loss.backward()
+        save(f"roberta_two_tower_{lt}", cfg, seed, spec,
+             dict(input_ids_1=ids1, attention_mask_1=mask1, token_type_ids_1=tt1, input_ids_2=ids2, attention_mask_2=mask2,
+                  token_type_ids_2=tt2, labels=labels), out,
+             grads_of(model, ["classifier.out_proj.weight", "roberta.encoder.layer.1.attention.self.value.weight",
+                              "roberta.embeddings.LayerNorm.bias"]))
+
+    # ---- PKGM one / two tower (Dk == H, and Dk != H with projectors)
+    for name, one, dk in [("pkgm_one_tower", True, 128), ("pkgm_one_tower_proj", True, 64), ("pkgm_two_tower", False, 128)]:
+        S, P = 8, 3
+        cfg = reference_config(**TINY, interaction_type="one_tower" if one else "two_tower", max_seq_len=S, max_pvs=P,
+                               num_entities=50, num_relations=9, kg_embedding_dim=dk, entity_projection_bias=False)
+        model = (M.PKGMOneTower if one else M.PKGMTwoTower)(cfg).eval()
+        seed = 13
+        spec = load_weights(model, seed)
+
+        def side():
+            text = rs.randint(3, cfg.vocab_size, size=(B, S)).astype(np.int64); text[:, 0] = 1
+            ent = rs.randint(1, 50, size=(B, 1)).astype(np.int64)
+            rel = rs.randint(1, 9, size=(B, P)).astype(np.int64)
+            return np.concatenate([text, ent, rel], axis=1)
+        if one:
+            ids = np.concatenate([side(), side()], axis=1)
+            Lm = 2 * (S + 2 * P)
+            mask = np.ones((B, Lm), dtype=np.int64); mask[1, -2:] = 0
+            tt = np.zeros((B, Lm), dtype=np.int64); tt[:, Lm // 2:] = 1
+            pos = np.tile(np.arange(1, Lm + 1, dtype=np.int64), (B, 1))
+            labels = np.array([0, 1, 0], dtype=np.int64)
+            out = model(input_ids=t(ids), attention_mask=t(mask), token_type_ids=t(tt), position_ids=t(pos), labels=t(labels))
+            out.loss.backward()
+            save(name, cfg, seed, spec, dict(input_ids=ids, attention_mask=mask, token_type_ids=tt, position_ids=pos, labels=labels),
+                 out, grads_of(model, ["classifier.out_proj.weight", "roberta.embeddings.proj_mat.weight", "roberta.embeddings.rel_emb.weight"]))
+        else:
+            Lm = S + 2 * P
+            a, b_ = side(), side()
+            mask = np.ones((B, Lm), dtype=np.int64)
+            tt = np.zeros((B, Lm), dtype=np.int64)
+            pos = np.tile(np.arange(1, Lm + 1, dtype=np.int64), (B, 1))
+            labels = np.array([0, 1, 0], dtype=np.int64)
+            out = model(input_ids_1=t(a), attention_mask_1=t(mask), token_type_ids_1=t(tt), position_ids_1=t(pos), input_ids_2=t(b_),
+                        attention_mask_2=t(mask), token_type_ids_2=t(tt), position_ids_2=t(pos), labels=t(labels))
+            out.loss.backward()
+            save(name, cfg, seed, spec, dict(input_ids_1=a, input_ids_2=b_, attention_mask=mask, token_type_ids=tt, position_ids=pos,
+                                             labels=labels), out, grads_of(model, ["classifier.out_proj.weight"]))
+
+    # ---- RoBERTa + image embeddings
+    IH = 48
+    for name, one, ens in [("roberta_image_one_tower_begin", True, "begin"), ("roberta_image_one_tower_end", True, "end"),
+                           ("roberta_image_two_tower_begin", False, "begin")]:
+        cfg = reference_config(**TINY, interaction_type="one_tower" if one else "two_tower", max_seq_len=8, max_seq_len_pv=12,
+                               ensemble=ens, image_hidden_size=IH)
+        model = (M.RobertaImageOneTower if one else M.RobertaImageTwoTower)(cfg).eval()
+        seed = 14
+        spec = load_weights(model, seed)
+        labels = np.array([1, 1, 0], dtype=np.int64)
+        if one:
+            ids, mask, tt = text_batch(rs, B, 40, cfg.vocab_size)
+            img1 = rs.standard_normal((B, IH)).astype(np.float32); img2 = rs.standard_normal((B, IH)).astype(np.float32)
+            image_indices = np.array([21, 19, 22], dtype=np.int64)
+            out = model(input_ids=t(ids), attention_mask=t(mask), token_type_ids=t(tt), position_ids=None, labels=t(labels),
+                        output_hidden_states=True, inputs_embeds=[t(img1), t(img2)], image_indices=t(image_indices))
+            out.loss.backward()
+            gnames = ["classifier.out_proj.weight"] + (["roberta.embeddings.img2txt.weight"] if ens == "begin" else ["classifier.dense_img.weight"])
+            save(name, cfg, seed, spec, dict(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, img1=img1, img2=img2,
+                                             image_indices=image_indices), out, grads_of(model, gnames))
+        else:
+            ids1, mask1, tt1 = text_batch(rs, B, 20, cfg.vocab_size); ids2, mask2, tt2 = text_batch(rs, B, 20, cfg.vocab_size)
+            tt1[:] = 0; tt2[:] = 0
+            img1 = rs.standard_normal((B, IH)).astype(np.float32); img2 = rs.standard_normal((B, IH)).astype(np.float32)
+            out = model(input_ids_1=t(ids1), attention_mask_1=t(mask1), token_type_ids_1=t(tt1), position_ids_1=None, images_1=t(img1),
+                        input_ids_2=t(ids2), attention_mask_2=t(mask2), token_type_ids_2=t(tt2), position_ids_2=None, images_2=t(img2),
+                        labels=t(labels))
+            out.loss.backward()
+            save(name, cfg, seed, spec, dict(input_ids_1=ids1, attention_mask_1=mask1, token_type_ids_1=tt1, input_ids_2=ids2,
+                                             attention_mask_2=mask2, token_type_ids_2=tt2, img1=img1, img2=img2, labels=labels), out,
+                 grads_of(model, ["classifier.out_proj.weight", "roberta.embeddings.img2txt.weight"]))
+
+    # ---- TextCNN two tower (config C1 shapes scaled down)
+    cfg = reference_config(**TINY, interaction_type="two_tower", max_seq_len=8, max_seq_len_pv=12, filter_sizes="1,2,3,5", num_filters=6)
+    emb_spec = [("word_embeddings.weight", (cfg.vocab_size, cfg.hidden_size)), ("position_embeddings.weight", (cfg.max_position_embeddings, cfg.hidden_size)),
+                ("token_type_embeddings.weight", (2, cfg.hidden_size)), ("LayerNorm.weight", (cfg.hidden_size,)), ("LayerNorm.bias", (cfg.hidden_size,))]
+    model = M.TextCNNTwoTower(cfg, seeded_state_dict(emb_spec, 5)).eval()
+    seed = 15
+    spec = load_weights(model, seed)
+    ids1, _, _ = text_batch(rs, B, 20, cfg.vocab_size); ids2, _, _ = text_batch(rs, B, 20, cfg.vocab_size)
+    labels = np.array([1, 0, 0], dtype=np.int64)
+    out = model(input_ids_1=t(ids1), input_ids_2=t(ids2), labels=t(labels))
+    out.loss.backward()
+    save("textcnn_two_tower", cfg, seed, spec, dict(input_ids_1=ids1, input_ids_2=ids2, labels=labels), out,
+         grads_of(model, ["classifier.out_proj.weight", "textcnn.convs1.2.weight", "textcnn.embedding1.word_embeddings.weight"]))
+
+    # ---- CoCa (sum / cross_attn).  timm is absent: the image encoder handed to the reference class is the
+    # oracle's ViT restatement wrapped as a module with timm's key names, so the wrapper code is pinned
+    # while the ViT arithmetic itself stays "unpinned by the reference" (cross-checked against HF ViT elsewhere).
+    class VitModule(torch.nn.Module):
+        def __init__(self, vcfg, spec):
+            super().__init__()
+            self.vcfg = vcfg
+            self.num_features = vcfg.embed_dim
+            self.params = torch.nn.ParameterDict()
+            self._keys = {}
+            for k, shp in spec:
+                pk = k.replace(".", "__")
+                self.params[pk] = torch.nn.Parameter(torch.zeros(shp))
+                self._keys[k] = pk
+
+        def _sd(self):
+            return {"v." + k: self.params[pk] for k, pk in self._keys.items()}
+
+        def forward_features(self, x):
+            return O.vit_forward_features(self._sd(), "v", self.vcfg, x)
+
+        def forward_head(self, x, pre_logits=False):
+            return O.vit_forward_head(x)
+
+        def state_dict(self, *a, **k):
+            sd = super().state_dict(*a, **k)
+            prefix = k.get("prefix", a[1] if len(a) > 1 else "")
+            return type(sd)((key.replace("params.", "").replace("__", "."), v) for key, v in sd.items())
+
+    from types import SimpleNamespace
+    vcfg = SimpleNamespace(embed_dim=128, depth=2, num_heads=2, patch_size=16, eps=1e-6, image_size=64)
+    npatch = (64 // 16) ** 2
+    vit_spec = [("cls_token", (1, 1, 128)), ("pos_embed", (1, npatch + 1, 128)), ("patch_embed.proj.weight", (128, 3, 16, 16)),
+                ("patch_embed.proj.bias", (128,))]
+    for i in range(vcfg.depth):
+        b = f"blocks.{i}"
+        vit_spec += [(b + ".norm1.weight", (128,)), (b + ".norm1.bias", (128,)), (b + ".attn.qkv.weight", (384, 128)), (b + ".attn.qkv.bias", (384,)),
+                     (b + ".attn.proj.weight", (128, 128)), (b + ".attn.proj.bias", (128,)), (b + ".norm2.weight", (128,)), (b + ".norm2.bias", (128,)),
+                     (b + ".mlp.fc1.weight", (512, 128)), (b + ".mlp.fc1.bias", (512,)), (b + ".mlp.fc2.weight", (128, 512)), (b + ".mlp.fc2.bias", (128,))]
+    vit_spec += [("norm.weight", (128,)), ("norm.bias", (128,))]
+    for ens in ["sum", "cross_attn"]:
+        cfg = reference_config(**TINY, interaction_type="two_tower", max_seq_len=8, max_seq_len_pv=12, ensemble=ens, image_size=64,
+                               num_hidden_layers_multimodal=2, num_attention_heads_multimodal=2, feedforward_multiplication_multimodal=2)
+        text_encoder = M.RobertaModel(cfg)
+        image_encoder = VitModule(vcfg, vit_spec)
+        model = M.CoCaForItemAlignment(cfg, image_encoder, text_encoder).eval()
+        seed = 16
+        # weights: text encoder + head (+ multimodal layers) by the reference's own key order, ViT by vit_spec
+        full = model.state_dict()
+        spec = []
+        for k, v in full.items():
+            if not torch.is_floating_point(v):
+                continue
+            if k.startswith("coca.img_encoder.params."):
+                kk = "coca.img_encoder." + k[len("coca.img_encoder.params."):].replace("__", ".")
+                spec.append((kk, tuple(v.shape)))
+            else:
+                spec.append((k, tuple(v.shape)))
+        sd = seeded_state_dict(spec, seed)
+        torch_sd = {}
+        for k, v in sd.items():
+            if k.startswith("coca.img_encoder."):
+                torch_sd["coca.img_encoder.params." + k[len("coca.img_encoder."):].replace(".", "__")] = v
+            else:
+                torch_sd[k] = v
+        missing, unexpected = model.load_state_dict(torch_sd, strict=False)
+        assert not unexpected, unexpected
+        ids1, mask1, tt1 = text_batch(rs, B, 20, cfg.vocab_size); ids2, mask2, tt2 = text_batch(rs, B, 20, cfg.vocab_size)
+        tt1[:] = 0; tt2[:] = 0
+        img1 = rs.standard_normal((B, 3, 64, 64)).astype(np.float32); img2 = rs.standard_normal((B, 3, 64, 64)).astype(np.float32)
+        labels = np.array([1, 0, 1], dtype=np.int64)
+        out = model(t(ids1), t(mask1), t(tt1), None, t(img1), t(ids2), t(mask2), t(tt2), None, t(img2), labels=t(labels))
+        out.loss.backward()
+        p = dict(model.named_parameters())
+        grads = {"classifier.out_proj.weight": p["classifier.out_proj.weight"].grad,
+                 "coca.text_encoder.encoder.layer.0.attention.self.query.weight": p["coca.text_encoder.encoder.layer.0.attention.self.query.weight"].grad,
+                 "coca.img_encoder.blocks.0.attn.qkv.weight": p["coca.img_encoder.params.blocks__0__attn__qkv__weight"].grad,
+                 "coca.img_encoder.patch_embed.proj.weight": p["coca.img_encoder.params.patch_embed__proj__weight"].grad,
+                 "coca.img_encoder.pos_embed": p["coca.img_encoder.params.pos_embed"].grad}
+        save(f"coca_{ens}", cfg, seed, spec, dict(input_ids_1=ids1, attention_mask_1=mask1, token_type_ids_1=tt1, input_ids_2=ids2,
+                                                    attention_mask_2=mask2, token_type_ids_2=tt2, img1=img1, img2=img2, labels=labels),
+             out, grads, extra=dict(vit=np.array([vcfg.embed_dim, vcfg.depth, vcfg.num_heads, vcfg.patch_size, vcfg.image_size])))
+
+    # ---- one full-width encoder layer (roberta_large geometry, L = 510): strided subsample of the output
+    cfg = reference_config(os.path.join("/root/reference/src/config/roberta_large.json"), interaction_type="one_tower", max_seq_len=50,
+                           max_seq_len_pv=205)
+    cfg.num_hidden_layers = 1
+    cfg.pad_token_id = 0
+    cfg.vocab_size = 2000
+    model = M.RobertaModel(cfg, add_pooling_layer=False).eval()
+    seed = 17
+    spec = load_weights(model, seed)
+    ids, mask, tt = text_batch(rs, 1, 510, cfg.vocab_size, ragged=False)
+    mask[0, 480:] = 0; ids[0, 480:] = 0
+    with torch.no_grad():
+        hs = model(t(ids), attention_mask=t(mask), token_type_ids=t(tt), output_hidden_states=True).hidden_states
+    from types import SimpleNamespace as NS
+    save("roberta_large_one_layer", cfg, seed, spec, dict(input_ids=ids, attention_mask=mask, token_type_ids=tt), NS(),
+         None, extra=dict(h0_sub=hs[0][0, ::16, ::16], h1_sub=hs[1][0, ::16, ::16], h1_norm=hs[1].norm(), h1_rows=hs[1][0, :4, :]))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,70 @@
+"""Helpers shared by the parity tests: load a golden fixture (captured from the reference by
+oracle/gen_golden.py), regenerate its seeded weights, and run the matching oracle function."""
+import json
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_case(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    cfg = SimpleNamespace(**meta["config"])
+    inputs = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
+    outs = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("out_")}
+    grads = {k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("grad_")}
+    extra = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("extra_")}
+    spec = [(k, tuple(s)) for k, s in meta["spec"]]
+    return SimpleNamespace(name=name, cfg=cfg, seed=meta["seed"], spec=spec, inputs=inputs, outs=outs, grads=grads, extra=extra)
+
+
+def case_names():
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+
+
+def weights(case, requires_grad=False):
+    from oracle.weights import seeded_state_dict
+    sd = seeded_state_dict(case.spec, case.seed)
+    if requires_grad:
+        for v in sd.values():
+            v.requires_grad_(True)
+    return sd
+
+
+def vit_cfg(case):
+    v = case.extra["vit"].tolist()
+    return SimpleNamespace(embed_dim=v[0], depth=v[1], num_heads=v[2], patch_size=v[3], image_size=v[4], eps=1e-6)
+
+
+def run_oracle(case, sd, training=False):
+    """Dispatch a fixture to the oracle function that restates the reference class it was captured from."""
+    from oracle import ref_models as O
+    i, cfg, n = case.inputs, case.cfg, case.name
+    g = i.get
+    if n.startswith("roberta_one_tower"):
+        lab = i["labels"].float() if cfg.loss_type == "bce" else i["labels"]
+        return O.roberta_one_tower(sd, cfg, i["input_ids"], i["attention_mask"], i["token_type_ids"], None, lab, training)
+    if n.startswith("roberta_two_tower"):
+        return O.roberta_two_tower(sd, cfg, i["input_ids_1"], i["attention_mask_1"], i["token_type_ids_1"], None, i["input_ids_2"],
+                                   i["attention_mask_2"], i["token_type_ids_2"], None, i["labels"], training)
+    if n.startswith("pkgm_one_tower"):
+        return O.pkgm_one_tower(sd, cfg, i["input_ids"], i["attention_mask"], i["token_type_ids"], i["position_ids"], i["labels"], training)
+    if n.startswith("pkgm_two_tower"):
+        return O.pkgm_two_tower(sd, cfg, i["input_ids_1"], i["attention_mask"], i["token_type_ids"], i["position_ids"], i["input_ids_2"],
+                                i["attention_mask"], i["token_type_ids"], i["position_ids"], i["labels"], training)
+    if n.startswith("roberta_image_one_tower"):
+        return O.roberta_image_one_tower(sd, cfg, i["input_ids"], i["attention_mask"], i["token_type_ids"], None, [i["img1"], i["img2"]],
+                                         i["image_indices"], i["labels"], training)
+    if n.startswith("roberta_image_two_tower"):
+        return O.roberta_image_two_tower(sd, cfg, i["input_ids_1"], i["attention_mask_1"], i["token_type_ids_1"], None, i["img1"],
+                                         i["input_ids_2"], i["attention_mask_2"], i["token_type_ids_2"], None, i["img2"], i["labels"], training)
+    if n.startswith("textcnn"):
+        return O.textcnn_two_tower(sd, cfg, i["input_ids_1"], i["input_ids_2"], i["labels"], training)
+    if n.startswith("coca"):
+        return O.coca_item_alignment(sd, cfg, vit_cfg(case), i["input_ids_1"], i["attention_mask_1"], i["token_type_ids_1"], None, i["img1"],
+                                     i["input_ids_2"], i["attention_mask_2"], i["token_type_ids_2"], None, i["img2"], i["labels"], training)
+    raise KeyError(n)

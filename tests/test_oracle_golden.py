@@ -1,0 +1,56 @@
+"""Pins the CPU oracle (oracle/ref_models.py) to the reference: every golden vector captured from the
+reference's own classes (oracle/gen_golden.py, build container) must be reproduced to fp32 round-off
+(1e-5 abs + 1e-4 rel), outputs and parameter gradients alike."""
+import pytest
+import torch
+
+from golden_util import case_names, load_case, run_oracle, weights
+
+CASES = [c for c in case_names() if c != "roberta_large_one_layer"]
+
+
+def close(a, b, what):
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert torch.allclose(a, b, atol=1e-5, rtol=1e-4), (what, (a - b).abs().max().item())
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_matches_reference(name):
+    case = load_case(name)
+    sd = weights(case, requires_grad=True)
+    out = run_oracle(case, sd)
+    for k, want in case.outs.items():
+        close(getattr(out, k).detach(), want, f"{name}.{k}")
+    if case.grads:
+        out.loss.backward()
+        for k, want in case.grads.items():
+            got = sd[k].grad
+            assert got is not None, k
+            close(got, want, f"{name}.grad[{k}]")
+    for k in ("hidden0", "hidden1", "hidden_last"):
+        if k in case.extra:
+            idx = {"hidden0": 0, "hidden1": 1, "hidden_last": -1}[k]
+            close(out.hidden_states[idx].detach(), case.extra[k], f"{name}.{k}")
+
+
+def test_full_width_layer():
+    """roberta_large geometry (H=1024, 16 heads, L=510, one layer): strided subsample + norm."""
+    from oracle import ref_models as O
+    case = load_case("roberta_large_one_layer")
+    sd = {"roberta." + k: v for k, v in weights(case).items()}   # captured from a bare RobertaModel (no prefix)
+    i = case.inputs
+    with torch.no_grad():
+        hs = O.roberta_model(sd, "roberta", case.cfg, i["input_ids"], i["attention_mask"], i["token_type_ids"], None)
+    close(hs[0][0, ::16, ::16], case.extra["h0_sub"], "h0_sub")
+    close(hs[1][0, ::16, ::16], case.extra["h1_sub"], "h1_sub")
+    close(hs[1][0, :4, :], case.extra["h1_rows"], "h1_rows")
+
+
+def test_known_answer_quirks():
+    """Closed-form behaviours the reference relies on."""
+    import torch.nn.functional as F
+    x = torch.randn(4, 1, 16)
+    assert torch.equal(F.normalize(x), torch.sign(x))                       # A1: normalize over a size-1 dim
+    from oracle.ref_models import create_position_ids_from_input_ids
+    ids = torch.tensor([[5, 6, 7, 0, 0], [9, 0, 3, 4, 0]])
+    assert create_position_ids_from_input_ids(ids, 0).tolist() == [[1, 2, 3, 0, 0], [1, 0, 2, 3, 0]]
