@@ -1,0 +1,131 @@
+"""Flat parameter arena: every trainable fp32 master parameter of a model lives in ONE contiguous HBM
+buffer, with four more buffers of identical element layout next to it (gradients, Adam exp_avg,
+exp_avg_sq, and the bf16 shadow the MFMA GEMMs read).
+
+Why (MI355X-first, 288 GB HBM): the optimiser is one HBM-bound launch over the arena instead of one per
+tensor; gradient buckets for the RCCL all-reduce are plain slices of the gradient arena (no packing
+copies); q/k/v projection weights are laid out back to back so the fused QKV GEMM reads one [3H, H]
+operand although the state_dict keeps the reference's separate query/key/value keys.
+
+The reference equivalent is torch.optim.AdamW over `model.named_parameters()` with two groups
+(finetune_multimodal.py:296-308): names containing "bias" or "LayerNorm.weight" get weight_decay 0.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, stream_ptr
+
+ALIGN = 64          # elements; 256 B for fp32, 128 B for the bf16 shadow
+CHUNK = 4096        # elements handled by one workgroup of the AdamW kernel
+NO_DECAY = ("bias", "LayerNorm.weight")
+
+
+def _round_up(n, a):
+    return (n + a - 1) // a * a
+
+
+class ParamArena:
+    def __init__(self, model, device, frozen_ok=True):
+        self.device = torch.device(device)
+        named = [(n, p) for n, p in model.named_parameters()]
+        by_id = {id(p): n for n, p in named}
+        # registration order, except that members of a contiguity group (fused QKV operands) are placed
+        # together where the group's first member appears; layers therefore stay in order and the
+        # backward pass completes the gradient arena from its end towards its start.
+        group_of = {}
+        for mod in model.modules():
+            for grp in getattr(mod, "arena_groups", lambda: [])():
+                for p in grp:
+                    group_of[id(p)] = grp
+        order, seen = [], set()
+        for n, p in named:
+            for q in group_of.get(id(p), (p,)):
+                if id(q) not in seen:
+                    order.append(q); seen.add(id(q))
+        self.names = [by_id[id(p)] for p in order]
+        self.params = order
+        self.offsets, off = [], 0
+        for p in order:
+            self.offsets.append(off)
+            off += _round_up(p.numel(), ALIGN)
+        self.numel = off
+        self.master = torch.zeros(off, device=self.device, dtype=torch.float32)
+        self.grad = torch.zeros(off, device=self.device, dtype=torch.float32)
+        self.exp_avg = torch.zeros(off, device=self.device, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros(off, device=self.device, dtype=torch.float32)
+        self.shadow = torch.zeros(off, device=self.device, dtype=torch.bfloat16)
+        self._shadow_of = {}
+        chunks = []
+        for name, p, o in zip(self.names, order, self.offsets):
+            n = p.numel()
+            view = self.master[o:o + n].view(p.shape)
+            view.copy_(p.data.to(self.device, torch.float32))
+            p.data = view
+            p.grad = self.grad[o:o + n].view(p.shape)
+            self._shadow_of[id(p)] = self.shadow[o:o + n].view(p.shape)
+            if p.requires_grad:
+                decay = 0 if any(nd in name for nd in NO_DECAY) else 1
+                for c in range(0, n, CHUNK):
+                    chunks.append(((o + c) & 0xFFFFFFFF, (o + c) >> 32, min(CHUNK, n - c), decay))
+        self.n_chunks = len(chunks)
+        self.chunk_table = torch.from_numpy(np.asarray(chunks, dtype=np.uint32).reshape(-1, 4)).to(self.device)
+        self.step_count = 0
+        self.refresh_shadow()
+
+    # ------------------------------------------------------------------ views
+    def shadow_of(self, p):
+        """bf16 copy of parameter p (refreshed by every optimiser step)."""
+        return self._shadow_of[id(p)]
+
+    def fused_shadow(self, params):
+        """bf16 view spanning several parameters that were laid out back to back (e.g. q|k|v)."""
+        first = self._shadow_of[id(params[0])]
+        total = sum(p.numel() for p in params)
+        start = first.storage_offset()
+        flat = self.shadow[start:start + total]
+        exp = start
+        for p in params:
+            if self._shadow_of[id(p)].storage_offset() != exp:
+                raise RuntimeError("parameters are not contiguous in the arena")
+            exp += p.numel()
+        return flat
+
+    def fused_master(self, params, grad=False):
+        buf = self.grad if grad else self.master
+        start = params[0].data.storage_offset() if not grad else params[0].grad.storage_offset()
+        total = sum(p.numel() for p in params)
+        return buf[start:start + total]
+
+    # ------------------------------------------------------------------ maintenance
+    def refresh_shadow(self):
+        lib = _lib.load()
+        check(lib.ia_cast_f32_to_bf16(self.master.data_ptr(), self.shadow.data_ptr(), self.numel, stream_ptr()), "ia_cast_f32_to_bf16")
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def reattach(self):
+        """p.grad can be dropped by user code (optimizer.zero_grad(set_to_none=True)); re-point it."""
+        for p, o in zip(self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+    def adamw_step(self, lr, betas=(0.9, 0.98), eps=1e-8, weight_decay=1e-5, grad_scale=1.0):
+        """One fused AdamW update over the whole arena + bf16 shadow refresh (single launch)."""
+        lib = _lib.load()
+        self.step_count += 1
+        check(lib.ia_adamw_flat(self.master.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                self.shadow.data_ptr(), self.chunk_table.data_ptr(), self.n_chunks, lr, betas[0], betas[1], eps,
+                                weight_decay, self.step_count, grad_scale, stream_ptr()), "ia_adamw_flat")
+
+    def grad_buckets(self, bucket_bytes=64 << 20):
+        """Contiguous slices of the gradient arena, last-to-first (backward produces the last layers'
+        gradients first), each about bucket_bytes: the units of the data-parallel all-reduce."""
+        per = max(ALIGN, bucket_bytes // 4 // ALIGN * ALIGN)
+        out, end = [], self.numel
+        while end > 0:
+            start = max(0, end - per)
+            out.append(self.grad[start:end])
+            end = start
+        return out

@@ -1,0 +1,341 @@
+"""torch.autograd glue between the model classes and the HIP engine.
+
+Each Function's forward/backward is a handful of C-ABI calls (item_alignment_amd._lib); no torch math
+runs on the hot path.  Parameter gradients are written straight into the fp32 gradient arena (the
+parameters' `.grad` views, see arena.py) by the kernels, with accumulate (+=) semantics, so the Functions
+return None for parameter inputs: autograd only carries activation gradients between Functions.
+"""
+import ctypes as C
+
+import torch
+
+from .. import _lib
+from .._lib import LayerCfg, LayerGrads, LayerWeights, check, ptr, stream_ptr
+
+BF16, F32 = torch.bfloat16, torch.float32
+_step_seed = [0x1234567]
+
+
+def set_step_seed(seed):
+    """Dropout streams are keyed by (step seed, layer, element); the train loop bumps this every step."""
+    _step_seed[0] = int(seed) & 0xFFFFFFFF
+
+
+def step_seed():
+    return _step_seed[0]
+
+
+def _need_gpu(t, what):
+    if not t.is_cuda:
+        raise _lib.ItemAlignError(f"{what} is on {t.device}: the MI355X engine has no CPU path (move the model and batch to cuda)")
+
+
+_notify_hooks = []
+
+
+def register_grad_ready_hook(fn):
+    """fn(list_of_parameters) is called right after the kernels that finish those parameters' gradients
+    have been enqueued on the current stream (used by the data-parallel bucket all-reduce)."""
+    _notify_hooks.append(fn)
+    return fn
+
+
+def clear_grad_ready_hooks():
+    del _notify_hooks[:]
+
+
+def _notify(params):
+    for fn in _notify_hooks:
+        fn(params)
+
+
+# ------------------------------------------------------------------------------------------ embeddings
+class EmbedLNFn(torch.autograd.Function):
+    """word (+ redirected extra rows) + token type + position -> LayerNorm -> dropout (reference base.py:238-279)."""
+
+    @staticmethod
+    def forward(ctx, anchor, emb, ids, tts, pids, extra_idx, extra, drop_p, stream_id):
+        lib = _lib.load()
+        _need_gpu(ids, "input_ids")
+        M = ids.numel()
+        H = emb.word_embeddings.weight.shape[1]
+        dev = ids.device
+        z = torch.empty((M, H), device=dev, dtype=BF16)
+        y = torch.empty((M, H), device=dev, dtype=BF16)
+        mean = torch.empty(M, device=dev, dtype=F32)
+        rstd = torch.empty(M, device=dev, dtype=F32)
+        seed = step_seed()
+        check(lib.ia_embed_ln_fwd(ids.data_ptr(), tts.data_ptr(), pids.data_ptr(), ptr(extra_idx), emb.word_embeddings.weight.data_ptr(),
+                                  emb.token_type_embeddings.weight.data_ptr(), emb.position_embeddings.weight.data_ptr(), ptr(extra),
+                                  emb.LayerNorm.weight.data_ptr(), emb.LayerNorm.bias.data_ptr(), z.data_ptr(), y.data_ptr(),
+                                  mean.data_ptr(), rstd.data_ptr(), M, H, emb.eps, drop_p, seed, stream_id, stream_ptr()), "ia_embed_ln_fwd")
+        ctx.emb, ctx.saved = emb, (ids, tts, pids, extra_idx, z, mean, rstd)
+        ctx.drop, ctx.seed, ctx.stream_id = drop_p, seed, stream_id
+        ctx.extra_shape = None if extra is None else extra.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        emb = ctx.emb
+        ids, tts, pids, extra_idx, z, mean, rstd = ctx.saved
+        M, H = z.shape
+        dy = dy.contiguous()
+        dextra = torch.zeros(ctx.extra_shape, device=dy.device, dtype=F32) if ctx.extra_shape is not None else None
+        ws_bytes = lib.ia_embed_ln_bwd_workspace_bytes(M, H)
+        ws = torch.empty(ws_bytes, device=dy.device, dtype=torch.uint8)
+
+        def g(p):
+            return p.grad.data_ptr() if p.requires_grad else None
+        check(lib.ia_embed_ln_bwd(dy.data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), emb.LayerNorm.weight.data_ptr(),
+                                  ids.data_ptr(), tts.data_ptr(), pids.data_ptr(), ptr(extra_idx), g(emb.word_embeddings.weight),
+                                  g(emb.token_type_embeddings.weight), g(emb.position_embeddings.weight), ptr(dextra),
+                                  g(emb.LayerNorm.weight), g(emb.LayerNorm.bias), M, H, emb.word_pad, emb.pos_pad, ctx.drop, ctx.seed,
+                                  ctx.stream_id, ws.data_ptr(), ws_bytes, stream_ptr()), "ia_embed_ln_bwd")
+        _notify([emb.word_embeddings.weight, emb.token_type_embeddings.weight, emb.position_embeddings.weight, emb.LayerNorm.weight,
+                 emb.LayerNorm.bias])
+        return None, None, None, None, None, None, dextra, None, None
+
+
+# --------------------------------------------------------------------------------------- encoder stack
+class EncoderStackFn(torch.autograd.Function):
+    """N encoder layers (post-LN RoBERTa or pre-LN ViT) through ia_layer_fwd / ia_layer_bwd.
+    Returns every layer's output (the reference's `hidden_states[1:]`, text.py:1452)."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, stack, key_mask, B, L, keep):
+        # `keep` = grad mode of the caller (inside Function.forward grad mode is always off): keep the
+        # per-layer activation stash for backward and, in train mode, apply dropout.
+        lib = _lib.load()
+        _need_gpu(x, "hidden states")
+        ctx.set_materialize_grads(False)
+        n = len(stack.layers)
+        training = stack.training and keep
+        seed = step_seed()
+        cfgs = [stack.layer_cfg(i, B, L, training, seed) for i in range(n)]
+        stash_bytes = lib.ia_layer_stash_bytes(C.byref(cfgs[0]))
+        stash = torch.empty((n if keep else 1) * stash_bytes, device=x.device, dtype=torch.uint8)
+        outs, cur = [], x.contiguous()
+        inputs = [cur]
+        mp = ptr(key_mask)
+        for i in range(n):
+            y = torch.empty_like(cur)
+            sp = stash.data_ptr() + (i * stash_bytes if keep else 0)
+            check(lib.ia_layer_fwd(C.byref(cfgs[i]), C.byref(stack.weights(i)), cur.data_ptr(), mp, y.data_ptr(), sp, stream_ptr()),
+                  f"ia_layer_fwd[{i}]")
+            outs.append(y)
+            cur = y
+            inputs.append(cur)
+        ctx.stack, ctx.cfgs, ctx.stash, ctx.stash_bytes = stack, cfgs, stash, stash_bytes
+        ctx.inputs, ctx.key_mask = inputs, key_mask
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        lib = _lib.load()
+        stack, cfgs, n = ctx.stack, ctx.cfgs, len(ctx.cfgs)
+        scratch_bytes = lib.ia_layer_bwd_scratch_bytes(C.byref(cfgs[0]))
+        scratch = torch.empty(scratch_bytes, device=ctx.stash.device, dtype=torch.uint8)
+        mp = ptr(ctx.key_mask)
+        dy = None
+        for i in reversed(range(n)):
+            g = grads[i]
+            if g is not None:
+                g = g.contiguous()
+                dy = g.clone() if dy is None else dy.add_(g)     # several tapped layers (cls_layers "1,2,..")
+            if dy is None:
+                continue                                          # layers above the last tapped one get no gradient
+            x = ctx.inputs[i]
+            check(lib.ia_layer_bwd(C.byref(cfgs[i]), C.byref(stack.weights(i)), C.byref(stack.grads(i)), x.data_ptr(), mp,
+                                   ctx.inputs[i + 1].data_ptr(), ctx.stash.data_ptr() + i * ctx.stash_bytes, dy.data_ptr(), dy.data_ptr(),
+                                   scratch.data_ptr(), scratch_bytes, stream_ptr()), f"ia_layer_bwd[{i}]")
+            _notify(stack.layer_params(i))
+        ctx.stash = None
+        ctx.inputs = None
+        return dy, None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------ small ops
+class GatherRowsFn(torch.autograd.Function):
+    """features[:, idx, :] -> dropout, as fp32 [B, H] (reference base.py:104 / :140-141)."""
+
+    @staticmethod
+    def forward(ctx, hidden, anchor, rows, drop_p, stream_id):
+        lib = _lib.load()
+        _need_gpu(hidden, "hidden states")
+        B, H = rows.numel(), hidden.shape[-1]
+        out = torch.empty((B, H), device=hidden.device, dtype=F32)
+        seed = step_seed()
+        check(lib.ia_gather_rows_fwd(hidden.data_ptr(), H, rows.data_ptr(), out.data_ptr(), B, H, drop_p, seed, stream_id, stream_ptr()),
+              "ia_gather_rows_fwd")
+        ctx.rows, ctx.shape, ctx.drop, ctx.seed, ctx.stream_id = rows, hidden.shape, drop_p, seed, stream_id
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        dsrc = torch.zeros(ctx.shape, device=dout.device, dtype=BF16)
+        dout = dout.contiguous()
+        B, H = dout.shape
+        check(lib.ia_gather_rows_bwd(dout.data_ptr(), H, ctx.rows.data_ptr(), dsrc.data_ptr(), B, H, ctx.drop, ctx.seed, ctx.stream_id, 0,
+                                     stream_ptr()), "ia_gather_rows_bwd")
+        return dsrc, None, None, None, None
+
+
+class LinearSmallFn(torch.autograd.Function):
+    """y = act(x W^T + b) on a few rows, fp32 (dense+tanh of the heads, img2txt; reference base.py:142-143,530)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, lin, act):
+        # `weight` (= lin.weight) is passed as a tensor input only so autograd records this node even when x
+        # needs no gradient (image embeddings); its gradient is written into the arena, not returned.
+        lib = _lib.load()
+        _need_gpu(x, "features")
+        x = x.contiguous()
+        B, K = x.shape
+        N = lin.weight.shape[0]
+        y = torch.empty((B, N), device=x.device, dtype=F32)
+        check(lib.ia_linear_small_fwd(x.data_ptr(), K, lin.weight.data_ptr(), ptr(lin.bias), y.data_ptr(), B, N, K, act, stream_ptr()),
+              "ia_linear_small_fwd")
+        ctx.lin, ctx.act, ctx.x, ctx.y = lin, act, x, y
+        ctx.need_dx = ctx.needs_input_grad[0]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        lin, x, y = ctx.lin, ctx.x, ctx.y
+        dy = dy.contiguous()
+        B, K = x.shape
+        N = lin.weight.shape[0]
+        dx = torch.empty_like(x) if ctx.need_dx else None
+        wg = lin.weight.requires_grad
+        check(lib.ia_linear_small_bwd(dy.data_ptr(), y.data_ptr(), x.data_ptr(), K, lin.weight.data_ptr(), ptr(dx), K,
+                                      lin.weight.grad.data_ptr() if wg else None,
+                                      lin.bias.grad.data_ptr() if (wg and lin.bias is not None) else None, B, N, K, ctx.act, stream_ptr()),
+              "ia_linear_small_bwd")
+        _notify([p for p in (lin.weight, lin.bias) if p is not None])
+        return dx, None, None, None
+
+
+class PairHeadCEFn(torch.autograd.Function):
+    """logits = [x | y] W^T + b ; probs = softmax ; loss = mean cross-entropy, fused (reference
+    base.py:114-115 + text.py:1360).  y may be None (single-feature head, base.py:155)."""
+
+    @staticmethod
+    def forward(ctx, x, y, lin, labels):
+        lib = _lib.load()
+        _need_gpu(x, "features")
+        x = x.contiguous()
+        y = None if y is None else y.contiguous()
+        B, D = x.shape
+        Cn = lin.weight.shape[0]
+        logits = torch.empty((B, Cn), device=x.device, dtype=F32)
+        probs = torch.empty((B, Cn), device=x.device, dtype=F32)
+        loss = torch.zeros((), device=x.device, dtype=F32)
+        per = torch.empty(B, device=x.device, dtype=F32)
+        check(lib.ia_pair_head_ce_fwd(x.data_ptr(), ptr(y), lin.weight.data_ptr(), ptr(lin.bias), ptr(labels), logits.data_ptr(),
+                                      probs.data_ptr(), loss.data_ptr(), per.data_ptr(), B, D, Cn, stream_ptr()), "ia_pair_head_ce_fwd")
+        ctx.lin, ctx.x, ctx.y, ctx.labels, ctx.probs = lin, x, y, labels, probs
+        ctx.mark_non_differentiable(logits, probs)
+        return logits, probs, loss
+
+    @staticmethod
+    def backward(ctx, _dlogits, _dprobs, dloss):
+        lib = _lib.load()
+        lin, x, y = ctx.lin, ctx.x, ctx.y
+        if ctx.labels is None:
+            raise RuntimeError("PairHeadCEFn.backward without labels")
+        B, D = x.shape
+        Cn = lin.weight.shape[0]
+        dloss = dloss.contiguous().to(F32)
+        dx = torch.empty_like(x)
+        dyv = torch.empty_like(y) if y is not None else None
+        wg = lin.weight.requires_grad
+        check(lib.ia_pair_head_ce_bwd(ctx.probs.data_ptr(), ctx.labels.data_ptr(), dloss.data_ptr(), x.data_ptr(), ptr(y),
+                                      lin.weight.data_ptr(), dx.data_ptr(), ptr(dyv), lin.weight.grad.data_ptr() if wg else None,
+                                      lin.bias.grad.data_ptr() if (wg and lin.bias is not None) else None, B, D, Cn, stream_ptr()),
+              "ia_pair_head_ce_bwd")
+        _notify([p for p in (lin.weight, lin.bias) if p is not None])
+        return dx, dyv, None, None
+
+
+class LayerNormFn(torch.autograd.Function):
+    """Plain LayerNorm over bf16 rows (final ViT norm; timm VisionTransformer.norm)."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, ln, eps):
+        lib = _lib.load()
+        _need_gpu(x, "tokens")
+        x = x.contiguous()
+        M, H = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(M, device=x.device, dtype=F32)
+        rstd = torch.empty(M, device=x.device, dtype=F32)
+        check(lib.ia_ln_fwd(x.data_ptr(), None, None, None, y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ln.weight.data_ptr(),
+                            ln.bias.data_ptr(), M, H, eps, 0.0, 0, 0, stream_ptr()), "ia_ln_fwd")
+        ctx.ln, ctx.saved = ln, (x, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        ln = ctx.ln
+        x, mean, rstd = ctx.saved
+        M, H = x.shape
+        dy = dy.contiguous()
+        dz = torch.empty_like(x)
+        ws_bytes = lib.ia_ln_bwd_workspace_bytes(M, H)
+        ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
+        wg = ln.weight.requires_grad
+        check(lib.ia_ln_bwd(dy.data_ptr(), None, x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ln.weight.data_ptr(), dz.data_ptr(), None,
+                            ln.weight.grad.data_ptr() if wg else None, ln.bias.grad.data_ptr() if wg else None, None, M, H, 0.0, 0, 0,
+                            ws.data_ptr(), ws_bytes, 1, stream_ptr()), "ia_ln_bwd")
+        _notify([ln.weight, ln.bias])
+        return dz, None, None, None
+
+
+class PatchEmbedFn(torch.autograd.Function):
+    """images [B,3,S,S] fp32 -> tokens [B*(np+1), H] bf16: im2col + MFMA GEMM (+bias) + cls/pos assembly
+    (timm PatchEmbed conv16/16 + cls_token + pos_embed, reference multimodal.py:811)."""
+
+    @staticmethod
+    def forward(ctx, images, anchor, vit):
+        lib = _lib.load()
+        _need_gpu(images, "images")
+        images = images.contiguous().to(F32)
+        B, Cc, S, _ = images.shape
+        P, H = vit.patch_size, vit.embed_dim
+        NP = (S // P) ** 2
+        K = Cc * P * P
+        dev = images.device
+        patches = torch.empty((B * NP, K), device=dev, dtype=BF16)
+        check(lib.ia_im2col_patch(images.data_ptr(), patches.data_ptr(), B, Cc, S, P, stream_ptr()), "ia_im2col_patch")
+        w = vit.arena.shadow_of(vit.patch_embed.proj.weight)        # [H, C*P*P] bf16
+        pe = torch.empty((B * NP, H), device=dev, dtype=BF16)
+        check(lib.ia_gemm_bf16(patches.data_ptr(), 0, K, w.data_ptr(), 0, K, pe.data_ptr(), 0, H, B * NP, H, K, 1,
+                               vit.patch_embed.proj.bias.data_ptr(), None, 0, None, 0, stream_ptr()), "ia_gemm_bf16[patch]")
+        tok = torch.empty((B * (NP + 1), H), device=dev, dtype=BF16)
+        check(lib.ia_vit_tokens_fwd(pe.data_ptr(), vit.cls_token.data_ptr(), vit.pos_embed.data_ptr(), tok.data_ptr(), B, NP, H, stream_ptr()),
+              "ia_vit_tokens_fwd")
+        ctx.vit, ctx.patches, ctx.dims = vit, patches, (B, NP, H, K)
+        return tok
+
+    @staticmethod
+    def backward(ctx, dtok):
+        lib = _lib.load()
+        vit, patches = ctx.vit, ctx.patches
+        B, NP, H, K = ctx.dims
+        dtok = dtok.contiguous()
+        dpe = torch.empty((B * NP, H), device=dtok.device, dtype=BF16)
+        check(lib.ia_vit_tokens_bwd(dtok.data_ptr(), dpe.data_ptr(), vit.cls_token.grad.data_ptr(), vit.pos_embed.grad.data_ptr(), B, NP, H, 1,
+                                    stream_ptr()), "ia_vit_tokens_bwd")
+        ws_bytes = lib.ia_colsum_workspace_bytes(B * NP, H)
+        ws = torch.empty(ws_bytes, device=dtok.device, dtype=torch.uint8)
+        check(lib.ia_colsum(dpe.data_ptr(), H, B * NP, H, vit.patch_embed.proj.bias.grad.data_ptr(), 1, ws.data_ptr(), ws_bytes, stream_ptr()),
+              "ia_colsum")
+        # dW[H, K] += dpe^T patches
+        check(lib.ia_gemm_bf16(dpe.data_ptr(), 1, H, patches.data_ptr(), 1, K, vit.patch_embed.proj.weight.grad.data_ptr(), 1, K, H, K, B * NP, 0,
+                               None, None, 0, None, 1, stream_ptr()), "ia_gemm_bf16[patch wgrad]")
+        _notify([vit.cls_token, vit.pos_embed, vit.patch_embed.proj.weight, vit.patch_embed.proj.bias])
+        return None, None, None

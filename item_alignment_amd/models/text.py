@@ -1,0 +1,354 @@
+"""Host-side mirror of the reference's src/models/text.py: RobertaModel, Roberta{One,Two}Tower,
+PKGM{One,Two}Tower, TextCNNTwoTower — same constructor / forward signatures, outputs and state_dict keys,
+encoder arithmetic on the HIP engine.  Two-tower models run both towers as ONE 2B batch (the reference runs
+the same weights twice sequentially, text.py:1325-1351; the maths per sample is identical).
+"""
+import os
+
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from ..utils import logger, ROBERTA_WEIGHTS_NAME, KG_WEIGHTS_NAME
+from . import functional as Fn
+from .base import (BaseModelOutput, HipModule, RobertaClassificationHead, RobertaEmbeddings, RobertaEncoder, RobertaPKGMEmbeddings,
+                   RobertaPooler, SequenceClassifierOutput, TwoTowerClassificationHead, VecSimClassificationHead, cls_rows,
+                   init_bert_weights)
+from .loss import make_loss, apply_loss
+
+
+class PretrainedMixin:
+    """`from_pretrained(path, config=cfg, ignore_mismatched_sizes=True)` of the reference classes
+    (RobertaPreTrainedModel.from_pretrained; PKGM variant merges two files, reference text.py:620-654)."""
+
+    weight_files = (ROBERTA_WEIGHTS_NAME,)
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, *model_args, config=None, ignore_mismatched_sizes=False, state_dict=None,
+                        **kwargs):
+        if config is None:
+            raise ValueError("config= is required (the reference always passes a BertConfig)")
+        model = cls(config, *model_args)
+        merged = {}
+        if state_dict is not None:
+            merged.update(state_dict)
+        elif pretrained_model_name_or_path is not None:
+            for fn in cls.weight_files:
+                f = os.path.join(str(pretrained_model_name_or_path), fn)
+                if os.path.exists(f):
+                    merged.update(torch.load(f, map_location="cpu"))
+                else:
+                    logger.warning(f"{f} not found: those weights keep their random initialisation")
+        if merged:
+            own = model.state_dict()
+            loaded, skipped = {}, []
+            for k, v in merged.items():
+                cands = [k, "roberta." + k, k.replace("bert.", "roberta.", 1), "roberta.embeddings." + k]
+                tgt = next((c for c in cands if c in own), None)
+                if tgt is None:
+                    continue
+                if own[tgt].shape != v.shape:
+                    if not ignore_mismatched_sizes:
+                        raise RuntimeError(f"size mismatch for {tgt}: {tuple(v.shape)} vs {tuple(own[tgt].shape)}")
+                    skipped.append(tgt)
+                    continue
+                loaded[tgt] = v
+            model.load_state_dict(loaded, strict=False)
+            if skipped:
+                logger.warning(f"ignored mismatched sizes: {skipped}")
+        model.eval()
+        return model
+
+
+def _key_mask(attention_mask):
+    return attention_mask
+
+
+class RobertaModel(HipModule, PretrainedMixin):
+    """reference text.py:1084-1266."""
+
+    def __init__(self, config, add_pooling_layer=True):
+        super().__init__()
+        self.config = config
+        self.embeddings = RobertaEmbeddings(config)
+        self.encoder = RobertaEncoder(config)
+        self.pooler = RobertaPooler(config) if add_pooling_layer else None
+        init_bert_weights(self, getattr(config, "initializer_range", 0.02))
+
+    def get_input_embeddings(self):
+        return self.embeddings.word_embeddings
+
+    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, cate_ids=None, head_mask=None,
+                inputs_embeds=None, output_attentions=None, output_hidden_states=None, return_dict=None, **unused):
+        (self._root if "_root" in self.__dict__ else self).ensure_arena()
+        if input_ids is None:
+            raise ValueError("You have to specify input_ids")
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        e = self.embeddings(input_ids=input_ids, position_ids=position_ids, token_type_ids=token_type_ids, cate_ids=cate_ids)
+        hs = self.encoder(e, attention_mask)
+        return BaseModelOutput(last_hidden_state=hs[-1], hidden_states=hs)
+
+
+def adopt(root, *children):
+    """sub-models built on their own (CoCa passes ready-made encoders in) share the root's arena."""
+    for c in children:
+        for m in c.modules():
+            m.__dict__["_root"] = root
+
+
+class _PairTowerBase(HipModule, PretrainedMixin):
+    def _finish(self, logits, probs, loss, src, tgt, labels, hidden_states=None):
+        cfg = self.config
+        if labels is not None and cfg.loss_type != "ce":
+            loss = apply_loss(self.loss_fct, cfg, logits, labels, src, tgt)
+        return SequenceClassifierOutput(loss=loss, logits=logits, probs=probs, src_embeds=src, tgt_embeds=tgt, hidden_states=hidden_states)
+
+
+class RobertaOneTower(_PairTowerBase):
+    """reference text.py:1379-1492."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.num_labels = config.num_labels
+        self.config = config
+        if config.max_seq_len_pv is None:
+            self.max_seq_len = config.max_seq_len
+        elif config.max_seq_len is None:
+            self.max_seq_len = config.max_seq_len_pv
+        else:
+            self.max_seq_len = config.max_seq_len + config.max_seq_len_pv
+        self.cls_layers = [-int(i) for i in config.cls_layers.split(",")]
+        self.roberta = self._make_backbone(config)
+        if config.classification_method == "vec_sim":
+            self.classifier = VecSimClassificationHead(config)
+        else:
+            self.classifier = RobertaClassificationHead(config)
+        self.loss_fct = make_loss(config)
+        if getattr(config, "auxiliary_task", False):
+            raise NotImplementedError("auxiliary_task (reference text.py:66-102) is outside the MI355X hot path (DESIGN.md, out of scope)")
+        init_bert_weights(self, getattr(config, "initializer_range", 0.02))
+        adopt(self, self.roberta)
+
+    def _make_backbone(self, config):
+        return RobertaModel(config, add_pooling_layer=False)
+
+    def _backbone(self, input_ids, attention_mask, token_type_ids, position_ids, cate_ids, inputs_embeds, image_indices):
+        return self.roberta(input_ids, attention_mask=attention_mask, token_type_ids=token_type_ids, position_ids=position_ids,
+                            cate_ids=cate_ids)
+
+    def _tgt_index(self):
+        return self.max_seq_len
+
+    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, cate_ids=None, head_mask=None,
+                inputs_embeds=None, image_indices=None, labels=None, output_attentions=None, output_hidden_states=None,
+                return_dict=None):
+        self.ensure_arena()
+        outputs = self._backbone(input_ids, attention_mask, token_type_ids, position_ids, cate_ids, inputs_embeds, image_indices)
+        hs = outputs.hidden_states
+        B, L, H = hs[-1].shape
+        dev = hs[-1].device
+        training = self.training and torch.is_grad_enabled()
+        p = self.classifier.drop_p if training else 0.0
+        taps = [hs[i] for i in self.cls_layers]
+
+        def pick(index, sid):
+            rows = cls_rows(B, L, index, dev)
+            feats = [Fn.GatherRowsFn.apply(t.reshape(B * L, H), self.anchor, rows, 0.0, 0) for t in taps]
+            f = torch.stack(feats).mean(dim=0) if self.config.cls_pool == "avg" else torch.cat(feats, dim=-1)
+            if p > 0:
+                f = F.dropout(f, p, True)
+            return f
+
+        if self.config.classification_method == "vec_sim":
+            src, tgt, logits, probs = self.classifier(pick(0, 0), pick(self._tgt_index(), 1))
+            loss = None
+        else:
+            ce = self.config.loss_type == "ce"
+            logits, probs2, loss = self.classifier(pick(0, 0), labels if ce else None, inputs_embeds=inputs_embeds,
+                                                   differentiable_logits=(labels is not None and not ce))
+            src, tgt, probs = probs2[:, 0], probs2[:, 1], probs2[:, 1]
+        return self._finish(logits, probs, loss, src, tgt, labels, hidden_states=hs if output_hidden_states else None)
+
+
+class RobertaTwoTower(_PairTowerBase):
+    """reference text.py:1269-1376 (probs stay [B, 2], embeddings are the dropped-out CLS vectors: quirk A3)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.num_labels = config.num_labels
+        self.config = config
+        self.roberta = self._make_backbone(config)
+        self.classifier = TwoTowerClassificationHead(config.hidden_size, dropout=config.hidden_dropout_prob, num_labels=config.num_labels)
+        self.loss_fct = make_loss(config)
+        init_bert_weights(self, getattr(config, "initializer_range", 0.02))
+        adopt(self, self.roberta)
+
+    def _make_backbone(self, config):
+        return RobertaModel(config, add_pooling_layer=False)
+
+    def _both(self, a, b):
+        if a is None or b is None:
+            return None
+        return torch.cat((a, b), dim=0)
+
+    def _backbone(self, ids, mask, tts, pids, extra1=None, extra2=None):
+        return self.roberta(ids, attention_mask=mask, token_type_ids=tts, position_ids=pids).last_hidden_state
+
+    def forward(self, input_ids_1=None, attention_mask_1=None, token_type_ids_1=None, cate_ids_1=None, position_ids_1=None,
+                input_ids_2=None, attention_mask_2=None, token_type_ids_2=None, cate_ids_2=None, position_ids_2=None,
+                head_mask=None, inputs_embeds=None, labels=None, output_attentions=None, output_hidden_states=None, return_dict=None,
+                images_1=None, images_2=None):
+        self.ensure_arena()
+        if input_ids_1.shape != input_ids_2.shape:
+            raise ValueError("both towers must be padded to the same length (the reference collate pads to max_length)")
+        if attention_mask_1 is None:
+            attention_mask_1 = torch.ones_like(input_ids_1)
+        if attention_mask_2 is None:
+            attention_mask_2 = torch.ones_like(input_ids_2)
+        B, L = input_ids_1.shape
+        seq = self._backbone(self._both(input_ids_1, input_ids_2), self._both(attention_mask_1, attention_mask_2),
+                             self._both(token_type_ids_1, token_type_ids_2), self._both(position_ids_1, position_ids_2), images_1, images_2)
+        L, H = seq.shape[1], seq.shape[-1]          # PKGM sequences grow after embedding (each relation -> 2 rows)
+        dev = seq.device
+        training = self.training and torch.is_grad_enabled()
+        p = self.classifier.drop_p if training else 0.0
+        flat = seq.reshape(2 * B * L, H)
+        f1 = Fn.GatherRowsFn.apply(flat, self.anchor, cls_rows(B, L, 0, dev), p, 2001)
+        f2 = Fn.GatherRowsFn.apply(flat, self.anchor, (cls_rows(B, L, 0, dev) + B * L).contiguous(), p, 2002)
+        ce = self.config.loss_type == "ce"
+        src, tgt, logits, probs, loss = self.classifier(f1, f2, labels if ce else None, differentiable_logits=(labels is not None and not ce))
+        return self._finish(logits, probs, loss, src, tgt, labels)
+
+
+# ------------------------------------------------------------------------------------------------ PKGM
+class RobertaPKGMModel(HipModule, PretrainedMixin):
+    """reference text.py:128-289."""
+    weight_files = (ROBERTA_WEIGHTS_NAME, KG_WEIGHTS_NAME)
+
+    def __init__(self, config, add_pooling_layer=False):
+        super().__init__()
+        self.config = config
+        self.embeddings = RobertaPKGMEmbeddings(config)
+        self.encoder = RobertaEncoder(config)
+        self.pooler = None
+        init_bert_weights(self, getattr(config, "initializer_range", 0.02))
+
+    def forward(self, input_ids, attention_mask, token_type_ids, position_ids, inputs_embeds=None, head_mask=None, **unused):
+        (self._root if "_root" in self.__dict__ else self).ensure_arena()
+        if input_ids is None or attention_mask is None or token_type_ids is None or position_ids is None:
+            raise ValueError("You have to specify input_ids, attention_mask, token_type_ids and position_ids")
+        e = self.embeddings(input_ids=input_ids, position_ids=position_ids, token_type_ids=token_type_ids)
+        hs = self.encoder(e, attention_mask)
+        return BaseModelOutput(last_hidden_state=hs[-1], hidden_states=hs)
+
+
+class PKGMOneTower(RobertaOneTower):
+    """reference text.py:691-783 (+ two-file from_pretrained :785-1080)."""
+    weight_files = (ROBERTA_WEIGHTS_NAME, KG_WEIGHTS_NAME)
+
+    def __init__(self, config):
+        if not hasattr(config, "cls_layers"):
+            config.cls_layers, config.cls_pool = "1", "cat"
+        if getattr(config, "max_seq_len_pv", None) is None and not hasattr(config, "max_seq_len_pv"):
+            config.max_seq_len_pv = None
+        super().__init__(config)
+        self.cls_layers = [-1]                      # PKGMOneTower always classifies on the last layer (text.py:753-760)
+
+    def _make_backbone(self, config):
+        return RobertaPKGMModel(config, add_pooling_layer=False)
+
+    def _backbone(self, input_ids, attention_mask, token_type_ids, position_ids, cate_ids, inputs_embeds, image_indices):
+        return self.roberta(input_ids, attention_mask=attention_mask, token_type_ids=token_type_ids, position_ids=position_ids)
+
+    def _tgt_index(self):
+        return self.config.max_seq_len + 2 * self.config.max_pvs
+
+
+class PKGMTwoTower(RobertaTwoTower):
+    """reference text.py:292-391."""
+    weight_files = (ROBERTA_WEIGHTS_NAME, KG_WEIGHTS_NAME)
+
+    def _make_backbone(self, config):
+        return RobertaPKGMModel(config, add_pooling_layer=False)
+
+
+# --------------------------------------------------------------------------------------------- TextCNN
+class _CpuEmbeddings(nn.Module):
+    """RobertaEmbeddings for the TextCNN plumbing config (BASELINE.json configs[0], CPU via finetune_text.py):
+    plain torch modules; this model family never touches the HIP engine (no kernel required)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(config.vocab_size, config.hidden_size, padding_idx=config.pad_token_id)
+        self.token_type_embeddings = nn.Embedding(config.type_vocab_size, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+        self.register_buffer("position_ids", torch.arange(config.max_position_embeddings).expand((1, -1)))
+        self.padding_idx = config.pad_token_id
+        self.position_embeddings = nn.Embedding(config.max_position_embeddings, config.hidden_size, padding_idx=self.padding_idx)
+
+    def forward(self, input_ids):
+        from .base import create_position_ids_from_input_ids
+        pos = create_position_ids_from_input_ids(input_ids, self.padding_idx)
+        e = self.word_embeddings(input_ids) + self.token_type_embeddings(torch.zeros_like(input_ids))
+        e = e + self.position_embeddings(pos)
+        return self.dropout(self.LayerNorm(e))
+
+
+class TextCNN(nn.Module):
+    """reference text.py:1496-1527."""
+
+    def __init__(self, config, embedding_state_dict):
+        super().__init__()
+        filter_sizes = [int(i) for i in config.filter_sizes.split(",")]
+        self.embedding1 = _CpuEmbeddings(config)
+        self.embedding1.load_state_dict(embedding_state_dict, strict=False)
+        self.embedding2 = _CpuEmbeddings(config)
+        self.embedding2.load_state_dict(embedding_state_dict, strict=False)
+        for value in self.embedding2.parameters():
+            value.requires_grad = False
+        self.convs1 = nn.ModuleList([nn.Conv2d(2, config.num_filters, (K, config.hidden_size)) for K in filter_sizes])
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+    def forward(self, x):
+        x = torch.stack((self.embedding1(x), self.embedding2(x)), dim=1)
+        x = [F.relu(conv(x)).squeeze(3) for conv in self.convs1]
+        x = [F.max_pool1d(i, i.size(2)).squeeze(2) for i in x]
+        return self.dropout(torch.cat(x, 1))
+
+
+class _TorchTwoTowerHead(nn.Module):
+    def __init__(self, hidden_size, dropout=0.0, num_labels=2):
+        super().__init__()
+        self.dropout = nn.Dropout(dropout)
+        self.out_proj = nn.Linear(hidden_size * 2, num_labels)
+
+    def forward(self, a, b):
+        x, y = self.dropout(a), self.dropout(b)
+        logits = self.out_proj(torch.cat((x, y), dim=1))
+        return x, y, logits, torch.softmax(logits, dim=1)
+
+
+class TextCNNTwoTower(nn.Module):
+    """reference text.py:1530-1609 — BASELINE.json configs[0], the reference's CPU-runnable plumbing case."""
+
+    def __init__(self, config, embedding_state_dict):
+        super().__init__()
+        self.num_labels = config.num_labels
+        self.config = config
+        self.textcnn = TextCNN(config, embedding_state_dict)
+        if config.classification_method == "vec_sim":
+            raise NotImplementedError("TextCNN + vec_sim is not used by the reference scripts (finetune_text.py never sets similarity_measure, quirk A14)")
+        hidden_size = len(config.filter_sizes.split(",")) * config.num_filters
+        self.classifier = _TorchTwoTowerHead(hidden_size, config.hidden_dropout_prob)
+        self.loss_fct = make_loss(config)
+
+    def forward(self, input_ids_1=None, attention_mask_1=None, token_type_ids_1=None, position_ids_1=None, input_ids_2=None,
+                attention_mask_2=None, token_type_ids_2=None, position_ids_2=None, head_mask=None, inputs_embeds=None, labels=None,
+                output_attentions=None, output_hidden_states=None, return_dict=None):
+        o1, o2 = self.textcnn(input_ids_1), self.textcnn(input_ids_2)
+        src, tgt, logits, probs = self.classifier(o1, o2)
+        src, tgt, probs = probs[:, 0], probs[:, 1], probs[:, 1]
+        loss = apply_loss(self.loss_fct, self.config, logits, labels, src, tgt, ce_too=True) if labels is not None else None
+        return SequenceClassifierOutput(loss=loss, probs=probs, logits=logits, src_embeds=src, tgt_embeds=tgt)

@@ -1,0 +1,96 @@
+"""Layer-engine parity on the GPU: ia_layer_fwd / ia_layer_bwd (one RoBERTa post-LN layer, one ViT pre-LN
+block) against the oracle's fp32 restatement of the same layer evaluated with torch autograd on the same
+bf16-rounded weights and inputs.  Tolerances: activations 2e-2 of max; gradients: cosine >= 0.995 and
+2e-2..5e-2 of max (bf16 activations)."""
+import ctypes as C
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-9)).item()
+
+
+def cos(a, b):
+    a, b = a.float().flatten(), b.float().flatten()
+    return (torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)).item()
+
+
+def make_layer(H, I, dev, seed):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s, sc=0.05: (torch.randn(*s, generator=g) * sc).to(dev)
+    return dict(w_qkv=r(3 * H, H), b_qkv=r(3 * H, sc=0.02), w_o=r(H, H), b_o=r(H, sc=0.02), ln1_g=1 + r(H, sc=0.1), ln1_b=r(H, sc=0.02),
+                w_fc1=r(I, H), b_fc1=r(I, sc=0.02), w_fc2=r(H, I), b_fc2=r(H, sc=0.02), ln2_g=1 + r(H, sc=0.1), ln2_b=r(H, sc=0.02))
+
+
+def ref_layer(P, x, mask, nh, pre_ln, eps):
+    import torch.nn.functional as F
+    B, L, H = x.shape
+    def attn(h):
+        qkv = F.linear(h, P["w_qkv"], P["b_qkv"]).view(B, L, 3, nh, 64)
+        q, k, v = qkv[:, :, 0].transpose(1, 2), qkv[:, :, 1].transpose(1, 2), qkv[:, :, 2].transpose(1, 2)
+        s = q @ k.transpose(-1, -2) * 0.125
+        if mask is not None:
+            s = s + (1.0 - mask.float())[:, None, None, :] * torch.finfo(torch.float32).min
+        return (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, L, H)
+    if not pre_ln:
+        a = F.layer_norm(F.linear(attn(x), P["w_o"], P["b_o"]) + x, (H,), P["ln1_g"], P["ln1_b"], eps)
+        h = F.linear(F.gelu(F.linear(a, P["w_fc1"], P["b_fc1"])), P["w_fc2"], P["b_fc2"])
+        return F.layer_norm(h + a, (H,), P["ln2_g"], P["ln2_b"], eps)
+    x2 = x + F.linear(attn(F.layer_norm(x, (H,), P["ln1_g"], P["ln1_b"], eps)), P["w_o"], P["b_o"])
+    return x2 + F.linear(F.gelu(F.linear(F.layer_norm(x2, (H,), P["ln2_g"], P["ln2_b"], eps), P["w_fc1"], P["b_fc1"])), P["w_fc2"], P["b_fc2"])
+
+
+@pytest.mark.parametrize("B,L,nh,pre_ln,masked", [(3, 40, 2, False, True), (2, 255, 4, False, True), (2, 65, 2, True, False),
+                                                   (2, 577, 12, True, False), (2, 510, 16, False, True)])
+def test_layer_fwd_bwd(gpu, B, L, nh, pre_ln, masked):
+    from item_alignment_amd import _lib
+    from item_alignment_amd._lib import LayerCfg, LayerGrads, LayerWeights
+    lib = _lib.load()
+    H, I = nh * 64, nh * 256
+    M = B * L
+    P32 = make_layer(H, I, gpu, 3)
+    bf = lambda t: t.to(torch.bfloat16)
+    mats = ("w_qkv", "w_o", "w_fc1", "w_fc2")
+    Pb = {k: bf(v) for k, v in P32.items() if k in mats}
+    Pref = {k: (Pb[k].float() if k in mats else v).clone().requires_grad_(True) for k, v in P32.items()}
+    x = bf(torch.randn(B, L, H, generator=torch.Generator().manual_seed(5)).to(gpu))
+    dy = bf(torch.randn(B, L, H, generator=torch.Generator().manual_seed(6)).to(gpu))
+    mask = None
+    if masked:
+        lens = torch.tensor([L - 2 - 3 * i for i in range(B)])
+        mask = (torch.arange(L)[None] < lens[:, None]).to(torch.uint8).to(gpu)
+    eps = 1e-6 if pre_ln else 1e-12
+    xr = x.float().requires_grad_(True)
+    yr = ref_layer(Pref, xr, mask, nh, pre_ln, eps)
+    yr.backward(dy.float())
+
+    cfg = LayerCfg(B=B, L=L, H=H, I=I, nh=nh, pre_ln=int(pre_ln), eps=eps, hidden_drop=0.0, attn_drop=0.0, seed=1, layer_id=0)
+    w, g = LayerWeights(), LayerGrads()
+    G = {k: torch.zeros_like(v) for k, v in P32.items()}
+    for k in P32:
+        setattr(w, k, (Pb[k] if k in mats else P32[k]).data_ptr())
+        setattr(g, k, G[k].data_ptr())
+    stash = torch.empty(lib.ia_layer_stash_bytes(C.byref(cfg)), device=gpu, dtype=torch.uint8)
+    y = torch.empty(M, H, device=gpu, dtype=torch.bfloat16)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.ia_layer_fwd(C.byref(cfg), C.byref(w), x.data_ptr(), _lib.ptr(mask), y.data_ptr(), stash.data_ptr(), st), "fwd")
+    valid = mask.bool().view(-1) if mask is not None else torch.ones(M, dtype=torch.bool, device=gpu)
+    assert rel(y[valid], yr.detach().view(M, H)[valid]) < 2e-2
+    scratch = torch.empty(lib.ia_layer_bwd_scratch_bytes(C.byref(cfg)), device=gpu, dtype=torch.uint8)
+    dx = dy.clone().view(M, H)
+    _lib.check(lib.ia_layer_bwd(C.byref(cfg), C.byref(w), C.byref(g), x.data_ptr(), _lib.ptr(mask), y.data_ptr(), stash.data_ptr(), dx.data_ptr(),
+                                dx.data_ptr(), scratch.data_ptr(), scratch.numel(), st), "bwd")
+    torch.cuda.synchronize()
+    assert torch.isfinite(dx.float()).all()
+    assert cos(dx, xr.grad.view(M, H)) > 0.995 and rel(dx, xr.grad.view(M, H)) < 5e-2
+    for k in P32:
+        want = Pref[k].grad
+        assert torch.isfinite(G[k]).all(), k
+        assert cos(G[k], want) > 0.995, (k, cos(G[k], want))
+        assert rel(G[k], want) < 5e-2, (k, rel(G[k], want))
