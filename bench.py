@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Headline benchmark: item-pairs/sec of the train step (forward + loss + backward + gradient all-reduce +
+fused AdamW) of the CoCa two-tower model roberta_large + ViT-B/16 @384, seq 50+205, bf16 activations /
+fp32 master weights, on synthetic pairs (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One JSON line on rank 0.  `value` = pairs processed by ALL ranks / max-over-ranks wall time of the K timed
+steps (inputs resident in HBM, weak scaling: per-GPU batch fixed).  Extra objects:
+  roofline     the dominant kernel (by summed time: the wgrad GEMM instantiation), timed per launch with HIP
+               events on its launch stream inside the timed region: achieved = algorithmic FLOPs / time.
+  cpu_baseline the CPU oracle (oracle/ref_models.py, a pure-torch port pinned to the reference by golden
+               vectors) running the same train step on the host cores, bounded sample, rank 0 at N=1 only.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TRAIN_FLOPS_PER_PAIR = 1.628e12      # 3 x (2 x text(255) + 2 x ViT-B/16@384) forward FLOPs
+WGRAD_VARIANT = 1101                 # gemm_kernel<A k-strided, B k-strided, EPI_NONE, fp32 out>  (dW = dY^T X)
+WGRAD_KERNEL = "gemm_kernel<true, true, 0, true>"
+
+
+def roberta_large_config(**over):
+    from types import SimpleNamespace
+    cfg = SimpleNamespace(
+        hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096, vocab_size=21128,
+        max_position_embeddings=512, type_vocab_size=2, pad_token_id=0, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
+        layer_norm_eps=1e-12, hidden_act="gelu", initializer_range=0.02, num_labels=2,
+        interaction_type="two_tower", classification_method="cls", similarity_measure="NA", loss_type="ce", max_seq_len=50,
+        max_seq_len_pv=205, loss_margin=1.0, cls_layers="1", cls_pool="cat", ensemble="sum", image_hidden_size=3072, image_size=384,
+        classifier_dropout=None, auxiliary_task=False)
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def build_model(cfg, image_model="vit_base_patch16_384", seed=2345):
+    import item_alignment_amd.models as M
+    torch.manual_seed(seed)
+    text = M.RobertaModel(cfg)
+    vit = M.create_model(image_model)
+    return M.CoCaForItemAlignment(cfg, vit, text)
+
+
+def linear_schedule(step, total, warmup):
+    """get_linear_schedule_with_warmup (reference finetune_multimodal.py:315)."""
+    if step < warmup:
+        return step / max(1, warmup)
+    return max(0.0, (total - step) / max(1, total - warmup))
+
+
+def cpu_baseline(cfg, image_model, pairs, steps, seed):
+    """Same train step on the host cores with the CPU oracle: fp32, dropout on, AdamW."""
+    from types import SimpleNamespace
+    from oracle import ref_models as O
+    from item_alignment_amd.data.synthetic import SyntheticCocaPairs
+    from item_alignment_amd.models.image import VIT_CONFIGS
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    model = build_model(cfg, image_model, seed)
+    sd = {k: v.detach().clone().float().requires_grad_(v.requires_grad) for k, v in model.named_parameters()}
+    names = [k for k, v in sd.items() if v.requires_grad]
+    s, p, d, depth, h = VIT_CONFIGS[image_model]
+    vcfg = SimpleNamespace(embed_dim=d, depth=depth, num_heads=h, patch_size=p, eps=1e-6)
+    data = SyntheticCocaPairs(max(pairs * (steps + 1), pairs), image_size=cfg.image_size, seed=seed)
+    m = [torch.zeros_like(sd[k]) for k in names]
+    v = [torch.zeros_like(sd[k]) for k in names]
+    decay = [not any(nd in k for nd in ("bias", "LayerNorm.weight")) for k in names]
+    times = []
+    for it in range(steps + 1):
+        b = data.batch(list(range(it * pairs, (it + 1) * pairs)), "cpu")
+        t0 = time.perf_counter()
+        out = O.coca_item_alignment(sd, cfg, vcfg, *b[:10], labels=b[10], training=True)
+        grads = torch.autograd.grad(out.loss, [sd[k] for k in names], allow_unused=True)
+        with torch.no_grad():
+            O.adamw_step([sd[k] for k in names], [g if g is not None else torch.zeros_like(sd[k]) for g, k in zip(grads, names)],
+                         m, v, it + 1, 1e-5, wd=1e-5, decay_mask=decay)
+        times.append(time.perf_counter() - t0)
+    t = sum(times[1:]) / max(1, len(times) - 1)
+    return {"value": pairs / t, "unit": "item-pairs/sec", "cores": threads, "kind": "port",
+            "sample": f"{steps} timed + 1 warm-up train steps of {pairs} pairs (same model/config, fp32, dropout on, oracle/ref_models.py on "
+                      f"{torch.get_num_threads()} torch threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs-per-gpu", type=int, default=64)
+    ap.add_argument("--image-model", default="vit_base_patch16_384")
+    ap.add_argument("--seed", type=int, default=2345)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--full-length", action="store_true", help="all sequences at the full 255 tokens (mask all ones)")
+    args = ap.parse_args()
+
+    from item_alignment_amd import _lib
+    from item_alignment_amd import dist as iadist
+    from item_alignment_amd.data.synthetic import SyntheticCocaPairs
+    from item_alignment_amd.models import functional as Fn
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    lib = _lib.load()
+    rank, world, local = iadist.init_from_env("cuda")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    cfg = roberta_large_config()
+    model = build_model(cfg, args.image_model, args.seed).to(dev).train()
+    arena = model.param_arena
+    iadist.broadcast_arena(arena)
+    reducer = iadist.GradBucketReducer.for_arena(arena)
+    Fn.clear_grad_ready_hooks()
+    Fn.register_grad_ready_hook(reducer.grads_ready)
+
+    B = args.pairs_per_gpu
+    n_steps = args.warmup + args.steps
+    data = SyntheticCocaPairs(B * world * 4, image_size=cfg.image_size, seed=args.seed, full_length=args.full_length)
+    # four distinct global batches, resident in HBM before timing starts; rank r owns pairs r::world of each
+    batches = [data.batch([g * B * world + rank + world * i for i in range(B)], dev) for g in range(4)]
+    total_opt_steps = max(n_steps, 100)
+    warm = int(0.3 * total_opt_steps)
+    base_lr = 1e-5
+
+    def step(i):
+        Fn.set_step_seed(args.seed * 1000003 + i)
+        arena.zero_grad()
+        out = model(*batches[i % 4][:10], labels=batches[i % 4][10])
+        out.loss.backward()
+        scale = reducer.finish()
+        arena.adamw_step(base_lr * linear_schedule(i, total_opt_steps, warm), betas=(0.9, 0.98), eps=1e-8, weight_decay=1e-5,
+                         grad_scale=scale)
+        return out.loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for i in range(args.warmup):
+        loss = step(i)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    _lib.check(lib.ia_prof_begin(WGRAD_VARIANT, 400 * args.steps), "ia_prof_begin")
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_steps):
+        loss = step(i)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms, fl, nl = C.c_double(), C.c_double(), C.c_int()
+    _lib.check(lib.ia_prof_end(C.byref(ms), C.byref(fl), C.byref(nl)), "ia_prof_end")
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = tmax.item()
+    final_loss = float(loss)
+
+    if rank == 0:
+        pairs = B * world * args.steps
+        achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        res = {
+            "metric": "item-pairs/sec (train step) RoBERTa-large+ViT-B two-tower", "value": pairs / dt, "unit": "item-pairs/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "coca(roberta_large + vit_base_patch16_384) two_tower cls/ce, ensemble=sum, seq 50+205, img 384, "
+                                   "dropout 0.1, fused AdamW; train step = fwd+bwd+allreduce+optimizer",
+                       "pairs_per_gpu": B, "global_batch": B * world, "seq_len": 255, "image_size": cfg.image_size,
+                       "parallelism": f"dp{world}", "full_length_sequences": bool(args.full_length),
+                       "deviation": "Linear(768->1024) on the image CLS (the named pairing is dimensionally inconsistent in the reference, SURVEY N1)"},
+            "model_tflops_per_gpu": pairs / dt * TRAIN_FLOPS_PER_PAIR / 1e12 / world,
+            "mfma_fraction_whole_step": pairs / dt * TRAIN_FLOPS_PER_PAIR / 1e12 / world / 2500.0,
+            "final_loss": final_loss,
+            "roofline": {"bound": "mfma", "kernel": WGRAD_KERNEL, "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": achieved / 2500.0, "traffic": None, "launches": nl.value,
+                         "avg_launch_us": ms.value * 1e3 / max(1, nl.value)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(cfg, args.image_model, args.cpu_pairs, args.cpu_steps, args.seed)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                res["cpu_baseline"] = {"value": None, "unit": "item-pairs/sec", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -48,7 +48,15 @@ int ia_abi_version(void);
 #define IA_EPI_BIAS_ADD 5  /* + bias + aux */
 int ia_gemm_bf16(const void* A, int a_kstrided, int lda, const void* B, int b_kstrided, int ldb, void* C, int c_is_f32, int ldc,
                  int M, int N, int K, int epilogue, const float* bias, const void* aux, int ldaux, void* C2, int accumulate,
-                 ia_stream_t stream);
+                 void* workspace, size_t workspace_bytes, ia_stream_t stream);
+/* fp32-output (weight-gradient) GEMMs cut K across workgroups when given this much scratch; partial sums are
+ * combined in a fixed order (deterministic).  workspace may be NULL (no split). */
+size_t ia_gemm_workspace_bytes(int M, int N, int K, int c_is_f32);
+
+/* per-launch HIP-event timing of one GEMM instantiation (variant = a_kstrided*1000 + b_kstrided*100 + epilogue*10 + c_is_f32),
+ * recorded on the launch stream; used by bench.py for the roofline of the dominant kernel. */
+int ia_prof_begin(int variant, int max_launches);
+int ia_prof_end(double* total_ms, double* total_flops, int* launches);
 
 /* ---- LayerNorm tails (RobertaSelfOutput / RobertaOutput: dense -> dropout -> +residual -> LayerNorm;
  * timm Block norm1/norm2).  z = residual + dropout(x + bias); y = LN(z).  z_out may alias x. */

@@ -497,6 +497,7 @@ int fill_args(AttnArgs& a, int B, int nh, int L, int ld_qkv, int ld_o, float sca
 extern "C" int ia_attn_fwd(const void* q, const void* k, const void* v, int ld_qkv, const uint8_t* key_mask, void* out,
                            int ld_o, float* lse2, int B, int nh, int L, float scale, float drop_p, uint32_t seed,
                            hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!q || !k || !v || !out) return IA_ERR_ARG;
   AttnArgs a{};
   int rc = fill_args(a, B, nh, L, ld_qkv, ld_o, scale, drop_p, seed);
@@ -512,6 +513,7 @@ extern "C" int ia_attn_fwd(const void* q, const void* k, const void* v, int ld_q
 extern "C" int ia_attn_bwd(const void* q, const void* k, const void* v, int ld_qkv, const uint8_t* key_mask, const void* out,
                            const void* d_out, int ld_o, const float* lse2, float* delta, void* dq, void* dk, void* dv,
                            int ld_dqkv, int B, int nh, int L, float scale, float drop_p, uint32_t seed, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!q || !k || !v || !out || !d_out || !lse2 || !delta || !dq || !dk || !dv) return IA_ERR_ARG;
   AttnArgs a{};
   int rc = fill_args(a, B, nh, L, ld_qkv, ld_o, scale, drop_p, seed);

@@ -317,6 +317,7 @@ extern "C" int ia_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, cons
                                const float* word, const float* type, const float* pos, const float* extra, const float* gamma,
                                const float* beta, void* z_out, void* y, float* mean, float* rstd, int M, int H, float eps,
                                float drop_p, uint32_t seed, uint32_t stream_id, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!ids || !type_ids || !pos_ids || !word || !type || !pos || !gamma || !beta || !z_out || !y || !mean || !rstd) return IA_ERR_ARG;
   if (M <= 0 || (H & 7) || H > 4096 || (extra_idx && !extra)) return IA_ERR_ARG;
   uint32_t thr16; float inv_keep; drop_params(drop_p, thr16, inv_keep);
@@ -338,6 +339,7 @@ extern "C" int ia_embed_ln_bwd(const void* dy, const void* z, const float* mean,
                                float* dword, float* dtype, float* dpos, float* dextra, float* dgamma, float* dbeta, int M, int H,
                                int word_pad, int pos_pad, float drop_p, uint32_t seed, uint32_t stream_id, void* workspace,
                                size_t workspace_bytes, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!dy || !z || !mean || !rstd || !gamma || !ids || !type_ids || !pos_ids) return IA_ERR_ARG;
   if (M <= 0 || (H & 7) || H > 4096) return IA_ERR_ARG;
   if (!workspace || workspace_bytes < ia_embed_ln_bwd_workspace_bytes(M, H)) return IA_ERR_WORKSPACE;
@@ -354,6 +356,7 @@ extern "C" int ia_embed_ln_bwd(const void* dy, const void* z, const float* mean,
 }
 
 extern "C" int ia_im2col_patch(const float* images, void* patches, int B, int C, int S, int P, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!images || !patches || B <= 0 || C <= 0 || P <= 0 || (P & 7) || S % P) return IA_ERR_ARG;
   const size_t items = (size_t)B * (S / P) * (S / P) * C * P * P / 8;
   hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(items)), dim3(256), 0, stream, images, (bf16*)patches, B, C, S, P);
@@ -362,6 +365,7 @@ extern "C" int ia_im2col_patch(const float* images, void* patches, int B, int C,
 
 extern "C" int ia_vit_tokens_fwd(const void* patch, const float* cls, const float* pos, void* tokens, int B, int NP, int H,
                                  hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!patch || !cls || !pos || !tokens || B <= 0 || NP <= 0 || (H & 7)) return IA_ERR_ARG;
   hipLaunchKernelGGL(vit_tokens_fwd_kernel, dim3(grid_for((size_t)B * (NP + 1) * H / 8)), dim3(256), 0, stream, (const bf16*)patch, cls, pos,
                      (bf16*)tokens, B, NP, H);
@@ -370,6 +374,7 @@ extern "C" int ia_vit_tokens_fwd(const void* patch, const float* cls, const floa
 
 extern "C" int ia_vit_tokens_bwd(const void* dtokens, void* dpatch, float* dcls, float* dpos, int B, int NP, int H, int accumulate,
                                  hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!dtokens || !dpatch || !dcls || !dpos || B <= 0 || NP <= 0 || (H & 7)) return IA_ERR_ARG;
   hipLaunchKernelGGL(vit_tokens_bwd_kernel, dim3(grid_for((size_t)(NP + 1) * H / 8)), dim3(256), 0, stream, (const bf16*)dtokens,
                      (bf16*)dpatch, dcls, dpos, B, NP, H, accumulate);
@@ -378,6 +383,7 @@ extern "C" int ia_vit_tokens_bwd(const void* dtokens, void* dpatch, float* dcls,
 
 extern "C" int ia_gather_rows_fwd(const void* src, int ld, const int32_t* rows, float* out, int B, int H, float drop_p, uint32_t seed,
                                   uint32_t stream_id, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!src || !rows || !out || B <= 0 || H <= 0) return IA_ERR_ARG;
   uint32_t thr16; float inv_keep; drop_params(drop_p, thr16, inv_keep);
   hipLaunchKernelGGL(gather_rows_fwd_kernel, dim3(grid_for((size_t)B * H)), dim3(256), 0, stream, (const bf16*)src, ld, rows, out, B, H,
@@ -387,6 +393,7 @@ extern "C" int ia_gather_rows_fwd(const void* src, int ld, const int32_t* rows, 
 
 extern "C" int ia_gather_rows_bwd(const float* dout, int ld, const int32_t* rows, void* dsrc, int B, int H, float drop_p, uint32_t seed,
                                   uint32_t stream_id, int accumulate, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!dout || !rows || !dsrc || B <= 0 || H <= 0) return IA_ERR_ARG;
   uint32_t thr16; float inv_keep; drop_params(drop_p, thr16, inv_keep);
   hipLaunchKernelGGL(gather_rows_bwd_kernel, dim3(grid_for((size_t)B * H)), dim3(256), 0, stream, dout, ld, rows, (bf16*)dsrc, B, H,

@@ -34,7 +34,7 @@ Stash carve_stash(const ia_layer_cfg* c, void* base) {
 }
 
 struct Scratch {
-  char* g0; char* g1; char* g2; char* gI; char* gqkv; float* delta; char* ws; size_t ws_bytes; size_t bytes;
+  char* g0; char* g1; char* g2; char* gI; char* gqkv; float* delta; char* ws; size_t ws_bytes; char* gws; size_t gws_bytes; size_t bytes;
 };
 
 size_t max3(size_t a, size_t b, size_t c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
@@ -50,6 +50,10 @@ Scratch carve_scratch(const ia_layer_cfg* c, void* base) {
   s.ws_bytes = max3(ia_ln_bwd_workspace_bytes((int)M, (int)H), ia_colsum_workspace_bytes((int)M, (int)I),
                     ia_colsum_workspace_bytes((int)M, (int)(3 * H)));
   s.ws = take(s.ws_bytes);
+  // split-K partial sums of the four weight-gradient GEMMs (largest of them)
+  s.gws_bytes = max3(ia_gemm_workspace_bytes((int)(3 * H), (int)H, (int)M, 1), ia_gemm_workspace_bytes((int)I, (int)H, (int)M, 1),
+                     max3(ia_gemm_workspace_bytes((int)H, (int)I, (int)M, 1), ia_gemm_workspace_bytes((int)H, (int)H, (int)M, 1), 0));
+  s.gws = take(s.gws_bytes);
   s.bytes = (size_t)(p - (char*)base);
   return s;
 }
@@ -63,17 +67,20 @@ bool cfg_ok(const ia_layer_cfg* c) {
 }  // namespace
 
 extern "C" size_t ia_layer_stash_bytes(const ia_layer_cfg* cfg) {
+  (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!cfg_ok(cfg)) return 0;
   return carve_stash(cfg, nullptr).bytes;
 }
 
 extern "C" size_t ia_layer_bwd_scratch_bytes(const ia_layer_cfg* cfg) {
+  (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!cfg_ok(cfg)) return 0;
   return carve_scratch(cfg, nullptr).bytes;
 }
 
 extern "C" int ia_layer_fwd(const ia_layer_cfg* c, const ia_layer_weights* w, const void* x, const uint8_t* key_mask, void* y,
                             void* stash, ia_stream_t st) {
+  (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!cfg_ok(c) || !w || !x || !y || !stash) return IA_ERR_ARG;
   const int M = c->B * c->L, H = c->H, I = c->I;
   const Stash s = carve_stash(c, stash);
@@ -81,29 +88,29 @@ extern "C" int ia_layer_fwd(const ia_layer_cfg* c, const ia_layer_weights* w, co
   const uint32_t attn_seed = c->seed * 2654435761u + c->layer_id * 97u + 17u;
   if (!c->pre_ln) {
     // qkv = x Wqkv^T + b
-    IA_TRY(ia_gemm_bf16(x, 0, H, w->w_qkv, 0, H, s.qkv, 0, 3 * H, M, 3 * H, H, IA_EPI_BIAS, w->b_qkv, nullptr, 0, nullptr, 0, st));
+    IA_TRY(ia_gemm_bf16(x, 0, H, w->w_qkv, 0, H, s.qkv, 0, 3 * H, M, 3 * H, H, IA_EPI_BIAS, w->b_qkv, nullptr, 0, nullptr, 0, nullptr, 0, st));
     IA_TRY(ia_attn_fwd(s.qkv, s.qkv + (size_t)H * 2, s.qkv + (size_t)2 * H * 2, 3 * H, key_mask, s.ctx, H, s.lse, c->B, c->nh, c->L,
                        scale, c->attn_drop, attn_seed, st));
     // z1 = x + dropout(ctx Wo^T + b_o); y1 = LN1(z1)
-    IA_TRY(ia_gemm_bf16(s.ctx, 0, H, w->w_o, 0, H, s.t0, 0, H, M, H, H, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, st));
+    IA_TRY(ia_gemm_bf16(s.ctx, 0, H, w->w_o, 0, H, s.t0, 0, H, M, H, H, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
     IA_TRY(ia_ln_fwd(s.t0, w->b_o, x, s.t0, s.t1, s.mean1, s.rstd1, w->ln1_g, w->ln1_b, M, H, c->eps, c->hidden_drop, c->seed,
                      c->layer_id * 4u + 0u, st));
     // h = gelu(y1 W1^T + b1)
-    IA_TRY(ia_gemm_bf16(s.t1, 0, H, w->w_fc1, 0, H, s.hact, 0, I, M, I, H, IA_EPI_BIAS_GELU, w->b_fc1, nullptr, 0, s.hpre, 0, st));
+    IA_TRY(ia_gemm_bf16(s.t1, 0, H, w->w_fc1, 0, H, s.hact, 0, I, M, I, H, IA_EPI_BIAS_GELU, w->b_fc1, nullptr, 0, s.hpre, 0, nullptr, 0, st));
     // z2 = y1 + dropout(h W2^T + b2); y = LN2(z2)
-    IA_TRY(ia_gemm_bf16(s.hact, 0, I, w->w_fc2, 0, I, s.t2, 0, H, M, H, I, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, st));
+    IA_TRY(ia_gemm_bf16(s.hact, 0, I, w->w_fc2, 0, I, s.t2, 0, H, M, H, I, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
     IA_TRY(ia_ln_fwd(s.t2, w->b_fc2, s.t1, s.t2, y, s.mean2, s.rstd2, w->ln2_g, w->ln2_b, M, H, c->eps, c->hidden_drop, c->seed,
                      c->layer_id * 4u + 1u, st));
   } else {
     if (c->hidden_drop > 0.f || c->attn_drop > 0.f) return IA_ERR_UNSUPPORTED;  // timm ViT default: no dropout
     IA_TRY(ia_ln_fwd(x, nullptr, nullptr, nullptr, s.t0, s.mean1, s.rstd1, w->ln1_g, w->ln1_b, M, H, c->eps, 0.f, 0, 0, st));
-    IA_TRY(ia_gemm_bf16(s.t0, 0, H, w->w_qkv, 0, H, s.qkv, 0, 3 * H, M, 3 * H, H, IA_EPI_BIAS, w->b_qkv, nullptr, 0, nullptr, 0, st));
+    IA_TRY(ia_gemm_bf16(s.t0, 0, H, w->w_qkv, 0, H, s.qkv, 0, 3 * H, M, 3 * H, H, IA_EPI_BIAS, w->b_qkv, nullptr, 0, nullptr, 0, nullptr, 0, st));
     IA_TRY(ia_attn_fwd(s.qkv, s.qkv + (size_t)H * 2, s.qkv + (size_t)2 * H * 2, 3 * H, key_mask, s.ctx, H, s.lse, c->B, c->nh, c->L,
                        scale, 0.f, 0, st));
-    IA_TRY(ia_gemm_bf16(s.ctx, 0, H, w->w_o, 0, H, s.t1, 0, H, M, H, H, IA_EPI_BIAS_ADD, w->b_o, x, H, nullptr, 0, st));
+    IA_TRY(ia_gemm_bf16(s.ctx, 0, H, w->w_o, 0, H, s.t1, 0, H, M, H, H, IA_EPI_BIAS_ADD, w->b_o, x, H, nullptr, 0, nullptr, 0, st));
     IA_TRY(ia_ln_fwd(s.t1, nullptr, nullptr, nullptr, s.t2, s.mean2, s.rstd2, w->ln2_g, w->ln2_b, M, H, c->eps, 0.f, 0, 0, st));
-    IA_TRY(ia_gemm_bf16(s.t2, 0, H, w->w_fc1, 0, H, s.hact, 0, I, M, I, H, IA_EPI_BIAS_GELU, w->b_fc1, nullptr, 0, s.hpre, 0, st));
-    IA_TRY(ia_gemm_bf16(s.hact, 0, I, w->w_fc2, 0, I, y, 0, H, M, H, I, IA_EPI_BIAS_ADD, w->b_fc2, s.t1, H, nullptr, 0, st));
+    IA_TRY(ia_gemm_bf16(s.t2, 0, H, w->w_fc1, 0, H, s.hact, 0, I, M, I, H, IA_EPI_BIAS_GELU, w->b_fc1, nullptr, 0, s.hpre, 0, nullptr, 0, st));
+    IA_TRY(ia_gemm_bf16(s.hact, 0, I, w->w_fc2, 0, I, y, 0, H, M, H, I, IA_EPI_BIAS_ADD, w->b_fc2, s.t1, H, nullptr, 0, nullptr, 0, st));
   }
   return IA_OK;
 }
@@ -111,6 +118,7 @@ extern "C" int ia_layer_fwd(const ia_layer_cfg* c, const ia_layer_weights* w, co
 extern "C" int ia_layer_bwd(const ia_layer_cfg* c, const ia_layer_weights* w, const ia_layer_grads* g, const void* x,
                             const uint8_t* key_mask, const void* y, const void* stash, const void* dy, void* dx, void* scratch,
                             size_t scratch_bytes, ia_stream_t st) {
+  (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   (void)y;
   if (!cfg_ok(c) || !w || !g || !x || !stash || !dy || !dx || !scratch) return IA_ERR_ARG;
   if (scratch_bytes < ia_layer_bwd_scratch_bytes(c)) return IA_ERR_WORKSPACE;
@@ -125,39 +133,39 @@ extern "C" int ia_layer_bwd(const ia_layer_cfg* c, const ia_layer_weights* w, co
     IA_TRY(ia_ln_bwd(dy, nullptr, s.t2, s.mean2, s.rstd2, w->ln2_g, k.g0, drop ? k.g1 : nullptr, g->ln2_g, g->ln2_b, g->b_fc2, M, H,
                      c->hidden_drop, c->seed, c->layer_id * 4u + 1u, k.ws, k.ws_bytes, 1, st));
     const char* d_ffn = drop ? k.g1 : k.g0;
-    IA_TRY(ia_gemm_bf16(d_ffn, 1, H, s.hact, 1, I, g->w_fc2, 1, I, H, I, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, st));
-    IA_TRY(ia_gemm_bf16(d_ffn, 0, H, w->w_fc2, 1, I, k.gI, 0, I, M, I, H, IA_EPI_DGELU, nullptr, s.hpre, I, nullptr, 0, st));
+    IA_TRY(ia_gemm_bf16(d_ffn, 1, H, s.hact, 1, I, g->w_fc2, 1, I, H, I, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
+    IA_TRY(ia_gemm_bf16(d_ffn, 0, H, w->w_fc2, 1, I, k.gI, 0, I, M, I, H, IA_EPI_DGELU, nullptr, s.hpre, I, nullptr, 0, nullptr, 0, st));
     IA_TRY(ia_colsum(k.gI, I, M, I, g->b_fc1, 1, k.ws, k.ws_bytes, st));
-    IA_TRY(ia_gemm_bf16(k.gI, 1, I, s.t1, 1, H, g->w_fc1, 1, H, I, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, st));
-    IA_TRY(ia_gemm_bf16(k.gI, 0, I, w->w_fc1, 1, H, k.g2, 0, H, M, H, I, IA_EPI_ADD, nullptr, k.g0, H, nullptr, 0, st));
+    IA_TRY(ia_gemm_bf16(k.gI, 1, I, s.t1, 1, H, g->w_fc1, 1, H, I, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
+    IA_TRY(ia_gemm_bf16(k.gI, 0, I, w->w_fc1, 1, H, k.g2, 0, H, M, H, I, IA_EPI_ADD, nullptr, k.g0, H, nullptr, 0, nullptr, 0, st));
     // LN1 backward
     IA_TRY(ia_ln_bwd(k.g2, nullptr, s.t0, s.mean1, s.rstd1, w->ln1_g, k.g0, drop ? k.g1 : nullptr, g->ln1_g, g->ln1_b, g->b_o, M, H,
                      c->hidden_drop, c->seed, c->layer_id * 4u + 0u, k.ws, k.ws_bytes, 1, st));
     const char* d_att = drop ? k.g1 : k.g0;
-    IA_TRY(ia_gemm_bf16(d_att, 1, H, s.ctx, 1, H, g->w_o, 1, H, H, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, st));
-    IA_TRY(ia_gemm_bf16(d_att, 0, H, w->w_o, 1, H, k.g2, 0, H, M, H, H, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, st));
+    IA_TRY(ia_gemm_bf16(d_att, 1, H, s.ctx, 1, H, g->w_o, 1, H, H, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
+    IA_TRY(ia_gemm_bf16(d_att, 0, H, w->w_o, 1, H, k.g2, 0, H, M, H, H, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
     IA_TRY(ia_attn_bwd(s.qkv, s.qkv + (size_t)H * 2, s.qkv + (size_t)2 * H * 2, 3 * H, key_mask, s.ctx, k.g2, H, s.lse, k.delta, k.gqkv,
                        k.gqkv + (size_t)H * 2, k.gqkv + (size_t)2 * H * 2, 3 * H, c->B, c->nh, c->L, scale, c->attn_drop, attn_seed, st));
     IA_TRY(ia_colsum(k.gqkv, 3 * H, M, 3 * H, g->b_qkv, 1, k.ws, k.ws_bytes, st));
-    IA_TRY(ia_gemm_bf16(k.gqkv, 1, 3 * H, x, 1, H, g->w_qkv, 1, H, 3 * H, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, st));
-    IA_TRY(ia_gemm_bf16(k.gqkv, 0, 3 * H, w->w_qkv, 1, H, dx, 0, H, M, H, 3 * H, IA_EPI_ADD, nullptr, k.g0, H, nullptr, 0, st));
+    IA_TRY(ia_gemm_bf16(k.gqkv, 1, 3 * H, x, 1, H, g->w_qkv, 1, H, 3 * H, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
+    IA_TRY(ia_gemm_bf16(k.gqkv, 0, 3 * H, w->w_qkv, 1, H, dx, 0, H, M, H, 3 * H, IA_EPI_ADD, nullptr, k.g0, H, nullptr, 0, nullptr, 0, st));
   } else {
     IA_TRY(ia_colsum(dy, H, M, H, g->b_fc2, 1, k.ws, k.ws_bytes, st));
-    IA_TRY(ia_gemm_bf16(dy, 1, H, s.hact, 1, I, g->w_fc2, 1, I, H, I, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, st));
-    IA_TRY(ia_gemm_bf16(dy, 0, H, w->w_fc2, 1, I, k.gI, 0, I, M, I, H, IA_EPI_DGELU, nullptr, s.hpre, I, nullptr, 0, st));
+    IA_TRY(ia_gemm_bf16(dy, 1, H, s.hact, 1, I, g->w_fc2, 1, I, H, I, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
+    IA_TRY(ia_gemm_bf16(dy, 0, H, w->w_fc2, 1, I, k.gI, 0, I, M, I, H, IA_EPI_DGELU, nullptr, s.hpre, I, nullptr, 0, nullptr, 0, st));
     IA_TRY(ia_colsum(k.gI, I, M, I, g->b_fc1, 1, k.ws, k.ws_bytes, st));
-    IA_TRY(ia_gemm_bf16(k.gI, 1, I, s.t2, 1, H, g->w_fc1, 1, H, I, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, st));
-    IA_TRY(ia_gemm_bf16(k.gI, 0, I, w->w_fc1, 1, H, k.g0, 0, H, M, H, I, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, st));
+    IA_TRY(ia_gemm_bf16(k.gI, 1, I, s.t2, 1, H, g->w_fc1, 1, H, I, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
+    IA_TRY(ia_gemm_bf16(k.gI, 0, I, w->w_fc1, 1, H, k.g0, 0, H, M, H, I, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
     // LN2 backward (+ residual path dy) -> g1 = d x2 ; its column sum is the proj-bias gradient
     IA_TRY(ia_ln_bwd(k.g0, dy, s.t1, s.mean2, s.rstd2, w->ln2_g, k.g1, nullptr, g->ln2_g, g->ln2_b, g->b_o, M, H, 0.f, 0, 0, k.ws,
                      k.ws_bytes, 1, st));
-    IA_TRY(ia_gemm_bf16(k.g1, 1, H, s.ctx, 1, H, g->w_o, 1, H, H, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, st));
-    IA_TRY(ia_gemm_bf16(k.g1, 0, H, w->w_o, 1, H, k.g2, 0, H, M, H, H, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, st));
+    IA_TRY(ia_gemm_bf16(k.g1, 1, H, s.ctx, 1, H, g->w_o, 1, H, H, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
+    IA_TRY(ia_gemm_bf16(k.g1, 0, H, w->w_o, 1, H, k.g2, 0, H, M, H, H, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
     IA_TRY(ia_attn_bwd(s.qkv, s.qkv + (size_t)H * 2, s.qkv + (size_t)2 * H * 2, 3 * H, key_mask, s.ctx, k.g2, H, s.lse, k.delta, k.gqkv,
                        k.gqkv + (size_t)H * 2, k.gqkv + (size_t)2 * H * 2, 3 * H, c->B, c->nh, c->L, scale, 0.f, 0, st));
     IA_TRY(ia_colsum(k.gqkv, 3 * H, M, 3 * H, g->b_qkv, 1, k.ws, k.ws_bytes, st));
-    IA_TRY(ia_gemm_bf16(k.gqkv, 1, 3 * H, s.t0, 1, H, g->w_qkv, 1, H, 3 * H, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, st));
-    IA_TRY(ia_gemm_bf16(k.gqkv, 0, 3 * H, w->w_qkv, 1, H, k.g0, 0, H, M, H, 3 * H, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, st));
+    IA_TRY(ia_gemm_bf16(k.gqkv, 1, 3 * H, s.t0, 1, H, g->w_qkv, 1, H, 3 * H, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
+    IA_TRY(ia_gemm_bf16(k.gqkv, 0, 3 * H, w->w_qkv, 1, H, k.g0, 0, H, M, H, 3 * H, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
     IA_TRY(ia_ln_bwd(k.g0, k.g1, x, s.mean1, s.rstd1, w->ln1_g, dx, nullptr, g->ln1_g, g->ln1_b, nullptr, M, H, 0.f, 0, 0, k.ws,
                      k.ws_bytes, 1, st));
   }

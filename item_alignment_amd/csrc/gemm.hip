@@ -33,6 +33,8 @@ struct GemmArgs {
   uint32_t a_bytes, b_bytes;
   int accumulate;
   int tiles_m, tiles_n;
+  int splits, nk_per_split;   // split-K (fp32 output only): blockIdx.y owns k-tiles [y*nk_per_split, ...)
+  float* ws;                  // [splits][M][N] fp32 partials when splits > 1
 };
 
 // 32-byte-slot swizzle of a k-strided tile row (row = k index within the 64-row tile)
@@ -105,15 +107,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (p.K + BK - 1) / BK;
-  stage_tile<AKS>(rsA, smem, 0, m0, p.lda, p.K, tid, wave);
-  stage_tile<BKS>(rsB, smem + TILE_BYTES, 0, n0, p.ldb, p.K, tid, wave);
+  const int nk_all = (p.K + BK - 1) / BK;
+  const int kt0 = blockIdx.y * p.nk_per_split;
+  const int nk = min(nk_all, kt0 + p.nk_per_split);
+  stage_tile<AKS>(rsA, smem, kt0, m0, p.lda, p.K, tid, wave);
+  stage_tile<BKS>(rsB, smem + TILE_BYTES, kt0, n0, p.ldb, p.K, tid, wave);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   const int g = lane >> 4, li = lane & 15;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
+  for (int kt = kt0; kt < nk; ++kt) {
+    const int buf = (kt - kt0) & 1;
     if (kt + 1 < nk) {
       char* nb = smem + (buf ^ 1) * 2 * TILE_BYTES;
       stage_tile<AKS>(rsA, nb, kt + 1, m0, p.lda, p.K, tid, wave);
@@ -179,6 +183,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad(bf2f(a[r]));
       }
       if (OUTF32) {
+        if (p.splits > 1) {   // partial sums; the second-stage kernel adds them into C in a fixed order
+          *reinterpret_cast<f32x4*>(p.ws + ((size_t)blockIdx.y * p.M + m) * p.N + n) = v;
+          continue;
+        }
         float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
         if (p.accumulate) { const f32x4 o = *reinterpret_cast<const f32x4*>(c); v += o; }
         *reinterpret_cast<f32x4*>(c) = v;
@@ -190,19 +198,75 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   }
 }
 
+// Optional per-launch timing of ONE kernel instantiation with HIP events on the launch stream
+// (bench.py's roofline leg): variant id = AKS*1000 + BKS*100 + EPI*10 + OUTF32.
+struct GemmProf {
+  bool on = false;
+  int variant = -1, n = 0, cap = 0;
+  double flops = 0.0;
+  hipEvent_t* ev = nullptr;
+};
+GemmProf g_prof;
+
+// C[m][n] (+)= sum_s ws[s][m][n]
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int M, int N, int ldc,
+                                                            int splits, int accumulate) {
+  const size_t total4 = (size_t)M * N / 4;
+  for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total4; t += (size_t)gridDim.x * 256) {
+    const size_t e = t * 4;
+    const int m = (int)(e / N), n = (int)(e % N);
+    f32x4 acc = *reinterpret_cast<const f32x4*>(ws + e);
+    for (int s = 1; s < splits; ++s) acc += *reinterpret_cast<const f32x4*>(ws + (size_t)s * M * N + e);
+    float* c = C + (size_t)m * ldc + n;
+    if (accumulate) acc += *reinterpret_cast<const f32x4*>(c);
+    *reinterpret_cast<f32x4*>(c) = acc;
+  }
+}
+
 template <bool AKS, bool BKS, int EPI, bool OUTF32>
 int launch(const GemmArgs& a, hipStream_t st) {
   const int grid = a.tiles_m * a.tiles_n;
-  hipLaunchKernelGGL((gemm_kernel<AKS, BKS, EPI, OUTF32>), dim3(grid), dim3(256), 0, st, a);
+  constexpr int vid = AKS * 1000 + BKS * 100 + EPI * 10 + (OUTF32 ? 1 : 0);
+  const bool rec = g_prof.on && g_prof.variant == vid && g_prof.n < g_prof.cap;
+  if (rec) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
+  hipLaunchKernelGGL((gemm_kernel<AKS, BKS, EPI, OUTF32>), dim3(grid, a.splits), dim3(256), 0, st, a);
+  if (OUTF32 && a.splits > 1) {
+    size_t g = ((size_t)a.M * a.N / 4 + 255) / 256; if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)g), dim3(256), 0, st, a.ws, (float*)a.C, a.M, a.N, a.ldc, a.splits, a.accumulate);
+  }
+  if (rec) {
+    (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st);
+    g_prof.flops += 2.0 * a.M * a.N * a.K;
+    ++g_prof.n;
+  }
   return ia_check_launch();
 }
 
 }  // namespace
 
+// split-K factor for the weight-gradient GEMMs: their outputs are only a few dozen 128x128 tiles
+// (1024x1024 -> 64) while K = #tokens is tens of thousands, so K is cut until >= 2 workgroups per CU exist.
+static int splitk_factor(int M, int N, int K) {
+  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  const int nk = (K + BK - 1) / BK;
+  int s = (512 + tiles - 1) / tiles;
+  if (s > nk / 8) s = nk / 8;
+  if (s > 32) s = 32;
+  return s < 1 ? 1 : s;
+}
+
+// workspace an fp32-output GEMM can use for split-K partial sums (0 = none needed)
+extern "C" size_t ia_gemm_workspace_bytes(int M, int N, int K, int c_is_f32) {
+  if (!c_is_f32 || M <= 0 || N <= 0 || K <= 0) return 0;
+  const int s = splitk_factor(M, N, K);
+  return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+}
+
 extern "C" int ia_gemm_bf16(const void* A, int a_kstrided, int lda, const void* B, int b_kstrided, int ldb,
                             void* C, int c_is_f32, int ldc, int M, int N, int K, int epilogue,
-                            const float* bias, const void* aux, int ldaux, void* C2, int accumulate,
-                            hipStream_t stream) {
+                            const float* bias, const void* aux, int ldaux, void* C2, int accumulate, void* workspace,
+                            size_t workspace_bytes, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return IA_ERR_ARG;
   if ((lda & 7) || (ldb & 7) || (ldc & 3) || (N & 3)) return IA_ERR_ARG;
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15)) return IA_ERR_ARG;
@@ -215,6 +279,15 @@ extern "C" int ia_gemm_bf16(const void* A, int a_kstrided, int lda, const void* 
   if (!a_kstrided && (K & 7)) return IA_ERR_ARG;
   g.a_bytes = (uint32_t)ab; g.b_bytes = (uint32_t)bb;
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
+  g.splits = 1; g.nk_per_split = (K + BK - 1) / BK; g.ws = nullptr;
+  if (c_is_f32 && workspace) {
+    const int s = splitk_factor(M, N, K);
+    if (s > 1 && workspace_bytes >= (size_t)s * M * N * sizeof(float)) {
+      g.nk_per_split = ((K + BK - 1) / BK + s - 1) / s;
+      g.splits = ((K + BK - 1) / BK + g.nk_per_split - 1) / g.nk_per_split;
+      g.ws = (float*)workspace;
+    }
+  }
   const bool needs_bias = epilogue == EPI_BIAS || epilogue == EPI_BIAS_GELU || epilogue == EPI_BIAS_ADD;
   const bool needs_aux = epilogue == EPI_ADD || epilogue == EPI_DGELU || epilogue == EPI_BIAS_ADD;
   if (needs_bias && !bias) return IA_ERR_ARG;
@@ -242,4 +315,37 @@ extern "C" int ia_gemm_bf16(const void* A, int a_kstrided, int lda, const void* 
     if (epilogue == EPI_BIAS) return launch<false, false, EPI_BIAS, true>(g, stream);
   }
   return IA_ERR_UNSUPPORTED;
+}
+
+// Start recording HIP events around every launch of GEMM instantiation `variant` (at most max_launches).
+extern "C" int ia_prof_begin(int variant, int max_launches) {
+  (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
+  if (max_launches <= 0) return IA_ERR_ARG;
+  if (g_prof.cap < max_launches) {
+    for (int i = 0; i < 2 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);
+    delete[] g_prof.ev;
+    g_prof.ev = new hipEvent_t[2 * max_launches];
+    for (int i = 0; i < 2 * max_launches; ++i)
+      if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) return IA_ERR_LAUNCH;
+    g_prof.cap = max_launches;
+  }
+  g_prof.variant = variant; g_prof.n = 0; g_prof.flops = 0.0; g_prof.on = true;
+  return IA_OK;
+}
+
+// Stop recording; synchronises on the recorded events and returns summed kernel time, FLOPs and launch count.
+extern "C" int ia_prof_end(double* total_ms, double* total_flops, int* launches) {
+  (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
+  g_prof.on = false;
+  double ms = 0.0;
+  for (int i = 0; i < g_prof.n; ++i) {
+    if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) return IA_ERR_LAUNCH;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return IA_ERR_LAUNCH;
+    ms += t;
+  }
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = g_prof.flops;
+  if (launches) *launches = g_prof.n;
+  return IA_OK;
 }

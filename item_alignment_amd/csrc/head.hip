@@ -142,6 +142,7 @@ __global__ __launch_bounds__(256) void pair_head_bwd_dw_kernel(const float* __re
 
 extern "C" int ia_linear_small_fwd(const float* x, int ldx, const float* W, const float* bias, float* y, int B, int N, int K, int act,
                                    hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!x || !W || !y || B <= 0 || N <= 0 || K <= 0 || (act != ACT_NONE && act != ACT_TANH)) return IA_ERR_ARG;
   hipLaunchKernelGGL(linear_small_fwd_kernel, dim3((B * N + 3) / 4), dim3(256), 0, stream, x, ldx, W, bias, y, B, N, K, act);
   return ia_check_launch();
@@ -150,6 +151,7 @@ extern "C" int ia_linear_small_fwd(const float* x, int ldx, const float* W, cons
 // dx may be null (input needs no gradient); dW / db accumulate (+=); y = forward output (for tanh').
 extern "C" int ia_linear_small_bwd(const float* dy, const float* y, const float* x, int ldx, const float* W, float* dx, int lddx,
                                    float* dW, float* db, int B, int N, int K, int act, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!dy || !x || !W || B <= 0 || N <= 0 || K <= 0 || (act == ACT_TANH && !y)) return IA_ERR_ARG;
   if (dx) hipLaunchKernelGGL(linear_small_bwd_dx_kernel, dim3((B * K + 255) / 256), dim3(256), 0, stream, dy, y, W, dx, lddx, B, N, K, act);
   if (dW) hipLaunchKernelGGL(linear_small_bwd_dw_kernel, dim3((N * K + 255) / 256), dim3(256), 0, stream, dy, y, x, ldx, dW, db, B, N, K, act);
@@ -160,6 +162,7 @@ extern "C" int ia_linear_small_bwd(const float* dy, const float* y, const float*
 // (then loss is not written); loss_per: scratch of B floats.
 extern "C" int ia_pair_head_ce_fwd(const float* x, const float* y, const float* W, const float* bias, const int64_t* labels,
                                    float* logits, float* probs, float* loss, float* loss_per, int B, int D, int C, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!x || !W || !logits || !probs || B <= 0 || D <= 0 || C <= 0 || C > 8) return IA_ERR_ARG;
   if (labels && (!loss || !loss_per)) return IA_ERR_ARG;
   hipLaunchKernelGGL(pair_head_fwd_kernel, dim3(B), dim3(64), 0, stream, x, y, W, bias, labels, logits, probs, loss_per, B, D, C);
@@ -170,6 +173,7 @@ extern "C" int ia_pair_head_ce_fwd(const float* x, const float* y, const float* 
 // dloss: device scalar (upstream gradient of the mean loss). dW/db accumulate; dx/dy are overwritten.
 extern "C" int ia_pair_head_ce_bwd(const float* probs, const int64_t* labels, const float* dloss, const float* x, const float* y,
                                    const float* W, float* dx, float* dy, float* dW, float* db, int B, int D, int C, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!probs || !labels || !dloss || !x || !W || !dx || B <= 0 || D <= 0 || C <= 0 || C > 8) return IA_ERR_ARG;
   const int two = y != nullptr;
   if (two && !dy) return IA_ERR_ARG;

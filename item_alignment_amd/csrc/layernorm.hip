@@ -259,6 +259,7 @@ int ln_blocks(int M) { int b = (M + 3) / 4; return b < 512 ? b : 512; }
 extern "C" int ia_ln_fwd(const void* x, const float* bias, const void* residual, void* z_out, void* y, float* mean,
                          float* rstd, const float* gamma, const float* beta, int M, int H, float eps, float drop_p,
                          uint32_t seed, uint32_t stream_id, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!x || !y || !mean || !rstd || !gamma || M <= 0 || H <= 0 || (H & 7) || H > 512 * MAXV) return IA_ERR_ARG;
   const uint32_t thr16 = drop_p > 0.f ? (uint32_t)(drop_p * 65536.f + 0.5f) : 0u;
   const float inv_keep = drop_p > 0.f ? 1.f / (1.f - (float)thr16 / 65536.f) : 1.f;
@@ -284,6 +285,7 @@ extern "C" int ia_ln_bwd(const void* dy, const void* dres, const void* z, const 
                          const float* gamma, void* dz, void* dx, float* dgamma, float* dbeta, float* dbias, int M, int H,
                          float drop_p, uint32_t seed, uint32_t stream_id, void* workspace, size_t workspace_bytes,
                          int accumulate, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!dy || !z || !mean || !rstd || !gamma || !dz || M <= 0 || (H & 7) || H > 512 * MAXV) return IA_ERR_ARG;
   if (workspace_bytes < ia_ln_bwd_workspace_bytes(M, H) || !workspace) return IA_ERR_WORKSPACE;
   const uint32_t thr16 = drop_p > 0.f ? (uint32_t)(drop_p * 65536.f + 0.5f) : 0u;
@@ -310,12 +312,14 @@ extern "C" int ia_ln_bwd(const void* dy, const void* dres, const void* z, const 
 }
 
 extern "C" size_t ia_colsum_workspace_bytes(int M, int N) {
+  (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   int rb = (M + 3) / 4; if (rb > 256) rb = 256;
   return (size_t)rb * N * sizeof(float);
 }
 
 extern "C" int ia_colsum(const void* x, int ld, int M, int N, float* out, int accumulate, void* workspace,
                          size_t workspace_bytes, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!x || !out || M <= 0 || N <= 0 || (N & 7) || (ld & 7)) return IA_ERR_ARG;
   if (!workspace || workspace_bytes < ia_colsum_workspace_bytes(M, N)) return IA_ERR_WORKSPACE;
   int rb = (M + 3) / 4; if (rb > 256) rb = 256;

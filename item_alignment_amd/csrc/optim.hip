@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16* __restri
 extern "C" int ia_adamw_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
                              const void* chunk_table, int n_chunks, float lr, float beta1, float beta2, float eps, float weight_decay,
                              int step, float grad_scale, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!params || !grads || !exp_avg || !exp_avg_sq || !chunk_table || n_chunks <= 0 || step <= 0) return IA_ERR_ARG;
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2 = 1.f - powf(beta2, (float)step);
@@ -87,6 +88,7 @@ extern "C" int ia_adamw_flat(float* params, const float* grads, float* exp_avg, 
 }
 
 extern "C" int ia_cast_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!src || !dst || n == 0) return IA_ERR_ARG;
   size_t g = (n / 4 + 255) / 256; if (g > 8192) g = 8192; if (g == 0) g = 1;
   hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((int)g), dim3(256), 0, stream, src, (bf16*)dst, n);
@@ -94,6 +96,7 @@ extern "C" int ia_cast_f32_to_bf16(const float* src, void* dst, size_t n, hipStr
 }
 
 extern "C" int ia_cast_bf16_to_f32(const void* src, float* dst, size_t n, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!src || !dst || n == 0) return IA_ERR_ARG;
   size_t g = (n + 255) / 256; if (g > 8192) g = 8192;
   hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3((int)g), dim3(256), 0, stream, (const bf16*)src, dst, n);

@@ -1,0 +1,127 @@
+"""Data parallelism for the pair batch: one process per GPU, gradients all-reduced with RCCL over xGMI
+(torch.distributed backend "nccl" is RCCL on ROCm), overlapped with backward.
+
+The reference is single-process / single-GPU (no torch.distributed anywhere), so this layer
+has no reference implementation to match — only the single-GPU maths: the reference loss is a mean over
+the batch (nn.CrossEntropyLoss default, text.py:1292), so equal shard sizes + averaged gradients reproduce
+the global-batch gradient.
+
+Design (MI355X-first): gradients already live in one flat fp32 arena (arena.py), so a bucket is a slice of
+it — no packing copies.  Backward fills the arena from its end; as soon as every parameter overlapping a
+bucket has been reported ready (models.functional.register_grad_ready_hook, called right after the layer's
+kernels were enqueued) the bucket's all-reduce is issued asynchronously: RCCL's stream waits for exactly
+the kernels enqueued so far and the remaining backward keeps the compute stream busy.  The 1/world
+averaging is folded into the optimiser's grad_scale, so no extra pass touches the gradients.
+xGMI is point-to-point (7 links/GPU); large buckets (default 128 MiB) keep per-link rings bandwidth-bound.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(device_type="cuda"):
+    """RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the launcher (torch.distributed.run).  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = "nccl" if device_type == "cuda" else "gloo"
+        if device_type == "cuda":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_indices(n_items, rank, world, epoch_seed, shuffle=True):
+    """Rank r takes positions r::world of the epoch permutation drawn from the shared seed: identical global
+    order at any world size; shards are truncated to equal length (the loss is a batch mean)."""
+    g = torch.Generator().manual_seed(int(epoch_seed))
+    perm = torch.randperm(n_items, generator=g) if shuffle else torch.arange(n_items)
+    per = n_items // world
+    return perm[rank:per * world:world]
+
+
+class GradBucketReducer:
+    """Bucketed asynchronous all-reduce over a flat gradient buffer.
+
+    flat_grad: 1-D tensor; params: list of (param, offset, numel) placed inside it (arena order).
+    """
+
+    def __init__(self, flat_grad, params, bucket_bytes=128 << 20, group=None):
+        self.flat = flat_grad
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        esz = flat_grad.element_size()
+        per = max(1, bucket_bytes // esz)
+        n = flat_grad.numel()
+        # buckets from the END of the arena (backward order) towards the start
+        self.buckets, end = [], n
+        while end > 0:
+            start = max(0, end - per)
+            self.buckets.append((start, end))
+            end = start
+        self.param_buckets = {}
+        self.need = [0] * len(self.buckets)
+        for p, off, numel in params:
+            if not getattr(p, "requires_grad", True):
+                continue
+            hit = [i for i, (s, e) in enumerate(self.buckets) if off < e and off + numel > s]
+            self.param_buckets[id(p)] = hit
+            for i in hit:
+                self.need[i] += 1
+        self.reset()
+
+    @classmethod
+    def for_arena(cls, arena, **kw):
+        return cls(arena.grad, [(p, o, p.numel()) for p, o in zip(arena.params, arena.offsets)], **kw)
+
+    def reset(self):
+        self.left = list(self.need)
+        self.launched = [False] * len(self.buckets)
+        self.seen = set()
+        self.works = []
+
+    def _launch(self, i):
+        s, e = self.buckets[i]
+        self.launched[i] = True
+        if self.world > 1:
+            self.works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def grads_ready(self, params):
+        """Hook target: these parameters' gradient kernels have been enqueued on the current stream."""
+        for p in params:
+            k = id(p)
+            if k in self.seen or k not in self.param_buckets:
+                continue
+            self.seen.add(k)
+            for i in self.param_buckets[k]:
+                self.left[i] -= 1
+                if self.left[i] == 0 and not self.launched[i]:
+                    self._launch(i)
+
+    def finish(self):
+        """Call after backward: reduce whatever is still pending (frozen / unreached parameters), then make the
+        compute stream wait for every bucket.  Returns the grad_scale (1/world) for the optimiser."""
+        for i in range(len(self.buckets)):
+            if not self.launched[i]:
+                self._launch(i)
+        for w in self.works:
+            w.wait()
+        self.reset()
+        return 1.0 / self.world
+
+
+def broadcast_arena(arena, src=0):
+    """Identical replicas: rank `src`'s master weights (and its bf16 shadow) everywhere."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(arena.master, src=src)
+        arena.refresh_shadow()
+
+
+def all_reduce_scalar(x, op=None):
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(x, op=op or dist.ReduceOp.SUM)
+    return x

@@ -314,7 +314,7 @@ class PatchEmbedFn(torch.autograd.Function):
         w = vit.arena.shadow_of(vit.patch_embed.proj.weight)        # [H, C*P*P] bf16
         pe = torch.empty((B * NP, H), device=dev, dtype=BF16)
         check(lib.ia_gemm_bf16(patches.data_ptr(), 0, K, w.data_ptr(), 0, K, pe.data_ptr(), 0, H, B * NP, H, K, 1,
-                               vit.patch_embed.proj.bias.data_ptr(), None, 0, None, 0, stream_ptr()), "ia_gemm_bf16[patch]")
+                               vit.patch_embed.proj.bias.data_ptr(), None, 0, None, 0, None, 0, stream_ptr()), "ia_gemm_bf16[patch]")
         tok = torch.empty((B * (NP + 1), H), device=dev, dtype=BF16)
         check(lib.ia_vit_tokens_fwd(pe.data_ptr(), vit.cls_token.data_ptr(), vit.pos_embed.data_ptr(), tok.data_ptr(), B, NP, H, stream_ptr()),
               "ia_vit_tokens_fwd")
@@ -335,7 +335,9 @@ class PatchEmbedFn(torch.autograd.Function):
         check(lib.ia_colsum(dpe.data_ptr(), H, B * NP, H, vit.patch_embed.proj.bias.grad.data_ptr(), 1, ws.data_ptr(), ws_bytes, stream_ptr()),
               "ia_colsum")
         # dW[H, K] += dpe^T patches
+        gws_bytes = lib.ia_gemm_workspace_bytes(H, K, B * NP, 1)
+        gws = torch.empty(gws_bytes, device=dtok.device, dtype=torch.uint8) if gws_bytes else None
         check(lib.ia_gemm_bf16(dpe.data_ptr(), 1, H, patches.data_ptr(), 1, K, vit.patch_embed.proj.weight.grad.data_ptr(), 1, K, H, K, B * NP, 0,
-                               None, None, 0, None, 1, stream_ptr()), "ia_gemm_bf16[patch wgrad]")
+                               None, None, 0, None, 1, ptr(gws), gws_bytes, stream_ptr()), "ia_gemm_bf16[patch wgrad]")
         _notify([vit.cls_token, vit.pos_embed, vit.patch_embed.proj.weight, vit.patch_embed.proj.bias])
         return None, None, None

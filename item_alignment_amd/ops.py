@@ -43,9 +43,11 @@ def gemm(a, b, *, a_kstrided=False, b_kstrided=False, epilogue=EPI_NONE, bias=No
     _need(out, F32 if out_f32 else BF16, "out")
     if epilogue == EPI_BIAS_GELU and pre_out is None:
         pre_out = torch.empty((M, N), device=a.device, dtype=BF16)
+    ws_bytes = lib.ia_gemm_workspace_bytes(M, N, K, int(out_f32))
+    ws = torch.empty(ws_bytes, device=a.device, dtype=torch.uint8) if ws_bytes else None
     check(lib.ia_gemm_bf16(a.data_ptr(), int(a_kstrided), a.shape[1], b.data_ptr(), int(b_kstrided), b.shape[1], out.data_ptr(),
                            int(out_f32), N, M, N, K, epilogue, ptr(bias), ptr(aux), N if aux is not None else 0, ptr(pre_out),
-                           int(accumulate), stream_ptr()), "ia_gemm_bf16")
+                           int(accumulate), ptr(ws), ws_bytes, stream_ptr()), "ia_gemm_bf16")
     if epilogue == EPI_BIAS_GELU:
         return out, pre_out
     return out

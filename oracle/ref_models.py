@@ -463,7 +463,10 @@ def coca_item_alignment(sd, cfg, vcfg, ids1, mask1, tt1, pos1, img1, ids2, mask2
     def side(ids, mask, tt, pos, img):
         hs = roberta_model(sd, "coca.text_encoder", cfg, ids, mask, tt, pos, training)[-1]
         tok = tower(img)
-        return hs[:, 0], hs, vit_forward_head(tok), tok
+        ie = vit_forward_head(tok)
+        if "img_proj.weight" in sd:      # product-side deviation N1: widths differ in the named C5 pairing
+            ie = linear(ie, sd, "img_proj")
+        return hs[:, 0], hs, ie, tok
 
     te1, tt_1, ie1, it1 = side(ids1, mask1, tt1, pos1, img1)
     te2, tt_2, ie2, it2 = side(ids2, mask2, tt2, pos2, img2)
