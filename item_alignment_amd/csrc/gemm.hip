@@ -12,16 +12,21 @@
 // flavours (y = xW^T, dx = dy W, dW = dy^T x; torch.nn.Linear under autograd, reference
 // src/models/text.py:1241 -> transformers RobertaLayer) all stream each operand from HBM once.
 //
-// Tile: 128x128x64 per 256-thread workgroup (4 waves as 2x2, 64x64 per wave, 4x4 MFMA 16x16x32
-// fragments), LDS double buffer (2 x 32 KiB) filled by buffer_load ... lds (16 B/lane, out-of-range
-// rows arrive as zeros so ragged M / K tails need no extra code), XOR-swizzled on the source side.
-// The MFMA is issued with swapped operands so each lane ends up with 4 consecutive output columns.
+// Two tile configurations share staging / epilogue code:
+//   T256: 256x256x64 per 512-thread workgroup (8 waves as 2x4, 128x64 per wave, 4x2 MFMA 32x32x16
+//         fragments, 128 KiB LDS double buffer) - the large-M encoder GEMMs.  The 128x64 wave tile halves
+//         the LDS bytes read per MFMA relative to T128 (whose 64x64 wave tile saturates the LDS port).
+//   T128: 128x128x64 per 256-thread workgroup (4 waves as 2x2, 64x64 per wave, 4x4 MFMA 16x16x32) -
+//         small outputs (heads, tiny test shapes).
+// LDS is filled by buffer_load ... lds (16 B/lane; out-of-range rows arrive as zeros, so ragged M / K
+// tails need no extra code) with the XOR swizzle applied on the source side.  The MFMA is issued with
+// swapped operands (C^T fragments) so each lane ends up with runs of consecutive output columns.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = 16384;   // one operand tile (128 x 64 bf16)
+constexpr int BK = 64;
 constexpr uint32_t OOB = 0xFFFFFFF0u;
 
 enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_ADD = 3, EPI_DGELU = 4, EPI_BIAS_ADD = 5 };
@@ -35,14 +40,72 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int splits, nk_per_split;   // split-K (fp32 output only): blockIdx.y owns k-tiles [y*nk_per_split, ...)
   float* ws;                  // [splits][M][N] fp32 partials when splits > 1
+  int dbg;                    // ablation switches for tuning runs (IA_GEMM_DBG env): results are WRONG when non-zero
 };
 
-// 32-byte-slot swizzle of a k-strided tile row (row = k index within the 64-row tile)
+// ---------------------------------------------------------------------------------- shared epilogue
+// v = 4 consecutive output columns n..n+3 of row m
+template <int EPI, bool OUTF32>
+IA_DEV void epi_store4(const GemmArgs& p, int m, int n, f32x4 v) {
+  if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_ADD) {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+    v += b;
+  }
+  if (EPI == EPI_BIAS_GELU) {
+    bf16x4 pre = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+    *reinterpret_cast<bf16x4*>(p.C2 + (size_t)m * p.ldc + n) = pre;
+    // activation is taken on the bf16-rounded pre-activation so the backward (which only has the
+    // stored bf16 value) differentiates exactly the function the forward evaluated
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(bf2f(pre[r]));
+  }
+  if (EPI == EPI_ADD || EPI == EPI_BIAS_ADD) {
+    const bf16x4 a = *reinterpret_cast<const bf16x4*>(p.aux + (size_t)m * p.ldaux + n);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] += bf2f(a[r]);
+  }
+  if (EPI == EPI_DGELU) {
+    const bf16x4 a = *reinterpret_cast<const bf16x4*>(p.aux + (size_t)m * p.ldaux + n);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad(bf2f(a[r]));
+  }
+  if (OUTF32) {
+    if (p.splits > 1) {   // partial sums; the second-stage kernel adds them into C in a fixed order
+      *reinterpret_cast<f32x4*>(p.ws + ((size_t)blockIdx.y * p.M + m) * p.N + n) = v;
+      return;
+    }
+    float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+    if (p.accumulate) { const f32x4 o = *reinterpret_cast<const f32x4*>(c); v += o; }
+    *reinterpret_cast<f32x4*>(c) = v;
+  } else {
+    bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n) = o;
+  }
+}
+
+// XCD-aware tile order: the 8 XCDs each take a contiguous run of tiles (bijective for any grid size), and
+// inside the run 8 m-tiles are swept per n so one XCD re-uses the same B panel from its private L2.
+IA_DEV void tile_of_block(const GemmArgs& p, int& bm, int& bn) {
+  int bid = blockIdx.x;
+  const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  const int GM = 8;
+  const int group = bid / (GM * p.tiles_n);
+  const int first_m = group * GM;
+  const int gsz = min(p.tiles_m - first_m, GM);
+  bm = first_m + (bid % (GM * p.tiles_n)) % gsz;
+  bn = (bid % (GM * p.tiles_n)) / gsz;
+}
+
+// ============================================================================== T128 (4 waves, 16x16x32)
+namespace t128 {
+constexpr int BM = 128, BN = 128, TILE_BYTES = 16384;
+
+// 32-byte-slot swizzle of a k-strided tile row (row = k index within the 64-row tile, 256 B rows)
 IA_DEV int ks_swz(int k) { return ((k & 3) | (((k >> 3) & 1) << 2)) << 1; }
 
 template <bool KS>
 IA_DEV void stage_tile(__amdgpu_buffer_rsrc_t rs, char* s, int kt, int x0, int ld, int K, int tid, int wave) {
-  // K-contiguous: tile [128 rows(x)][64 k] (128 B rows); k-strided: tile [64 rows(k)][128 x] (256 B rows)
 #pragma unroll
   for (int issue = 0; issue < 4; ++issue) {
     uint32_t off;
@@ -63,11 +126,11 @@ IA_DEV void stage_tile(__amdgpu_buffer_rsrc_t rs, char* s, int kt, int x0, int l
   }
 }
 
-IA_DEV bf16x8 lds_frag_kc(const char* s, int row, int chunk) {
+IA_DEV bf16x8 frag_kc(const char* s, int row, int chunk) {
   return *reinterpret_cast<const bf16x8*>(s + row * 128 + ((chunk ^ (row & 7)) << 4));
 }
 
-IA_DEV bf16x8 lds_frag_ks(const char* s, int k, int col) {
+IA_DEV bf16x8 frag_ks(const char* s, int k, int col) {
   // 16-lane group reads a [4 k][16 col] block twice (k, k+4); lane p supplies row k+(p>>2), 4 cols.
   const int addr = k * 256 + ((((col >> 3) ^ ks_swz(k))) << 4) + (col & 7) * 2;
   s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(s + addr));
@@ -82,22 +145,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-
-  // XCD-aware tile order: the 8 XCDs each take a contiguous run of tiles (bijective for any grid).
-  int bid = blockIdx.x;
-  {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  // group 8 m-tiles per n sweep so one XCD re-uses the same B panel from its L2
-  const int GM = 8;
-  const int group = bid / (GM * p.tiles_n);
-  const int first_m = group * GM;
-  const int gsz = min(p.tiles_m - first_m, GM);
-  const int bm = first_m + (bid % (GM * p.tiles_n)) % gsz;
-  const int bn = (bid % (GM * p.tiles_n)) / gsz;
+  int bm, bn;
+  tile_of_block(p, bm, bn);
   const int m0 = bm * BM, n0 = bn * BN;
-
   const __amdgpu_buffer_rsrc_t rsA = ia_rsrc(p.A, p.a_bytes);
   const __amdgpu_buffer_rsrc_t rsB = ia_rsrc(p.B, p.b_bytes);
 
@@ -130,15 +180,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
       bf16x8 af[4], bfr[4];
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
-        if (!AKS) af[mi] = lds_frag_kc(sA, wm * 64 + mi * 16 + li, ks * 4 + g);
-        else      af[mi] = lds_frag_ks(sA, ks * 32 + g * 8 + (li >> 2), wm * 64 + mi * 16 + (li & 3) * 4);
+        if (!AKS) af[mi] = frag_kc(sA, wm * 64 + mi * 16 + li, ks * 4 + g);
+        else      af[mi] = frag_ks(sA, ks * 32 + g * 8 + (li >> 2), wm * 64 + mi * 16 + (li & 3) * 4);
       }
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
         // k-contiguous B: fragment row i <-> n = (i>>2)*16 + ni*4 + (i&3), so lane group g ends up
         // holding 16 consecutive n; k-strided B: plain n = ni*16 + i (conflict-free transpose read).
-        if (!BKS) bfr[ni] = lds_frag_kc(sB, wn * 64 + (li >> 2) * 16 + ni * 4 + (li & 3), ks * 4 + g);
-        else      bfr[ni] = lds_frag_ks(sB, ks * 32 + g * 8 + (li >> 2), wn * 64 + ni * 16 + (li & 3) * 4);
+        if (!BKS) bfr[ni] = frag_kc(sB, wn * 64 + (li >> 2) * 16 + ni * 4 + (li & 3), ks * 4 + g);
+        else      bfr[ni] = frag_ks(sB, ks * 32 + g * 8 + (li >> 2), wn * 64 + ni * 16 + (li & 3) * 4);
       }
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
@@ -150,7 +200,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     __syncthreads();
   }
 
-  // epilogue: lane (g, li) holds C[m = ..+li][n = nb .. nb+3] in acc[mi][ni]
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
     const int m = m0 + wm * 64 + mi * 16 + li;
@@ -159,44 +208,211 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     for (int ni = 0; ni < 4; ++ni) {
       const int n = n0 + wn * 64 + (BKS ? ni * 16 + g * 4 : g * 16 + ni * 4);
       if (n >= p.N) continue;
-      f32x4 v = acc[mi][ni];
-      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_ADD) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
-        v += b;
-      }
-      if (EPI == EPI_BIAS_GELU) {
-        bf16x4 pre = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        *reinterpret_cast<bf16x4*>(p.C2 + (size_t)m * p.ldc + n) = pre;
-        // activation is taken on the bf16-rounded pre-activation so the backward (which only has
-        // the stored bf16 value) differentiates exactly the function the forward evaluated
+      epi_store4<EPI, OUTF32>(p, m, n, acc[mi][ni]);
+    }
+  }
+}
+}  // namespace t128
+
+// ============================================================================== T256 (8 waves, 32x32x16)
+namespace t256 {
+constexpr int BM = 256, BN = 256, TILE_BYTES = 32768, LDS_BYTES = 4 * TILE_BYTES;
+
+template <bool KS>
+IA_DEV void stage_tile(__amdgpu_buffer_rsrc_t rs, char* s, int kt, int x0, int ld, int K, int tid, int wave) {
+  // k-contiguous: [256 rows(x)][64 k], 128 B rows, chunk XOR (row>>1)&7 (conflict-free ds_read_b128 for any
+  // 16 rows distinct mod 16); k-strided: [64 rows(k)][256 x], 512 B rows, 32 B slot XOR (k&3)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(bf2f(pre[r]));
-      }
-      if (EPI == EPI_ADD || EPI == EPI_BIAS_ADD) {
-        const bf16x4 a = *reinterpret_cast<const bf16x4*>(p.aux + (size_t)m * p.ldaux + n);
+  for (int issue = 0; issue < 4; ++issue) {
+    uint32_t off;
+    if (!KS) {
+      const int row = issue * 64 + (tid >> 3);
+      const int c = (tid & 7) ^ ((row >> 1) & 7);
+      const int k = kt * BK + c * 8;
+      off = (uint32_t)(((x0 + row) * ld + k) * 2);
+      if (k >= K) off = OOB;
+    } else {
+      const int row = issue * 16 + (tid >> 5);
+      const int c = (tid & 31) ^ ((row & 3) << 2);
+      const int k = kt * BK + row;
+      off = (uint32_t)((k * ld + x0 + c * 8) * 2);
+      if (k >= K) off = OOB;
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, IA_LDS(s + issue * 8192 + wave * 1024), 16, off, 0, 0, 0);
+  }
+}
+
+// fragment of MFMA 32x32x16: lane (i = lane&31, half = lane>>5) holds operand row i, k = half*8 .. +7
+IA_DEV bf16x8 frag_kc(const char* s, int row, int chunk) {
+  return *reinterpret_cast<const bf16x8*>(s + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+}
+
+// same fragment out of a k-strided tile: each 16-lane group transposes a [4 k][16 col] block; lane (i -> column
+// col0 + i, half) gets k rows k0 + 8*half + {0..3} from the first read and + {4..7} from the second, i.e. the
+// standard k order of the MFMA operand.
+IA_DEV bf16x8 frag_ks(const char* s, int k0, int col0, int lane) {
+  const int p = lane & 15, G = lane >> 4;
+  const int row = k0 + 8 * (G >> 1) + (p >> 2);
+  const int col = col0 + 16 * (G & 1) + (p & 3) * 4;
+  const int addr = row * 512 + ((((col >> 3) ^ ((row & 3) << 2))) << 4) + (col & 7) * 2;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(s + addr));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(s + addr + 4 * 512));
+  s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+// Ping-pong main loop of one wave group (GRP 0: rows 0..127 of the block tile and the A-operand DMA;
+// GRP 1: rows 128..255 and the B-operand DMA).  See the schedule comment in gemm_kernel.
+template <int GRP, bool AKS, bool BKS>
+IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][2], __amdgpu_buffer_rsrc_t rs, int x0, int ld, int kt0,
+                      int n_tiles, int nk_all, int wn, int lane) {
+  constexpr bool MYKS = GRP ? BKS : AKS;            // layout of the operand this group streams
+  const int hh = lane >> 5, li = lane & 31;
+  const int gt = wn * 64 + lane;                    // thread index inside the group (0..255)
+  // loop-invariant per-lane byte offsets of the 8 DMA pieces; the k-tile advance is a scalar (soffset)
+  uint32_t voff[8];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += bf2f(a[r]);
-      }
-      if (EPI == EPI_DGELU) {
-        const bf16x4 a = *reinterpret_cast<const bf16x4*>(p.aux + (size_t)m * p.ldaux + n);
+  for (int i = 0; i < 8; ++i) {
+    if (!MYKS) {
+      const int row = i * 32 + (gt >> 3);
+      voff[i] = (uint32_t)(((x0 + row) * ld + (((gt & 7) ^ ((row >> 1) & 7)) * 8)) * 2);
+    } else {
+      const int row = i * 8 + (gt >> 5);
+      voff[i] = (uint32_t)((row * ld + x0 + (((gt & 31) ^ ((row & 3) << 2)) * 8)) * 2);
+    }
+  }
+  const uint32_t kstep = MYKS ? (uint32_t)(BK * ld * 2) : (uint32_t)(BK * 2);
+  const bool ragged_k = (p.K & (BK - 1)) != 0;
+  char* const my_half = smem + (GRP ? TILE_BYTES : 0) + wn * 1024;
+
+  auto dma_piece = [&](int u, int i) {             // piece i of this group's half of k-tile u -> buffer u&1
+    char* dst = my_half + (u & 1) * 2 * TILE_BYTES + i * 4096;
+    const int kt = kt0 + u;
+    if (!ragged_k || kt != nk_all - 1) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, IA_LDS(dst), 16, voff[i], (int)(kt * kstep), 0, 0);
+    } else {                                        // last, partial k-tile: lanes past K fetch zeros
+      const int k = MYKS ? kt * BK + i * 8 + (gt >> 5) : kt * BK + ((gt & 7) ^ (((i * 32 + (gt >> 3)) >> 1) & 7)) * 8;
+      const uint32_t off = k < p.K ? voff[i] + kt * kstep : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, IA_LDS(dst), 16, off, 0, 0, 0);
+    }
+  };
+
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad(bf2f(a[r]));
+  for (int i = 0; i < 8; ++i) dma_piece(0, i);
+  if (n_tiles > 1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma_piece(1, i);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (GRP == 1) __builtin_amdgcn_s_barrier();      // G1 idles through phase 0
+
+  // B fragment row i <-> n so that a lane ends up with 16 consecutive output columns (k-contiguous B only)
+  const int nperm = ((li >> 2) & 1) * 16 + (li >> 3) * 4 + (li & 3);
+  const bool dma_on = !(p.dbg & 2);
+
+  for (int u = 0; u < n_tiles; ++u) {
+    const char* sA = smem + (u & 1) * 2 * TILE_BYTES;
+    const char* sB = sA + TILE_BYTES;
+    // ------------------------------------------------------------------ LOAD phase
+    if (GRP == 0 && u >= 1 && u + 1 < n_tiles && dma_on) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dma_piece(u + 1, i);
+    }
+    bf16x8 af[4][4], bfr[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        if (AKS) af[ks][mi] = frag_ks(sA, ks * 16, GRP * 128 + mi * 32, lane);
+        else af[ks][mi] = frag_kc(sA, GRP * 128 + mi * 32 + li, ks * 2 + hh);
       }
-      if (OUTF32) {
-        if (p.splits > 1) {   // partial sums; the second-stage kernel adds them into C in a fixed order
-          *reinterpret_cast<f32x4*>(p.ws + ((size_t)blockIdx.y * p.M + m) * p.N + n) = v;
-          continue;
-        }
-        float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
-        if (p.accumulate) { const f32x4 o = *reinterpret_cast<const f32x4*>(c); v += o; }
-        *reinterpret_cast<f32x4*>(c) = v;
-      } else {
-        bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n) = o;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        if (BKS) bfr[ks][ni] = frag_ks(sB, ks * 16, wn * 64 + ni * 32, lane);
+        else bfr[ks][ni] = frag_kc(sB, wn * 64 + ni * 32 + nperm, ks * 2 + hh);
+      }
+    }
+    if (GRP == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // G1's DMA issued in its previous COMPUTE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ------------------------------------------------------------------ COMPUTE phase
+    // G1 streams its 8 DMA pieces of k-tile u+2 in the shadow of its own MFMAs: one piece per 4 MFMAs
+    const bool stage_now = GRP == 1 && u + 2 < n_tiles && dma_on;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        if (GRP == 1 && (mi & 1) == 0 && stage_now) dma_piece(u + 2, ks * 2 + (mi >> 1));
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][ni], af[ks][mi], acc[mi][ni], 0, 0, 0);
+      }
+    __builtin_amdgcn_s_setprio(0);
+    if (GRP == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // G0's DMA issued in this iteration's LOAD
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (GRP == 0) __builtin_amdgcn_s_barrier();      // matches G1's last phase
+}
+
+template <bool AKS, bool BKS, int EPI, bool OUTF32>
+__global__ __launch_bounds__(512) void gemm_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, li = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;          // 2 x 4 waves, 128 x 64 each; waves w and w+4 share a SIMD
+  int bm, bn;
+  tile_of_block(p, bm, bn);
+  const int m0 = bm * BM, n0 = bn * BN;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk_all = (p.K + BK - 1) / BK;
+  const int kt0 = blockIdx.y * p.nk_per_split;
+  const int n_tiles = min(nk_all, kt0 + p.nk_per_split) - kt0;
+
+  // Ping-pong schedule.  The 8 waves form two groups (grp = wm: rows 0..127 / 128..255 of the block tile); every
+  // SIMD hosts one wave of each group.  A wave alternates a LOAD phase (all 24 fragment reads of one k-tile into
+  // registers) and a COMPUTE phase (its 32 MFMAs from registers); group 1 runs one phase behind group 0, so on
+  // each SIMD one wave feeds the matrix pipe while the other one reads LDS.  One s_barrier per phase boundary.
+  //   phase 2u   : G0 LOAD(u)     | G1 COMPUTE(u-1)
+  //   phase 2u+1 : G0 COMPUTE(u)  | G1 LOAD(u)
+  // LDS holds two k-tiles; tile u+2 goes into the buffer of tile u once both groups have read it (after phase
+  // 2u+1): G0 streams the A half during its LOAD(u+1), G1 the B half between the MFMAs of its COMPUTE(u), and
+  // each waits for its own DMA one phase later, i.e. before the barrier that ends phase 2u+3.
+  if (wm == 0) main_loop<0, AKS, BKS>(p, smem, acc, ia_rsrc(p.A, p.a_bytes), m0, p.lda, kt0, n_tiles, nk_all, wn, lane);
+  else         main_loop<1, AKS, BKS>(p, smem, acc, ia_rsrc(p.B, p.b_bytes), n0, p.ldb, kt0, n_tiles, nk_all, wn, lane);
+
+  // C^T fragment: lane (m = li, half hh) register r <-> fragment row i = (r&3) + 8*(r>>2) + 4*hh;
+  // k-contiguous B: n = hh*16 + r (16 consecutive columns); k-strided B: n = i.
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = m0 + wm * 128 + mi * 32 + li;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int n = n0 + wn * 64 + ni * 32 + (BKS ? rg * 8 + hh * 4 : hh * 16 + rg * 4);
+        if (n >= p.N) continue;
+        const f32x4 v = {acc[mi][ni][rg * 4], acc[mi][ni][rg * 4 + 1], acc[mi][ni][rg * 4 + 2], acc[mi][ni][rg * 4 + 3]};
+        epi_store4<EPI, OUTF32>(p, m, n, v);
       }
     }
   }
 }
+}  // namespace t256
 
 // Optional per-launch timing of ONE kernel instantiation with HIP events on the launch stream
 // (bench.py's roofline leg): variant id = AKS*1000 + BKS*100 + EPI*10 + OUTF32.
@@ -223,13 +439,42 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+struct Plan { bool big; int splits; };
+
+// Tile choice + split-K factor.  Weight-gradient GEMMs have outputs of only a few dozen tiles (1024x1024 ->
+// 16 tiles of 256x256) while K = #tokens is tens of thousands, so K is cut until every CU has a workgroup.
+Plan make_plan(int M, int N, int K, bool f32_out) {
+  Plan pl;
+  const int nk = (K + BK - 1) / BK;
+  const long t256n = (long)((M + 255) / 256) * ((N + 255) / 256);
+  const int smax = f32_out ? (nk / 8 > 32 ? 32 : (nk / 8 < 1 ? 1 : nk / 8)) : 1;
+  pl.big = M >= 256 && N >= 256 && t256n * smax >= 160;
+  const long tiles = pl.big ? t256n : (long)((M + 127) / 128) * ((N + 127) / 128);
+  const int target = pl.big ? 256 : 512;
+  int s = (int)((target + tiles - 1) / tiles);
+  if (s > smax) s = smax;
+  pl.splits = s < 1 ? 1 : s;
+  return pl;
+}
+
 template <bool AKS, bool BKS, int EPI, bool OUTF32>
-int launch(const GemmArgs& a, hipStream_t st) {
-  const int grid = a.tiles_m * a.tiles_n;
+int launch(GemmArgs a, bool big, hipStream_t st) {
   constexpr int vid = AKS * 1000 + BKS * 100 + EPI * 10 + (OUTF32 ? 1 : 0);
   const bool rec = g_prof.on && g_prof.variant == vid && g_prof.n < g_prof.cap;
   if (rec) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
-  hipLaunchKernelGGL((gemm_kernel<AKS, BKS, EPI, OUTF32>), dim3(grid, a.splits), dim3(256), 0, st, a);
+  if (big) {
+    a.tiles_m = (a.M + t256::BM - 1) / t256::BM; a.tiles_n = (a.N + t256::BN - 1) / t256::BN;
+    static bool attr_set = false;
+    auto kern = t256::gemm_kernel<AKS, BKS, EPI, OUTF32>;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES) != hipSuccess) return IA_ERR_LAUNCH;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n, a.splits), dim3(512), t256::LDS_BYTES, st, a);
+  } else {
+    a.tiles_m = (a.M + t128::BM - 1) / t128::BM; a.tiles_n = (a.N + t128::BN - 1) / t128::BN;
+    hipLaunchKernelGGL((t128::gemm_kernel<AKS, BKS, EPI, OUTF32>), dim3(a.tiles_m * a.tiles_n, a.splits), dim3(256), 0, st, a);
+  }
   if (OUTF32 && a.splits > 1) {
     size_t g = ((size_t)a.M * a.N / 4 + 255) / 256; if (g > 4096) g = 4096;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)g), dim3(256), 0, st, a.ws, (float*)a.C, a.M, a.N, a.ldc, a.splits, a.accumulate);
@@ -244,22 +489,11 @@ int launch(const GemmArgs& a, hipStream_t st) {
 
 }  // namespace
 
-// split-K factor for the weight-gradient GEMMs: their outputs are only a few dozen 128x128 tiles
-// (1024x1024 -> 64) while K = #tokens is tens of thousands, so K is cut until >= 2 workgroups per CU exist.
-static int splitk_factor(int M, int N, int K) {
-  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-  const int nk = (K + BK - 1) / BK;
-  int s = (512 + tiles - 1) / tiles;
-  if (s > nk / 8) s = nk / 8;
-  if (s > 32) s = 32;
-  return s < 1 ? 1 : s;
-}
-
 // workspace an fp32-output GEMM can use for split-K partial sums (0 = none needed)
 extern "C" size_t ia_gemm_workspace_bytes(int M, int N, int K, int c_is_f32) {
   if (!c_is_f32 || M <= 0 || N <= 0 || K <= 0) return 0;
-  const int s = splitk_factor(M, N, K);
-  return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+  const Plan pl = make_plan(M, N, K, true);
+  return pl.splits > 1 ? (size_t)pl.splits * M * N * sizeof(float) : 0;
 }
 
 extern "C" int ia_gemm_bf16(const void* A, int a_kstrided, int lda, const void* B, int b_kstrided, int ldb,
@@ -278,48 +512,49 @@ extern "C" int ia_gemm_bf16(const void* A, int a_kstrided, int lda, const void* 
   if (ab >= 0x7FFFFFFFull || bb >= 0x7FFFFFFFull) return IA_ERR_ARG;
   if (!a_kstrided && (K & 7)) return IA_ERR_ARG;
   g.a_bytes = (uint32_t)ab; g.b_bytes = (uint32_t)bb;
-  g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
-  g.splits = 1; g.nk_per_split = (K + BK - 1) / BK; g.ws = nullptr;
-  if (c_is_f32 && workspace) {
-    const int s = splitk_factor(M, N, K);
-    if (s > 1 && workspace_bytes >= (size_t)s * M * N * sizeof(float)) {
-      g.nk_per_split = ((K + BK - 1) / BK + s - 1) / s;
-      g.splits = ((K + BK - 1) / BK + g.nk_per_split - 1) / g.nk_per_split;
-      g.ws = (float*)workspace;
-    }
+  g.tiles_m = g.tiles_n = 0;
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("IA_GEMM_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
+  const int nk = (K + BK - 1) / BK;
+  Plan pl = make_plan(M, N, K, c_is_f32 != 0);
+  g.splits = 1; g.nk_per_split = nk; g.ws = nullptr;
+  if (c_is_f32 && pl.splits > 1 && workspace && workspace_bytes >= (size_t)pl.splits * M * N * sizeof(float)) {
+    g.nk_per_split = (nk + pl.splits - 1) / pl.splits;
+    g.splits = (nk + g.nk_per_split - 1) / g.nk_per_split;
+    g.ws = (float*)workspace;
   }
   const bool needs_bias = epilogue == EPI_BIAS || epilogue == EPI_BIAS_GELU || epilogue == EPI_BIAS_ADD;
   const bool needs_aux = epilogue == EPI_ADD || epilogue == EPI_DGELU || epilogue == EPI_BIAS_ADD;
   if (needs_bias && !bias) return IA_ERR_ARG;
   if (needs_aux && (!aux || (ldaux & 3))) return IA_ERR_ARG;
   if (epilogue == EPI_BIAS_GELU && !C2) return IA_ERR_ARG;
+  const bool big = pl.big;
 
   if (!a_kstrided && !b_kstrided && !c_is_f32) {
     switch (epilogue) {
-      case EPI_NONE: return launch<false, false, EPI_NONE, false>(g, stream);
-      case EPI_BIAS: return launch<false, false, EPI_BIAS, false>(g, stream);
-      case EPI_BIAS_GELU: return launch<false, false, EPI_BIAS_GELU, false>(g, stream);
-      case EPI_BIAS_ADD: return launch<false, false, EPI_BIAS_ADD, false>(g, stream);
-      case EPI_ADD: return launch<false, false, EPI_ADD, false>(g, stream);
+      case EPI_NONE: return launch<false, false, EPI_NONE, false>(g, big, stream);
+      case EPI_BIAS: return launch<false, false, EPI_BIAS, false>(g, big, stream);
+      case EPI_BIAS_GELU: return launch<false, false, EPI_BIAS_GELU, false>(g, big, stream);
+      case EPI_BIAS_ADD: return launch<false, false, EPI_BIAS_ADD, false>(g, big, stream);
+      case EPI_ADD: return launch<false, false, EPI_ADD, false>(g, big, stream);
     }
   } else if (!a_kstrided && b_kstrided && !c_is_f32) {
     switch (epilogue) {
-      case EPI_NONE: return launch<false, true, EPI_NONE, false>(g, stream);
-      case EPI_ADD: return launch<false, true, EPI_ADD, false>(g, stream);
-      case EPI_DGELU: return launch<false, true, EPI_DGELU, false>(g, stream);
+      case EPI_NONE: return launch<false, true, EPI_NONE, false>(g, big, stream);
+      case EPI_ADD: return launch<false, true, EPI_ADD, false>(g, big, stream);
+      case EPI_DGELU: return launch<false, true, EPI_DGELU, false>(g, big, stream);
     }
   } else if (a_kstrided && b_kstrided && c_is_f32) {
-    if (epilogue == EPI_NONE) return launch<true, true, EPI_NONE, true>(g, stream);
+    if (epilogue == EPI_NONE) return launch<true, true, EPI_NONE, true>(g, big, stream);
   } else if (!a_kstrided && !b_kstrided && c_is_f32) {
-    if (epilogue == EPI_NONE) return launch<false, false, EPI_NONE, true>(g, stream);
-    if (epilogue == EPI_BIAS) return launch<false, false, EPI_BIAS, true>(g, stream);
+    if (epilogue == EPI_NONE) return launch<false, false, EPI_NONE, true>(g, big, stream);
+    if (epilogue == EPI_BIAS) return launch<false, false, EPI_BIAS, true>(g, big, stream);
   }
   return IA_ERR_UNSUPPORTED;
 }
 
 // Start recording HIP events around every launch of GEMM instantiation `variant` (at most max_launches).
 extern "C" int ia_prof_begin(int variant, int max_launches) {
-  (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
+  (void)hipGetLastError();
   if (max_launches <= 0) return IA_ERR_ARG;
   if (g_prof.cap < max_launches) {
     for (int i = 0; i < 2 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);
@@ -335,7 +570,7 @@ extern "C" int ia_prof_begin(int variant, int max_launches) {
 
 // Stop recording; synchronises on the recorded events and returns summed kernel time, FLOPs and launch count.
 extern "C" int ia_prof_end(double* total_ms, double* total_flops, int* launches) {
-  (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
+  (void)hipGetLastError();
   g_prof.on = false;
   double ms = 0.0;
   for (int i = 0; i < g_prof.n; ++i) {
