@@ -65,7 +65,9 @@ def cpu_baseline(cfg, image_model, pairs, steps, seed):
     from oracle import ref_models as O
     from item_alignment_amd.data.synthetic import SyntheticCocaPairs
     from item_alignment_amd.models.image import VIT_CONFIGS
-    threads = os.cpu_count() or 1
+    # torch's intra-op pool stops scaling (and can thrash) far below the 256 hardware threads of the GPU box's host:
+    # use at most 64 threads and report exactly that many as `cores`
+    threads = min(os.cpu_count() or 1, int(os.environ.get("IA_CPU_BASELINE_THREADS", "64")))
     torch.set_num_threads(threads)
     model = build_model(cfg, image_model, seed)
     sd = {k: v.detach().clone().float().requires_grad_(v.requires_grad) for k, v in model.named_parameters()}

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Image-only two-tower pair matching (ViT / ECA-NFNet / ResNetV2 through `create_model`): CLI-compatible with
+the reference's finetune_image.py (flags :17-74, dispatch :192-218, loop :310-348).  This round only the ViT family
+has a HIP encoder; the conv towers raise NotImplementedError."""
+import argparse
+import json
+import os
+
+import torch
+
+from item_alignment_amd import train
+from item_alignment_amd.cli_common import add_common_flags, freeze_and_resume, load_config, pick_device
+from item_alignment_amd.data.datasets import PairedImageDataset, collate_image
+from item_alignment_amd.models.image import create_model
+from item_alignment_amd.utils import logger
+from src.models import NFNetTwoTower, ResNetTwoTower, VitTwoTower
+
+
+def get_parser():
+    p = argparse.ArgumentParser()
+    add_common_flags(p, config_required=False)
+    a = p.add_argument
+    a("--loss_type", default="ce", type=str)
+    a("--image_size", default=1000, type=int)
+    a("--hflip", default=0.5, type=float)
+    a("--color_jitter", default=None, type=float)
+    a("--num_classes", default=2, type=int)
+    a("--in_chans", default=3, type=int)
+    a("--global_pool", default="avg", type=str)
+    a("--stride", default=32, type=int)
+    for name, d, t in (("depths", "2,4,12,6", str), ("channels", "256,512,1536,1536", str), ("stem_type", "deep_quad", str), ("stem_chs", 128, int),
+                       ("group_size", 128, int), ("bottle_ratio", 0.5, float), ("feat_mult", 2.0, float), ("act_layer", "gelu", str),
+                       ("attn_layer", "se", str), ("attn_kwargs", None, str)):
+        a("--" + name, default=d, type=t, help="NfCfg field: parsed but unused, as in the reference (finetune_image.py:56-72,193-207)")
+    return p.parse_args()
+
+
+def load_raw_data(args):
+    """reference finetune_image.py:77-172."""
+    id2image = {}
+    with open(os.path.join(args.data_dir, "item_info.jsonl"), "r", encoding="utf-8") as r:
+        for line in r:
+            if line.strip():
+                d = json.loads(line)
+                id2image[d["item_id"]] = d["item_image_name"]
+
+    def pairs(name, enabled):
+        out = []
+        if not enabled:
+            return out
+        with open(os.path.join(args.data_dir, name), "r", encoding="utf-8") as r:
+            for line in r:
+                if line.strip():
+                    d = json.loads(line)
+                    img = lambda i: os.path.join(args.data_dir, "item_images", id2image[i])
+                    out.append((int(d.get("item_label", 0)), d["src_item_id"], img(d["src_item_id"]), d["tgt_item_id"], img(d["tgt_item_id"])))
+        return out
+    return pairs("item_train_pair.jsonl", args.do_train), pairs("item_valid_pair.jsonl", args.do_eval), pairs("item_test_pair.jsonl", args.do_pred)
+
+
+def main():
+    args = get_parser()
+    train.seed_everything(args.seed)
+    config = load_config(args.config_file, loss_type=args.loss_type, loss_margin=args.margin, image_size=args.image_size)
+    image_encoder = create_model(args.model_name, pretrained=True, img_size=args.image_size)
+    if "nfnet" in args.model_name:
+        model = NFNetTwoTower(config, image_encoder)
+    elif "vit" in args.model_name:
+        config.hidden_size = image_encoder.num_features
+        model = VitTwoTower(config, image_encoder)
+    elif "resnet" in args.model_name:
+        model = ResNetTwoTower(config, image_encoder)
+    else:
+        raise ValueError(f"Unsupported model name: {args.model_name}")
+    freeze_and_resume(args, model)
+    train_data, valid_data, test_data = load_raw_data(args)
+    logger.info(f"# train samples: {len(train_data)}, # valid samples: {len(valid_data)}, # test samples: {len(test_data)}")
+    is_training = False if "vit" in args.model_name else True          # quirk A16 (reference :246)
+    make = lambda data, tr: PairedImageDataset(data, args.image_size, tr, args.hflip, args.color_jitter)
+    device = pick_device(model)
+    model.to(device)
+    args.interaction_type = "two_tower"
+    train.run(args, model, dict(train=make(train_data, is_training) if args.do_train else None, valid=make(valid_data, False) if args.do_eval else None,
+                                test=make(test_data, False) if args.do_pred else None),
+              collate_image, lambda m, b: m(b[0], b[1], b[2]), "image_finetune", ["model_name", "data_version", "interaction_type", "loss_type"], device)
+
+
+if __name__ == "__main__":
+    main()

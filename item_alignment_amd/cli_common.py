@@ -1,0 +1,88 @@
+"""Pieces the three finetune_*.py scripts share: flags common to all of them, config /
+tokenizer loading, the optional freeze / resume handling (reference finetune_multimodal.py:233-267)."""
+import json
+import os
+from types import SimpleNamespace
+
+import torch
+
+from .utils import BOS_TOKEN, logger
+
+
+def add_common_flags(parser, config_required=True):
+    a = parser.add_argument
+    a("--data_dir", required=True, type=str, help="模型训练数据地址")
+    a("--output_dir", required=True, type=str, help="The output directory where the model checkpoints will be written.")
+    a("--config_file", required=config_required, default=None, type=str, help="The config file which specified the model details.")
+    a("--model_name", required=True, type=str, help="model saving name")
+    a("--data_version", required=True, type=str, help="data version")
+    a("--do_train", action="store_true")
+    a("--do_eval", action="store_true")
+    a("--do_pred", action="store_true")
+    a("--seed", default=2345, type=int)
+    a("--train_batch_size", default=64, type=int, help="Total batch size for training.")
+    a("--eval_batch_size", default=64, type=int)
+    a("--learning_rate", default=1e-3, type=float)
+    a("--start_epoch", default=0, type=int)
+    a("--num_train_epochs", default=10, type=int)
+    a("--weight_decay", default=1e-5, type=float)
+    a("--log_steps", default=10, type=int)
+    a("--pretrained_model_path", default=None, type=str)
+    a("--file_state_dict", default=None, type=str)
+    a("--parameters_to_freeze", default=None, type=str)
+    a("--threshold", default=0.5, type=float)
+    a("--warmup_proportion", default=0.3, type=float)
+    a("--gradient_accumulation_steps", default=1, type=int)
+    a("--adam_epsilon", default=1e-8, type=float)
+    a("--fp16", action="store_true", help="kept for CLI compatibility: the HIP engine always computes in bf16 with fp32 master weights")
+    a("--margin", default=1.0, type=float)
+
+
+def load_config(path, **overrides):
+    """BertConfig.from_json_file equivalent without the transformers dependency: every JSON key becomes an attribute,
+    BertConfig defaults the reference relies on are filled in, then the script's flags are copied on top."""
+    defaults = dict(hidden_act="gelu", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, layer_norm_eps=1e-12, pad_token_id=0,
+                    type_vocab_size=2, initializer_range=0.02, num_labels=2, classifier_dropout=None, max_position_embeddings=512,
+                    similarity_measure="NA", ensemble=None, auxiliary_task=False, cls_layers="1", cls_pool="cat", loss_margin=1.0,
+                    max_seq_len=None, max_seq_len_pv=None, max_pvs=0)
+    d = dict(defaults)
+    if path:
+        with open(path, "r", encoding="utf-8") as f:
+            d.update(json.load(f))
+    d.update(overrides)
+    return SimpleNamespace(**d)
+
+
+def load_tokenizer(args):
+    """reference finetune_text.py:186-189."""
+    from transformers import BertTokenizer
+    tk = BertTokenizer.from_pretrained(args.pretrained_model_path, do_lower_case=args.do_lower_case)
+    tk.do_basic_tokenize = False
+    tk.bos_token = BOS_TOKEN
+    logger.info(f"vocab size: {tk.vocab_size}")
+    return tk
+
+
+def freeze_and_resume(args, model):
+    if args.parameters_to_freeze is not None:
+        names = json.load(open(args.parameters_to_freeze, "r", encoding="utf-8"))
+        frozen = []
+        for key, value in dict(model.named_parameters()).items():
+            if key.replace("roberta.", "") in names:
+                frozen.append(key)
+                value.requires_grad = False
+        logger.info(f"Parameters freezed: {frozen}")
+    if args.file_state_dict is not None:
+        model.load_state_dict(torch.load(args.file_state_dict, map_location="cpu"))
+
+
+def pick_device(model):
+    """HIP models need the GPU; the TextCNN plumbing config is plain torch and runs wherever torch does."""
+    from .models.base import HipModule
+    if isinstance(model, HipModule):
+        if not torch.cuda.is_available():
+            raise SystemExit("this model runs on the MI355X HIP engine only (no CPU path); no GPU is visible")
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        return torch.device("cuda", local)
+    return torch.device("cuda" if torch.cuda.is_available() else "cpu")

@@ -1,0 +1,334 @@
+"""Datasets and collate functions producing the tensor layouts of the reference's src/data/data.py.
+
+Scope: the *formats* feeding the train step are part of the hot-path boundary —
+every collate_* below returns the reference's tuple order (two id lists first, then tensors / None), so the
+train scripts can slice batch[2:] exactly as the reference does.  Tokenisation itself is host-side plumbing:
+the tokenizer is whatever object the script passes in (transformers.BertTokenizer when a vocab.txt exists);
+jieba word segmentation is used when importable and skipped otherwise; image decoding uses PIL + numpy with a
+plain resize / normalise (timm's create_transform is third-party and absent offline; a GPU-side decode/resize
+pipeline is the listed next step).
+"""
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+IMG_TOKEN = "[unused99]"
+IMG_TOKEN_ID = 99
+
+try:                                    # reference data.py:1
+    import jieba
+
+    def _cut(text):
+        return " ".join(jieba.cut(text))
+except Exception:                       # not installed in this image: keep the raw attribute string
+    def _cut(text):
+        return text
+
+
+def _tok(tokenizer, text, max_length, text_pair=None):
+    out = tokenizer(text=text, text_pair=text_pair, max_length=max_length, padding="max_length", truncation="longest_first")
+    return out.data if hasattr(out, "data") else out
+
+
+def _item_text(tokenizer, title, pvs, max_seq_len, max_seq_len_pv):
+    """reference data.py:533-545 / :799-806: title [SEP] segmented-pvs, and the padded length."""
+    if max_seq_len is None:
+        return pvs, max_seq_len_pv
+    if max_seq_len_pv is None:
+        return title, max_seq_len
+    return " ".join((title, tokenizer.sep_token, _cut(pvs))), max_seq_len + max_seq_len_pv
+
+
+# ------------------------------------------------------------------------------------------------ collates
+def _t(x, dtype=torch.long):
+    return torch.tensor(x, dtype=dtype)
+
+
+def collate_one_tower(inputs):
+    """reference data.py:172-201."""
+    pos = [i["position_ids"] for i in inputs if "position_ids" in i]
+    pair_indices = [_t(i["pair_indices"]) for i in inputs if "pair_indices" in i]
+    return ([i["src_item_id"] for i in inputs], [i["tgt_item_id"] for i in inputs], pair_indices,
+            _t([i["input_ids"] for i in inputs]), _t([i["token_type_ids"] for i in inputs]),
+            _t([i["attention_mask"] for i in inputs]), _t(pos) if pos else None, _t([i["labels"] for i in inputs]))
+
+
+def collate_two_tower(inputs):
+    """reference data.py:204-240."""
+    pos = [i["position_ids"] for i in inputs if "position_ids" in i]
+    return ([i["src_item_id"] for i in inputs], [i["tgt_item_id"] for i in inputs],
+            _t([i["input_ids_1"] for i in inputs]), _t([i["attention_mask_1"] for i in inputs]), _t([i["token_type_ids_1"] for i in inputs]),
+            _t([i["input_ids_2"] for i in inputs]), _t([i["attention_mask_2"] for i in inputs]), _t([i["token_type_ids_2"] for i in inputs]),
+            _t(pos) if pos else None, _t([i["labels"] for i in inputs]))
+
+
+def collate_image(inputs):
+    """reference data.py:77-95: samples whose image failed to load are dropped."""
+    keep = [i for i in inputs if "src_input" in i and "tgt_input" in i]
+    return ([i["src_item_id"] for i in keep], [i["tgt_item_id"] for i in keep], torch.stack([i["src_input"] for i in keep]),
+            torch.stack([i["tgt_input"] for i in keep]), _t([i["labels"] for i in keep]))
+
+
+def collate_multimodal(inputs):
+    """reference data.py:98-128 (RoBERTa + image embeddings, one tower)."""
+    pos = [i["position_ids"] for i in inputs if "position_ids" in i]
+    return ([i["src_item_id"] for i in inputs], [i["tgt_item_id"] for i in inputs], _t([i["image_indices"] for i in inputs]),
+            _t([i["src_image_emb"] for i in inputs], torch.float32), _t([i["tgt_image_emb"] for i in inputs], torch.float32),
+            _t([i["input_ids"] for i in inputs]), _t([i["token_type_ids"] for i in inputs]), _t([i["attention_mask"] for i in inputs]),
+            _t(pos) if pos else None, _t([i["labels"] for i in inputs]))
+
+
+def collate_multimodal_two_tower(inputs):
+    """reference data.py:131-169."""
+    return ([i["src_item_id"] for i in inputs], [i["tgt_item_id"] for i in inputs],
+            _t([i["input_ids_1"] for i in inputs]), _t([i["attention_mask_1"] for i in inputs]), _t([i["token_type_ids_1"] for i in inputs]), None,
+            _t([i["src_image_emb"] for i in inputs], torch.float32),
+            _t([i["input_ids_2"] for i in inputs]), _t([i["attention_mask_2"] for i in inputs]), _t([i["token_type_ids_2"] for i in inputs]), None,
+            _t([i["tgt_image_emb"] for i in inputs], torch.float32), _t([i["labels"] for i in inputs]))
+
+
+def collate_coca_pair(inputs):
+    """reference data.py:37-74."""
+    keep = [i for i in inputs if "src_image" in i and "tgt_image" in i]
+    spos = [i["src_position_ids"] for i in keep if "src_position_ids" in i]
+    tpos = [i["tgt_position_ids"] for i in keep if "tgt_position_ids" in i]
+    return ([i["src_item_id"] for i in keep], [i["tgt_item_id"] for i in keep],
+            _t([i["src_input_ids"] for i in keep]), _t([i["src_attention_mask"] for i in keep]), _t([i["src_token_type_ids"] for i in keep]),
+            _t(spos) if spos else None, torch.stack([i["src_image"] for i in keep]),
+            _t([i["tgt_input_ids"] for i in keep]), _t([i["tgt_attention_mask"] for i in keep]), _t([i["tgt_token_type_ids"] for i in keep]),
+            _t(tpos) if tpos else None, torch.stack([i["tgt_image"] for i in keep]), _t([i["labels"] for i in keep]))
+
+
+# ------------------------------------------------------------------------------------------------ datasets
+class RobertaOneTowerDataset(Dataset):
+    """reference data.py:519-620 (auxiliary_task pair indices are out of scope)."""
+
+    def __init__(self, data, text_tokenizer, max_seq_len, classification_method, max_seq_len_pv=None, auxiliary_task=False):
+        if auxiliary_task:
+            raise NotImplementedError("auxiliary_task is outside the hot path (DESIGN.md)")
+        self.data, self.tk = data, text_tokenizer
+        self.max_seq_len, self.max_seq_len_pv, self.method = max_seq_len, max_seq_len_pv, classification_method
+
+    def __len__(self):
+        return len(self.data)
+
+    def __getitem__(self, item):
+        label, src_id, _sc, src_title, src_pvs, tgt_id, _tc, tgt_title, tgt_pvs = self.data[item]
+        src_text, L = _item_text(self.tk, src_title, src_pvs, self.max_seq_len, self.max_seq_len_pv)
+        tgt_text, _ = _item_text(self.tk, tgt_title, tgt_pvs, self.max_seq_len, self.max_seq_len_pv)
+        if self.method == "vec_sim":
+            s, t = _tok(self.tk, src_text, L), _tok(self.tk, tgt_text, L)
+            rec = {"input_ids": s["input_ids"] + [self.tk.bos_token_id] + t["input_ids"][1:],
+                   "token_type_ids": s["token_type_ids"] + [x + 1 for x in t["token_type_ids"]],
+                   "attention_mask": s["attention_mask"] + t["attention_mask"]}
+        else:
+            rec = dict(_tok(self.tk, src_text, 2 * L, text_pair=tgt_text))
+        rec.update(labels=int(label), src_item_id=src_id, tgt_item_id=tgt_id)
+        return rec
+
+
+class RobertaTwoTowerDataset(Dataset):
+    """reference data.py:786-832."""
+
+    def __init__(self, data, text_tokenizer, max_seq_en, max_seq_len_pv=None):
+        self.data, self.tk, self.max_seq_len, self.max_seq_len_pv = data, text_tokenizer, max_seq_en, max_seq_len_pv
+
+    def __len__(self):
+        return len(self.data)
+
+    def __getitem__(self, item):
+        label, src_id, _sc, src_title, src_pvs, tgt_id, _tc, tgt_title, tgt_pvs = self.data[item]
+        pv = self.max_seq_len_pv
+        src_text, L = _item_text(self.tk, src_title, src_pvs, self.max_seq_len, pv) if pv is not None else (src_title, self.max_seq_len)
+        tgt_text, _ = _item_text(self.tk, tgt_title, tgt_pvs, self.max_seq_len, pv) if pv is not None else (tgt_title, self.max_seq_len)
+        s, t = _tok(self.tk, src_text, L), _tok(self.tk, tgt_text, L)
+        return {"input_ids_1": s["input_ids"], "token_type_ids_1": s["token_type_ids"], "attention_mask_1": s["attention_mask"],
+                "input_ids_2": t["input_ids"], "token_type_ids_2": t["token_type_ids"], "attention_mask_2": t["attention_mask"],
+                "labels": int(label), "src_item_id": src_id, "tgt_item_id": tgt_id}
+
+
+class _PKGMBase(Dataset):
+    def __init__(self, data, text_tokenizer, kg_entity_tokenizer, kg_relation_tokenizer, max_seq_en, max_pvs, classification_method="cls"):
+        self.data, self.tk = data, text_tokenizer
+        self.ent, self.rel = kg_entity_tokenizer, kg_relation_tokenizer
+        self.max_seq_len, self.max_pvs, self.method = max_seq_en, max_pvs, classification_method
+
+    def __len__(self):
+        return len(self.data)
+
+    def _kg_ids(self, item_id, pvs):
+        """reference data.py:300-318: relation ids of the attributes, preceded by the item's entity id."""
+        ids = []
+        for pv in pvs.split(";"):
+            try:
+                r, _ = pv.split(":", maxsplit=1)
+            except ValueError:
+                continue
+            ids.append(self.rel[r])
+        if ids:
+            ids.insert(0, self.ent[f"/item/{item_id}"])
+        return ids[:1 + self.max_pvs]
+
+    def _text(self, title, first_id, type_id):
+        ids = self.tk.convert_tokens_to_ids(self.tk.tokenize(title))[:self.max_seq_len - 2]
+        ids = [first_id] + ids + [self.tk.sep_token_id]
+        n = len(ids)
+        pad = self.max_seq_len - n
+        return ids + [0] * pad, [1] * n + [0] * pad, [type_id] * self.max_seq_len
+
+    def _kg(self, ids, type_id):
+        """reference pad_kg_sequence: 1 entity + max_pvs relations as ids; masks / types cover 2*max_pvs embedded rows."""
+        n_rel = max(len(ids) - 1, 0)
+        ids = ids + [0] * (1 + self.max_pvs - len(ids))
+        mask = [1] * (2 * n_rel) + [0] * (2 * (self.max_pvs - n_rel))
+        return ids, mask, [type_id] * (2 * self.max_pvs)
+
+
+class PKGMOneTowerDataset(_PKGMBase):
+    """reference data.py:277-391: ids [B, 2*(S+P+1)], mask / types / positions [B, 2*(S+2P)]."""
+
+    def __getitem__(self, item):
+        label, src_id, _sc, src_title, src_pvs, tgt_id, _tc, tgt_title, tgt_pvs = self.data[item]
+        st, sm, stt = self._text(src_title, self.tk.cls_token_id, 0)
+        first = self.tk.bos_token_id if self.method == "vec_sim" else self.tk.sep_token_id
+        tt, tm, ttt = self._text(tgt_title, first, 1)
+        sk, skm, skt = self._kg(self._kg_ids(src_id, src_pvs), 0)
+        tk_, tkm, tkt = self._kg(self._kg_ids(tgt_id, tgt_pvs), 1)
+        rec = {"input_ids": st + sk + tt + tk_, "attention_mask": sm + skm + tm + tkm, "token_type_ids": stt + skt + ttt + tkt,
+               "position_ids": list(range(2 * (self.max_seq_len + 2 * self.max_pvs))), "labels": int(label), "src_item_id": src_id,
+               "tgt_item_id": tgt_id}
+        assert len(rec["input_ids"]) == 2 * (self.max_seq_len + self.max_pvs + 1)
+        assert len(rec["token_type_ids"]) == len(rec["position_ids"]) == len(rec["attention_mask"])
+        return rec
+
+
+class PKGMTwoTowerDataset(_PKGMBase):
+    """reference data.py:394-516."""
+
+    def __getitem__(self, item):
+        label, src_id, _sc, src_title, src_pvs, tgt_id, _tc, tgt_title, tgt_pvs = self.data[item]
+        st, sm, stt = self._text(src_title, self.tk.cls_token_id, 0)
+        tt, tm, ttt = self._text(tgt_title, self.tk.cls_token_id, 0)
+        sk, skm, skt = self._kg(self._kg_ids(src_id, src_pvs), 0)
+        tk_, tkm, tkt = self._kg(self._kg_ids(tgt_id, tgt_pvs), 0)
+        return {"input_ids_1": st + sk, "attention_mask_1": sm + skm, "token_type_ids_1": stt + skt,
+                "input_ids_2": tt + tk_, "attention_mask_2": tm + tkm, "token_type_ids_2": ttt + tkt,
+                "position_ids": list(range(self.max_seq_len + 2 * self.max_pvs)), "labels": int(label), "src_item_id": src_id,
+                "tgt_item_id": tgt_id}
+
+
+class RobertaImageOneTowerDataset(Dataset):
+    """reference data.py:623-679: text pair with an [unused99] image token after each [CLS]/[SEP] + the two
+    pre-extracted image embeddings (data rows carry them as JSON lists)."""
+
+    def __init__(self, data, text_tokenizer, max_seq_len, max_seq_len_pv=None, ensemble="begin"):
+        self.data, self.tk, self.max_seq_len, self.max_seq_len_pv, self.ensemble = data, text_tokenizer, max_seq_len, max_seq_len_pv, ensemble
+
+    def __len__(self):
+        return len(self.data)
+
+    def __getitem__(self, item):
+        import json
+        label, src_id, src_title, src_pvs, src_emb, tgt_id, tgt_title, tgt_pvs, tgt_emb = self.data[item]
+        src_text, L = _item_text(self.tk, src_title, src_pvs, self.max_seq_len, self.max_seq_len_pv)
+        tgt_text, _ = _item_text(self.tk, tgt_title, tgt_pvs, self.max_seq_len, self.max_seq_len_pv)
+        if self.ensemble == "begin":
+            src_text, tgt_text = " ".join((IMG_TOKEN, src_text)), " ".join((IMG_TOKEN, tgt_text))
+        rec = dict(_tok(self.tk, src_text, 2 * L, text_pair=tgt_text))
+        img_pos = [i for i, t in enumerate(rec["input_ids"]) if t == IMG_TOKEN_ID]
+        rec.update(image_indices=img_pos[1] if len(img_pos) > 1 else 0, src_image_emb=json.loads(src_emb) if isinstance(src_emb, str) else src_emb,
+                   tgt_image_emb=json.loads(tgt_emb) if isinstance(tgt_emb, str) else tgt_emb, labels=int(label), src_item_id=src_id,
+                   tgt_item_id=tgt_id)
+        return rec
+
+
+class RobertaImageTwoTowerDataset(Dataset):
+    """reference data.py:682-753."""
+
+    def __init__(self, data, text_tokenizer, max_seq_len, max_seq_len_pv=None, ensemble="begin"):
+        self.data, self.tk, self.max_seq_len, self.max_seq_len_pv, self.ensemble = data, text_tokenizer, max_seq_len, max_seq_len_pv, ensemble
+
+    def __len__(self):
+        return len(self.data)
+
+    def __getitem__(self, item):
+        import json
+        label, src_id, src_title, src_pvs, src_emb, tgt_id, tgt_title, tgt_pvs, tgt_emb = self.data[item]
+        src_text, L = _item_text(self.tk, src_title, src_pvs, self.max_seq_len, self.max_seq_len_pv)
+        tgt_text, _ = _item_text(self.tk, tgt_title, tgt_pvs, self.max_seq_len, self.max_seq_len_pv)
+        if self.ensemble == "begin":
+            src_text, tgt_text = " ".join((IMG_TOKEN, src_text)), " ".join((IMG_TOKEN, tgt_text))
+        s, t = _tok(self.tk, src_text, L), _tok(self.tk, tgt_text, L)
+        return {"input_ids_1": s["input_ids"], "token_type_ids_1": s["token_type_ids"], "attention_mask_1": s["attention_mask"],
+                "input_ids_2": t["input_ids"], "token_type_ids_2": t["token_type_ids"], "attention_mask_2": t["attention_mask"],
+                "src_image_emb": json.loads(src_emb) if isinstance(src_emb, str) else src_emb,
+                "tgt_image_emb": json.loads(tgt_emb) if isinstance(tgt_emb, str) else tgt_emb, "labels": int(label), "src_item_id": src_id,
+                "tgt_item_id": tgt_id}
+
+
+IMAGENET_MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32)
+IMAGENET_STD = np.array([0.229, 0.224, 0.225], dtype=np.float32)
+
+
+def load_image(path, size, is_training=False, hflip=0.5, rng=None):
+    """PIL open -> RGB -> bicubic resize to size x size -> (train: random horizontal flip) -> ImageNet mean/std,
+    CHW fp32: the tensor layout timm's create_transform yields (reference data.py:838-866)."""
+    from PIL import Image
+    img = Image.open(path).convert("RGB").resize((size, size), Image.BICUBIC)
+    a = np.asarray(img, dtype=np.float32) / 255.0
+    if is_training and hflip and (rng or np.random).random() < hflip:
+        a = a[:, ::-1]
+    a = (a - IMAGENET_MEAN) / IMAGENET_STD
+    return torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))
+
+
+class PairedImageDataset(Dataset):
+    """reference data.py:835-869."""
+
+    def __init__(self, data, input_size, is_training, hflip=0.5, color_jitter=None):
+        self.data, self.size, self.train, self.hflip = data, input_size, is_training, hflip
+
+    def __len__(self):
+        return len(self.data)
+
+    def __getitem__(self, item):
+        label, src_id, src_path, tgt_id, tgt_path = self.data[item]
+        rec = {"labels": int(label), "src_item_id": src_id, "tgt_item_id": tgt_id}
+        try:
+            rec["src_input"] = load_image(src_path, self.size, self.train, self.hflip)
+            rec["tgt_input"] = load_image(tgt_path, self.size, self.train, self.hflip)
+        except Exception:
+            pass                        # the collate drops samples without images (reference data.py:848-860, :84)
+        return rec
+
+
+class PairedMultimodalDataset(Dataset):
+    """reference data.py:918-989 (CoCa pairs: text ids with explicit position ids 0..L-1 + two images)."""
+
+    def __init__(self, data, ensemble, image_size, is_training, text_tokenizer, max_seq_len, max_seq_len_pv=None, hflip=0.5,
+                 color_jitter=None):
+        self.data, self.ensemble, self.size, self.train, self.hflip = data, ensemble, image_size, is_training, hflip
+        self.tk, self.max_seq_len, self.max_seq_len_pv = text_tokenizer, max_seq_len, max_seq_len_pv
+
+    def __len__(self):
+        return len(self.data)
+
+    def __getitem__(self, item):
+        label, src_id, src_title, src_pvs, src_path, tgt_id, tgt_title, tgt_pvs, tgt_path = self.data[item]
+        pv = self.max_seq_len_pv
+        src_text, L = _item_text(self.tk, src_title, src_pvs, self.max_seq_len, pv) if pv is not None else (src_title, self.max_seq_len)
+        tgt_text, _ = _item_text(self.tk, tgt_title, tgt_pvs, self.max_seq_len, pv) if pv is not None else (tgt_title, self.max_seq_len)
+        if self.ensemble == "sum":
+            src_text, tgt_text = " ".join((self.tk.bos_token, src_text)), " ".join((self.tk.bos_token, tgt_text))
+        s, t = _tok(self.tk, src_text, L), _tok(self.tk, tgt_text, L)
+        rec = {"src_item_id": src_id, "tgt_item_id": tgt_id, "labels": int(label),
+               "src_input_ids": s["input_ids"], "src_token_type_ids": s["token_type_ids"], "src_attention_mask": s["attention_mask"],
+               "src_position_ids": list(range(len(s["input_ids"]))),
+               "tgt_input_ids": t["input_ids"], "tgt_token_type_ids": t["token_type_ids"], "tgt_attention_mask": t["attention_mask"],
+               "tgt_position_ids": list(range(len(t["input_ids"])))}
+        try:
+            rec["src_image"] = load_image(src_path, self.size, self.train, self.hflip)
+            rec["tgt_image"] = load_image(tgt_path, self.size, self.train, self.hflip)
+        except Exception:
+            pass
+        return rec
