@@ -90,7 +90,7 @@ int ia_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int64_t* 
 size_t ia_embed_ln_bwd_workspace_bytes(int M, int H);
 int ia_embed_ln_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma, const int64_t* ids,
                     const int64_t* type_ids, const int64_t* pos_ids, const int32_t* extra_idx, float* dword, float* dtype, float* dpos,
-                    float* dextra, float* dgamma, float* dbeta, int M, int H, int word_pad, int pos_pad, float drop_p, uint32_t seed,
+                    float* dextra, float* dgamma, float* dbeta, int M, int H, int L, int word_pad, int pos_pad, float drop_p, uint32_t seed,
                     uint32_t stream_id, void* workspace, size_t workspace_bytes, ia_stream_t stream);
 
 /* ---- ViT input side (timm PatchEmbed + cls token + pos_embed; src/models/multimodal.py:811) */

@@ -45,7 +45,7 @@ SIGNATURES = {
     "ia_attn_bwd": (i32, [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, u32, vp]),
     "ia_embed_ln_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, u32, u32, vp]),
     "ia_embed_ln_bwd_workspace_bytes": (sz, [i32, i32]),
-    "ia_embed_ln_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u32, u32,
+    "ia_embed_ln_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, u32, u32,
                                vp, sz, vp]),
     "ia_im2col_patch": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ia_vit_tokens_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),

@@ -57,12 +57,20 @@ IA_DEV uint32_t ia_rng(uint32_t seed, uint32_t stream, uint32_t idx) {
   return ia_mix32(idx ^ ia_mix32(stream ^ (seed * 0x9E3779B9U)));
 }
 
-IA_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-IA_DEV float gelu_erf_grad(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+// erf-GELU (the reference's hidden_act = "gelu": x * Phi(x)).  erf comes from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7,
+// far below bf16 resolution) on one v_rcp + one v_exp, because the GELU epilogues run on the VALU in the shadow of no
+// MFMA work (libm erff costs ~2x as many instructions); exp(-x^2/2) is shared by Phi and the density phi.
+IA_DEV void gelu_parts(float x, float& cdf, float& pdf) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.4426950408889634f));      // exp(-x^2/2) = exp(-z^2)
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - poly * e;
+  cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+  pdf = 0.3989422804014327f * e;
 }
+IA_DEV float gelu_erf(float x) { float c, d; gelu_parts(x, c, d); return x * c; }
+IA_DEV float gelu_erf_grad(float x) { float c, d; gelu_parts(x, c, d); return c + x * d; }
 
 static inline int ia_check_launch() {
   hipError_t e = hipGetLastError();

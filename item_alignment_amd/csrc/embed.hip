@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16* __restric
                                                            const int64_t* __restrict__ tts, const int64_t* __restrict__ pids,
                                                            const int32_t* __restrict__ xidx, float* __restrict__ dword,
                                                            float* __restrict__ dtype, float* __restrict__ dpos,
-                                                           float* __restrict__ dextra, float* __restrict__ part, int M, int H,
+                                                           float* __restrict__ dextra, float* __restrict__ part, int M, int H, int L,
                                                            int word_pad, int pos_pad, uint32_t thr16, float inv_keep, uint32_t seed,
                                                            uint32_t stream) {
   __shared__ float red[2][4][512];
@@ -106,7 +106,38 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16* __restric
   for (int i = 0; i < NV; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; }
-  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+  // A wave owns one position l of the sequence layout [S, L] and walks (its slice of) the S sequences: the rows it
+  // visits share their position id and almost always their token type, so those two gradients are run-length
+  // accumulated in registers and flushed with one atomicAdd per column per run (33M contended atomics on 2+512
+  // table rows became ~L*G*H); word-row gradients go out per token (random rows, no contention).
+  const int S = M / L;
+  const int s_lo = (int)(((long)S * blockIdx.y) / gridDim.y), s_hi = (int)(((long)S * (blockIdx.y + 1)) / gridDim.y);
+  float accp[NV][8], acct[NV][8];
+  for (int l = blockIdx.x * 4 + wave; l < L; l += gridDim.x * 4) {
+  long curp = -1, curt = -1;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { accp[i][j] = 0.f; acct[i][j] = 0.f; }
+  auto flush = [&](float (&acc)[NV][8], float* table, long rowid) {
+    if (table && rowid >= 0) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int col = i * 512 + lane * 8;
+        if (col < H) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) atomicAdd(table + (size_t)rowid * H + col + j, acc[i][j]);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+  };
+  for (int sq = s_lo; sq <= s_hi; ++sq) {
+    if (sq == s_hi) { flush(accp, dpos, curp); flush(acct, dtype, curt); break; }
+    const int row = sq * L + l;
     const float mu = mean[row], rs = rstd[row];
     float g[NV][8], xh[NV][8];
     float s1 = 0.f, s2 = 0.f;
@@ -149,8 +180,10 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16* __restric
     const int64_t wid = ids[row], pid = pids[row];
     float* wdst = xi >= 0 ? (dextra ? dextra + (size_t)xi * H : nullptr)
                           : ((dword && wid != word_pad) ? dword + (size_t)wid * H : nullptr);
-    float* tdst = dtype ? dtype + (size_t)tts[row] * H : nullptr;
-    float* pdst = (dpos && pid != pos_pad) ? dpos + (size_t)pid * H : nullptr;
+    const long tid_now = tts[row];
+    const long pid_now = (pid != pos_pad) ? (long)pid : -1;      // padding_idx row gets no gradient
+    if (pid_now != curp) { flush(accp, dpos, curp); curp = pid_now; }
+    if (tid_now != curt) { flush(acct, dtype, curt); curt = tid_now; }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int col = i * 512 + lane * 8;
@@ -159,11 +192,12 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16* __restric
         for (int j = 0; j < 8; ++j) {
           const float o = rs * (g[i][j] - s1 - xh[i][j] * s2);
           if (wdst) atomicAdd(wdst + col + j, o);
-          if (tdst) atomicAdd(tdst + col + j, o);
-          if (pdst) atomicAdd(pdst + col + j, o);
+          accp[i][j] += o;
+          acct[i][j] += o;
         }
       }
     }
+  }
   }
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -174,7 +208,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16* __restric
     for (int c = threadIdx.x; c < 512 * 2; c += 256) {
       const int w = c / 512, cc = c % 512;
       const int col = i * 512 + cc;
-      if (col < H) part[((size_t)blockIdx.x * 2 + w) * H + col] = red[w][0][cc] + red[w][1][cc] + red[w][2][cc] + red[w][3][cc];
+      if (col < H) part[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + w) * H + col] = red[w][0][cc] + red[w][1][cc] + red[w][2][cc] + red[w][3][cc];
     }
   }
 }
@@ -330,25 +364,36 @@ extern "C" int ia_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, cons
   return ia_check_launch();
 }
 
-extern "C" size_t ia_embed_ln_bwd_workspace_bytes(int M, int H) { return (size_t)ln_blocks(M) * 2 * H * sizeof(float); }
+// grid of the backward kernel: x = blocks of 4 sequence positions, y = slices of the batch of sequences
+static void embed_bwd_grid(int M, int L, int& gx, int& gy) {
+  if (L <= 0 || M % L) L = M;
+  const int S = M / L;
+  gx = (L + 3) / 4; if (gx > 512) gx = 512;
+  gy = 2048 / (gx * 4); if (gy < 1) gy = 1; if (gy > S) gy = S;
+}
+
+extern "C" size_t ia_embed_ln_bwd_workspace_bytes(int M, int H) { return (size_t)2048 * 2 * H * sizeof(float); }
 
 // word_pad / pos_pad: rows of the word / position tables that receive no gradient (nn.Embedding
 // padding_idx, reference base.py:213,234-236); pass -1 for none.  All gradients accumulate (+=).
 extern "C" int ia_embed_ln_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
                                const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const int32_t* extra_idx,
                                float* dword, float* dtype, float* dpos, float* dextra, float* dgamma, float* dbeta, int M, int H,
-                               int word_pad, int pos_pad, float drop_p, uint32_t seed, uint32_t stream_id, void* workspace,
+                               int L, int word_pad, int pos_pad, float drop_p, uint32_t seed, uint32_t stream_id, void* workspace,
                                size_t workspace_bytes, hipStream_t stream) {
   (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!dy || !z || !mean || !rstd || !gamma || !ids || !type_ids || !pos_ids) return IA_ERR_ARG;
   if (M <= 0 || (H & 7) || H > 4096) return IA_ERR_ARG;
   if (!workspace || workspace_bytes < ia_embed_ln_bwd_workspace_bytes(M, H)) return IA_ERR_WORKSPACE;
   uint32_t thr16; float inv_keep; drop_params(drop_p, thr16, inv_keep);
-  const int nb = ln_blocks(M), nv = (H + 511) / 512;
+  if (L <= 0 || M % L) L = M;      // no sequence structure given: every row is its own position
+  int gx, gy; embed_bwd_grid(M, L, gx, gy);
+  const int nb = gx * gy, nv = (H + 511) / 512;
+  if ((size_t)nb * 2 * H * sizeof(float) > workspace_bytes) return IA_ERR_WORKSPACE;
   float* part = (float*)workspace;
-  dim3 grid(nb), blk(256);
+  dim3 grid(gx, gy), blk(256);
 #define IA_E(NV) hipLaunchKernelGGL((embed_ln_bwd_kernel<NV>), grid, blk, 0, stream, (const bf16*)dy, (const bf16*)z, mean, rstd, gamma, ids, \
-    type_ids, pos_ids, extra_idx, dword, dtype, dpos, dextra, part, M, H, word_pad, pos_pad, thr16, inv_keep, seed, stream_id)
+    type_ids, pos_ids, extra_idx, dword, dtype, dpos, dextra, part, M, H, L, word_pad, pos_pad, thr16, inv_keep, seed, stream_id)
   switch (nv) { case 1: IA_E(1); break; case 2: IA_E(2); break; case 3: IA_E(3); break; case 4: IA_E(4); break; default: IA_E(8); }
 #undef IA_E
   hipLaunchKernelGGL(reduce2_kernel, dim3((2 * H + 31) / 32), dim3(1024), 0, stream, part, nb, H, dgamma, dbeta);

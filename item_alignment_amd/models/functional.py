@@ -72,6 +72,7 @@ class EmbedLNFn(torch.autograd.Function):
         ctx.emb, ctx.saved = emb, (ids, tts, pids, extra_idx, z, mean, rstd)
         ctx.drop, ctx.seed, ctx.stream_id = drop_p, seed, stream_id
         ctx.extra_shape = None if extra is None else extra.shape
+        ctx.seq_len = ids.shape[-1] if ids.dim() == 2 else M
         return y
 
     @staticmethod
@@ -90,7 +91,7 @@ class EmbedLNFn(torch.autograd.Function):
         check(lib.ia_embed_ln_bwd(dy.data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), emb.LayerNorm.weight.data_ptr(),
                                   ids.data_ptr(), tts.data_ptr(), pids.data_ptr(), ptr(extra_idx), g(emb.word_embeddings.weight),
                                   g(emb.token_type_embeddings.weight), g(emb.position_embeddings.weight), ptr(dextra),
-                                  g(emb.LayerNorm.weight), g(emb.LayerNorm.bias), M, H, emb.word_pad, emb.pos_pad, ctx.drop, ctx.seed,
+                                  g(emb.LayerNorm.weight), g(emb.LayerNorm.bias), M, H, ctx.seq_len, emb.word_pad, emb.pos_pad, ctx.drop, ctx.seed,
                                   ctx.stream_id, ws.data_ptr(), ws_bytes, stream_ptr()), "ia_embed_ln_bwd")
         _notify([emb.word_embeddings.weight, emb.token_type_embeddings.weight, emb.position_embeddings.weight, emb.LayerNorm.weight,
                  emb.LayerNorm.bias])
