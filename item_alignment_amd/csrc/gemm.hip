@@ -83,11 +83,49 @@ IA_DEV void epi_store4(const GemmArgs& p, int m, int n, f32x4 v) {
   }
 }
 
+// v = 8 consecutive output columns n..n+7 of row m (row-coalesced epilogue of the T256 kernel)
+template <int EPI, bool OUTF32>
+IA_DEV void epi_store8(const GemmArgs& p, int m, int n, f32x4 lo, f32x4 hi) {
+  float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_ADD) {
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { v[r] += b0[r]; v[4 + r] += b1[r]; }
+  }
+  if (EPI == EPI_BIAS_GELU) {
+    bf16x8 pre;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) pre[r] = f2bf(v[r]);
+    *reinterpret_cast<bf16x8*>(p.C2 + (size_t)m * p.ldc + n) = pre;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = gelu_erf(bf2f(pre[r]));
+  }
+  if (EPI == EPI_ADD || EPI == EPI_BIAS_ADD || EPI == EPI_DGELU) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p.aux + (size_t)m * p.ldaux + n);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      if (EPI == EPI_DGELU) v[r] *= gelu_erf_grad(bf2f(a[r]));
+      else v[r] += bf2f(a[r]);
+    }
+  }
+  if (OUTF32) {
+    float* c = p.splits > 1 ? p.ws + ((size_t)blockIdx.y * p.M + m) * p.N + n : reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+    f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+    if (p.splits <= 1 && p.accumulate) { o0 += *reinterpret_cast<const f32x4*>(c); o1 += *reinterpret_cast<const f32x4*>(c + 4); }
+    *reinterpret_cast<f32x4*>(c) = o0;
+    *reinterpret_cast<f32x4*>(c + 4) = o1;
+  } else {
+    bf16x8 o;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) o[r] = f2bf(v[r]);
+    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n) = o;
+  }
+}
+
 // XCD-aware tile order: the 8 XCDs each take a contiguous run of tiles (bijective for any grid size), and
 // inside the run 8 m-tiles are swept per n so one XCD re-uses the same B panel from its private L2.
-IA_DEV void tile_of_block(const GemmArgs& p, int& bm, int& bn) {
-  int bid = blockIdx.x;
-  const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+IA_DEV void tile_of_index(const GemmArgs& p, int bid, int nwg, int& bm, int& bn) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
   bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   const int GM = 8;
   const int group = bid / (GM * p.tiles_n);
@@ -146,7 +184,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   int bm, bn;
-  tile_of_block(p, bm, bn);
+  tile_of_index(p, blockIdx.x, gridDim.x, bm, bn);
   const int m0 = bm * BM, n0 = bn * BN;
   const __amdgpu_buffer_rsrc_t rsA = ia_rsrc(p.A, p.a_bytes);
   const __amdgpu_buffer_rsrc_t rsB = ia_rsrc(p.B, p.b_bytes);
@@ -216,7 +254,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 
 // ============================================================================== T256 (8 waves, 32x32x16)
 namespace t256 {
-constexpr int BM = 256, BN = 256, TILE_BYTES = 32768, LDS_BYTES = 4 * TILE_BYTES;
+constexpr int BM = 256, BN = 256, TILE_BYTES = 32768;
+constexpr int EPI_ROW = 260;                               // floats per staged output row (256 + 4 pad: conflict-free 16 B writes)
+constexpr int LDS_BYTES = 2 * 64 * EPI_ROW * 4;           // 133,120 B: >= the 128 KiB k-tile double buffer
 
 template <bool KS>
 IA_DEV void stage_tile(__amdgpu_buffer_rsrc_t rs, char* s, int kt, int x0, int ld, int K, int tid, int wave) {
@@ -265,21 +305,22 @@ IA_DEV bf16x8 frag_ks(const char* s, int k0, int col0, int lane) {
 // GRP 1: rows 128..255 and the B-operand DMA).  See the schedule comment in gemm_kernel.
 template <int GRP, bool AKS, bool BKS>
 IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][2], __amdgpu_buffer_rsrc_t rs, int x0, int ld, int kt0,
-                      int n_tiles, int nk_all, int wn, int lane) {
+                      int n_tiles, int nk_all, int wn, int lane, bool prologue_only) {
   constexpr bool MYKS = GRP ? BKS : AKS;            // layout of the operand this group streams
   const int hh = lane >> 5, li = lane & 31;
   const int gt = wn * 64 + lane;                    // thread index inside the group (0..255)
-  // loop-invariant per-lane byte offsets of the 8 DMA pieces; the k-tile advance is a scalar (soffset)
-  uint32_t voff[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    if (!MYKS) {
-      const int row = i * 32 + (gt >> 3);
-      voff[i] = (uint32_t)(((x0 + row) * ld + (((gt & 7) ^ ((row >> 1) & 7)) * 8)) * 2);
-    } else {
-      const int row = i * 8 + (gt >> 5);
-      voff[i] = (uint32_t)((row * ld + x0 + (((gt & 31) ^ ((row & 3) << 2)) * 8)) * 2);
-    }
+  // One per-lane byte offset serves all 8 DMA pieces of a half tile: the swizzled chunk a lane fetches does not
+  // depend on the piece (the row advance per piece is a multiple of the swizzle period), so piece and k-tile
+  // advances are both scalars folded into the instruction's soffset.
+  uint32_t voff0, piece_step;
+  if (!MYKS) {
+    const int row = gt >> 3;
+    voff0 = (uint32_t)(((x0 + row) * ld + (((gt & 7) ^ ((row >> 1) & 7)) * 8)) * 2);
+    piece_step = (uint32_t)(32 * ld * 2);
+  } else {
+    const int row = gt >> 5;
+    voff0 = (uint32_t)((row * ld + x0 + (((gt & 31) ^ ((row & 3) << 2)) * 8)) * 2);
+    piece_step = (uint32_t)(8 * ld * 2);
   }
   const uint32_t kstep = MYKS ? (uint32_t)(BK * ld * 2) : (uint32_t)(BK * 2);
   const bool ragged_k = (p.K & (BK - 1)) != 0;
@@ -289,21 +330,24 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][2], __amdg
     char* dst = my_half + (u & 1) * 2 * TILE_BYTES + i * 4096;
     const int kt = kt0 + u;
     if (!ragged_k || kt != nk_all - 1) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, IA_LDS(dst), 16, voff[i], (int)(kt * kstep), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, IA_LDS(dst), 16, voff0, (int)(kt * kstep + i * piece_step), 0, 0);
     } else {                                        // last, partial k-tile: lanes past K fetch zeros
-      const int k = MYKS ? kt * BK + i * 8 + (gt >> 5) : kt * BK + ((gt & 7) ^ (((i * 32 + (gt >> 3)) >> 1) & 7)) * 8;
-      const uint32_t off = k < p.K ? voff[i] + kt * kstep : OOB;
+      const int k = MYKS ? kt * BK + i * 8 + (gt >> 5) : kt * BK + ((gt & 7) ^ (((gt >> 3) >> 1) & 7)) * 8;
+      const uint32_t off = k < p.K ? voff0 + kt * kstep + i * piece_step : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, IA_LDS(dst), 16, off, 0, 0, 0);
     }
   };
 
+  if (prologue_only) {       // called ahead of time (before the previous tile's epilogue): just start the first two k-tiles
 #pragma unroll
-  for (int i = 0; i < 8; ++i) dma_piece(0, i);
-  if (n_tiles > 1) {
+    for (int i = 0; i < 8; ++i) dma_piece(0, i);
+    if (n_tiles > 1) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dma_piece(1, i);
+      for (int i = 0; i < 8; ++i) dma_piece(1, i);
+    }
+    return;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prologue DMA (and the previous tile's stores)
   __builtin_amdgcn_s_barrier();
   if (GRP == 1) __builtin_amdgcn_s_barrier();      // G1 idles through phase 0
 
@@ -320,6 +364,7 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][2], __amdg
       for (int i = 0; i < 8; ++i) dma_piece(u + 1, i);
     }
     bf16x8 af[4][4], bfr[4][2];
+    if (!(p.dbg & 8) || u == 0)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
@@ -336,7 +381,7 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][2], __amdg
     if (GRP == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // G1's DMA issued in its previous COMPUTE
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
+    if (!(p.dbg & 16)) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     // ------------------------------------------------------------------ COMPUTE phase
     // G1 streams its 8 DMA pieces of k-tile u+2 in the shadow of its own MFMAs: one piece per 4 MFMAs
@@ -354,7 +399,7 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][2], __amdg
     __builtin_amdgcn_s_setprio(0);
     if (GRP == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // G0's DMA issued in this iteration's LOAD
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
+    if (!(p.dbg & 16)) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   }
   if (GRP == 0) __builtin_amdgcn_s_barrier();      // matches G1's last phase
@@ -363,24 +408,13 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][2], __amdg
 template <bool AKS, bool BKS, int EPI, bool OUTF32>
 __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, li = lane & 31;
+  const int tid = threadIdx.x, lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;          // 2 x 4 waves, 128 x 64 each; waves w and w+4 share a SIMD
-  int bm, bn;
-  tile_of_block(p, bm, bn);
-  const int m0 = bm * BM, n0 = bn * BN;
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
   const int nk_all = (p.K + BK - 1) / BK;
   const int kt0 = blockIdx.y * p.nk_per_split;
   const int n_tiles = min(nk_all, kt0 + p.nk_per_split) - kt0;
+  const int total_tiles = p.tiles_m * p.tiles_n;
 
   // Ping-pong schedule.  The 8 waves form two groups (grp = wm: rows 0..127 / 128..255 of the block tile); every
   // SIMD hosts one wave of each group.  A wave alternates a LOAD phase (all 24 fragment reads of one k-tile into
@@ -391,25 +425,80 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs p) {
   // LDS holds two k-tiles; tile u+2 goes into the buffer of tile u once both groups have read it (after phase
   // 2u+1): G0 streams the A half during its LOAD(u+1), G1 the B half between the MFMAs of its COMPUTE(u), and
   // each waits for its own DMA one phase later, i.e. before the barrier that ends phase 2u+3.
-  if (wm == 0) main_loop<0, AKS, BKS>(p, smem, acc, ia_rsrc(p.A, p.a_bytes), m0, p.lda, kt0, n_tiles, nk_all, wn, lane);
-  else         main_loop<1, AKS, BKS>(p, smem, acc, ia_rsrc(p.B, p.b_bytes), n0, p.ldb, kt0, n_tiles, nk_all, wn, lane);
+  //
+  // The workgroup is persistent over output tiles (one workgroup per CU): the DMA of the NEXT tile's first two
+  // k-tiles is issued before the current tile's epilogue, so the ~2 us HBM round trip of a tile prologue hides
+  // behind the epilogue's stores instead of idling the CU.
+  auto run = [&](int tile, bool prologue_only, f32x16 (&acc)[4][2]) {
+    int bm, bn;
+    tile_of_index(p, tile, total_tiles, bm, bn);
+    // keep per-lane address arithmetic from being hoisted out of the tile loop (it would stay live across the
+    // epilogue and push the 256-register kernel into scratch): every call derives it afresh from an opaque lane id
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    if (wm == 0) main_loop<0, AKS, BKS>(p, smem, acc, ia_rsrc(p.A, p.a_bytes), bm * BM, p.lda, kt0, n_tiles, nk_all, wn, lane, prologue_only);
+    else         main_loop<1, AKS, BKS>(p, smem, acc, ia_rsrc(p.B, p.b_bytes), bn * BN, p.ldb, kt0, n_tiles, nk_all, wn, lane, prologue_only);
+  };
 
-  // C^T fragment: lane (m = li, half hh) register r <-> fragment row i = (r&3) + 8*(r>>2) + 4*hh;
-  // k-contiguous B: n = hh*16 + r (16 consecutive columns); k-strided B: n = i.
+  f32x16 acc[4][2];
+  int tile = blockIdx.x;
+  run(tile, true, acc);
+  while (true) {
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int m = m0 + wm * 128 + mi * 32 + li;
-    if (m >= p.M) continue;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int n = n0 + wn * 64 + ni * 32 + (BKS ? rg * 8 + hh * 4 : hh * 16 + rg * 4);
-        if (n >= p.N) continue;
-        const f32x4 v = {acc[mi][ni][rg * 4], acc[mi][ni][rg * 4 + 1], acc[mi][ni][rg * 4 + 2], acc[mi][ni][rg * 4 + 3]};
-        epi_store4<EPI, OUTF32>(p, m, n, v);
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    run(tile, false, acc);
+    const int next = tile + gridDim.x;
+
+    // Epilogue through LDS (free once the main loop's last barrier has passed): the MFMA C^T fragments give each lane
+    // 4-element runs scattered over 32 rows, which as direct global stores cost ~11 us per tile (64 separate
+    // segments per store instruction).  Instead each group stages 64 rows x 256 columns of fp32 at a time, then
+    // every wave streams whole 1 KiB rows: bias / residual / GELU inputs are read and all outputs written fully
+    // coalesced (16 B per lane, 512 B runs).  C^T fragment: lane (m = li, half hh) register r <-> fragment row
+    // i = (r&3) + 8*(r>>2) + 4*hh; k-contiguous B: n = hh*16 + r; k-strided B: n = i.
+    int bm, bn;
+    tile_of_index(p, tile, total_tiles, bm, bn);
+    const int m0 = bm * BM, n0 = bn * BN;
+    int lane_e = lane0;
+    asm volatile("" : "+v"(lane_e));
+    const int hh = lane_e >> 5, li = lane_e & 31;
+    float* gbuf = reinterpret_cast<float*>(smem) + wm * (64 * EPI_ROW);
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh) {
+        const int mi = ps * 2 + mh;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int ncol = wn * 64 + ni * 32 + (BKS ? rg * 8 + hh * 4 : hh * 16 + rg * 4);
+            const f32x4 v = {acc[mi][ni][rg * 4], acc[mi][ni][rg * 4 + 1], acc[mi][ni][rg * 4 + 2], acc[mi][ni][rg * 4 + 3]};
+            *reinterpret_cast<f32x4*>(gbuf + (mh * 32 + li) * EPI_ROW + ncol) = v;
+          }
+        }
       }
+      __syncthreads();
+      // wave wn streams rows wn*16 .. wn*16+15 of the staged 64; a half-wave covers one row (32 lanes x 8 columns)
+#pragma unroll 2
+      for (int st = 0; st < 8; ++st) {
+        const int rl = wn * 16 + st * 2 + hh;
+        const int m = m0 + wm * 128 + ps * 64 + rl;
+        const int n = n0 + li * 8;
+        if (m < p.M && n < p.N) {
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(gbuf + rl * EPI_ROW + li * 8);
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(gbuf + rl * EPI_ROW + li * 8 + 4);
+          epi_store8<EPI, OUTF32>(p, m, n, lo, hi);
+        }
+      }
+      __syncthreads();
     }
+    if (next < total_tiles) run(next, true, acc);     // start the next tile's first two k-tiles right away
+    if (next >= total_tiles) break;
+    tile = next;
   }
 }
 }  // namespace t256
@@ -448,7 +537,7 @@ Plan make_plan(int M, int N, int K, bool f32_out) {
   const int nk = (K + BK - 1) / BK;
   const long t256n = (long)((M + 255) / 256) * ((N + 255) / 256);
   const int smax = f32_out ? (nk / 8 > 32 ? 32 : (nk / 8 < 1 ? 1 : nk / 8)) : 1;
-  pl.big = M >= 256 && N >= 256 && t256n * smax >= 160;
+  pl.big = M >= 256 && N >= 256 && (N & 7) == 0 && t256n * smax >= 160;
   const long tiles = pl.big ? t256n : (long)((M + 127) / 128) * ((N + 127) / 128);
   const int target = pl.big ? 256 : 512;
   int s = (int)((target + tiles - 1) / tiles);
@@ -470,7 +559,9 @@ int launch(GemmArgs a, bool big, hipStream_t st) {
       if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES) != hipSuccess) return IA_ERR_LAUNCH;
       attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n, a.splits), dim3(512), t256::LDS_BYTES, st, a);
+    const int ntile = a.tiles_m * a.tiles_n;
+    const int gx = a.splits > 1 ? ntile : (ntile < 256 ? ntile : 256);   // persistent over tiles, one workgroup per CU
+    hipLaunchKernelGGL(kern, dim3(gx, a.splits), dim3(512), t256::LDS_BYTES, st, a);
   } else {
     a.tiles_m = (a.M + t128::BM - 1) / t128::BM; a.tiles_n = (a.N + t128::BN - 1) / t128::BN;
     hipLaunchKernelGGL((t128::gemm_kernel<AKS, BKS, EPI, OUTF32>), dim3(a.tiles_m * a.tiles_n, a.splits), dim3(256), 0, st, a);
