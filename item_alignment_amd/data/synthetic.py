@@ -54,7 +54,7 @@ def one_tower_text(rs, n_pairs, max_title=50, max_pv=205, full_length=False):
 
 class SyntheticCocaPairs:
     """Batches for CoCaForItemAlignment in collate_coca_pair order (reference data.py:73-74, after the two id lists):
-    input_ids_1, attention_mask_1, token_type_ids_1, position_ids_1(None), images_1, ..._2, labels."""
+    input_ids_1, attention_mask_1, token_type_ids_1, position_ids_1, images_1, ..._2, labels."""
 
     def __init__(self, n_pairs, image_size=384, max_title=50, max_pv=205, seed=2345, full_length=False):
         rs = np.random.RandomState(seed)
@@ -70,5 +70,7 @@ class SyntheticCocaPairs:
         im1 = torch.randn((len(idx), 3, S, S), generator=g).to(device)
         im2 = torch.randn((len(idx), 3, S, S), generator=g).to(device)
         labels = torch.from_numpy(self.labels[idx]).to(device)
-        return (t["input_ids_1"], t["attention_mask_1"], t["token_type_ids_1"], None, im1,
-                t["input_ids_2"], t["attention_mask_2"], t["token_type_ids_2"], None, im2, labels)
+        # PairedMultimodalDataset emits explicit position ids 0..L-1 (reference data.py:979,984)
+        pos = torch.arange(t["input_ids_1"].shape[1], device=device).unsqueeze(0).expand(len(idx), -1).contiguous()
+        return (t["input_ids_1"], t["attention_mask_1"], t["token_type_ids_1"], pos, im1,
+                t["input_ids_2"], t["attention_mask_2"], t["token_type_ids_2"], pos, im2, labels)

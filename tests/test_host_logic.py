@@ -53,7 +53,7 @@ def test_synthetic_batches_have_the_collate_layouts():
     from item_alignment_amd.data.synthetic import SyntheticCocaPairs, one_tower_text
     d = SyntheticCocaPairs(8, image_size=32, seed=2345)
     b = d.batch([0, 1, 2], "cpu")
-    assert len(b) == 11 and b[3] is None and b[8] is None
+    assert len(b) == 11 and b[3].shape == (3, 255) and b[3][0, :3].tolist() == [0, 1, 2]
     ids, mask = b[0], b[1]
     assert ids.shape == (3, 255) and ids.dtype == torch.int64 and (ids[:, 0] == 101).all()
     assert torch.equal(mask, (ids != 0).long())
