@@ -81,6 +81,9 @@ def load():
         raise ItemAlignError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C item_alignment_amd/csrc`). The MI355X path has no CPU fallback.")
+    # torch must be imported first: it brings its own libamdhip64, and the extension has to bind to THAT runtime
+    # instance (loading /opt/rocm's copy first leaves the process with a runtime that sees no device)
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so is stale

@@ -72,7 +72,10 @@ IA_DEV void gelu_parts(float x, float& cdf, float& pdf) {
 IA_DEV float gelu_erf(float x) { float c, d; gelu_parts(x, c, d); return x * c; }
 IA_DEV float gelu_erf_grad(float x) { float c, d; gelu_parts(x, c, d); return c + x * d; }
 
+// last HIP status seen by a failed launch check (reported by ia_strerror(IA_ERR_LAUNCH))
+inline hipError_t g_ia_last_hip_error = hipSuccess;
 static inline int ia_check_launch() {
   hipError_t e = hipGetLastError();
+  if (e != hipSuccess) g_ia_last_hip_error = e;
   return e == hipSuccess ? IA_OK : IA_ERR_LAUNCH;
 }

@@ -6,6 +6,7 @@
 // live in four flat arenas with identical element offsets; one launch walks a static chunk table
 // {offset, count, weight-decay flag} and also refreshes the bf16 shadow copy the GEMMs read.
 #include "common.h"
+#include <cstdio>
 
 namespace {
 
@@ -107,7 +108,11 @@ extern "C" const char* ia_strerror(int code) {
   switch (code) {
     case IA_OK: return "ok";
     case IA_ERR_ARG: return "invalid argument (null pointer, shape or alignment)";
-    case IA_ERR_LAUNCH: return "HIP kernel launch failed";
+    case IA_ERR_LAUNCH: {
+      static char buf[256];
+      snprintf(buf, sizeof buf, "HIP kernel launch failed: %s", hipGetErrorString(g_ia_last_hip_error));
+      return buf;
+    }
     case IA_ERR_WORKSPACE: return "workspace missing or too small";
     case IA_ERR_UNSUPPORTED: return "unsupported operand layout / epilogue combination";
   }
