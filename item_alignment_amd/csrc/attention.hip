@@ -17,6 +17,7 @@
 //   attn_bwd_dq  (block owns 128 queries, S^T orientation):  dQ^T += K^T dS^T
 //   attn_bwd_dkv (block owns 128 keys,   S orientation):     dV^T += dO^T P ; dK^T += Q^T dS
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -38,6 +39,34 @@ struct AttnArgs {
   float scale;                                    // softmax scale
   uint32_t thr16; float inv_keep; uint32_t seed;
 };
+
+// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): renumber them so that consecutive
+// work items -- the 128-row tiles of one (sequence, head), which all stream the same K/V -- share an XCD.
+IA_DEV void attn_block_coords(const AttnArgs& p, int& tile, int& h, int& b) {
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int per = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+#ifdef IA_NO_XCD
+  int w = bid;
+#else
+  int w = (xcd < r ? xcd * (per + 1) : r * (per + 1) + (xcd - r) * per) + idx;
+#endif
+  const int nt = (p.L + 127) >> 7;
+  tile = w % nt; w /= nt;
+  h = w % p.nh; b = w / p.nh;
+}
+
+// Per 64-key tile, the ballot of attendable keys (in range and not masked), built once per workgroup: a mask byte
+// fetched inside the tile loop would make the wave wait for the next tile's LDS-DMA as well (vmcnt is in-order).
+constexpr int MAX_KT = 32;   // L <= 2048
+IA_DEV void build_valid_table(const AttnArgs& p, uint32_t (*s_valid)[2], size_t rowbase, int L, int lane, int wave) {
+  const int nkt = (L + 63) >> 6;
+  for (int t = wave; t < nkt; t += 4) {
+    const int key = t * 64 + lane;
+    const bool kv = key < L && (p.mask == nullptr || p.mask[rowbase + key] != 0);
+    const uint64_t vb = __ballot(kv);
+    if (lane == 0) { s_valid[t][0] = (uint32_t)vb; s_valid[t][1] = (uint32_t)(vb >> 32); }
+  }
+}
 
 // K tile / Q tile read with ds_read_b128 (row = key or query, 128 B rows, 16 B chunk XOR row&7)
 IA_DEV int swz_b128(int row) { return row & 7; }
@@ -62,16 +91,43 @@ IA_DEV bf16x8 frag_b128(const char* s, int row, int chunk) {
 }
 
 // A^T fragment for MFMA 32x32x16 out of a row-major [row][64] tile: lane (i = lane&31 -> column,
-// half = lane>>5) gets rows row0 + {0..3, 8..11} + 4*half of column col0 + i.
-IA_DEV bf16x8 frag_tr(const char* s, int row0, int col0, int lane) {
+// half = lane>>5) gets rows row0 + {0..3, 8..11} + 4*half of column col0 + i  (ds_read_b64_tr_b16 x2).
+//
+// The reads are issued through inline asm: hipcc (ROCm 7.2) treats the transpose-read builtin as possibly aliasing a
+// pending LDS-DMA and drains vmcnt(0) in front of it, which serialises the next tile's K/V fetch with this tile's
+// math. An asm read is invisible to the compiler's counters, so every use sits behind tr_wait<N>().
+IA_DEV uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)IA_LDS(p); }
+
+// byte offset of this lane's element inside a tile for column block col0 (0 or 32), row block 0
+IA_DEV uint32_t tr_lane_off(int lane, int col0) {
   const int p = lane & 15, G = lane >> 4;
-  const int row = row0 + 4 * (G >> 1) + (p >> 2);
+  const int row = 4 * (G >> 1) + (p >> 2);
   const int col = col0 + 16 * (G & 1) + (p & 3) * 4;
-  const int addr = row * 128 + ((((col >> 3) ^ swz_tr(row))) << 4) + (col & 7) * 2;
-  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(s + addr));
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(s + addr + 8 * 128));
-  s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf16x8, r);
+  return (uint32_t)(row * 128 + ((((col >> 3) ^ swz_tr(row))) << 4) + (col & 7) * 2);
+}
+
+template <int OFF>
+IA_DEV s16x4 tr_read(uint32_t base) {
+  s16x4 d;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(base), "n"(OFF));
+  return d;
+}
+
+struct TrPair {   // the two A^T fragments (columns 0..31 and 32..63) of one 16-row step
+  s16x4 lo0, hi0, lo1, hi1;
+  IA_DEV bf16x8 a0() const { s16x8 r = {lo0[0], lo0[1], lo0[2], lo0[3], hi0[0], hi0[1], hi0[2], hi0[3]}; return __builtin_bit_cast(bf16x8, r); }
+  IA_DEV bf16x8 a1() const { s16x8 r = {lo1[0], lo1[1], lo1[2], lo1[3], hi1[0], hi1[1], hi1[2], hi1[3]}; return __builtin_bit_cast(bf16x8, r); }
+};
+// rows ROW0 .. ROW0+15 (ROW0 a multiple of 16) of the tile whose lane bases are b0 / b1 (tr_lane_off for col0 = 0 / 32)
+template <int ROW0>
+IA_DEV void tr_issue(TrPair& f, uint32_t b0, uint32_t b1) {
+  f.lo0 = tr_read<ROW0 * 128>(b0); f.hi0 = tr_read<ROW0 * 128 + 1024>(b0);
+  f.lo1 = tr_read<ROW0 * 128>(b1); f.hi1 = tr_read<ROW0 * 128 + 1024>(b1);
+}
+// wait until at most N LDS operations issued after this pair are still outstanding (LDS returns in order)
+template <int N>
+IA_DEV void tr_wait(TrPair& f) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f.lo0), "+v"(f.hi0), "+v"(f.lo1), "+v"(f.hi1) : "n"(N));
 }
 
 IA_DEV f32x16 zero16() {
@@ -91,14 +147,101 @@ IA_DEV bool drop_keep(uint32_t seed, uint32_t stream, int q, int key, uint32_t t
   return u >= thr16;
 }
 
+// One 64-key tile of the forward pass for this wave's 32 queries (S^T orientation, see the header comment).
+// m_run / l_run: running max (scaled log2 domain) and sum of this lane's half of the keys.
+template <bool DROPOUT>
+IA_DEV void fwd_tile(const AttnArgs& p, const char* sK, const bf16x8 (&qf)[4], uint32_t valid_lo, uint32_t valid_hi, float& m_run,
+                     float& l_run, f32x16& o0, f32x16& o1, int lane, int q, int kt, uint32_t stream_id) {
+  const int hh = lane >> 5, lq = lane & 31;
+  const char* sV = sK + 8192;
+  f32x16 s0 = zero16(), s1 = zero16();
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    const bf16x8 k0 = frag_b128(sK, lq, kb * 2 + hh);
+    const bf16x8 k1 = frag_b128(sK, 32 + lq, kb * 2 + hh);
+    s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[kb], s0, 0, 0, 0);
+    s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[kb], s1, 0, 0, 0);
+  }
+  // V^T fragments of the first two 16-key steps land while the softmax runs
+  const uint32_t vb0 = lds_addr(sV) + tr_lane_off(lane, 0), vb1 = lds_addr(sV) + tr_lane_off(lane, 32);
+  TrPair va, vb;
+  tr_issue<0>(va, vb0, vb1);
+  tr_issue<16>(vb, vb0, vb1);
+  if ((valid_lo & valid_hi) != 0xFFFFFFFFu) {   // wave-uniform: only a ragged / padded tile pays for the selects
+    const uint32_t vlo = hh ? valid_lo >> 4 : valid_lo, vhi = hh ? valid_hi >> 4 : valid_hi;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int bit = (r & 3) + 8 * (r >> 2);
+      if (!((vlo >> bit) & 1)) s0[r] = -INFINITY;
+      if (!((vhi >> bit) & 1)) s1[r] = -INFINITY;
+    }
+  }
+  float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+  for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.sc;   // sc > 0: max(s) * sc == max(s * sc)
+  const float m_new = fmaxf(m_run, mx);
+  const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+  const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+  const float neg_m = -m_use;
+  float rs = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], p.sc, neg_m));
+    s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], p.sc, neg_m));
+    rs += s0[r] + s1[r];
+  }
+  l_run = l_run * alpha + rs;
+  m_run = m_new;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+  if (DROPOUT) {
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const int kl = ACC_ROW(r, hh);   // even key, r+1 is the odd neighbour
+      const uint32_t ra = ia_rng(p.seed, stream_id, (uint32_t)q * 1024u + (uint32_t)((kt * 64 + kl) >> 1));
+      const uint32_t rb = ia_rng(p.seed, stream_id, (uint32_t)q * 1024u + (uint32_t)((kt * 64 + 32 + kl) >> 1));
+      if ((ra & 0xFFFFu) < p.thr16) s0[r] = 0.f;
+      if ((ra >> 16) < p.thr16) s0[r + 1] = 0.f;
+      if ((rb & 0xFFFFu) < p.thr16) s1[r] = 0.f;
+      if ((rb >> 16) < p.thr16) s1[r + 1] = 0.f;
+    }
+  }
+  bf16x8 pf[4];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    pf[0][j] = f2bf(s0[j]); pf[1][j] = f2bf(s0[8 + j]);
+    pf[2][j] = f2bf(s1[j]); pf[3][j] = f2bf(s1[8 + j]);
+  }
+  tr_wait<4>(va);
+  o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va.a0(), pf[0], o0, 0, 0, 0);
+  o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va.a1(), pf[0], o1, 0, 0, 0);
+  TrPair vc, vd;
+  tr_issue<32>(vc, vb0, vb1);
+  tr_wait<4>(vb);
+  o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb.a0(), pf[1], o0, 0, 0, 0);
+  o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb.a1(), pf[1], o1, 0, 0, 0);
+  tr_issue<48>(vd, vb0, vb1);
+  tr_wait<4>(vc);
+  o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vc.a0(), pf[2], o0, 0, 0, 0);
+  o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vc.a1(), pf[2], o1, 0, 0, 0);
+  tr_wait<0>(vd);
+  o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vd.a0(), pf[3], o0, 0, 0, 0);
+  o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vd.a1(), pf[3], o1, 0, 0, 0);
+}
+
 // ------------------------------------------------------------------------------------------ forward
 template <bool DROPOUT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
+  // one __shared__ object only: with a second one hipcc drains vmcnt(0) before every LDS read while a DMA is in flight
+  __shared__ __attribute__((aligned(16))) char smem[2 * 16384 + MAX_KT * 8];
+  uint32_t (*s_valid)[2] = reinterpret_cast<uint32_t (*)[2]>(smem + 2 * 16384);
   const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, lq = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.z, h = blockIdx.y, L = p.L;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  int tile, h, b;
+  attn_block_coords(p, tile, h, b);
+  const int L = p.L;
+  const int q0 = tile * 128 + wave * 32;
   const size_t rowbase = (size_t)b * L;
   const bool active = q0 < L;
   const int q = q0 + lq;
@@ -118,6 +261,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
   const int nkt = (L + 63) >> 6;
   stage64<false>(rsK, smem, rowbase, L, p.ld_qkv, h * 64, tid, wave);
   stage64<true>(rsV, smem + 8192, rowbase, L, p.ld_qkv, h * 64, tid, wave);
+  build_valid_table(p, s_valid, rowbase, L, lane, wave);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const uint32_t stream_id = (uint32_t)(b * p.nh + h);
@@ -131,69 +275,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     }
     if (active) {
       const char* sK = smem + buf * 16384;
-      const char* sV = sK + 8192;
-      const int key = kt * 64 + lane;
-      const bool kv = key < L && (p.mask == nullptr || p.mask[rowbase + key] != 0);
-      const uint64_t valid = __ballot(kv);
-      uint32_t vlo = (uint32_t)valid, vhi = (uint32_t)(valid >> 32);
-      if (hh) { vlo >>= 4; vhi >>= 4; }
-
-      f32x16 s0 = zero16(), s1 = zero16();
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {
-        const bf16x8 k0 = frag_b128(sK, lq, kb * 2 + hh);
-        const bf16x8 k1 = frag_b128(sK, 32 + lq, kb * 2 + hh);
-        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[kb], s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[kb], s1, 0, 0, 0);
-      }
-      float mx = -INFINITY;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int bit = (r & 3) + 8 * (r >> 2);
-        s0[r] = ((vlo >> bit) & 1) ? s0[r] * p.sc : -INFINITY;
-        s1[r] = ((vhi >> bit) & 1) ? s1[r] * p.sc : -INFINITY;
-        mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-      float rs = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_use);
-        s1[r] = __builtin_amdgcn_exp2f(s1[r] - m_use);
-        rs += s0[r] + s1[r];
-      }
-      l_run = l_run * alpha + rs;
-      m_run = m_new;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-      if (DROPOUT) {
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const int kl = ACC_ROW(r, hh);   // even key, r+1 is the odd neighbour
-          const uint32_t ra = ia_rng(p.seed, stream_id, (uint32_t)q * 1024u + (uint32_t)((kt * 64 + kl) >> 1));
-          const uint32_t rb = ia_rng(p.seed, stream_id, (uint32_t)q * 1024u + (uint32_t)((kt * 64 + 32 + kl) >> 1));
-          if ((ra & 0xFFFFu) < p.thr16) s0[r] = 0.f;
-          if ((ra >> 16) < p.thr16) s0[r + 1] = 0.f;
-          if ((rb & 0xFFFFu) < p.thr16) s1[r] = 0.f;
-          if ((rb >> 16) < p.thr16) s1[r + 1] = 0.f;
-        }
-      }
-      bf16x8 pf[4];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        pf[0][j] = f2bf(s0[j]); pf[1][j] = f2bf(s0[8 + j]);
-        pf[2][j] = f2bf(s1[j]); pf[3][j] = f2bf(s1[8 + j]);
-      }
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {
-        const bf16x8 v0 = frag_tr(sV, kb * 16, 0, lane);
-        const bf16x8 v1 = frag_tr(sV, kb * 16, 32, lane);
-        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf[kb], o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf[kb], o1, 0, 0, 0);
-      }
+      const uint32_t valid_lo = __builtin_amdgcn_readfirstlane(s_valid[kt][0]);
+      const uint32_t valid_hi = __builtin_amdgcn_readfirstlane(s_valid[kt][1]);
+      // a tile with no attendable key contributes nothing
+      if ((valid_lo | valid_hi) != 0u) fwd_tile<DROPOUT>(p, sK, qf, valid_lo, valid_hi, m_run, l_run, o0, o1, lane, q, kt, stream_id);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -235,14 +320,87 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs p) {
 }
 
 // ------------------------------------------------------------------------------------- backward: dQ
+// One 64-key tile for this wave's 32 queries: dQ^T += K^T dS^T with dS^T = P^T (dP^T - delta) (the softmax scale is
+// applied once, when dQ is stored).
 template <bool DROPOUT>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
-  // per buffer: K (b128 layout) | K (transpose-read layout) | V (b128 layout) = 24 KiB
-  __shared__ __attribute__((aligned(16))) char smem[2 * 24576];
+IA_DEV void dq_tile(const AttnArgs& p, const char* sK, const bf16x8 (&qf)[4], const bf16x8 (&gf)[4], uint32_t valid_lo,
+                    uint32_t valid_hi, float lse, float dlt, f32x16& dq0, f32x16& dq1, int lane, int q, int kt, uint32_t stream_id) {
+  const int hh = lane >> 5, lq = lane & 31;
+  const char* sKt = sK + 8192;
+  const char* sV = sK + 16384;
+  f32x16 s0 = zero16(), s1 = zero16(), dp0 = zero16(), dp1 = zero16();
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    const bf16x8 k0 = frag_b128(sK, lq, kb * 2 + hh);
+    const bf16x8 k1 = frag_b128(sK, 32 + lq, kb * 2 + hh);
+    s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[kb], s0, 0, 0, 0);
+    s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[kb], s1, 0, 0, 0);
+    const bf16x8 v0 = frag_b128(sV, lq, kb * 2 + hh);
+    const bf16x8 v1 = frag_b128(sV, 32 + lq, kb * 2 + hh);
+    dp0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, gf[kb], dp0, 0, 0, 0);
+    dp1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, gf[kb], dp1, 0, 0, 0);
+  }
+  const uint32_t kb0 = lds_addr(sKt) + tr_lane_off(lane, 0), kb1 = lds_addr(sKt) + tr_lane_off(lane, 32);
+  TrPair ka, kb_;
+  tr_issue<0>(ka, kb0, kb1);
+  tr_issue<16>(kb_, kb0, kb1);
+  if ((valid_lo & valid_hi) != 0xFFFFFFFFu) {   // wave-uniform
+    const uint32_t vlo = hh ? valid_lo >> 4 : valid_lo, vhi = hh ? valid_hi >> 4 : valid_hi;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int bit = (r & 3) + 8 * (r >> 2);
+      if (!((vlo >> bit) & 1)) s0[r] = -INFINITY;
+      if (!((vhi >> bit) & 1)) s1[r] = -INFINITY;
+    }
+  }
+  const float neg_lse = -lse;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float pa = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], p.sc, neg_lse));
+    const float pb = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], p.sc, neg_lse));
+    float da = dp0[r], db = dp1[r];
+    if (DROPOUT) {
+      const int kl = kt * 64 + ACC_ROW(r, hh);
+      da = drop_keep(p.seed, stream_id, q, kl, p.thr16) ? da * p.inv_keep : 0.f;
+      db = drop_keep(p.seed, stream_id, q, kl + 32, p.thr16) ? db * p.inv_keep : 0.f;
+    }
+    s0[r] = pa * (da - dlt);
+    s1[r] = pb * (db - dlt);
+  }
+  bf16x8 sf[4];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sf[0][j] = f2bf(s0[j]); sf[1][j] = f2bf(s0[8 + j]);
+    sf[2][j] = f2bf(s1[j]); sf[3][j] = f2bf(s1[8 + j]);
+  }
+  tr_wait<4>(ka);
+  dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka.a0(), sf[0], dq0, 0, 0, 0);
+  dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka.a1(), sf[0], dq1, 0, 0, 0);
+  TrPair kc, kd;
+  tr_issue<32>(kc, kb0, kb1);
+  tr_wait<4>(kb_);
+  dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb_.a0(), sf[1], dq0, 0, 0, 0);
+  dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb_.a1(), sf[1], dq1, 0, 0, 0);
+  tr_issue<48>(kd, kb0, kb1);
+  tr_wait<4>(kc);
+  dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc.a0(), sf[2], dq0, 0, 0, 0);
+  dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc.a1(), sf[2], dq1, 0, 0, 0);
+  tr_wait<0>(kd);
+  dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kd.a0(), sf[3], dq0, 0, 0, 0);
+  dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kd.a1(), sf[3], dq1, 0, 0, 0);
+}
+
+template <bool DROPOUT>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
+  // per buffer: K (b128 layout) | K (transpose-read layout) | V (b128 layout) = 24 KiB; then the valid-key table
+  __shared__ __attribute__((aligned(16))) char smem[2 * 24576 + MAX_KT * 8];
+  uint32_t (*s_valid)[2] = reinterpret_cast<uint32_t (*)[2]>(smem + 2 * 24576);
   const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, lq = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.z, h = blockIdx.y, L = p.L;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  int tile, h, b;
+  attn_block_coords(p, tile, h, b);
+  const int L = p.L;
+  const int q0 = tile * 128 + wave * 32;
   const size_t rowbase = (size_t)b * L;
   const bool active = q0 < L;
   const int q = q0 + lq;
@@ -270,6 +428,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
   stage64<false>(rsK, smem, rowbase, L, p.ld_qkv, h * 64, tid, wave);
   stage64<true>(rsK, smem + 8192, rowbase, L, p.ld_qkv, h * 64, tid, wave);
   stage64<false>(rsV, smem + 16384, rowbase, L, p.ld_qkv, h * 64, tid, wave);
+  build_valid_table(p, s_valid, rowbase, L, lane, wave);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -283,80 +442,43 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
       stage64<false>(rsV, nb + 16384, r0, nv, p.ld_qkv, h * 64, tid, wave);
     }
     if (active) {
-      const char* sK = smem + buf * 24576;
-      const char* sKt = sK + 8192;
-      const char* sV = sK + 16384;
-      const int key = kt * 64 + lane;
-      const bool kv = key < L && (p.mask == nullptr || p.mask[rowbase + key] != 0);
-      const uint64_t valid = __ballot(kv);
-      uint32_t vlo = (uint32_t)valid, vhi = (uint32_t)(valid >> 32);
-      if (hh) { vlo >>= 4; vhi >>= 4; }
-
-      f32x16 s0 = zero16(), s1 = zero16(), dp0 = zero16(), dp1 = zero16();
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {
-        const bf16x8 k0 = frag_b128(sK, lq, kb * 2 + hh);
-        const bf16x8 k1 = frag_b128(sK, 32 + lq, kb * 2 + hh);
-        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[kb], s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[kb], s1, 0, 0, 0);
-        const bf16x8 v0 = frag_b128(sV, lq, kb * 2 + hh);
-        const bf16x8 v1 = frag_b128(sV, 32 + lq, kb * 2 + hh);
-        dp0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, gf[kb], dp0, 0, 0, 0);
-        dp1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, gf[kb], dp1, 0, 0, 0);
-      }
-      // dS^T = P^T * (dP^T_eff - delta) * scale
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int bit = (r & 3) + 8 * (r >> 2);
-        const float pa = ((vlo >> bit) & 1) ? __builtin_amdgcn_exp2f(s0[r] * p.sc - lse) : 0.f;
-        const float pb = ((vhi >> bit) & 1) ? __builtin_amdgcn_exp2f(s1[r] * p.sc - lse) : 0.f;
-        float da = dp0[r], db = dp1[r];
-        if (DROPOUT) {
-          const int kl = kt * 64 + ACC_ROW(r, hh);
-          da = drop_keep(p.seed, stream_id, q, kl, p.thr16) ? da * p.inv_keep : 0.f;
-          db = drop_keep(p.seed, stream_id, q, kl + 32, p.thr16) ? db * p.inv_keep : 0.f;
-        }
-        s0[r] = pa * (da - dlt) * p.scale;
-        s1[r] = pb * (db - dlt) * p.scale;
-      }
-      bf16x8 sf[4];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        sf[0][j] = f2bf(s0[j]); sf[1][j] = f2bf(s0[8 + j]);
-        sf[2][j] = f2bf(s1[j]); sf[3][j] = f2bf(s1[8 + j]);
-      }
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {
-        const bf16x8 k0 = frag_tr(sKt, kb * 16, 0, lane);
-        const bf16x8 k1 = frag_tr(sKt, kb * 16, 32, lane);
-        dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, sf[kb], dq0, 0, 0, 0);
-        dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, sf[kb], dq1, 0, 0, 0);
-      }
+      const uint32_t valid_lo = __builtin_amdgcn_readfirstlane(s_valid[kt][0]);
+      const uint32_t valid_hi = __builtin_amdgcn_readfirstlane(s_valid[kt][1]);
+      if ((valid_lo | valid_hi) != 0u)
+        dq_tile<DROPOUT>(p, smem + buf * 24576, qf, gf, valid_lo, valid_hi, lse, dlt, dq0, dq1, lane, q, kt, stream_id);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
   if (!active || q >= L) return;
   bf16* op = p.dq + (rowbase + q) * p.ld_dqkv + h * 64;
+  const float sc = p.scale;
 #pragma unroll
   for (int rg = 0; rg < 4; ++rg) {
     const int d = 8 * rg + 4 * hh;
-    bf16x4 a = {f2bf(dq0[rg * 4]), f2bf(dq0[rg * 4 + 1]), f2bf(dq0[rg * 4 + 2]), f2bf(dq0[rg * 4 + 3])};
-    bf16x4 c = {f2bf(dq1[rg * 4]), f2bf(dq1[rg * 4 + 1]), f2bf(dq1[rg * 4 + 2]), f2bf(dq1[rg * 4 + 3])};
+    bf16x4 a = {f2bf(dq0[rg * 4] * sc), f2bf(dq0[rg * 4 + 1] * sc), f2bf(dq0[rg * 4 + 2] * sc), f2bf(dq0[rg * 4 + 3] * sc)};
+    bf16x4 c = {f2bf(dq1[rg * 4] * sc), f2bf(dq1[rg * 4 + 1] * sc), f2bf(dq1[rg * 4 + 2] * sc), f2bf(dq1[rg * 4 + 3] * sc)};
     *reinterpret_cast<bf16x4*>(op + d) = a;
     *reinterpret_cast<bf16x4*>(op + 32 + d) = c;
   }
 }
 
 // ---------------------------------------------------------------------------------- backward: dK, dV
+// S orientation: rows = queries (accumulator registers), column = key = lane. A column of P / dS only ever reaches
+// that key's dK / dV, so the key mask needs no per-element work: a masked key's outputs are simply stored as zero.
+// Rows past the end of the sequence cost nothing either: their Q, dO, lse and delta arrive zero-filled from the DMA
+// (P = 1, dP = 0, dS = 0).
 template <bool DROPOUT>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
-  // per buffer: Q (b128) | Q (transpose-read) | dO (b128) | dO (transpose-read) = 32 KiB
-  __shared__ __attribute__((aligned(16))) char smem[2 * 32768];
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
+  // per buffer: Q (b128) | Q (transpose-read) | dO (b128) | dO (transpose-read) | lse[64] | delta[64]
+  constexpr int BUF = 32768 + 512;
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
   const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, lk = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.z, h = blockIdx.y, L = p.L;
-  const int k0 = blockIdx.x * 128 + wave * 32;
+  int tile, h, b;
+  attn_block_coords(p, tile, h, b);
+  const int L = p.L;
+  const int k0 = tile * 128 + wave * 32;
   const size_t rowbase = (size_t)b * L;
   const bool active = k0 < L;
   const int key = k0 + lk;
@@ -375,9 +497,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
   }
   const __amdgpu_buffer_rsrc_t rsQ = ia_rsrc(p.q, p.qkv_bytes);
   const __amdgpu_buffer_rsrc_t rsG = ia_rsrc(p.d_o, p.o_bytes);
+  const __amdgpu_buffer_rsrc_t rsL = ia_rsrc(p.lse2 + ((size_t)b * p.nh + h) * L, (uint32_t)L * 4u);
+  const __amdgpu_buffer_rsrc_t rsD = ia_rsrc(p.delta + ((size_t)b * p.nh + h) * L, (uint32_t)L * 4u);
   const uint32_t stream_id = (uint32_t)(b * p.nh + h);
-  const float* lse_base = p.lse2 + ((size_t)b * p.nh + h) * L;
-  const float* dlt_base = p.delta + ((size_t)b * p.nh + h) * L;
 
   f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
   const int nqt = (L + 63) >> 6;
@@ -387,6 +509,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
     stage64<true>(rsQ, s + 8192, r0, nv, p.ld_qkv, h * 64, tid, wave);
     stage64<false>(rsG, s + 16384, r0, nv, p.ld_o, h * 64, tid, wave);
     stage64<true>(rsG, s + 24576, r0, nv, p.ld_o, h * 64, tid, wave);
+    // 64 x fp32 each, one 4-byte-per-lane DMA; out-of-range rows read as zero
+    if (wave == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsL, IA_LDS(s + 32768), 4, (uint32_t)(qt * 64 + lane) * 4u, 0, 0, 0);
+    if (wave == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, IA_LDS(s + 32768 + 256), 4, (uint32_t)(qt * 64 + lane) * 4u, 0, 0, 0);
   };
   stage_all(smem, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -394,16 +519,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
 
   for (int qt = 0; qt < nqt; ++qt) {
     const int buf = qt & 1;
-    if (qt + 1 < nqt) stage_all(smem + (buf ^ 1) * 32768, qt + 1);
+    if (qt + 1 < nqt) stage_all(smem + (buf ^ 1) * BUF, qt + 1);
     if (active) {
-      const char* sQ = smem + buf * 32768;
-      const char* sQt = sQ + 8192;
+      const char* sQ = smem + buf * BUF;
       const char* sG = sQ + 16384;
-      const char* sGt = sQ + 24576;
-#pragma unroll
-      for (int qs = 0; qs < 2; ++qs) {
+      const uint32_t qt0 = lds_addr(sQ + 8192) + tr_lane_off(lane, 0), qt1 = lds_addr(sQ + 8192) + tr_lane_off(lane, 32);
+      const uint32_t gt0 = lds_addr(sQ + 24576) + tr_lane_off(lane, 0), gt1 = lds_addr(sQ + 24576) + tr_lane_off(lane, 32);
+      const float* sL = reinterpret_cast<const float*>(sQ + 32768);
+      const float* sD = sL + 64;
+      auto sub_tile = [&](auto QS) {
+        constexpr int qs = decltype(QS)::value;
         const int qb = qt * 64 + qs * 32;     // first query of this 32-row sub tile
-        if (qb >= L) break;
         // S[q][key] = Q K^T ; dP[q][key] = dO V^T   (rows = q in registers, column = key = lane)
         f32x16 s = zero16(), dp = zero16();
 #pragma unroll
@@ -413,46 +539,49 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
           const bf16x8 g = frag_b128(sG, qs * 32 + lk, kb * 2 + hh);
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g, vf[kb], dp, 0, 0, 0);
         }
+        TrPair g0, a0, g1, a1;
+        tr_issue<qs * 32>(g0, gt0, gt1);
+        tr_issue<qs * 32>(a0, qt0, qt1);
+        tr_issue<qs * 32 + 16>(g1, gt0, gt1);
+        tr_issue<qs * 32 + 16>(a1, qt0, qt1);
         bf16x8 pf[2], sf[2];
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-          const int qrow = qb + 8 * rg + 4 * hh;                 // 4 consecutive queries
-          f32x4 ls, dl;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int qi = qrow + j < L ? qrow + j : L - 1;
-            ls[j] = lse_base[qi]; dl[j] = dlt_base[qi];
-          }
+          const int qoff = qs * 32 + 8 * rg + 4 * hh;              // 4 consecutive queries
+          const f32x4 ls = *reinterpret_cast<const f32x4*>(sL + qoff);
+          const f32x4 dl = *reinterpret_cast<const f32x4*>(sD + qoff);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int r = rg * 4 + j;
-            const bool ok = key_ok && (qrow + j < L);
-            float pv = ok ? __builtin_amdgcn_exp2f(s[r] * p.sc - ls[j]) : 0.f;
+            const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], p.sc, -ls[j]));
             float d = dp[r];
             float pd = pv;
             if (DROPOUT) {
-              const bool keep = drop_keep(p.seed, stream_id, qrow + j, key, p.thr16);
+              const bool keep = drop_keep(p.seed, stream_id, qb + 8 * rg + 4 * hh + j, key, p.thr16);
               d = keep ? d * p.inv_keep : 0.f;
               pd = keep ? pv * p.inv_keep : 0.f;
             }
-            const float ds = pv * (d - dl[j]) * p.scale;
+            const float ds = pv * (d - dl[j]);
             pf[r >> 3][r & 7] = f2bf(pd);
             sf[r >> 3][r & 7] = f2bf(ds);
           }
         }
         // dV^T[d][key] += dO^T[d][q] P[q][key] ; dK^T[d][key] += Q^T[d][q] dS[q][key]
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          const bf16x8 g0 = frag_tr(sGt, qs * 32 + kb * 16, 0, lane);
-          const bf16x8 g1 = frag_tr(sGt, qs * 32 + kb * 16, 32, lane);
-          dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, pf[kb], dv0, 0, 0, 0);
-          dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, pf[kb], dv1, 0, 0, 0);
-          const bf16x8 a0 = frag_tr(sQt, qs * 32 + kb * 16, 0, lane);
-          const bf16x8 a1 = frag_tr(sQt, qs * 32 + kb * 16, 32, lane);
-          dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, sf[kb], dk0, 0, 0, 0);
-          dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, sf[kb], dk1, 0, 0, 0);
-        }
-      }
+        tr_wait<12>(g0);
+        dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0.a0(), pf[0], dv0, 0, 0, 0);
+        dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0.a1(), pf[0], dv1, 0, 0, 0);
+        tr_wait<8>(a0);
+        dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.a0(), sf[0], dk0, 0, 0, 0);
+        dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.a1(), sf[0], dk1, 0, 0, 0);
+        tr_wait<4>(g1);
+        dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1.a0(), pf[1], dv0, 0, 0, 0);
+        dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1.a1(), pf[1], dv1, 0, 0, 0);
+        tr_wait<0>(a1);
+        dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.a0(), sf[1], dk0, 0, 0, 0);
+        dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.a1(), sf[1], dk1, 0, 0, 0);
+      };
+      sub_tile(std::integral_constant<int, 0>{});
+      if (qt * 64 + 32 < L) sub_tile(std::integral_constant<int, 1>{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -460,15 +589,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
   if (!active || key >= L) return;
   bf16* kp = p.dk + (rowbase + key) * p.ld_dqkv + h * 64;
   bf16* vp = p.dv + (rowbase + key) * p.ld_dqkv + h * 64;
+  const float sk = key_ok ? p.scale : 0.f, sv = key_ok ? 1.f : 0.f;
 #pragma unroll
   for (int rg = 0; rg < 4; ++rg) {
     const int d = 8 * rg + 4 * hh;
-    bf16x4 a = {f2bf(dk0[rg * 4]), f2bf(dk0[rg * 4 + 1]), f2bf(dk0[rg * 4 + 2]), f2bf(dk0[rg * 4 + 3])};
-    bf16x4 c = {f2bf(dk1[rg * 4]), f2bf(dk1[rg * 4 + 1]), f2bf(dk1[rg * 4 + 2]), f2bf(dk1[rg * 4 + 3])};
+    bf16x4 a, c, e, f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // a masked key may hold inf / nan (its P is not bounded by the saved log-sum-exp): select, do not multiply
+      a[j] = f2bf(key_ok ? dk0[rg * 4 + j] * sk : 0.f); c[j] = f2bf(key_ok ? dk1[rg * 4 + j] * sk : 0.f);
+      e[j] = f2bf(key_ok ? dv0[rg * 4 + j] * sv : 0.f); f[j] = f2bf(key_ok ? dv1[rg * 4 + j] * sv : 0.f);
+    }
     *reinterpret_cast<bf16x4*>(kp + d) = a;
     *reinterpret_cast<bf16x4*>(kp + 32 + d) = c;
-    bf16x4 e = {f2bf(dv0[rg * 4]), f2bf(dv0[rg * 4 + 1]), f2bf(dv0[rg * 4 + 2]), f2bf(dv0[rg * 4 + 3])};
-    bf16x4 f = {f2bf(dv1[rg * 4]), f2bf(dv1[rg * 4 + 1]), f2bf(dv1[rg * 4 + 2]), f2bf(dv1[rg * 4 + 3])};
     *reinterpret_cast<bf16x4*>(vp + d) = e;
     *reinterpret_cast<bf16x4*>(vp + 32 + d) = f;
   }
@@ -503,7 +636,7 @@ extern "C" int ia_attn_fwd(const void* q, const void* k, const void* v, int ld_q
   int rc = fill_args(a, B, nh, L, ld_qkv, ld_o, scale, drop_p, seed);
   if (rc) return rc;
   a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.out = (bf16*)out; a.mask = key_mask; a.lse2 = lse2;
-  dim3 grid((L + 127) / 128, nh, B), blk(256);
+  dim3 grid(((L + 127) / 128) * nh * B), blk(256);
   if (a.thr16) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, blk, 0, stream, a);
   else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, blk, 0, stream, a);
   return ia_check_launch();
@@ -524,7 +657,7 @@ extern "C" int ia_attn_bwd(const void* q, const void* k, const void* v, int ld_q
   a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.ld_dqkv = ld_dqkv;
   const int total = B * L * nh;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((total * 8 + 255) / 256), dim3(256), 0, stream, a);
-  dim3 grid((L + 127) / 128, nh, B), blk(256);
+  dim3 grid(((L + 127) / 128) * nh * B), blk(256);
   if (a.thr16) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, blk, 0, stream, a);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, blk, 0, stream, a);

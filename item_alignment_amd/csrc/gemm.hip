@@ -178,7 +178,7 @@ IA_DEV bf16x8 frag_ks(const char* s, int k, int col) {
 }
 
 template <bool AKS, bool BKS, int EPI, bool OUTF32>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
