@@ -148,12 +148,19 @@ IA_DEV bool drop_keep(uint32_t seed, uint32_t stream, int q, int key, uint32_t t
 }
 
 // One 64-key tile of the forward pass for this wave's 32 queries (S^T orientation, see the header comment).
-// m_run / l_run: running max (scaled log2 domain) and sum of this lane's half of the keys.
-template <bool DROPOUT>
-IA_DEV void fwd_tile(const AttnArgs& p, const char* sK, const bf16x8 (&qf)[4], uint32_t valid_lo, uint32_t valid_hi, float& m_run,
-                     float& l_run, f32x16& o0, f32x16& o1, int lane, int q, int kt, uint32_t stream_id) {
+//
+// Online softmax with a lazily updated reference: probabilities are formed as exp2(s*sc - m_ref) against the
+// reference m_ref the lane already holds, and m_ref only moves (with the O / l rescale that implies) when some
+// row of the wave would exceed 2^RESCALE_THR or has nothing accumulated yet. The result is the same softmax
+// (any reference cancels in O / l); the common tile costs fma + max + exp2 per score and no cross-lane traffic.
+// m_ref is shared by the two lanes of a query (lane, lane^32); l_run is this lane's half of the row sum.
+constexpr float RESCALE_THR = 8.f;
+
+template <int BUF, bool DROPOUT>
+IA_DEV void fwd_tile(const AttnArgs& p, const char* smem, const bf16x8 (&qf)[4], uint32_t valid_lo, uint32_t valid_hi,
+                     float& m_ref, float& l_run, f32x16& o0, f32x16& o1, int lane, int q, int kt, uint32_t stream_id) {
   const int hh = lane >> 5, lq = lane & 31;
-  const char* sV = sK + 8192;
+  const char* sK = smem + BUF * 16384;
   f32x16 s0 = zero16(), s1 = zero16();
 #pragma unroll
   for (int kb = 0; kb < 4; ++kb) {
@@ -163,11 +170,13 @@ IA_DEV void fwd_tile(const AttnArgs& p, const char* sK, const bf16x8 (&qf)[4], u
     s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[kb], s1, 0, 0, 0);
   }
   // V^T fragments of the first two 16-key steps land while the softmax runs
-  const uint32_t vb0 = lds_addr(sV) + tr_lane_off(lane, 0), vb1 = lds_addr(sV) + tr_lane_off(lane, 32);
+  const uint32_t vb0 = lds_addr(smem) + tr_lane_off(lane, 0), vb1 = lds_addr(smem) + tr_lane_off(lane, 32);
+  constexpr int VOFF = (BUF * 16384 + 8192) / 128;   // tr_issue takes its offset in 128-byte rows
   TrPair va, vb;
-  tr_issue<0>(va, vb0, vb1);
-  tr_issue<16>(vb, vb0, vb1);
+  tr_issue<VOFF>(va, vb0, vb1);
+  tr_issue<VOFF + 16>(vb, vb0, vb1);
   if ((valid_lo & valid_hi) != 0xFFFFFFFFu) {   // wave-uniform: only a ragged / padded tile pays for the selects
+    asm volatile("" ::: "memory");   // keeps hipcc from flattening this branch into 64 always-executed selects
     const uint32_t vlo = hh ? valid_lo >> 4 : valid_lo, vhi = hh ? valid_hi >> 4 : valid_hi;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -176,25 +185,32 @@ IA_DEV void fwd_tile(const AttnArgs& p, const char* sK, const bf16x8 (&qf)[4], u
       if (!((vhi >> bit) & 1)) s1[r] = -INFINITY;
     }
   }
-  float mx = fmaxf(s0[0], s1[0]);
+  const float neg_m = -m_ref;
+  float tmax = -INFINITY;
 #pragma unroll
-  for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.sc;   // sc > 0: max(s) * sc == max(s * sc)
-  const float m_new = fmaxf(m_run, mx);
-  const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-  const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-  const float neg_m = -m_use;
+  for (int r = 0; r < 16; ++r) {
+    s0[r] = __builtin_fmaf(s0[r], p.sc, neg_m);
+    s1[r] = __builtin_fmaf(s1[r], p.sc, neg_m);
+    tmax = fmaxf(tmax, fmaxf(s0[r], s1[r]));
+  }
+  if (__ballot(tmax > RESCALE_THR || l_run == 0.f) != 0ull) {   // wave-uniform, rare after the first tile
+    const float tm = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const bool fresh = (l_run + __shfl_xor(l_run, 32, 64)) == 0.f;   // nothing accumulated: re-basing is free
+    const float delta = (tm == -INFINITY) ? 0.f : (fresh ? tm : fmaxf(tm, 0.f));
+    const float alpha = fresh ? 0.f : __builtin_amdgcn_exp2f(-delta);
+    m_ref += delta;
+    l_run *= alpha;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] -= delta; s1[r] -= delta; o0[r] *= alpha; o1[r] *= alpha; }
+  }
   float rs = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], p.sc, neg_m));
-    s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], p.sc, neg_m));
+    s0[r] = __builtin_amdgcn_exp2f(s0[r]);
+    s1[r] = __builtin_amdgcn_exp2f(s1[r]);
     rs += s0[r] + s1[r];
   }
-  l_run = l_run * alpha + rs;
-  m_run = m_new;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+  l_run += rs;
   if (DROPOUT) {
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
@@ -217,11 +233,11 @@ IA_DEV void fwd_tile(const AttnArgs& p, const char* sK, const bf16x8 (&qf)[4], u
   o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va.a0(), pf[0], o0, 0, 0, 0);
   o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va.a1(), pf[0], o1, 0, 0, 0);
   TrPair vc, vd;
-  tr_issue<32>(vc, vb0, vb1);
+  tr_issue<VOFF + 32>(vc, vb0, vb1);
   tr_wait<4>(vb);
   o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb.a0(), pf[1], o0, 0, 0, 0);
   o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb.a1(), pf[1], o1, 0, 0, 0);
-  tr_issue<48>(vd, vb0, vb1);
+  tr_issue<VOFF + 48>(vd, vb0, vb1);
   tr_wait<4>(vc);
   o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vc.a0(), pf[2], o0, 0, 0, 0);
   o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vc.a1(), pf[2], o1, 0, 0, 0);
@@ -233,7 +249,8 @@ IA_DEV void fwd_tile(const AttnArgs& p, const char* sK, const bf16x8 (&qf)[4], u
 // ------------------------------------------------------------------------------------------ forward
 template <bool DROPOUT>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
-  // one __shared__ object only: with a second one hipcc drains vmcnt(0) before every LDS read while a DMA is in flight
+  // K | V tile, double buffered, then the valid-key table. One __shared__ object only: with a second one hipcc
+  // drains vmcnt(0) before every LDS read while a DMA is in flight.
   __shared__ __attribute__((aligned(16))) char smem[2 * 16384 + MAX_KT * 8];
   uint32_t (*s_valid)[2] = reinterpret_cast<uint32_t (*)[2]>(smem + 2 * 16384);
   const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, lq = lane & 31;
@@ -256,38 +273,45 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   const __amdgpu_buffer_rsrc_t rsK = ia_rsrc(p.k, p.qkv_bytes);
   const __amdgpu_buffer_rsrc_t rsV = ia_rsrc(p.v, p.qkv_bytes);
 
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_ref = 0.f, l_run = 0.f;
   f32x16 o0 = zero16(), o1 = zero16();
   const int nkt = (L + 63) >> 6;
-  stage64<false>(rsK, smem, rowbase, L, p.ld_qkv, h * 64, tid, wave);
-  stage64<true>(rsV, smem + 8192, rowbase, L, p.ld_qkv, h * 64, tid, wave);
-  build_valid_table(p, s_valid, rowbase, L, lane, wave);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
   const uint32_t stream_id = (uint32_t)(b * p.nh + h);
-
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nkt) {
-      char* nb = smem + (buf ^ 1) * 16384;
-      stage64<false>(rsK, nb, rowbase + (kt + 1) * 64, L - (kt + 1) * 64, p.ld_qkv, h * 64, tid, wave);
-      stage64<true>(rsV, nb + 8192, rowbase + (kt + 1) * 64, L - (kt + 1) * 64, p.ld_qkv, h * 64, tid, wave);
+  auto prefetch = [&](int buf, int kt) {
+    if (kt < nkt) {
+      char* nb = smem + buf * 16384;
+      stage64<false>(rsK, nb, rowbase + kt * 64, L - kt * 64, p.ld_qkv, h * 64, tid, wave);
+      stage64<true>(rsV, nb + 8192, rowbase + kt * 64, L - kt * 64, p.ld_qkv, h * 64, tid, wave);
     }
+  };
+  auto compute = [&](auto BUF, int kt) {
     if (active) {
-      const char* sK = smem + buf * 16384;
       const uint32_t valid_lo = __builtin_amdgcn_readfirstlane(s_valid[kt][0]);
       const uint32_t valid_hi = __builtin_amdgcn_readfirstlane(s_valid[kt][1]);
       // a tile with no attendable key contributes nothing
-      if ((valid_lo | valid_hi) != 0u) fwd_tile<DROPOUT>(p, sK, qf, valid_lo, valid_hi, m_run, l_run, o0, o1, lane, q, kt, stream_id);
+      if ((valid_lo | valid_hi) != 0u)
+        fwd_tile<decltype(BUF)::value, DROPOUT>(p, smem, qf, valid_lo, valid_hi, m_ref, l_run, o0, o1, lane, q, kt, stream_id);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+  };
+  prefetch(0, 0);
+  build_valid_table(p, s_valid, rowbase, L, lane, wave);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nkt; kt += 2) {
+    prefetch(1, kt + 1);
+    compute(std::integral_constant<int, 0>{}, kt);
+    if (kt + 1 < nkt) {
+      prefetch(0, kt + 2);
+      compute(std::integral_constant<int, 1>{}, kt + 1);
+    }
   }
   if (!active) return;
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? p.inv_keep / l_tot : 0.f;
   if (q < L) {
-    if (hh == 0 && p.lse2) p.lse2[((size_t)b * p.nh + h) * L + q] = m_run + __builtin_amdgcn_logf(l_tot);
+    if (hh == 0 && p.lse2) p.lse2[((size_t)b * p.nh + h) * L + q] = m_ref + __builtin_amdgcn_logf(l_tot);
     bf16* op = p.out + (rowbase + q) * p.ld_o + h * 64;
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
@@ -345,6 +369,7 @@ IA_DEV void dq_tile(const AttnArgs& p, const char* sK, const bf16x8 (&qf)[4], co
   tr_issue<0>(ka, kb0, kb1);
   tr_issue<16>(kb_, kb0, kb1);
   if ((valid_lo & valid_hi) != 0xFFFFFFFFu) {   // wave-uniform
+    asm volatile("" ::: "memory");   // keeps hipcc from flattening this branch into 64 always-executed selects
     const uint32_t vlo = hh ? valid_lo >> 4 : valid_lo, vhi = hh ? valid_hi >> 4 : valid_hi;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
