@@ -82,6 +82,27 @@ int ia_attn_bwd(const void* q, const void* k, const void* v, int ld_qkv, const u
                 int ld_o, const float* lse2, float* delta, void* dq, void* dk, void* dv, int ld_dqkv, int B, int nh, int L,
                 float scale, float drop_p, uint32_t seed, ia_stream_t stream);
 
+/* General form (cross-attention and multi-query attention of the CoCa multimodal layers, src/models/multimodal.py:590-616
+ * ParallelTransformerBlock and :665-706 CrossAttention): Lq queries attend to Lk keys per (sequence, head).  q / out /
+ * d_out rows are b*Lq + i (strides ld_q, ld_o), k / v rows are b*Lk + j (stride ld_kv), head h at column h*64.  One
+ * K/V head shared by all query heads = the nh = 1 case with the query heads folded into rows (q viewed as
+ * [B, n*heads, 64], ld_q = 64, Lq = n*heads).  key_mask is [B, Lk] or NULL; lse2 / delta are [B, nh, Lq]. */
+int ia_attn_fwd_x(const void* q, int ld_q, const void* k, const void* v, int ld_kv, const uint8_t* key_mask, void* out, int ld_o,
+                  float* lse2, int B, int nh, int Lq, int Lk, float scale, float drop_p, uint32_t seed, ia_stream_t stream);
+int ia_attn_bwd_x(const void* q, int ld_q, const void* k, const void* v, int ld_kv, const uint8_t* key_mask, const void* out,
+                  const void* d_out, int ld_o, const float* lse2, float* delta, void* dq, int ld_dq, void* dk, void* dv, int ld_dkv,
+                  int B, int nh, int Lq, int Lk, float scale, float drop_p, uint32_t seed, ia_stream_t stream);
+
+/* ---- CoCa multimodal-layer element-wise ops (src/models/multimodal.py:495-524).
+ * rotary_split: src rows [M, ld_src] hold q (nh heads x 64) | k (64) | v (64) from column 0 (the head of the fused
+ * projection, :586); position = row % n.  q_out [M, nh*64] = rotary(q); kv_out [M, 128] = rotary(k) | v.  The backward
+ * call writes (R^T dq | R^T dk | dv) into dsrc[:, 0 : nh*64 + 128].
+ * swiglu: src points at 2F columns (x | gate); out [M, F] = silu(gate) * x. */
+int ia_rotary_split_fwd(const void* src, int ld_src, void* q_out, void* kv_out, int M, int n, int nh, ia_stream_t stream);
+int ia_rotary_split_bwd(const void* dq, const void* dkv, void* dsrc, int ld_src, int M, int n, int nh, ia_stream_t stream);
+int ia_swiglu_fwd(const void* src, int ld_src, void* out, int M, int F, ia_stream_t stream);
+int ia_swiglu_bwd(const void* dout, const void* src, int ld_src, void* dsrc, int ld_dsrc, int M, int F, ia_stream_t stream);
+
 /* ---- embeddings (src/models/base.py:238-279, :501-556, :394-442) */
 int ia_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const int32_t* extra_idx, const float* word,
                     const float* type, const float* pos, const float* extra, const float* gamma, const float* beta, void* z_out,

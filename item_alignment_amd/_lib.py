@@ -43,6 +43,12 @@ SIGNATURES = {
     "ia_colsum": (i32, [vp, i32, i32, i32, vp, i32, vp, sz, vp]),
     "ia_attn_fwd": (i32, [vp, vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, f32, f32, u32, vp]),
     "ia_attn_bwd": (i32, [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, u32, vp]),
+    "ia_attn_fwd_x": (i32, [vp, i32, vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, f32, f32, u32, vp]),
+    "ia_attn_bwd_x": (i32, [vp, i32, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, f32, f32, u32, vp]),
+    "ia_rotary_split_fwd": (i32, [vp, i32, vp, vp, i32, i32, i32, vp]),
+    "ia_rotary_split_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "ia_swiglu_fwd": (i32, [vp, i32, vp, i32, i32, vp]),
+    "ia_swiglu_bwd": (i32, [vp, vp, i32, vp, i32, i32, i32, vp]),
     "ia_embed_ln_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, u32, u32, vp]),
     "ia_embed_ln_bwd_workspace_bytes": (sz, [i32, i32]),
     "ia_embed_ln_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, u32, u32,

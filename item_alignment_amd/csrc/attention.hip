@@ -32,9 +32,9 @@ struct AttnArgs {
   const uint8_t* mask;                            // [B, L] 1 = attend, may be null
   float* lse2;                                    // [B, nh, L]  log2-domain log-sum-exp of scaled scores
   float* delta;                                   // [B, nh, L]  rowsum(dO * O)
-  int B, nh, L;
-  int ld_qkv, ld_o, ld_dqkv;                      // row strides in elements
-  uint32_t qkv_bytes, o_bytes;
+  int B, nh, Lq, Lk;                              // queries / keys per sequence (self-attention: Lq == Lk)
+  int ld_q, ld_kv, ld_o, ld_dq, ld_dkv;           // row strides in elements (q & o rows: b*Lq + i; k & v rows: b*Lk + j)
+  uint32_t q_bytes, kv_bytes, o_bytes;
   float sc;                                       // softmax scale * log2(e)
   float scale;                                    // softmax scale
   uint32_t thr16; float inv_keep; uint32_t seed;
@@ -42,7 +42,7 @@ struct AttnArgs {
 
 // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): renumber them so that consecutive
 // work items -- the 128-row tiles of one (sequence, head), which all stream the same K/V -- share an XCD.
-IA_DEV void attn_block_coords(const AttnArgs& p, int& tile, int& h, int& b) {
+IA_DEV void attn_block_coords(const AttnArgs& p, int len, int& tile, int& h, int& b) {
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int per = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
 #ifdef IA_NO_XCD
@@ -50,7 +50,7 @@ IA_DEV void attn_block_coords(const AttnArgs& p, int& tile, int& h, int& b) {
 #else
   int w = (xcd < r ? xcd * (per + 1) : r * (per + 1) + (xcd - r) * per) + idx;
 #endif
-  const int nt = (p.L + 127) >> 7;
+  const int nt = (len + 127) >> 7;
   tile = w % nt; w /= nt;
   h = w % p.nh; b = w / p.nh;
 }
@@ -92,11 +92,8 @@ IA_DEV bf16x8 frag_b128(const char* s, int row, int chunk) {
 
 // A^T fragment for MFMA 32x32x16 out of a row-major [row][64] tile: lane (i = lane&31 -> column,
 // half = lane>>5) gets rows row0 + {0..3, 8..11} + 4*half of column col0 + i  (ds_read_b64_tr_b16 x2).
-//
-// The reads are issued through inline asm: hipcc (ROCm 7.2) treats the transpose-read builtin as possibly aliasing a
-// pending LDS-DMA and drains vmcnt(0) in front of it, which serialises the next tile's K/V fetch with this tile's
-// math. An asm read is invisible to the compiler's counters, so every use sits behind tr_wait<N>().
-IA_DEV uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)IA_LDS(p); }
+// The reads go through ia_tr_read (inline asm, see common.h), so every use sits behind tr_wait<N>().
+IA_DEV uint32_t lds_addr(const void* p) { return ia_lds_addr(p); }
 
 // byte offset of this lane's element inside a tile for column block col0 (0 or 32), row block 0
 IA_DEV uint32_t tr_lane_off(int lane, int col0) {
@@ -107,11 +104,7 @@ IA_DEV uint32_t tr_lane_off(int lane, int col0) {
 }
 
 template <int OFF>
-IA_DEV s16x4 tr_read(uint32_t base) {
-  s16x4 d;
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(base), "n"(OFF));
-  return d;
-}
+IA_DEV s16x4 tr_read(uint32_t base) { return ia_tr_read<OFF>(base); }
 
 struct TrPair {   // the two A^T fragments (columns 0..31 and 32..63) of one 16-row step
   s16x4 lo0, hi0, lo1, hi1;
@@ -256,22 +249,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, lq = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int tile, h, b;
-  attn_block_coords(p, tile, h, b);
-  const int L = p.L;
+  attn_block_coords(p, p.Lq, tile, h, b);
+  const int Lq = p.Lq, L = p.Lk;                  // L: keys
   const int q0 = tile * 128 + wave * 32;
-  const size_t rowbase = (size_t)b * L;
-  const bool active = q0 < L;
+  const size_t qbase = (size_t)b * Lq, rowbase = (size_t)b * L;
+  const bool active = q0 < Lq;
   const int q = q0 + lq;
-  const int qc = q < L ? q : L - 1;
+  const int qc = q < Lq ? q : Lq - 1;
 
   bf16x8 qf[4];
   {
-    const bf16* qp = p.q + (rowbase + qc) * p.ld_qkv + h * 64 + hh * 8;
+    const bf16* qp = p.q + (qbase + qc) * p.ld_q + h * 64 + hh * 8;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) qf[kb] = *reinterpret_cast<const bf16x8*>(qp + kb * 16);
   }
-  const __amdgpu_buffer_rsrc_t rsK = ia_rsrc(p.k, p.qkv_bytes);
-  const __amdgpu_buffer_rsrc_t rsV = ia_rsrc(p.v, p.qkv_bytes);
+  const __amdgpu_buffer_rsrc_t rsK = ia_rsrc(p.k, p.kv_bytes);
+  const __amdgpu_buffer_rsrc_t rsV = ia_rsrc(p.v, p.kv_bytes);
 
   float m_ref = 0.f, l_run = 0.f;
   f32x16 o0 = zero16(), o1 = zero16();
@@ -280,8 +273,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   auto prefetch = [&](int buf, int kt) {
     if (kt < nkt) {
       char* nb = smem + buf * 16384;
-      stage64<false>(rsK, nb, rowbase + kt * 64, L - kt * 64, p.ld_qkv, h * 64, tid, wave);
-      stage64<true>(rsV, nb + 8192, rowbase + kt * 64, L - kt * 64, p.ld_qkv, h * 64, tid, wave);
+      stage64<false>(rsK, nb, rowbase + kt * 64, L - kt * 64, p.ld_kv, h * 64, tid, wave);
+      stage64<true>(rsV, nb + 8192, rowbase + kt * 64, L - kt * 64, p.ld_kv, h * 64, tid, wave);
     }
   };
   auto compute = [&](auto BUF, int kt) {
@@ -310,9 +303,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   if (!active) return;
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? p.inv_keep / l_tot : 0.f;
-  if (q < L) {
-    if (hh == 0 && p.lse2) p.lse2[((size_t)b * p.nh + h) * L + q] = m_ref + __builtin_amdgcn_logf(l_tot);
-    bf16* op = p.out + (rowbase + q) * p.ld_o + h * 64;
+  if (q < Lq) {
+    if (hh == 0 && p.lse2) p.lse2[((size_t)b * p.nh + h) * Lq + q] = m_ref + __builtin_amdgcn_logf(l_tot);
+    bf16* op = p.out + (qbase + q) * p.ld_o + h * 64;
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
       const int d = 8 * rg + 4 * hh;
@@ -328,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs p) {
   // one 8-lane group per (token, head): 64 columns = 8 lanes x 8 bf16
   const int gid = (blockIdx.x * 256 + threadIdx.x) >> 3, sub = threadIdx.x & 7;
-  const int total = p.B * p.L * p.nh;
+  const int total = p.B * p.Lq * p.nh;
   if (gid >= total) return;
   const int tok = gid / p.nh, h = gid % p.nh;
   const bf16x8 a = *reinterpret_cast<const bf16x8*>(p.o + (size_t)tok * p.ld_o + h * 64 + sub * 8);
@@ -338,8 +331,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs p) {
   for (int j = 0; j < 8; ++j) s += bf2f(a[j]) * bf2f(g[j]);
   s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
   if (sub == 0) {
-    const int b = tok / p.L, l = tok % p.L;
-    p.delta[((size_t)b * p.nh + h) * p.L + l] = s;
+    const int b = tok / p.Lq, l = tok % p.Lq;
+    p.delta[((size_t)b * p.nh + h) * p.Lq + l] = s;
   }
 }
 
@@ -423,36 +416,36 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, lq = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int tile, h, b;
-  attn_block_coords(p, tile, h, b);
-  const int L = p.L;
+  attn_block_coords(p, p.Lq, tile, h, b);
+  const int Lq = p.Lq, L = p.Lk;                  // L: keys
   const int q0 = tile * 128 + wave * 32;
-  const size_t rowbase = (size_t)b * L;
-  const bool active = q0 < L;
+  const size_t qbase = (size_t)b * Lq, rowbase = (size_t)b * L;
+  const bool active = q0 < Lq;
   const int q = q0 + lq;
-  const int qc = q < L ? q : L - 1;
+  const int qc = q < Lq ? q : Lq - 1;
 
   bf16x8 qf[4], gf[4];
   {
-    const bf16* qp = p.q + (rowbase + qc) * p.ld_qkv + h * 64 + hh * 8;
-    const bf16* gp = p.d_o + (rowbase + qc) * p.ld_o + h * 64 + hh * 8;
+    const bf16* qp = p.q + (qbase + qc) * p.ld_q + h * 64 + hh * 8;
+    const bf16* gp = p.d_o + (qbase + qc) * p.ld_o + h * 64 + hh * 8;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       qf[kb] = *reinterpret_cast<const bf16x8*>(qp + kb * 16);
       gf[kb] = *reinterpret_cast<const bf16x8*>(gp + kb * 16);
     }
   }
-  const size_t sidx = ((size_t)b * p.nh + h) * L + qc;
+  const size_t sidx = ((size_t)b * p.nh + h) * Lq + qc;
   const float lse = p.lse2[sidx];
   const float dlt = p.delta[sidx];
-  const __amdgpu_buffer_rsrc_t rsK = ia_rsrc(p.k, p.qkv_bytes);
-  const __amdgpu_buffer_rsrc_t rsV = ia_rsrc(p.v, p.qkv_bytes);
+  const __amdgpu_buffer_rsrc_t rsK = ia_rsrc(p.k, p.kv_bytes);
+  const __amdgpu_buffer_rsrc_t rsV = ia_rsrc(p.v, p.kv_bytes);
   const uint32_t stream_id = (uint32_t)(b * p.nh + h);
 
   f32x16 dq0 = zero16(), dq1 = zero16();
   const int nkt = (L + 63) >> 6;
-  stage64<false>(rsK, smem, rowbase, L, p.ld_qkv, h * 64, tid, wave);
-  stage64<true>(rsK, smem + 8192, rowbase, L, p.ld_qkv, h * 64, tid, wave);
-  stage64<false>(rsV, smem + 16384, rowbase, L, p.ld_qkv, h * 64, tid, wave);
+  stage64<false>(rsK, smem, rowbase, L, p.ld_kv, h * 64, tid, wave);
+  stage64<true>(rsK, smem + 8192, rowbase, L, p.ld_kv, h * 64, tid, wave);
+  stage64<false>(rsV, smem + 16384, rowbase, L, p.ld_kv, h * 64, tid, wave);
   build_valid_table(p, s_valid, rowbase, L, lane, wave);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -462,9 +455,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     if (kt + 1 < nkt) {
       char* nb = smem + (buf ^ 1) * 24576;
       const size_t r0 = rowbase + (kt + 1) * 64; const int nv = L - (kt + 1) * 64;
-      stage64<false>(rsK, nb, r0, nv, p.ld_qkv, h * 64, tid, wave);
-      stage64<true>(rsK, nb + 8192, r0, nv, p.ld_qkv, h * 64, tid, wave);
-      stage64<false>(rsV, nb + 16384, r0, nv, p.ld_qkv, h * 64, tid, wave);
+      stage64<false>(rsK, nb, r0, nv, p.ld_kv, h * 64, tid, wave);
+      stage64<true>(rsK, nb + 8192, r0, nv, p.ld_kv, h * 64, tid, wave);
+      stage64<false>(rsV, nb + 16384, r0, nv, p.ld_kv, h * 64, tid, wave);
     }
     if (active) {
       const uint32_t valid_lo = __builtin_amdgcn_readfirstlane(s_valid[kt][0]);
@@ -475,8 +468,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  if (!active || q >= L) return;
-  bf16* op = p.dq + (rowbase + q) * p.ld_dqkv + h * 64;
+  if (!active || q >= Lq) return;
+  bf16* op = p.dq + (qbase + q) * p.ld_dq + h * 64;
   const float sc = p.scale;
 #pragma unroll
   for (int rg = 0; rg < 4; ++rg) {
@@ -501,10 +494,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, lk = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int tile, h, b;
-  attn_block_coords(p, tile, h, b);
-  const int L = p.L;
+  attn_block_coords(p, p.Lk, tile, h, b);
+  const int Lq = p.Lq, L = p.Lk;                  // L: keys
   const int k0 = tile * 128 + wave * 32;
-  const size_t rowbase = (size_t)b * L;
+  const size_t qbase = (size_t)b * Lq, rowbase = (size_t)b * L;
   const bool active = k0 < L;
   const int key = k0 + lk;
   const int kc = key < L ? key : L - 1;
@@ -512,26 +505,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
 
   bf16x8 kf[4], vf[4];
   {
-    const bf16* kp = p.k + (rowbase + kc) * p.ld_qkv + h * 64 + hh * 8;
-    const bf16* vp = p.v + (rowbase + kc) * p.ld_qkv + h * 64 + hh * 8;
+    const bf16* kp = p.k + (rowbase + kc) * p.ld_kv + h * 64 + hh * 8;
+    const bf16* vp = p.v + (rowbase + kc) * p.ld_kv + h * 64 + hh * 8;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       kf[kb] = *reinterpret_cast<const bf16x8*>(kp + kb * 16);
       vf[kb] = *reinterpret_cast<const bf16x8*>(vp + kb * 16);
     }
   }
-  const __amdgpu_buffer_rsrc_t rsQ = ia_rsrc(p.q, p.qkv_bytes);
+  const __amdgpu_buffer_rsrc_t rsQ = ia_rsrc(p.q, p.q_bytes);
   const __amdgpu_buffer_rsrc_t rsG = ia_rsrc(p.d_o, p.o_bytes);
-  const __amdgpu_buffer_rsrc_t rsL = ia_rsrc(p.lse2 + ((size_t)b * p.nh + h) * L, (uint32_t)L * 4u);
-  const __amdgpu_buffer_rsrc_t rsD = ia_rsrc(p.delta + ((size_t)b * p.nh + h) * L, (uint32_t)L * 4u);
+  const __amdgpu_buffer_rsrc_t rsL = ia_rsrc(p.lse2 + ((size_t)b * p.nh + h) * Lq, (uint32_t)Lq * 4u);
+  const __amdgpu_buffer_rsrc_t rsD = ia_rsrc(p.delta + ((size_t)b * p.nh + h) * Lq, (uint32_t)Lq * 4u);
   const uint32_t stream_id = (uint32_t)(b * p.nh + h);
 
   f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
-  const int nqt = (L + 63) >> 6;
+  const int nqt = (Lq + 63) >> 6;
   auto stage_all = [&](char* s, int qt) {
-    const size_t r0 = rowbase + (size_t)qt * 64; const int nv = L - qt * 64;
-    stage64<false>(rsQ, s, r0, nv, p.ld_qkv, h * 64, tid, wave);
-    stage64<true>(rsQ, s + 8192, r0, nv, p.ld_qkv, h * 64, tid, wave);
+    const size_t r0 = qbase + (size_t)qt * 64; const int nv = Lq - qt * 64;
+    stage64<false>(rsQ, s, r0, nv, p.ld_q, h * 64, tid, wave);
+    stage64<true>(rsQ, s + 8192, r0, nv, p.ld_q, h * 64, tid, wave);
     stage64<false>(rsG, s + 16384, r0, nv, p.ld_o, h * 64, tid, wave);
     stage64<true>(rsG, s + 24576, r0, nv, p.ld_o, h * 64, tid, wave);
     // 64 x fp32 each, one 4-byte-per-lane DMA; out-of-range rows read as zero
@@ -606,14 +599,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
         dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.a1(), sf[1], dk1, 0, 0, 0);
       };
       sub_tile(std::integral_constant<int, 0>{});
-      if (qt * 64 + 32 < L) sub_tile(std::integral_constant<int, 1>{});
+      if (qt * 64 + 32 < Lq) sub_tile(std::integral_constant<int, 1>{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
   if (!active || key >= L) return;
-  bf16* kp = p.dk + (rowbase + key) * p.ld_dqkv + h * 64;
-  bf16* vp = p.dv + (rowbase + key) * p.ld_dqkv + h * 64;
+  bf16* kp = p.dk + (rowbase + key) * p.ld_dkv + h * 64;
+  bf16* vp = p.dv + (rowbase + key) * p.ld_dkv + h * 64;
   const float sk = key_ok ? p.scale : 0.f, sv = key_ok ? 1.f : 0.f;
 #pragma unroll
   for (int rg = 0; rg < 4; ++rg) {
@@ -632,14 +625,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   }
 }
 
-int fill_args(AttnArgs& a, int B, int nh, int L, int ld_qkv, int ld_o, float scale, float drop_p, uint32_t seed) {
-  if (B <= 0 || nh <= 0 || L <= 0 || L > 2048 || (ld_qkv & 7) || (ld_o & 7)) return IA_ERR_ARG;
-  const uint64_t qb = (uint64_t)B * L * ld_qkv * 2, ob = (uint64_t)B * L * ld_o * 2;
-  if (qb >= 0x7FFFFFFFull || ob >= 0x7FFFFFFFull) return IA_ERR_ARG;
-  a.B = B; a.nh = nh; a.L = L; a.ld_qkv = ld_qkv; a.ld_o = ld_o; a.ld_dqkv = ld_qkv;
-  // the rsrc is based at the k / v / q pointer itself: it may start up to 3*H columns into the
-  // packed row, so the window covers "to the end of the last row" from that pointer at most
-  a.qkv_bytes = (uint32_t)(qb - (uint64_t)(ld_qkv - nh * 64) * 2);
+int fill_args(AttnArgs& a, int B, int nh, int Lq, int Lk, int ld_q, int ld_kv, int ld_o, float scale, float drop_p, uint32_t seed) {
+  if (B <= 0 || nh <= 0 || Lq <= 0 || Lk <= 0 || Lk > 64 * MAX_KT || Lq > (1 << 20) || (ld_q & 7) || (ld_kv & 7) || (ld_o & 7))
+    return IA_ERR_ARG;
+  if (ld_q < nh * 64 || ld_kv < nh * 64 || ld_o < nh * 64) return IA_ERR_ARG;
+  const uint64_t qb = (uint64_t)B * Lq * ld_q * 2, kb = (uint64_t)B * Lk * ld_kv * 2, ob = (uint64_t)B * Lq * ld_o * 2;
+  if (qb >= 0x7FFFFFFFull || kb >= 0x7FFFFFFFull || ob >= 0x7FFFFFFFull) return IA_ERR_ARG;
+  a.B = B; a.nh = nh; a.Lq = Lq; a.Lk = Lk; a.ld_q = ld_q; a.ld_kv = ld_kv; a.ld_o = ld_o; a.ld_dq = ld_q; a.ld_dkv = ld_kv;
+  // each rsrc is based at the operand pointer itself, which may start some columns into a packed row, so the
+  // window covers "to the end of the last row" from that pointer at most
+  a.q_bytes = (uint32_t)(qb - (uint64_t)(ld_q - nh * 64) * 2);
+  a.kv_bytes = (uint32_t)(kb - (uint64_t)(ld_kv - nh * 64) * 2);
   a.o_bytes = (uint32_t)ob;
   a.scale = scale; a.sc = scale * LOG2E;
   a.thr16 = drop_p > 0.f ? (uint32_t)(drop_p * 65536.f + 0.5f) : 0u;
@@ -650,45 +646,63 @@ int fill_args(AttnArgs& a, int B, int nh, int L, int ld_qkv, int ld_o, float sca
 
 }  // namespace
 
-// q, k, v: pointers to the first column of head 0 of each operand; all three share row stride ld_qkv
-// (packed [tokens, 3H] projection output, or three separate [tokens, H] tensors with ld_qkv = H).
-extern "C" int ia_attn_fwd(const void* q, const void* k, const void* v, int ld_qkv, const uint8_t* key_mask, void* out,
-                           int ld_o, float* lse2, int B, int nh, int L, float scale, float drop_p, uint32_t seed,
-                           hipStream_t stream) {
+// General form: Lq queries attend to Lk keys per (sequence, head).  q / out / d_out rows are b*Lq + i (strides ld_q,
+// ld_o), k / v rows are b*Lk + j (stride ld_kv); head h sits at column h*64 of each.  Multi-query attention (one K/V
+// head shared by all query heads, reference multimodal.py:590-616) is the nh = 1 case with the query heads folded
+// into rows: q viewed as [B, n*heads, 64] (ld_q = 64), Lq = n*heads.  key_mask is [B, Lk].
+extern "C" int ia_attn_fwd_x(const void* q, int ld_q, const void* k, const void* v, int ld_kv, const uint8_t* key_mask, void* out,
+                             int ld_o, float* lse2, int B, int nh, int Lq, int Lk, float scale, float drop_p, uint32_t seed,
+                             hipStream_t stream) {
   (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!q || !k || !v || !out) return IA_ERR_ARG;
   AttnArgs a{};
-  int rc = fill_args(a, B, nh, L, ld_qkv, ld_o, scale, drop_p, seed);
+  int rc = fill_args(a, B, nh, Lq, Lk, ld_q, ld_kv, ld_o, scale, drop_p, seed);
   if (rc) return rc;
   a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.out = (bf16*)out; a.mask = key_mask; a.lse2 = lse2;
-  dim3 grid(((L + 127) / 128) * nh * B), blk(256);
+  dim3 grid(((Lq + 127) / 128) * nh * B), blk(256);
   if (a.thr16) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, blk, 0, stream, a);
   else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, blk, 0, stream, a);
   return ia_check_launch();
 }
 
-// delta: caller-provided scratch of B*nh*L floats.
-extern "C" int ia_attn_bwd(const void* q, const void* k, const void* v, int ld_qkv, const uint8_t* key_mask, const void* out,
-                           const void* d_out, int ld_o, const float* lse2, float* delta, void* dq, void* dk, void* dv,
-                           int ld_dqkv, int B, int nh, int L, float scale, float drop_p, uint32_t seed, hipStream_t stream) {
+// delta: caller-provided scratch of B*nh*Lq floats.
+extern "C" int ia_attn_bwd_x(const void* q, int ld_q, const void* k, const void* v, int ld_kv, const uint8_t* key_mask,
+                             const void* out, const void* d_out, int ld_o, const float* lse2, float* delta, void* dq, int ld_dq,
+                             void* dk, void* dv, int ld_dkv, int B, int nh, int Lq, int Lk, float scale, float drop_p, uint32_t seed,
+                             hipStream_t stream) {
   (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!q || !k || !v || !out || !d_out || !lse2 || !delta || !dq || !dk || !dv) return IA_ERR_ARG;
   AttnArgs a{};
-  int rc = fill_args(a, B, nh, L, ld_qkv, ld_o, scale, drop_p, seed);
+  int rc = fill_args(a, B, nh, Lq, Lk, ld_q, ld_kv, ld_o, scale, drop_p, seed);
   if (rc) return rc;
-  if (ld_dqkv & 3) return IA_ERR_ARG;
+  if ((ld_dq & 3) || (ld_dkv & 3) || ld_dq < nh * 64 || ld_dkv < nh * 64) return IA_ERR_ARG;
   a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.o = (const bf16*)out; a.d_o = (const bf16*)d_out;
   a.mask = key_mask; a.lse2 = const_cast<float*>(lse2); a.delta = delta;
-  a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.ld_dqkv = ld_dqkv;
-  const int total = B * L * nh;
+  a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.ld_dq = ld_dq; a.ld_dkv = ld_dkv;
+  const int total = B * Lq * nh;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((total * 8 + 255) / 256), dim3(256), 0, stream, a);
-  dim3 grid(((L + 127) / 128) * nh * B), blk(256);
+  dim3 gq(((Lq + 127) / 128) * nh * B), gk(((Lk + 127) / 128) * nh * B), blk(256);
   if (a.thr16) {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, blk, 0, stream, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, blk, 0, stream, a);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gq, blk, 0, stream, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, gk, blk, 0, stream, a);
   } else {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, blk, 0, stream, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, blk, 0, stream, a);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gq, blk, 0, stream, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, gk, blk, 0, stream, a);
   }
   return ia_check_launch();
+}
+
+// Self-attention over a packed projection: q, k, v point at the first column of head 0 of each operand and share
+// row stride ld_qkv (packed [tokens, 3H] projection output, or three separate [tokens, H] tensors with ld_qkv = H).
+extern "C" int ia_attn_fwd(const void* q, const void* k, const void* v, int ld_qkv, const uint8_t* key_mask, void* out,
+                           int ld_o, float* lse2, int B, int nh, int L, float scale, float drop_p, uint32_t seed,
+                           hipStream_t stream) {
+  return ia_attn_fwd_x(q, ld_qkv, k, v, ld_qkv, key_mask, out, ld_o, lse2, B, nh, L, L, scale, drop_p, seed, stream);
+}
+
+extern "C" int ia_attn_bwd(const void* q, const void* k, const void* v, int ld_qkv, const uint8_t* key_mask, const void* out,
+                           const void* d_out, int ld_o, const float* lse2, float* delta, void* dq, void* dk, void* dv,
+                           int ld_dqkv, int B, int nh, int L, float scale, float drop_p, uint32_t seed, hipStream_t stream) {
+  return ia_attn_bwd_x(q, ld_qkv, k, v, ld_qkv, key_mask, out, d_out, ld_o, lse2, delta, dq, ld_dqkv, dk, dv, ld_dqkv, B, nh, L, L, scale,
+                       drop_p, seed, stream);
 }

@@ -20,6 +20,18 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 #define IA_LDS(p) ((__attribute__((address_space(3))) void*)(p))
 #define IA_DEV __device__ __forceinline__
 
+// ---- LDS transpose read through inline asm.  hipcc (ROCm 7.2) treats __builtin_amdgcn_ds_read_tr16_b64 as possibly
+// aliasing a pending LDS-DMA (buffer_load ... lds) and drains vmcnt(0) in front of it, which serialises the next
+// tile's fetch with this tile's math.  An asm read is invisible to the compiler's counters: every use must sit behind
+// an explicit s_waitcnt lgkmcnt (plus a sched_barrier or a "+v" dependency so the consumer cannot be hoisted above it).
+IA_DEV uint32_t ia_lds_addr(const void* p) { return (uint32_t)(uintptr_t)IA_LDS(p); }
+template <int OFF>
+IA_DEV s16x4 ia_tr_read(uint32_t lds_byte_addr) {
+  s16x4 d;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(lds_byte_addr), "n"(OFF));
+  return d;
+}
+
 // error codes of the C-ABI (ia_strerror in capi.hip)
 #define IA_OK 0
 #define IA_ERR_ARG (-1)      // bad shape / alignment / null pointer

@@ -171,8 +171,9 @@ IA_DEV bf16x8 frag_kc(const char* s, int row, int chunk) {
 IA_DEV bf16x8 frag_ks(const char* s, int k, int col) {
   // 16-lane group reads a [4 k][16 col] block twice (k, k+4); lane p supplies row k+(p>>2), 4 cols.
   const int addr = k * 256 + ((((col >> 3) ^ ks_swz(k))) << 4) + (col & 7) * 2;
-  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(s + addr));
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(s + addr + 4 * 256));
+  const uint32_t a = ia_lds_addr(s) + (uint32_t)addr;   // asm reads: the caller waits lgkmcnt(0) before the MFMAs
+  s16x4 lo = ia_tr_read<0>(a);
+  s16x4 hi = ia_tr_read<4 * 256>(a);
   s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, r);
 }
@@ -227,6 +228,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         // holding 16 consecutive n; k-strided B: plain n = ni*16 + i (conflict-free transpose read).
         if (!BKS) bfr[ni] = frag_kc(sB, wn * 64 + (li >> 2) * 16 + ni * 4 + (li & 3), ks * 4 + g);
         else      bfr[ni] = frag_ks(sB, ks * 32 + g * 8 + (li >> 2), wn * 64 + ni * 16 + (li & 3) * 4);
+      }
+      if (AKS || BKS) {   // the transpose reads are asm (common.h): order the MFMAs behind their data
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
@@ -295,8 +300,9 @@ IA_DEV bf16x8 frag_ks(const char* s, int k0, int col0, int lane) {
   const int row = k0 + 8 * (G >> 1) + (p >> 2);
   const int col = col0 + 16 * (G & 1) + (p & 3) * 4;
   const int addr = row * 512 + ((((col >> 3) ^ ((row & 3) << 2))) << 4) + (col & 7) * 2;
-  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(s + addr));
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(s + addr + 4 * 512));
+  const uint32_t a = ia_lds_addr(s) + (uint32_t)addr;   // asm reads: main_loop waits lgkmcnt(0) before the MFMAs
+  s16x4 lo = ia_tr_read<0>(a);
+  s16x4 hi = ia_tr_read<4 * 512>(a);
   s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, r);
 }

@@ -6,4 +6,5 @@ from .base import (InnerProduct, VecSimClassificationHead, TwoTowerClassificatio
 from .text import (RobertaModel, RobertaOneTower, RobertaTwoTower, RobertaPKGMModel, PKGMOneTower, PKGMTwoTower, TextCNN,
                    TextCNNTwoTower)
 from .image import VisionTransformer, VitTwoTower, NFNetTwoTower, ResNetTwoTower, create_model
-from .multimodal import RobertaImageModel, RobertaImageOneTower, RobertaImageTwoTower, CoCaModel, CoCaForItemAlignment
+from .multimodal import (RobertaImageModel, RobertaImageOneTower, RobertaImageTwoTower, CoCaModel, CoCaForItemAlignment, LayerNorm,
+                         Residual, RotaryEmbedding, SwiGLU, ParallelTransformerBlock, CrossAttention)

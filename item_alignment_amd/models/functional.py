@@ -342,3 +342,176 @@ class PatchEmbedFn(torch.autograd.Function):
                                None, None, 0, None, 1, ptr(gws), gws_bytes, stream_ptr()), "ia_gemm_bf16[patch wgrad]")
         _notify([vit.cls_token, vit.pos_embed, vit.patch_embed.proj.weight, vit.patch_embed.proj.bias])
         return None, None, None
+
+
+# ------------------------------------------------------------------ CoCa multimodal layers (cross_attn ensemble)
+def _gemm(lib, a, a_ks, lda, b, b_ks, ldb, c, c_f32, ldc, M, N, K, epi=0, aux=None, ldaux=0, accumulate=0, what="ia_gemm_bf16"):
+    ws_bytes = lib.ia_gemm_workspace_bytes(M, N, K, int(c_f32))
+    ws = torch.empty(ws_bytes, device=c.device, dtype=torch.uint8) if ws_bytes else None
+    check(lib.ia_gemm_bf16(a.data_ptr(), a_ks, lda, b.data_ptr(), b_ks, ldb, c.data_ptr(), int(c_f32), ldc, M, N, K, epi, None, ptr(aux),
+                           ldaux, None, accumulate, ptr(ws), ws_bytes, stream_ptr()), what)
+
+
+class LinearBf16Fn(torch.autograd.Function):
+    """y = x W^T (+ add) for the bias-free Linears of the CoCa blocks (reference multimodal.py:545-551,646-659):
+    MFMA GEMM on the weight's bf16 shadow; dgrad k-strided; wgrad accumulated in fp32 straight into the arena."""
+
+    @staticmethod
+    def forward(ctx, x, add, weight, owner):
+        lib = _lib.load()
+        _need_gpu(x, "tokens")
+        x = x.contiguous()
+        M, K = x.shape
+        w = owner.arena.shadow_of(weight)
+        N = w.shape[0]
+        y = torch.empty((M, N), device=x.device, dtype=BF16)
+        if add is not None:
+            add = add.contiguous()
+        _gemm(lib, x, 0, K, w, 0, K, y, False, N, M, N, K, epi=3 if add is not None else 0, aux=add, ldaux=N if add is not None else 0)
+        ctx.weight, ctx.owner, ctx.x = weight, owner, x
+        ctx.need_dx, ctx.has_add = ctx.needs_input_grad[0], add is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        weight, x = ctx.weight, ctx.x
+        dy = dy.contiguous()
+        M, K = x.shape
+        N = weight.shape[0]
+        dx = None
+        if ctx.need_dx:
+            dx = torch.empty_like(x)
+            w = ctx.owner.arena.shadow_of(weight)
+            _gemm(lib, dy, 0, N, w, 1, K, dx, False, K, M, K, N, what="ia_gemm_bf16[dgrad]")
+        if weight.requires_grad:
+            _gemm(lib, dy, 1, N, x, 1, K, weight.grad, True, K, N, K, M, accumulate=1, what="ia_gemm_bf16[wgrad]")
+            _notify([weight])
+        return dx, (dy if ctx.has_add else None), None, None
+
+
+class GammaLayerNormFn(torch.autograd.Function):
+    """LayerNorm with a learned gamma and a constant zero beta (reference multimodal.py:475-482)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        lib = _lib.load()
+        _need_gpu(x, "tokens")
+        x = x.contiguous()
+        M, H = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(M, device=x.device, dtype=F32)
+        rstd = torch.empty(M, device=x.device, dtype=F32)
+        check(lib.ia_ln_fwd(x.data_ptr(), None, None, None, y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                            M, H, eps, 0.0, 0, 0, stream_ptr()), "ia_ln_fwd")
+        ctx.gamma, ctx.saved = gamma, (x, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        gamma = ctx.gamma
+        x, mean, rstd = ctx.saved
+        M, H = x.shape
+        dy = dy.contiguous()
+        dz = torch.empty_like(x)
+        ws_bytes = lib.ia_ln_bwd_workspace_bytes(M, H)
+        ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
+        wg = gamma.requires_grad
+        check(lib.ia_ln_bwd(dy.data_ptr(), None, x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), dz.data_ptr(), None,
+                            gamma.grad.data_ptr() if wg else None, None, None, M, H, 0.0, 0, 0, ws.data_ptr(), ws_bytes, 1, stream_ptr()),
+              "ia_ln_bwd")
+        if wg:
+            _notify([gamma])
+        return dz, None, None, None
+
+
+class FusedSplitFn(torch.autograd.Function):
+    """Consumes the fused projection of a ParallelTransformerBlock, rows = [q (heads*64) | k (64) | v (64) | x (F) | gate (F)]
+    (reference multimodal.py:586): returns rotary(q) [M, heads*64], rotary(k) | v [M, 128] and silu(gate) * x [M, F]
+    (:596-603, :521-524).  Backward assembles the whole projection gradient in one buffer (no torch adds)."""
+
+    @staticmethod
+    def forward(ctx, fused, n, heads, F_):
+        lib = _lib.load()
+        M, ld = fused.shape
+        if ld != heads * 64 + 128 + 2 * F_:
+            raise ValueError("fused projection width does not match (heads*64, 64, 64, 2*ff_inner)")
+        q = torch.empty((M, heads * 64), device=fused.device, dtype=BF16)
+        kv = torch.empty((M, 128), device=fused.device, dtype=BF16)
+        s = torch.empty((M, F_), device=fused.device, dtype=BF16)
+        check(lib.ia_rotary_split_fwd(fused.data_ptr(), ld, q.data_ptr(), kv.data_ptr(), M, n, heads, stream_ptr()), "ia_rotary_split_fwd")
+        check(lib.ia_swiglu_fwd(fused.data_ptr() + 2 * (heads * 64 + 128), ld, s.data_ptr(), M, F_, stream_ptr()), "ia_swiglu_fwd")
+        ctx.fused, ctx.dims = fused, (M, ld, n, heads, F_)
+        return q, kv, s
+
+    @staticmethod
+    def backward(ctx, dq, dkv, ds):
+        lib = _lib.load()
+        M, ld, n, heads, F_ = ctx.dims
+        fused = ctx.fused
+        dfused = torch.empty((M, ld), device=fused.device, dtype=BF16)
+        off = 2 * (heads * 64 + 128)
+        check(lib.ia_rotary_split_bwd(dq.contiguous().data_ptr(), dkv.contiguous().data_ptr(), dfused.data_ptr(), ld, M, n, heads,
+                                      stream_ptr()), "ia_rotary_split_bwd")
+        check(lib.ia_swiglu_bwd(ds.contiguous().data_ptr(), fused.data_ptr() + off, ld, dfused.data_ptr() + off, ld, M, F_, stream_ptr()),
+              "ia_swiglu_bwd")
+        ctx.fused = None
+        return dfused, None, None, None
+
+
+class SwiGLUFn(torch.autograd.Function):
+    """silu(gate) * x for rows [x (F) | gate (F)] (reference multimodal.py:521-524, the CrossAttention feed-forward :655-659)."""
+
+    @staticmethod
+    def forward(ctx, src):
+        lib = _lib.load()
+        src = src.contiguous()
+        M, ld = src.shape
+        F_ = ld // 2
+        out = torch.empty((M, F_), device=src.device, dtype=BF16)
+        check(lib.ia_swiglu_fwd(src.data_ptr(), ld, out.data_ptr(), M, F_, stream_ptr()), "ia_swiglu_fwd")
+        ctx.src = src
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        src = ctx.src
+        M, ld = src.shape
+        dsrc = torch.empty_like(src)
+        check(lib.ia_swiglu_bwd(dout.contiguous().data_ptr(), src.data_ptr(), ld, dsrc.data_ptr(), ld, M, ld // 2, stream_ptr()), "ia_swiglu_bwd")
+        ctx.src = None
+        return dsrc
+
+
+class AttentionXFn(torch.autograd.Function):
+    """softmax(q k^T * scale) v with Lq queries on Lk keys per sequence (ia_attn_fwd_x / ia_attn_bwd_x).
+    q: [B*Lq, nh*64]; kv: [B*Lk, 2*nh*64] = k | v.  Multi-query attention passes nh = 1 with the query heads folded
+    into rows (q.view(B*n*heads, 64), Lq = n*heads)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, B, nh, Lq, Lk, scale):
+        lib = _lib.load()
+        q, kv = q.contiguous(), kv.contiguous()
+        H = nh * 64
+        out = torch.empty((B * Lq, H), device=q.device, dtype=BF16)
+        lse = torch.empty((B, nh, Lq), device=q.device, dtype=F32)
+        check(lib.ia_attn_fwd_x(q.data_ptr(), H, kv.data_ptr(), kv.data_ptr() + 2 * H, 2 * H, None, out.data_ptr(), H, lse.data_ptr(), B, nh,
+                                Lq, Lk, scale, 0.0, 0, stream_ptr()), "ia_attn_fwd_x")
+        ctx.saved, ctx.dims = (q, kv, out, lse), (B, nh, Lq, Lk, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        q, kv, out, lse = ctx.saved
+        B, nh, Lq, Lk, scale = ctx.dims
+        H = nh * 64
+        dout = dout.contiguous()
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        delta = torch.empty((B, nh, Lq), device=q.device, dtype=F32)
+        check(lib.ia_attn_bwd_x(q.data_ptr(), H, kv.data_ptr(), kv.data_ptr() + 2 * H, 2 * H, None, out.data_ptr(), dout.data_ptr(), H,
+                                lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), H, dkv.data_ptr(), dkv.data_ptr() + 2 * H, 2 * H, B, nh, Lq,
+                                Lk, scale, 0.0, 0, stream_ptr()), "ia_attn_bwd_x")
+        return dq, dkv, None, None, None, None, None

@@ -150,3 +150,65 @@ def test_attention_dropout_statistics(gpu):
     assert torch.equal(ctx, ctx2)
     ctx3, _ = ops.attn_fwd(qkv, B, L, nh, drop_p=0.1, seed=124)
     assert not torch.equal(ctx, ctx3)
+
+
+# ------------------------------------------------------------------ CoCa multimodal-layer kernels
+@pytest.mark.parametrize("B,nh,Lq,Lk", [(2, 3, 100, 177), (3, 1, 20 * 2, 17), (2, 1, 255 * 4, 577), (1, 2, 130, 64)])
+def test_attention_x_fwd_bwd(gpu, B, nh, Lq, Lk):
+    """ia_attn_fwd_x / ia_attn_bwd_x (cross attention; nh = 1 with folded query heads = multi-query attention)
+    against fp32 softmax(q k^T / 8) v on the same bf16 inputs (reference multimodal.py:605-620, :686-696)."""
+    from item_alignment_amd.models import functional as Fn
+    H = nh * 64
+    q = rnd((B * Lq, H), gpu, 1.0, 1).requires_grad_(True)
+    kv = rnd((B * Lk, 2 * H), gpu, 1.0, 2).requires_grad_(True)
+    dout = rnd((B * Lq, H), gpu, 1.0, 3)
+    out = Fn.AttentionXFn.apply(q, kv, B, nh, Lq, Lk, 0.125)
+    out.backward(dout)
+    qf = q.detach().float().view(B, Lq, nh, 64).transpose(1, 2).requires_grad_(True)
+    kf = kv.detach().float()[:, :H].reshape(B, Lk, nh, 64).transpose(1, 2).requires_grad_(True)
+    vf = kv.detach().float()[:, H:].reshape(B, Lk, nh, 64).transpose(1, 2).requires_grad_(True)
+    ref = torch.softmax(qf @ kf.transpose(-1, -2) * 0.125, dim=-1) @ vf
+    ref.backward(dout.float().view(B, Lq, nh, 64).transpose(1, 2))
+    back = lambda t: t.transpose(1, 2).reshape(t.shape[0] * t.shape[2], H)
+    assert rel_err(out, back(ref)) < 2e-2
+    assert rel_err(q.grad, back(qf.grad)) < 3e-2
+    assert rel_err(kv.grad[:, :H], back(kf.grad)) < 3e-2
+    assert rel_err(kv.grad[:, H:], back(vf.grad)) < 3e-2
+
+
+def test_rotary_split_and_swiglu(gpu):
+    """ia_rotary_split_* and ia_swiglu_* through FusedSplitFn against the reference formulas
+    (multimodal.py:495-524: inv_freq = 10000^(-2i/64), rotate_half, silu(gate) * x)."""
+    from item_alignment_amd.models import functional as Fn
+    B, n, heads, F_ = 3, 37, 4, 96
+    M, ld = B * n, heads * 64 + 128 + 2 * F_
+    fused = rnd((M, ld), gpu, 1.0, 5).requires_grad_(True)
+    q, kv, s = Fn.FusedSplitFn.apply(fused, n, heads, F_)
+    gq, gkv, gs = rnd(q.shape, gpu, 1.0, 6), rnd(kv.shape, gpu, 1.0, 7), rnd(s.shape, gpu, 1.0, 8)
+    torch.autograd.backward([q, kv, s], [gq, gkv, gs])
+
+    f = fused.detach().float().requires_grad_(True)
+    fq, fk, fv, ff = f.split((heads * 64, 64, 64, 2 * F_), dim=-1)
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, 64, 2, device=gpu).float() / 64))
+    pos = torch.arange(n, device=gpu).float().repeat(B)[:, None] * inv_freq[None, :]
+    pos = torch.cat((pos, pos), dim=-1)                                     # [M, 64]
+
+    def rot(t):
+        x1, x2 = t[..., :32], t[..., 32:]
+        return t * pos.cos().view(M, *([1] * (t.dim() - 2)), 64) + torch.cat((-x2, x1), dim=-1) * pos.sin().view(M, *([1] * (t.dim() - 2)), 64)
+    rq = rot(fq.reshape(M, heads, 64)).reshape(M, heads * 64)
+    rkv = torch.cat((rot(fk), fv), dim=-1)
+    xg, gate = ff.chunk(2, dim=-1)
+    rs = torch.nn.functional.silu(gate) * xg
+    torch.autograd.backward([rq, rkv, rs], [gq.float(), gkv.float(), gs.float()])
+    assert rel_err(q, rq) < 2e-2 and rel_err(kv, rkv) < 2e-2 and rel_err(s, rs) < 2e-2
+    assert rel_err(fused.grad, f.grad) < 2e-2
+
+    src = rnd((M, 2 * F_), gpu, 1.0, 9).requires_grad_(True)
+    out = Fn.SwiGLUFn.apply(src)
+    out.backward(gs)
+    sf = src.detach().float().requires_grad_(True)
+    a, b = sf.chunk(2, dim=-1)
+    r = torch.nn.functional.silu(b) * a
+    r.backward(gs.float())
+    assert rel_err(out, r) < 2e-2 and rel_err(src.grad, sf.grad) < 2e-2

@@ -142,6 +142,27 @@ def test_coca_sum(gpu):
     check(case, out, model)
 
 
+def test_coca_cross_attn(gpu):
+    """--ensemble cross_attn: rotary multi-query ParallelTransformerBlock + CrossAttention over the image tokens
+    (reference multimodal.py:529-706, 1003-1013), golden captured from the reference classes."""
+    import item_alignment_amd.models as M
+    case = load_case("coca_cross_attn")
+    v = vit_cfg(case)
+    cfg = cfg_of(case)
+    text = M.RobertaModel(cfg)
+    vit = M.VisionTransformer(img_size=v.image_size, patch_size=v.patch_size, embed_dim=v.embed_dim, depth=v.depth, num_heads=v.num_heads)
+    model = M.CoCaForItemAlignment(cfg, vit, text)
+    sd = weights(case)
+    assert any(k.startswith("multimodal_layers.1.1.fn.ff.2.weight") for k in sd)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(("position_ids" in k or "pooler" in k or ".head." in k or "inv_freq" in k) for k in missing), missing
+    model = model.cuda().eval()
+    out = model(g(case, "input_ids_1"), g(case, "attention_mask_1"), g(case, "token_type_ids_1"), None, g(case, "img1"),
+                g(case, "input_ids_2"), g(case, "attention_mask_2"), g(case, "token_type_ids_2"), None, g(case, "img2"), labels=g(case, "labels"))
+    check(case, out, model)
+
+
 def test_full_width_layer(gpu):
     """roberta_large geometry, one layer, L = 510 (the C2 shapes): hidden states vs the reference subsample."""
     import item_alignment_amd.models as M
