@@ -103,6 +103,32 @@ int ia_rotary_split_bwd(const void* dq, const void* dkv, void* dsrc, int ld_src,
 int ia_swiglu_fwd(const void* src, int ld_src, void* out, int M, int F, ia_stream_t stream);
 int ia_swiglu_bwd(const void* dout, const void* src, int ld_src, void* dsrc, int ld_dsrc, int M, int F, ia_stream_t stream);
 
+/* ---- PKGM knowledge-graph rows (src/models/base.py:347-392 RobertaPKGMEmbeddings.kg_embeddings).  ids: [B, ld_ids] int64
+ * with the entity id at column ent_col and P relation ids from column rel_lo.  gather: h_sign [B, Dk] = sign(ent[e])
+ * (F.normalize over a size-1 dim), r [B*P, Dk] = rel[r_p]; its backward scatters dr into the relation table's gradient
+ * (fp32 atomics; the entity table gets none, d sign = 0).  rows: rows[b, row0 + p] = h[b] + r[b, p],
+ * rows[b, row0 + P + p] = hp[b] - r[b, p] inside a [B, rows_per_item, H] buffer (hp = proj_mat(h), computed by the
+ * caller with ia_linear_small_fwd). */
+int ia_kg_gather_fwd(const float* ent_table, const float* rel_table, const int64_t* ids, int ld_ids, int ent_col, int rel_lo,
+                     float* h_sign, float* r, int B, int P, int Dk, ia_stream_t stream);
+int ia_kg_gather_bwd(const float* dr, const int64_t* ids, int ld_ids, int rel_lo, float* rel_grad, int B, int P, int Dk,
+                     ia_stream_t stream);
+int ia_kg_rows_fwd(const float* h, const float* r, const float* hp, float* rows, int rows_per_item, int row0, int B, int P, int H,
+                   ia_stream_t stream);
+int ia_kg_rows_bwd(const float* drows, int rows_per_item, int row0, float* dh, float* dr, float* dhp, int B, int P, int H,
+                   ia_stream_t stream);
+
+/* ---- vector-similarity head (src/models/base.py:10-34 InnerProduct, :75-88 VecSimClassificationHead.forward) on fp32
+ * [B, D] features: sim [B] and the probability it maps to.  measure: */
+#define IA_SIM_INNER 0   /* sum(x*y); probs = sigmoid(sim) */
+#define IA_SIM_COSINE 1  /* F.cosine_similarity (eps 1e-8); probs = (sim + 1) / 2 */
+#define IA_SIM_L1 2      /* F.pairwise_distance p=1 (eps 1e-6 added to the difference); probs = exp(-sim) */
+#define IA_SIM_L2 3      /* F.pairwise_distance p=2; probs = exp(-sim) */
+int ia_pair_sim_fwd(const float* x, const float* y, float* sim, float* probs, int B, int D, int measure, ia_stream_t stream);
+/* dsim / dprobs: upstream gradients of the two outputs (either may be NULL) */
+int ia_pair_sim_bwd(const float* x, const float* y, const float* sim, const float* probs, const float* dsim, const float* dprobs,
+                    float* dx, float* dy, int B, int D, int measure, ia_stream_t stream);
+
 /* ---- embeddings (src/models/base.py:238-279, :501-556, :394-442) */
 int ia_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const int32_t* extra_idx, const float* word,
                     const float* type, const float* pos, const float* extra, const float* gamma, const float* beta, void* z_out,

@@ -49,6 +49,12 @@ SIGNATURES = {
     "ia_rotary_split_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "ia_swiglu_fwd": (i32, [vp, i32, vp, i32, i32, vp]),
     "ia_swiglu_bwd": (i32, [vp, vp, i32, vp, i32, i32, i32, vp]),
+    "ia_kg_gather_fwd": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, i32, i32, i32, vp]),
+    "ia_kg_gather_bwd": (i32, [vp, vp, i32, i32, vp, i32, i32, i32, vp]),
+    "ia_kg_rows_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "ia_kg_rows_bwd": (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, vp]),
+    "ia_pair_sim_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "ia_pair_sim_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "ia_embed_ln_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, u32, u32, vp]),
     "ia_embed_ln_bwd_workspace_bytes": (sz, [i32, i32]),
     "ia_embed_ln_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, u32, u32,

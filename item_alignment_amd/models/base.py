@@ -217,26 +217,24 @@ class RobertaPKGMEmbeddings(RobertaEmbeddings):
             self.entity_projection_projetor = None
 
     def kg_rows(self, input_ids):
-        """[B, n_sides * 2P, H] fp32 KG rows (base.py:347-392).  The gathers / sign / adds touch B*(1+P) rows
-        and run as small torch index ops on the fp32 master tables; the three projections go through the
-        HIP small-linear kernel.  (A fused gather kernel is the listed next step, DESIGN.md.)"""
+        """[B, n_sides * 2P, H] fp32 KG rows (base.py:347-392): ia_kg_gather_fwd (entity sign + relation gather),
+        the projections through the HIP small-linear kernel, ia_kg_rows_fwd (h + r | M h - r)."""
         cfg = self.config
         S, P = cfg.max_seq_len, cfg.max_pvs
-        sides = [(S, S + 1, S + P + 1)]
+        sides = [(S, S + 1)]
         if cfg.interaction_type == "one_tower":
-            sides.append((2 * S + P + 1, 2 * S + P + 2, input_ids.shape[1]))
-        rows = []
-        for ent_col, lo, hi in sides:
-            h = torch.sign(self.ent_emb.weight[input_ids[:, ent_col]])            # F.normalize over a size-1 dim == sign (quirk A1)
-            r = self.rel_emb.weight[input_ids[:, lo:hi]]                           # [B, P, Dk]
+            sides.append((2 * S + P + 1, 2 * S + P + 2))
+        B = input_ids.shape[0]
+        parts = []
+        for ent_col, lo in sides:
+            h, r = Fn.KGGatherFn.apply(self.anchor, self, input_ids, ent_col, lo, P)     # sign (quirk A1) [B, Dk], [B*P, Dk]
             hp = Fn.LinearSmallFn.apply(h, self.proj_mat.weight, self.proj_mat, ACT_NONE)
             if self.entity_embedding_projetor is not None:
-                B, Pn, Dk = r.shape
                 h = Fn.LinearSmallFn.apply(h, self.entity_embedding_projetor.weight, self.entity_embedding_projetor, ACT_NONE)
-                r = Fn.LinearSmallFn.apply(r.reshape(B * Pn, Dk), self.relation_embedding_projetor.weight, self.relation_embedding_projetor, ACT_NONE).view(B, Pn, -1)
+                r = Fn.LinearSmallFn.apply(r, self.relation_embedding_projetor.weight, self.relation_embedding_projetor, ACT_NONE)
                 hp = Fn.LinearSmallFn.apply(hp, self.entity_projection_projetor.weight, self.entity_projection_projetor, ACT_NONE)
-            rows.append(torch.cat((h.unsqueeze(1) + r, hp.unsqueeze(1) - r), dim=1))
-        return torch.cat(rows, dim=1)
+            parts += [h, r, hp]
+        return Fn.KGRowsFn.apply(P, *parts)
 
     def forward(self, input_ids=None, token_type_ids=None, position_ids=None, inputs_embeds=None, past_key_values_length=0):
         cfg = self.config
@@ -488,8 +486,7 @@ class InnerProduct(nn.Module):
 
 
 class VecSimClassificationHead(nn.Module):
-    """reference base.py:37-88.  dense+tanh run on the HIP small-linear kernel; the similarity itself is a
-    [B]-sized reduction done with torch elementwise ops."""
+    """reference base.py:37-88.  dense+tanh on the HIP small-linear kernel, similarity + probability on ia_pair_sim_*."""
 
     def __init__(self, config):
         super().__init__()
@@ -504,14 +501,5 @@ class VecSimClassificationHead(nn.Module):
     def forward(self, features_1, features_2):
         x = _dropout_small(Fn.LinearSmallFn.apply(features_1, self.dense.weight, self.dense, ACT_TANH), self.drop_p, self.training)
         y = _dropout_small(Fn.LinearSmallFn.apply(features_2, self.dense.weight, self.dense, ACT_TANH), self.drop_p, self.training)
-        sm = self.config.similarity_measure
-        if sm == "cosine":
-            sim = nn.functional.cosine_similarity(x, y)
-            probs = (sim + 1) / 2
-        elif sm in ("l1", "l2"):
-            sim = nn.functional.pairwise_distance(x, y, p=1 if sm == "l1" else 2)
-            probs = torch.exp(-sim)
-        else:
-            sim = (x * y).sum(-1)
-            probs = torch.sigmoid(sim)
+        sim, probs = Fn.PairSimFn.apply(x, y, Fn.SIM_MEASURES[self.config.similarity_measure])
         return x, y, sim, probs

@@ -515,3 +515,99 @@ class AttentionXFn(torch.autograd.Function):
                                 lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), H, dkv.data_ptr(), dkv.data_ptr() + 2 * H, 2 * H, B, nh, Lq,
                                 Lk, scale, 0.0, 0, stream_ptr()), "ia_attn_bwd_x")
         return dq, dkv, None, None, None, None, None
+
+
+# -------------------------------------------------------------------------------- PKGM rows, similarity head
+class KGGatherFn(torch.autograd.Function):
+    """sign(ent_emb[e]) [B, Dk] and rel_emb[r_1..P] [B*P, Dk] for one item side (reference base.py:347-367)."""
+
+    @staticmethod
+    def forward(ctx, anchor, emb, input_ids, ent_col, rel_lo, P):
+        lib = _lib.load()
+        _need_gpu(input_ids, "input_ids")
+        ids = input_ids.contiguous()
+        B, ld = ids.shape
+        Dk = emb.ent_emb.weight.shape[1]
+        h = torch.empty((B, Dk), device=ids.device, dtype=F32)
+        r = torch.empty((B * P, Dk), device=ids.device, dtype=F32)
+        check(lib.ia_kg_gather_fwd(emb.ent_emb.weight.data_ptr(), emb.rel_emb.weight.data_ptr(), ids.data_ptr(), ld, ent_col, rel_lo,
+                                   h.data_ptr(), r.data_ptr(), B, P, Dk, stream_ptr()), "ia_kg_gather_fwd")
+        ctx.emb, ctx.ids, ctx.dims = emb, ids, (B, ld, rel_lo, P, Dk)
+        ctx.mark_non_differentiable(h)        # d sign(x)/dx = 0: the entity table gets no gradient (quirk A1)
+        return h, r
+
+    @staticmethod
+    def backward(ctx, _dh, dr):
+        lib = _lib.load()
+        B, ld, rel_lo, P, Dk = ctx.dims
+        w = ctx.emb.rel_emb.weight
+        if w.requires_grad and dr is not None:
+            check(lib.ia_kg_gather_bwd(dr.contiguous().data_ptr(), ctx.ids.data_ptr(), ld, rel_lo, w.grad.data_ptr(), B, P, Dk, stream_ptr()),
+                  "ia_kg_gather_bwd")
+        _notify([ctx.emb.ent_emb.weight, w])
+        return None, None, None, None, None, None
+
+
+class KGRowsFn(torch.autograd.Function):
+    """[h + r | M h - r] rows of every item side, written side by side into one [B, sides*2P, H] buffer
+    (reference base.py:369-392).  Inputs: (h, r, hp) per side."""
+
+    @staticmethod
+    def forward(ctx, P, *sides):
+        lib = _lib.load()
+        n = len(sides) // 3
+        B, H = sides[0].shape
+        rows = torch.empty((B, n * 2 * P, H), device=sides[0].device, dtype=F32)
+        for i in range(n):
+            h, r, hp = (t.contiguous() for t in sides[3 * i:3 * i + 3])
+            check(lib.ia_kg_rows_fwd(h.data_ptr(), r.data_ptr(), hp.data_ptr(), rows.data_ptr(), n * 2 * P, i * 2 * P, B, P, H, stream_ptr()),
+                  "ia_kg_rows_fwd")
+        ctx.dims = (n, B, P, H)
+        return rows
+
+    @staticmethod
+    def backward(ctx, drows):
+        lib = _lib.load()
+        n, B, P, H = ctx.dims
+        drows = drows.contiguous()
+        out = []
+        for i in range(n):
+            dh = torch.empty((B, H), device=drows.device, dtype=F32)
+            dr = torch.empty((B * P, H), device=drows.device, dtype=F32)
+            dhp = torch.empty((B, H), device=drows.device, dtype=F32)
+            check(lib.ia_kg_rows_bwd(drows.data_ptr(), n * 2 * P, i * 2 * P, dh.data_ptr(), dr.data_ptr(), dhp.data_ptr(), B, P, H, stream_ptr()),
+                  "ia_kg_rows_bwd")
+            out += [dh, dr, dhp]
+        return (None, *out)
+
+
+SIM_MEASURES = {"inner_product": 0, "cosine": 1, "l1": 2, "l2": 3}
+
+
+class PairSimFn(torch.autograd.Function):
+    """sim [B], probs [B] of two fp32 feature matrices (reference base.py:75-88)."""
+
+    @staticmethod
+    def forward(ctx, x, y, measure):
+        lib = _lib.load()
+        _need_gpu(x, "features")
+        x, y = x.contiguous(), y.contiguous()
+        B, D = x.shape
+        sim = torch.empty(B, device=x.device, dtype=F32)
+        probs = torch.empty(B, device=x.device, dtype=F32)
+        check(lib.ia_pair_sim_fwd(x.data_ptr(), y.data_ptr(), sim.data_ptr(), probs.data_ptr(), B, D, measure, stream_ptr()), "ia_pair_sim_fwd")
+        ctx.saved, ctx.measure = (x, y, sim, probs), measure
+        ctx.set_materialize_grads(False)
+        return sim, probs
+
+    @staticmethod
+    def backward(ctx, dsim, dprobs):
+        lib = _lib.load()
+        x, y, sim, probs = ctx.saved
+        B, D = x.shape
+        dx, dy = torch.empty_like(x), torch.empty_like(y)
+        dsim = None if dsim is None else dsim.contiguous().to(F32)
+        dprobs = None if dprobs is None else dprobs.contiguous().to(F32)
+        check(lib.ia_pair_sim_bwd(x.data_ptr(), y.data_ptr(), sim.data_ptr(), probs.data_ptr(), ptr(dsim), ptr(dprobs), dx.data_ptr(),
+                                  dy.data_ptr(), B, D, ctx.measure, stream_ptr()), "ia_pair_sim_bwd")
+        return dx, dy, None

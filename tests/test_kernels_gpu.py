@@ -212,3 +212,26 @@ def test_rotary_split_and_swiglu(gpu):
     r = torch.nn.functional.silu(b) * a
     r.backward(gs.float())
     assert rel_err(out, r) < 2e-2 and rel_err(src.grad, sf.grad) < 2e-2
+
+
+@pytest.mark.parametrize("measure", ["inner_product", "cosine", "l1", "l2"])
+def test_pair_sim_head(gpu, measure):
+    """ia_pair_sim_fwd/bwd against torch.nn.functional (what reference base.py:75-88 calls), fp32: 1e-4."""
+    from item_alignment_amd.models import functional as Fn
+    import torch.nn.functional as F
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x = (torch.randn((7, 200), generator=g) * 0.3).to(gpu).requires_grad_(True)
+    y = (torch.randn((7, 200), generator=g) * 0.3).to(gpu).requires_grad_(True)
+    sim, probs = Fn.PairSimFn.apply(x, y, Fn.SIM_MEASURES[measure])
+    w1, w2 = torch.randn(7, device=gpu), torch.randn(7, device=gpu)
+    ((sim * w1).sum() + (probs * w2).sum()).backward()
+    xr, yr = x.detach().clone().requires_grad_(True), y.detach().clone().requires_grad_(True)
+    if measure == "cosine":
+        s = F.cosine_similarity(xr, yr); p = (s + 1) / 2
+    elif measure in ("l1", "l2"):
+        s = F.pairwise_distance(xr, yr, p=1 if measure == "l1" else 2); p = torch.exp(-s)
+    else:
+        s = (xr * yr).sum(-1); p = torch.sigmoid(s)
+    ((s * w1).sum() + (p * w2).sum()).backward()
+    assert rel_err(sim, s) < 1e-4 and rel_err(probs, p) < 1e-4
+    assert rel_err(x.grad, xr.grad) < 1e-4 and rel_err(y.grad, yr.grad) < 1e-4
