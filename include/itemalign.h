@@ -129,6 +129,44 @@ int ia_pair_sim_fwd(const float* x, const float* y, float* sim, float* probs, in
 int ia_pair_sim_bwd(const float* x, const float* y, const float* sim, const float* probs, const float* dsim, const float* dprobs,
                     float* dx, float* dy, int B, int D, int measure, ia_stream_t stream);
 
+/* ---- NHWC convolution tower (ECA-NFNet, src/models/image.py:191-199,253-257 -> timm NormFreeNet / NormFreeBlock /
+ * ScaledStdConv2d / EcaModule / DownsampleAvg).  Activations are [B, H, W, C] bf16 rows; a standardised weight is
+ * what[Cout][k*k*(C/groups)] bf16 with the tap index outermost inside a row (tap = ky*3 + kx).  k = 1 (stride 1,
+ * groups 1) is a plain GEMM; k = 3 (stride 1 or 2, padding 1) gathers patches into the workspace and runs one GEMM
+ * per group.  C/groups and Cout/groups must be multiples of 8 (the 3-channel stem input is zero-padded to 8). */
+int ia_nchw_to_nhwc_bf16(const float* in, void* out, int B, int C, int H, int W, int Cp, ia_stream_t stream);
+size_t ia_conv_nhwc_workspace_bytes(int B, int H, int W, int C, int Cout, int k, int stride, int groups);
+int ia_conv_nhwc_fwd(const void* x, const void* what, const float* bias, void* y, int B, int H, int W, int C, int Cout, int k, int stride,
+                     int groups, void* workspace, size_t workspace_bytes, ia_stream_t stream);
+int ia_conv_nhwc_bwd_data(const void* dy, const void* what, void* dx, int B, int H, int W, int C, int Cout, int k, int stride, int groups,
+                          void* workspace, size_t workspace_bytes, ia_stream_t stream);
+/* dwhat [Cout][k*k*C/groups] fp32 is overwritten; dbias [Cout] (may be NULL) is accumulated */
+int ia_conv_nhwc_bwd_weight(const void* x, const void* dy, float* dwhat, float* dbias, int B, int H, int W, int C, int Cout, int k,
+                            int stride, int groups, void* workspace, size_t workspace_bytes, ia_stream_t stream);
+/* ScaledStdConv2d weight: what[o][t*Cgp + c] = (w[o][c][t] - mean_o) * rstd_o * gain[o] * scale (statistics over the
+ * Cg*kk fan-in, biased variance, eps inside the sqrt; channels Cg..Cgp-1 zero).  bwd accumulates into dw / dgain. */
+int ia_ws_conv_weight_fwd(const float* w, const float* gain, void* what, float* mean, float* rstd, int Cout, int Cg, int kk, int Cgp,
+                          float scale, float eps, ia_stream_t stream);
+int ia_ws_conv_weight_bwd(const float* dwhat, const float* w, const float* gain, const float* mean, const float* rstd, float* dw,
+                          float* dgain, int Cout, int Cg, int kk, int Cgp, float scale, ia_stream_t stream);
+/* y = silu(x) * scale ; dx = dy * scale * silu'(x) (+ dadd) over n bf16 elements */
+int ia_silu_fwd(const void* x, void* y, size_t n, float scale, ia_stream_t stream);
+int ia_silu_bwd(const void* dy, const void* x, const void* dadd, void* dx, size_t n, float scale, ia_stream_t stream);
+/* AvgPool2d(2, 2, ceil_mode=True, count_include_pad=False) on NHWC */
+int ia_avgpool2_fwd(const void* x, void* y, int B, int H, int W, int C, ia_stream_t stream);
+int ia_avgpool2_bwd(const void* dy, void* dx, int B, int H, int W, int C, ia_stream_t stream);
+/* global average pool [B, HW, C] bf16 -> [B, C] fp32 */
+size_t ia_gap_workspace_bytes(int B, int HW, int C);
+int ia_gap_fwd(const void* x, float* pooled, int B, int HW, int C, void* workspace, size_t workspace_bytes, ia_stream_t stream);
+int ia_gap_bwd(const float* dpooled, void* dx, int B, int HW, int C, ia_stream_t stream);
+/* block tail: out = x * sigmoid(conv1d_k(mean_HW x))[b, c] * coef + shortcut (coef = attn_gain * alpha); pooled / gate
+ * [B, C] fp32 are saved for ia_eca_bwd, which returns dx (the shortcut's gradient is dout) and accumulates dconv_w [k] */
+int ia_eca_fwd(const void* x, const float* conv_w, int k, const void* shortcut, void* out, float* pooled, float* gate, int B, int HW, int C,
+               float coef, void* workspace, size_t workspace_bytes, ia_stream_t stream);
+size_t ia_eca_bwd_workspace_bytes(int B, int HW, int C);
+int ia_eca_bwd(const void* dout, const void* x, const float* conv_w, int k, const float* pooled, const float* gate, void* dx,
+               float* dconv_w, int B, int HW, int C, float coef, void* workspace, size_t workspace_bytes, ia_stream_t stream);
+
 /* ---- embeddings (src/models/base.py:238-279, :501-556, :394-442) */
 int ia_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const int32_t* extra_idx, const float* word,
                     const float* type, const float* pos, const float* extra, const float* gamma, const float* beta, void* z_out,

@@ -55,6 +55,23 @@ SIGNATURES = {
     "ia_kg_rows_bwd": (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, vp]),
     "ia_pair_sim_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "ia_pair_sim_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "ia_nchw_to_nhwc_bf16": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "ia_conv_nhwc_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32, i32, i32]),
+    "ia_conv_nhwc_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "ia_conv_nhwc_bwd_data": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "ia_conv_nhwc_bwd_weight": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "ia_ws_conv_weight_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, vp]),
+    "ia_ws_conv_weight_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
+    "ia_silu_fwd": (i32, [vp, vp, sz, f32, vp]),
+    "ia_silu_bwd": (i32, [vp, vp, vp, vp, sz, f32, vp]),
+    "ia_avgpool2_fwd": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "ia_avgpool2_bwd": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "ia_gap_workspace_bytes": (sz, [i32, i32, i32]),
+    "ia_gap_fwd": (i32, [vp, vp, i32, i32, i32, vp, sz, vp]),
+    "ia_gap_bwd": (i32, [vp, vp, i32, i32, i32, vp]),
+    "ia_eca_fwd": (i32, [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, sz, vp]),
+    "ia_eca_bwd_workspace_bytes": (sz, [i32, i32, i32]),
+    "ia_eca_bwd": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, sz, vp]),
     "ia_embed_ln_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, u32, u32, vp]),
     "ia_embed_ln_bwd_workspace_bytes": (sz, [i32, i32]),
     "ia_embed_ln_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, u32, u32,

@@ -1,0 +1,546 @@
+// NHWC convolution tower pieces for the norm-free ResNets (ECA-NFNet; reference src/models/image.py:191-199 -> timm
+// NormFreeNet / NormFreeBlock / ScaledStdConv2d / EcaModule): activations are [B, H, W, C] bf16 (= [B*H*W, C] rows),
+// so a 1x1 convolution IS the bf16 MFMA GEMM of gemm.hip and a (grouped) 3x3 convolution is a patch gather
+// (im2col, HBM-bound) followed by one GEMM per channel group; weights arrive standardised and laid out [Cout][tap][Cin/g].
+// Everything else here is an HBM-bound element-wise / reduction kernel with 16-byte accesses.
+#include "common.h"
+#include "../../include/itemalign.h"
+
+namespace {
+
+// ----------------------------------------------------------------------------------- layout conversion
+// images [B, C, H, W] fp32 (what the collate functions produce, reference data.py:92) -> [B, H, W, Cp] bf16, channels >= C zero
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, bf16* __restrict__ out, int C, int HW, int Cp,
+                                                           size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % Cp);
+  const size_t pix = idx / Cp, b = pix / HW, hw = pix % HW;
+  out[idx] = f2bf(c < C ? in[(b * C + c) * HW + hw] : 0.f);
+}
+
+// ------------------------------------------------------------------------------------------- im2col
+// cols[m][g*9*Cg + t*Cg + c] = x[b, oy*s + ky - 1, ox*s + kx - 1, g*Cg + c]   (t = ky*3 + kx, zero outside the image)
+__global__ __launch_bounds__(256) void im2col3_kernel(const bf16* __restrict__ x, bf16* __restrict__ cols, int H, int W, int C, int Cg,
+                                                      int Ho, int Wo, int stride, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c8n = C >> 3;
+  const int c = (int)(idx % c8n) * 8;
+  const int t = (int)((idx / c8n) % 9);
+  const size_t m = idx / ((size_t)c8n * 9);
+  const int ox = (int)(m % Wo), oy = (int)((m / Wo) % Ho);
+  const size_t b = m / ((size_t)Wo * Ho);
+  const int iy = oy * stride + t / 3 - 1, ix = ox * stride + t % 3 - 1;
+  bf16x8 v;
+  if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const bf16x8*>(x + ((b * H + iy) * W + ix) * C + c);
+  else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = f2bf(0.f);
+  }
+  const int g = c / Cg, cg = c % Cg;
+  *reinterpret_cast<bf16x8*>(cols + m * (size_t)(9 * C) + (size_t)g * 9 * Cg + t * Cg + cg) = v;
+}
+
+// dx[b, y, x, c] = sum over taps of dcols at the output positions that read this pixel (gather form: deterministic)
+__global__ __launch_bounds__(256) void col2im3_kernel(const bf16* __restrict__ dcols, bf16* __restrict__ dx, int H, int W, int C, int Cg,
+                                                      int Ho, int Wo, int stride, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c8n = C >> 3;
+  const int c = (int)(idx % c8n) * 8;
+  const size_t pix = idx / c8n;
+  const int ix = (int)(pix % W), iy = (int)((pix / W) % H);
+  const size_t b = pix / ((size_t)W * H);
+  const int g = c / Cg, cg = c % Cg;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int ny = iy + 1 - t / 3, nx = ix + 1 - t % 3;
+    if (ny < 0 || nx < 0 || (ny % stride) || (nx % stride)) continue;
+    const int oy = ny / stride, ox = nx / stride;
+    if (oy >= Ho || ox >= Wo) continue;
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(dcols + ((b * Ho + oy) * Wo + ox) * (size_t)(9 * C) + (size_t)g * 9 * Cg + t * Cg + cg);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += bf2f(v[j]);
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = f2bf(acc[j]);
+  *reinterpret_cast<bf16x8*>(dx + pix * C + c) = o;
+}
+
+// ------------------------------------------------------------------------------ weight standardisation
+// ScaledStdConv2d: what[o][t*Cgp + c] = (w[o][c][t] - mean_o) * rstd_o * gain[o] * scale, statistics over the real fan-in
+// (Cg*kk, biased variance, eps inside the sqrt); channels c >= Cg (padding of the 3-channel stem) are zero.  One wave per o.
+__global__ __launch_bounds__(256) void ws_weight_fwd_kernel(const float* __restrict__ w, const float* __restrict__ gain,
+                                                            bf16* __restrict__ what, float* __restrict__ mean, float* __restrict__ rstd,
+                                                            int Cout, int Cg, int kk, int Cgp, float scale, float eps) {
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (o >= Cout) return;
+  const int fan = Cg * kk;
+  const float* wo = w + (size_t)o * fan;
+  float s = 0.f, ss = 0.f;
+  for (int i = lane; i < fan; i += 64) { const float v = wo[i]; s += v; ss += v * v; }
+  s = wave_sum(s); ss = wave_sum(ss);
+  const float mu = s / fan;
+  const float var = fmaxf(ss / fan - mu * mu, 0.f);
+  const float rs = rsqrtf(var + eps);
+  if (lane == 0) { mean[o] = mu; rstd[o] = rs; }
+  const float a = rs * gain[o] * scale;
+  for (int i = lane; i < kk * Cgp; i += 64) {
+    const int t = i / Cgp, c = i % Cgp;
+    what[(size_t)o * kk * Cgp + i] = f2bf(c < Cg ? (wo[c * kk + t] - mu) * a : 0.f);
+  }
+}
+
+// dgain[o] (+)= scale * sum_i g_i xhat_i ; dw_i (+)= gain*scale*rstd * (g_i - mean(g) - xhat_i * mean(g * xhat))
+__global__ __launch_bounds__(256) void ws_weight_bwd_kernel(const float* __restrict__ dwhat, const float* __restrict__ w,
+                                                            const float* __restrict__ gain, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, float* __restrict__ dw, float* __restrict__ dgain,
+                                                            int Cout, int Cg, int kk, int Cgp, float scale) {
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (o >= Cout) return;
+  const int fan = Cg * kk;
+  const float* wo = w + (size_t)o * fan;
+  const float* go = dwhat + (size_t)o * kk * Cgp;
+  const float mu = mean[o], rs = rstd[o];
+  float sg = 0.f, sgx = 0.f;
+  for (int i = lane; i < fan; i += 64) {
+    const int c = i / kk, t = i % kk;
+    const float g = go[t * Cgp + c], xh = (wo[i] - mu) * rs;
+    sg += g; sgx += g * xh;
+  }
+  sg = wave_sum(sg); sgx = wave_sum(sgx);
+  if (lane == 0 && dgain) dgain[o] += scale * sgx;
+  if (!dw) return;
+  const float a = gain[o] * scale * rs, mg = sg / fan, mgx = sgx / fan;
+  for (int i = lane; i < fan; i += 64) {
+    const int c = i / kk, t = i % kk;
+    const float g = go[t * Cgp + c], xh = (wo[i] - mu) * rs;
+    dw[(size_t)o * fan + i] += a * (g - mg - xh * mgx);
+  }
+}
+
+// ------------------------------------------------------------------------------------------- SiLU
+__global__ __launch_bounds__(256) void silu_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, size_t n8, float scale) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + i * 8);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const float a = bf2f(v[j]); o[j] = f2bf(a / (1.f + __expf(-a)) * scale); }
+  *reinterpret_cast<bf16x8*>(y + i * 8) = o;
+}
+
+__global__ __launch_bounds__(256) void silu_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x, const bf16* __restrict__ dadd,
+                                                       bf16* __restrict__ dx, size_t n8, float scale) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const bf16x8 g = *reinterpret_cast<const bf16x8*>(dy + i * 8), v = *reinterpret_cast<const bf16x8*>(x + i * 8);
+  bf16x8 e;
+  if (dadd) e = *reinterpret_cast<const bf16x8*>(dadd + i * 8);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float a = bf2f(v[j]), sg = 1.f / (1.f + __expf(-a));
+    o[j] = f2bf(bf2f(g[j]) * scale * sg * (1.f + a * (1.f - sg)) + (dadd ? bf2f(e[j]) : 0.f));
+  }
+  *reinterpret_cast<bf16x8*>(dx + i * 8) = o;
+}
+
+// ----------------------------------------------------------------------------------------- avg-pool
+// AvgPool2d(2, stride 2, ceil_mode=True, count_include_pad=False) on NHWC (timm DownsampleAvg)
+__global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, int H, int W, int C, int Ho,
+                                                           int Wo, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c8n = C >> 3, c = (int)(idx % c8n) * 8;
+  const size_t m = idx / c8n;
+  const int ox = (int)(m % Wo), oy = (int)((m / Wo) % Ho);
+  const size_t b = m / ((size_t)Wo * Ho);
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  int cnt = 0;
+  for (int dy = 0; dy < 2; ++dy)
+    for (int dx = 0; dx < 2; ++dx) {
+      const int iy = oy * 2 + dy, ix = ox * 2 + dx;
+      if (iy >= H || ix >= W) continue;
+      ++cnt;
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + ((b * H + iy) * W + ix) * C + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += bf2f(v[j]);
+    }
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = f2bf(acc[j] / cnt);
+  *reinterpret_cast<bf16x8*>(y + m * C + c) = o;
+}
+
+__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const bf16* __restrict__ dy, bf16* __restrict__ dx, int H, int W, int C, int Ho,
+                                                           int Wo, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c8n = C >> 3, c = (int)(idx % c8n) * 8;
+  const size_t pix = idx / c8n;
+  const int ix = (int)(pix % W), iy = (int)((pix / W) % H);
+  const size_t b = pix / ((size_t)W * H);
+  const int oy = iy >> 1, ox = ix >> 1;
+  const int cnt = ((oy * 2 + 1 < H) ? 2 : 1) * ((ox * 2 + 1 < W) ? 2 : 1);
+  const bf16x8 g = *reinterpret_cast<const bf16x8*>(dy + ((b * Ho + oy) * Wo + ox) * C + c);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(g[j]) / cnt);
+  *reinterpret_cast<bf16x8*>(dx + pix * C + c) = o;
+}
+
+// ------------------------------------------------------------------------------- spatial reductions
+// part[b][s][c] = sum over the s-th slice of HW of x[b, hw, c] (* y[b, hw, c] if y); fixed slice order -> deterministic
+__global__ __launch_bounds__(256) void spatial_sum_kernel(const bf16* __restrict__ x, const bf16* __restrict__ y, float* __restrict__ part,
+                                                          int HW, int C, int nsplit) {
+  const int b = blockIdx.y, s = blockIdx.x;
+  const int per = (HW + nsplit - 1) / nsplit, h0 = s * per, h1 = min(HW, h0 + per);
+  for (int c = threadIdx.x * 8; c < C; c += 256 * 8) {
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int hw = h0; hw < h1; ++hw) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + ((size_t)b * HW + hw) * C + c);
+      if (y) {
+        const bf16x8 u = *reinterpret_cast<const bf16x8*>(y + ((size_t)b * HW + hw) * C + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += bf2f(v[j]) * bf2f(u[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += bf2f(v[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[((size_t)b * nsplit + s) * C + c + j] = acc[j];
+  }
+}
+
+__global__ __launch_bounds__(256) void spatial_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int C, int nsplit,
+                                                             float scale, int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int b = idx / C, c = idx % C;
+  float s = 0.f;
+  for (int i = 0; i < nsplit; ++i) s += part[((size_t)b * nsplit + i) * C + c];
+  out[idx] = s * scale;
+}
+
+// dx[b, hw, c] = g[b, c] * scale  (backward of the global average pool)
+__global__ __launch_bounds__(256) void spatial_bcast_kernel(const float* __restrict__ g, bf16* __restrict__ dx, int HW, int C, float scale,
+                                                            size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c8n = C >> 3, c = (int)(idx % c8n) * 8;
+  const size_t b = idx / ((size_t)c8n * HW);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = f2bf(g[b * C + c + j] * scale);
+  *reinterpret_cast<bf16x8*>(dx + idx * 8) = o;
+}
+
+// ---------------------------------------------------------------------------------------------- ECA
+// gate[b, c] = sigmoid(sum_j w[j] * pooled[b, c + j - pad])   (timm EcaModule: conv1d over the channel axis, zero padded)
+__global__ __launch_bounds__(256) void eca_gate_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ w,
+                                                           float* __restrict__ gate, int C, int k, int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int b = idx / C, c = idx % C, pad = (k - 1) / 2;
+  float s = 0.f;
+  for (int j = 0; j < k; ++j) {
+    const int cc = c + j - pad;
+    if (cc >= 0 && cc < C) s += w[j] * pooled[b * C + cc];
+  }
+  gate[idx] = 1.f / (1.f + __expf(-s));
+}
+
+// ds = dgate * gate (1 - gate); dpooled[b, c] = sum_j w[j] ds[b, c - j + pad]
+__global__ __launch_bounds__(256) void eca_gate_bwd_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
+                                                           const float* __restrict__ w, float* __restrict__ dpooled, int C, int k, int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int b = idx / C, c = idx % C, pad = (k - 1) / 2;
+  float s = 0.f;
+  for (int j = 0; j < k; ++j) {
+    const int cc = c - j + pad;
+    if (cc >= 0 && cc < C) { const float gt = gate[b * C + cc]; s += w[j] * dgate[b * C + cc] * gt * (1.f - gt); }
+  }
+  dpooled[idx] = s;
+}
+
+// dw[j] += sum_{b, c} ds[b, c] * pooled[b, c + j - pad]     (one block, k <= 16 taps)
+__global__ __launch_bounds__(256) void eca_gate_wgrad_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
+                                                             const float* __restrict__ pooled, float* __restrict__ dw, int B, int C, int k) {
+  __shared__ float red[4];
+  const int pad = (k - 1) / 2;
+  for (int j = 0; j < k; ++j) {
+    float s = 0.f;
+    for (int idx = threadIdx.x; idx < B * C; idx += 256) {
+      const int b = idx / C, c = idx % C, cc = c + j - pad;
+      if (cc >= 0 && cc < C) { const float gt = gate[idx]; s += dgate[idx] * gt * (1.f - gt) * pooled[b * C + cc]; }
+    }
+    s = wave_sum(s);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) dw[j] += red[0] + red[1] + red[2] + red[3];
+  }
+}
+
+// out = x * gate[b, c] * coef + shortcut      (attn_gain * ECA(x) * alpha + shortcut, timm NormFreeBlock.forward tail)
+__global__ __launch_bounds__(256) void scale_residual_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ gate,
+                                                                 const bf16* __restrict__ shortcut, bf16* __restrict__ out, int HW, int C,
+                                                                 float coef, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c8n = C >> 3, c = (int)(idx % c8n) * 8;
+  const size_t b = idx / ((size_t)c8n * HW);
+  const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + idx * 8), sc = *reinterpret_cast<const bf16x8*>(shortcut + idx * 8);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(v[j]) * gate[b * C + c + j] * coef + bf2f(sc[j]));
+  *reinterpret_cast<bf16x8*>(out + idx * 8) = o;
+}
+
+// dx = dout * gate * coef + dpooled[b, c] / HW
+__global__ __launch_bounds__(256) void scale_residual_bwd_kernel(const bf16* __restrict__ dout, const float* __restrict__ gate,
+                                                                 const float* __restrict__ dpooled, bf16* __restrict__ dx, int HW, int C,
+                                                                 float coef, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c8n = C >> 3, c = (int)(idx % c8n) * 8;
+  const size_t b = idx / ((size_t)c8n * HW);
+  const bf16x8 g = *reinterpret_cast<const bf16x8*>(dout + idx * 8);
+  const float inv = 1.f / HW;
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(g[j]) * gate[b * C + c + j] * coef + dpooled[b * C + c + j] * inv);
+  *reinterpret_cast<bf16x8*>(dx + idx * 8) = o;
+}
+
+inline unsigned blocks_of(size_t total) { return (unsigned)((total + 255) / 256); }
+inline int nsplit_of(int HW) { int n = HW / 64; return n < 1 ? 1 : (n > 64 ? 64 : n); }
+
+struct ConvGeom { int B, H, W, C, Cout, k, stride, groups, Ho, Wo, Cg, Ng, K; size_t M; };
+int geom(ConvGeom& g, int B, int H, int W, int C, int Cout, int k, int stride, int groups) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || Cout <= 0 || groups <= 0 || (k != 1 && k != 3) || stride < 1 || stride > 2) return IA_ERR_ARG;
+  if (k == 1 && (stride != 1 || groups != 1)) return IA_ERR_UNSUPPORTED;
+  if ((C % groups) || (Cout % groups)) return IA_ERR_ARG;
+  g = ConvGeom{B, H, W, C, Cout, k, stride, groups, 0, 0, C / groups, Cout / groups, 0, 0};
+  if ((g.Cg & 7) || (g.Ng & 7)) return IA_ERR_ARG;
+  g.Ho = k == 1 ? H : (H + 2 - 3) / stride + 1;
+  g.Wo = k == 1 ? W : (W + 2 - 3) / stride + 1;
+  g.K = k * k * g.Cg;
+  g.M = (size_t)B * g.Ho * g.Wo;
+  // one GEMM operand window must stay below 2 GiB (32-bit buffer offsets)
+  if (g.M * (size_t)(k * k * C) * 2 >= 0x7FFFFFFFull || g.M * (size_t)Cout * 2 >= 0x7FFFFFFFull) return IA_ERR_ARG;
+  return IA_OK;
+}
+
+}  // namespace
+
+extern "C" int ia_nchw_to_nhwc_bf16(const float* in, void* out, int B, int C, int H, int W, int Cp, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!in || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0 || Cp < C) return IA_ERR_ARG;
+  const size_t total = (size_t)B * H * W * Cp;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, in, (bf16*)out, C, H * W, Cp, total);
+  return ia_check_launch();
+}
+
+// workspace: the im2col buffer (3x3 only) + the split-K scratch of the weight-gradient GEMMs
+extern "C" size_t ia_conv_nhwc_workspace_bytes(int B, int H, int W, int C, int Cout, int k, int stride, int groups) {
+  ConvGeom g;
+  if (geom(g, B, H, W, C, Cout, k, stride, groups)) return 0;
+  size_t cols = k == 3 ? g.M * (size_t)(9 * C) * 2 : 0;
+  cols = (cols + 255) & ~(size_t)255;
+  const size_t gw = ia_gemm_workspace_bytes(g.Ng, g.K, (int)g.M, 1), cs = ia_colsum_workspace_bytes((int)g.M, Cout);
+  return cols + (gw > cs ? gw : cs);
+}
+
+// y [B*Ho*Wo, Cout] = conv(x [B*H*W, C], what [Cout][k*k*Cg]) + bias
+extern "C" int ia_conv_nhwc_fwd(const void* x, const void* what, const float* bias, void* y, int B, int H, int W, int C, int Cout, int k,
+                                int stride, int groups, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  (void)hipGetLastError();
+  ConvGeom g;
+  int rc = geom(g, B, H, W, C, Cout, k, stride, groups);
+  if (rc) return rc;
+  if (!x || !what || !y) return IA_ERR_ARG;
+  const int epi = bias ? IA_EPI_BIAS : IA_EPI_NONE;
+  if (k == 1) return ia_gemm_bf16(x, 0, C, what, 0, C, y, 0, Cout, (int)g.M, Cout, C, epi, bias, nullptr, 0, nullptr, 0, nullptr, 0, stream);
+  if (!workspace || workspace_bytes < ia_conv_nhwc_workspace_bytes(B, H, W, C, Cout, k, stride, groups)) return IA_ERR_WORKSPACE;
+  bf16* cols = (bf16*)workspace;
+  const size_t total = g.M * 9 * (size_t)(C >> 3);
+  hipLaunchKernelGGL(im2col3_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)x, cols, H, W, C, g.Cg, g.Ho, g.Wo, stride, total);
+  rc = ia_check_launch();
+  for (int gi = 0; gi < groups && !rc; ++gi)
+    rc = ia_gemm_bf16(cols + (size_t)gi * g.K, 0, 9 * C, (const bf16*)what + (size_t)gi * g.Ng * g.K, 0, g.K, (bf16*)y + gi * g.Ng, 0, Cout,
+                      (int)g.M, g.Ng, g.K, epi, bias ? bias + gi * g.Ng : nullptr, nullptr, 0, nullptr, 0, nullptr, 0, stream);
+  return rc;
+}
+
+// dx [B*H*W, C] from dy [B*Ho*Wo, Cout]
+extern "C" int ia_conv_nhwc_bwd_data(const void* dy, const void* what, void* dx, int B, int H, int W, int C, int Cout, int k, int stride,
+                                     int groups, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  (void)hipGetLastError();
+  ConvGeom g;
+  int rc = geom(g, B, H, W, C, Cout, k, stride, groups);
+  if (rc) return rc;
+  if (!dy || !what || !dx) return IA_ERR_ARG;
+  if (k == 1) return ia_gemm_bf16(dy, 0, Cout, what, 1, C, dx, 0, C, (int)g.M, C, Cout, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, stream);
+  if (!workspace || workspace_bytes < ia_conv_nhwc_workspace_bytes(B, H, W, C, Cout, k, stride, groups)) return IA_ERR_WORKSPACE;
+  bf16* dcols = (bf16*)workspace;
+  for (int gi = 0; gi < groups && !rc; ++gi)
+    rc = ia_gemm_bf16((const bf16*)dy + gi * g.Ng, 0, Cout, (const bf16*)what + (size_t)gi * g.Ng * g.K, 1, g.K, dcols + (size_t)gi * g.K, 0,
+                      9 * C, (int)g.M, g.K, g.Ng, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, stream);
+  if (rc) return rc;
+  const size_t total = (size_t)B * H * W * (C >> 3);
+  hipLaunchKernelGGL(col2im3_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, dcols, (bf16*)dx, H, W, C, g.Cg, g.Ho, g.Wo, stride, total);
+  return ia_check_launch();
+}
+
+// dwhat [Cout][k*k*Cg] fp32 (overwritten) and dbias [Cout] (+=, may be NULL) from x and dy
+extern "C" int ia_conv_nhwc_bwd_weight(const void* x, const void* dy, float* dwhat, float* dbias, int B, int H, int W, int C, int Cout, int k,
+                                       int stride, int groups, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  (void)hipGetLastError();
+  ConvGeom g;
+  int rc = geom(g, B, H, W, C, Cout, k, stride, groups);
+  if (rc) return rc;
+  if (!x || !dy || !dwhat) return IA_ERR_ARG;
+  const size_t need = ia_conv_nhwc_workspace_bytes(B, H, W, C, Cout, k, stride, groups);
+  if (need && (!workspace || workspace_bytes < need)) return IA_ERR_WORKSPACE;
+  size_t cols_bytes = k == 3 ? g.M * (size_t)(9 * C) * 2 : 0;
+  cols_bytes = (cols_bytes + 255) & ~(size_t)255;
+  const bf16* a = (const bf16*)x;
+  int lda = C;
+  if (k == 3) {
+    bf16* cols = (bf16*)workspace;
+    const size_t total = g.M * 9 * (size_t)(C >> 3);
+    hipLaunchKernelGGL(im2col3_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)x, cols, H, W, C, g.Cg, g.Ho, g.Wo, stride, total);
+    rc = ia_check_launch();
+    a = cols; lda = 9 * C;
+  }
+  void* gws = need > cols_bytes ? (char*)workspace + cols_bytes : nullptr;
+  for (int gi = 0; gi < groups && !rc; ++gi)
+    rc = ia_gemm_bf16((const bf16*)dy + gi * g.Ng, 1, Cout, a + (size_t)gi * g.K, 1, lda, dwhat + (size_t)gi * g.Ng * g.K, 1, g.K, g.Ng, g.K,
+                      (int)g.M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, gws, need - cols_bytes, stream);
+  if (rc || !dbias) return rc;
+  // bias gradient: column sums of dy, through the same scratch (the GEMMs above are stream-ordered before it)
+  const size_t cs = ia_colsum_workspace_bytes((int)g.M, Cout);
+  if (need - cols_bytes < cs) return IA_ERR_WORKSPACE;
+  return ia_colsum(dy, Cout, (int)g.M, Cout, dbias, 1, gws, need - cols_bytes, stream);
+}
+
+// what [Cout][kk*Cgp] bf16 from w [Cout][Cg][kk] fp32 (PyTorch conv weight), gain [Cout]; saves mean / rstd [Cout]
+extern "C" int ia_ws_conv_weight_fwd(const float* w, const float* gain, void* what, float* mean, float* rstd, int Cout, int Cg, int kk,
+                                     int Cgp, float scale, float eps, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!w || !gain || !what || !mean || !rstd || Cout <= 0 || Cg <= 0 || kk <= 0 || Cgp < Cg) return IA_ERR_ARG;
+  hipLaunchKernelGGL(ws_weight_fwd_kernel, dim3((Cout + 3) / 4), dim3(256), 0, stream, w, gain, (bf16*)what, mean, rstd, Cout, Cg, kk, Cgp, scale, eps);
+  return ia_check_launch();
+}
+
+// dw [Cout][Cg][kk] and dgain [Cout] (both +=, either may be NULL) from dwhat [Cout][kk*Cgp] fp32
+extern "C" int ia_ws_conv_weight_bwd(const float* dwhat, const float* w, const float* gain, const float* mean, const float* rstd, float* dw,
+                                     float* dgain, int Cout, int Cg, int kk, int Cgp, float scale, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dwhat || !w || !gain || !mean || !rstd || Cout <= 0 || Cg <= 0 || kk <= 0 || Cgp < Cg) return IA_ERR_ARG;
+  hipLaunchKernelGGL(ws_weight_bwd_kernel, dim3((Cout + 3) / 4), dim3(256), 0, stream, dwhat, w, gain, mean, rstd, dw, dgain, Cout, Cg, kk, Cgp, scale);
+  return ia_check_launch();
+}
+
+// y = silu(x) * scale over n bf16 elements (n % 8 == 0)
+extern "C" int ia_silu_fwd(const void* x, void* y, size_t n, float scale, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!x || !y || !n || (n & 7)) return IA_ERR_ARG;
+  hipLaunchKernelGGL(silu_fwd_kernel, dim3(blocks_of(n >> 3)), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, n >> 3, scale);
+  return ia_check_launch();
+}
+
+// dx = dy * scale * silu'(x) (+ dadd if not NULL: gradient arriving on a second use of x, e.g. the identity shortcut)
+extern "C" int ia_silu_bwd(const void* dy, const void* x, const void* dadd, void* dx, size_t n, float scale, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dy || !x || !dx || !n || (n & 7)) return IA_ERR_ARG;
+  hipLaunchKernelGGL(silu_bwd_kernel, dim3(blocks_of(n >> 3)), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)x, (const bf16*)dadd, (bf16*)dx, n >> 3, scale);
+  return ia_check_launch();
+}
+
+extern "C" int ia_avgpool2_fwd(const void* x, void* y, int B, int H, int W, int C, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7)) return IA_ERR_ARG;
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const size_t total = (size_t)B * Ho * Wo * (C >> 3);
+  hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, H, W, C, Ho, Wo, total);
+  return ia_check_launch();
+}
+
+extern "C" int ia_avgpool2_bwd(const void* dy, void* dx, int B, int H, int W, int C, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dy || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7)) return IA_ERR_ARG;
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const size_t total = (size_t)B * H * W * (C >> 3);
+  hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)dy, (bf16*)dx, H, W, C, Ho, Wo, total);
+  return ia_check_launch();
+}
+
+extern "C" size_t ia_gap_workspace_bytes(int B, int HW, int C) { return (size_t)B * nsplit_of(HW) * C * sizeof(float); }
+
+// pooled [B, C] fp32 = mean over HW of x [B, HW, C] bf16   (head.global_pool, reference image.py:255)
+extern "C" int ia_gap_fwd(const void* x, float* pooled, int B, int HW, int C, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!x || !pooled || B <= 0 || HW <= 0 || C <= 0 || (C & 7)) return IA_ERR_ARG;
+  if (!workspace || workspace_bytes < ia_gap_workspace_bytes(B, HW, C)) return IA_ERR_WORKSPACE;
+  const int ns = nsplit_of(HW);
+  hipLaunchKernelGGL(spatial_sum_kernel, dim3(ns, B), dim3(256), 0, stream, (const bf16*)x, (const bf16*)nullptr, (float*)workspace, HW, C, ns);
+  hipLaunchKernelGGL(spatial_finish_kernel, dim3((B * C + 255) / 256), dim3(256), 0, stream, (const float*)workspace, pooled, C, ns, 1.f / HW, B * C);
+  return ia_check_launch();
+}
+
+extern "C" int ia_gap_bwd(const float* dpooled, void* dx, int B, int HW, int C, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dpooled || !dx || B <= 0 || HW <= 0 || C <= 0 || (C & 7)) return IA_ERR_ARG;
+  const size_t total = (size_t)B * HW * (C >> 3);
+  hipLaunchKernelGGL(spatial_bcast_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, dpooled, (bf16*)dx, HW, C, 1.f / HW, total);
+  return ia_check_launch();
+}
+
+// out = x * sigmoid(conv1d_k(mean_HW(x)))[b, c] * coef + shortcut ; saves pooled, gate [B, C] fp32 for the backward pass
+extern "C" int ia_eca_fwd(const void* x, const float* conv_w, int k, const void* shortcut, void* out, float* pooled, float* gate, int B,
+                          int HW, int C, float coef, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!x || !conv_w || !shortcut || !out || !pooled || !gate || k <= 0 || k > 16 || !(k & 1)) return IA_ERR_ARG;
+  int rc = ia_gap_fwd(x, pooled, B, HW, C, workspace, workspace_bytes, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(eca_gate_fwd_kernel, dim3((B * C + 255) / 256), dim3(256), 0, stream, (const float*)pooled, conv_w, gate, C, k, B * C);
+  const size_t total = (size_t)B * HW * (C >> 3);
+  hipLaunchKernelGGL(scale_residual_fwd_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)x, (const float*)gate,
+                     (const bf16*)shortcut, (bf16*)out, HW, C, coef, total);
+  return ia_check_launch();
+}
+
+// dx (gradient of x); the shortcut's gradient is dout itself.  dconv_w [k] +=.  scratch: 2*B*C floats after the gap workspace.
+extern "C" size_t ia_eca_bwd_workspace_bytes(int B, int HW, int C) { return ia_gap_workspace_bytes(B, HW, C) + (size_t)2 * B * C * sizeof(float); }
+extern "C" int ia_eca_bwd(const void* dout, const void* x, const float* conv_w, int k, const float* pooled, const float* gate, void* dx,
+                          float* dconv_w, int B, int HW, int C, float coef, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dout || !x || !conv_w || !pooled || !gate || !dx || k <= 0 || k > 16 || !(k & 1) || (C & 7)) return IA_ERR_ARG;
+  if (!workspace || workspace_bytes < ia_eca_bwd_workspace_bytes(B, HW, C)) return IA_ERR_WORKSPACE;
+  const int ns = nsplit_of(HW);
+  float* part = (float*)workspace;
+  float* dgate = part + (size_t)B * ns * C;
+  float* dpooled = dgate + (size_t)B * C;
+  hipLaunchKernelGGL(spatial_sum_kernel, dim3(ns, B), dim3(256), 0, stream, (const bf16*)dout, (const bf16*)x, part, HW, C, ns);
+  hipLaunchKernelGGL(spatial_finish_kernel, dim3((B * C + 255) / 256), dim3(256), 0, stream, (const float*)part, dgate, C, ns, coef, B * C);
+  hipLaunchKernelGGL(eca_gate_bwd_kernel, dim3((B * C + 255) / 256), dim3(256), 0, stream, (const float*)dgate, gate, conv_w, dpooled, C, k, B * C);
+  if (dconv_w) hipLaunchKernelGGL(eca_gate_wgrad_kernel, dim3(1), dim3(256), 0, stream, (const float*)dgate, gate, pooled, dconv_w, B, C, k);
+  const size_t total = (size_t)B * HW * (C >> 3);
+  hipLaunchKernelGGL(scale_residual_bwd_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)dout, gate, (const float*)dpooled,
+                     (bf16*)dx, HW, C, coef, total);
+  return ia_check_launch();
+}

@@ -116,8 +116,11 @@ def create_model(model_name, pretrained=False, **kwargs):
     if model_name in VIT_CONFIGS:
         s, p, d, depth, h = VIT_CONFIGS[model_name]
         return VisionTransformer(img_size=kwargs.get("img_size", s), patch_size=p, embed_dim=d, depth=depth, num_heads=h)
-    raise NotImplementedError(f"image encoder {model_name!r}: only the ViT family runs on the HIP engine this round "
-                              "(eca_nfnet / resnetv2 conv towers are the next §8 row, DESIGN.md)")
+    from .nfnet import NFNET_CONFIGS, create_nfnet
+    if model_name in NFNET_CONFIGS:
+        return create_nfnet(model_name, **kwargs)
+    raise NotImplementedError(f"image encoder {model_name!r}: the ViT family and eca_nfnet_l0/l1/l2 run on the HIP engine "
+                              "(resnetv2 towers are not built, DESIGN.md)")
 
 
 class _ImageTwoTower(HipModule):

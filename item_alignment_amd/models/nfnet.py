@@ -1,0 +1,370 @@
+"""ECA-NFNet image tower on the HIP engine (reference src/models/image.py:40-199 NormFreeNet, built there from timm 0.6.5's
+NormFreeBlock / create_stem / ScaledStdConv2d / EcaModule / DownsampleAvg; timm itself is absent offline, so the block
+definitions follow timm's published source and only the in-tree bookkeeping, image.py:98-137, could be read directly).
+
+Activations are NHWC bf16 ([B*H*W, C] rows): a 1x1 convolution is the bf16 MFMA GEMM, a (grouped) 3x3 convolution is a patch
+gather + one GEMM per group (csrc/conv.hip).  Module / parameter names are timm's, so `image_encoder.bin` state_dicts load:
+`stem.conv{1..4}.{weight,bias,gain}`, `stages.{s}.{b}.{downsample.conv,conv1,conv2,conv2b,conv3}.{weight,bias,gain}`,
+`stages.{s}.{b}.attn_last.conv.weight`, `final_conv.*`, `head.fc.*`.
+"""
+import math
+
+import torch
+from torch import nn
+
+from .. import _lib
+from .._lib import check, ptr, stream_ptr
+from . import functional as Fn
+from .base import HipModule
+
+BF16, F32 = torch.bfloat16, torch.float32
+NONLIN_GAMMA_SILU = 1.7881293296813965          # timm nfnet.py _nonlin_gamma['silu']
+
+NFNET_CONFIGS = {   # timm nfnet.py model_cfgs (_nfnet_cfg): depths, channels, feat_mult
+    "eca_nfnet_l0": ((1, 2, 6, 3), (256, 512, 1536, 1536), 1.5),
+    "eca_nfnet_l1": ((2, 4, 12, 6), (256, 512, 1536, 1536), 2.0),
+    "eca_nfnet_l2": ((3, 6, 18, 9), (256, 512, 1536, 1536), 2.0),
+}
+
+
+def make_divisible(v, divisor=8, min_value=None, round_limit=0.9):
+    min_value = min_value or divisor
+    new_v = max(min_value, int(v + divisor / 2) // divisor * divisor)
+    if new_v < round_limit * v:
+        new_v += divisor
+    return new_v
+
+
+def _ws(dev, nbytes):
+    return torch.empty(max(int(nbytes), 16), device=dev, dtype=torch.uint8)
+
+
+# ----------------------------------------------------------------------------------------- autograd glue
+class StdConvFn(torch.autograd.Function):
+    """ScaledStdConv2d on NHWC rows: standardise the weight (ia_ws_conv_weight_fwd), convolve (ia_conv_nhwc_fwd); backward
+    = data gradient, weight gradient of the standardised weight, then back through the standardisation into the arena."""
+
+    @staticmethod
+    def forward(ctx, x, weight, conv, B, H, W):
+        lib = _lib.load()
+        Fn._need_gpu(x, "feature map")
+        x = x.contiguous()
+        C, Cout, k, s, g = conv.in_pad, conv.out_channels, conv.kernel_size, conv.stride, conv.groups
+        Cg, Cgp, kk = conv.weight.shape[1], C // g, k * k
+        dev = x.device
+        what = torch.empty((Cout, kk * Cgp), device=dev, dtype=BF16)
+        mean = torch.empty(Cout, device=dev, dtype=F32)
+        rstd = torch.empty(Cout, device=dev, dtype=F32)
+        check(lib.ia_ws_conv_weight_fwd(conv.weight.data_ptr(), conv.gain.data_ptr(), what.data_ptr(), mean.data_ptr(), rstd.data_ptr(), Cout, Cg,
+                                        kk, Cgp, conv.scale, conv.eps, stream_ptr()), "ia_ws_conv_weight_fwd")
+        Ho, Wo = (H, W) if k == 1 else ((H - 1) // s + 1, (W - 1) // s + 1)
+        y = torch.empty((B * Ho * Wo, Cout), device=dev, dtype=BF16)
+        wsb = lib.ia_conv_nhwc_workspace_bytes(B, H, W, C, Cout, k, s, g)
+        ws = _ws(dev, wsb)
+        check(lib.ia_conv_nhwc_fwd(x.data_ptr(), what.data_ptr(), ptr(conv.bias), y.data_ptr(), B, H, W, C, Cout, k, s, g, ws.data_ptr(), wsb,
+                                   stream_ptr()), "ia_conv_nhwc_fwd")
+        ctx.conv, ctx.saved, ctx.dims = conv, (x, what, mean, rstd), (B, H, W, C, Cout, k, s, g, Cg, Cgp, kk)
+        ctx.need_dx = ctx.needs_input_grad[0]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        conv = ctx.conv
+        x, what, mean, rstd = ctx.saved
+        B, H, W, C, Cout, k, s, g, Cg, Cgp, kk = ctx.dims
+        dy = dy.contiguous()
+        dev = dy.device
+        wsb = lib.ia_conv_nhwc_workspace_bytes(B, H, W, C, Cout, k, s, g)
+        ws = _ws(dev, wsb)
+        dx = None
+        if ctx.need_dx:
+            dx = torch.empty_like(x)
+            check(lib.ia_conv_nhwc_bwd_data(dy.data_ptr(), what.data_ptr(), dx.data_ptr(), B, H, W, C, Cout, k, s, g, ws.data_ptr(), wsb,
+                                            stream_ptr()), "ia_conv_nhwc_bwd_data")
+        if conv.weight.requires_grad:
+            dwhat = torch.empty((Cout, kk * Cgp), device=dev, dtype=F32)
+            bg = conv.bias.grad.data_ptr() if conv.bias is not None and conv.bias.requires_grad else None
+            check(lib.ia_conv_nhwc_bwd_weight(x.data_ptr(), dy.data_ptr(), dwhat.data_ptr(), bg, B, H, W, C, Cout, k, s, g, ws.data_ptr(), wsb,
+                                              stream_ptr()), "ia_conv_nhwc_bwd_weight")
+            check(lib.ia_ws_conv_weight_bwd(dwhat.data_ptr(), conv.weight.data_ptr(), conv.gain.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                            conv.weight.grad.data_ptr(), conv.gain.grad.data_ptr(), Cout, Cg, kk, Cgp, conv.scale, stream_ptr()),
+                  "ia_ws_conv_weight_bwd")
+            Fn._notify([p for p in (conv.weight, conv.bias, conv.gain) if p is not None])
+        ctx.saved = None
+        return dx, None, None, None, None, None
+
+
+class SiluFn(torch.autograd.Function):
+    """y = silu(x) * scale.  With `passthrough`, also hands x back as a second output (the identity shortcut of a
+    NormFreeBlock) so that both gradients are combined inside ia_silu_bwd instead of by a torch add."""
+
+    @staticmethod
+    def forward(ctx, x, scale, passthrough):
+        lib = _lib.load()
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        check(lib.ia_silu_fwd(x.data_ptr(), y.data_ptr(), x.numel(), scale, stream_ptr()), "ia_silu_fwd")
+        ctx.x, ctx.scale = x, scale
+        ctx.set_materialize_grads(False)
+        return (y, x.view_as(x)) if passthrough else y
+
+    @staticmethod
+    def backward(ctx, dy, dpass=None):
+        lib = _lib.load()
+        x = ctx.x
+        if dy is None:
+            return dpass, None, None
+        dx = torch.empty_like(x)
+        dp = None if dpass is None else dpass.contiguous()
+        check(lib.ia_silu_bwd(dy.contiguous().data_ptr(), x.data_ptr(), ptr(dp), dx.data_ptr(), x.numel(), ctx.scale, stream_ptr()), "ia_silu_bwd")
+        return dx, None, None
+
+
+class AvgPool2Fn(torch.autograd.Function):
+    """AvgPool2d(2, 2, ceil_mode=True, count_include_pad=False) (timm DownsampleAvg)."""
+
+    @staticmethod
+    def forward(ctx, x, B, H, W):
+        lib = _lib.load()
+        x = x.contiguous()
+        C = x.shape[1]
+        y = torch.empty((B * ((H + 1) // 2) * ((W + 1) // 2), C), device=x.device, dtype=BF16)
+        check(lib.ia_avgpool2_fwd(x.data_ptr(), y.data_ptr(), B, H, W, C, stream_ptr()), "ia_avgpool2_fwd")
+        ctx.dims = (B, H, W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        B, H, W, C = ctx.dims
+        dx = torch.empty((B * H * W, C), device=dy.device, dtype=BF16)
+        check(lib.ia_avgpool2_bwd(dy.contiguous().data_ptr(), dx.data_ptr(), B, H, W, C, stream_ptr()), "ia_avgpool2_bwd")
+        return dx, None, None, None
+
+
+class EcaResidualFn(torch.autograd.Function):
+    """out = x * sigmoid(conv1d(mean_HW x)) * (attn_gain * alpha) + shortcut  (timm EcaModule + NormFreeBlock.forward tail)."""
+
+    @staticmethod
+    def forward(ctx, x, shortcut, conv_w, eca, B, HW, coef):
+        lib = _lib.load()
+        x, shortcut = x.contiguous(), shortcut.contiguous()
+        C, k = x.shape[1], conv_w.shape[-1]
+        dev = x.device
+        out = torch.empty_like(x)
+        pooled = torch.empty((B, C), device=dev, dtype=F32)
+        gate = torch.empty((B, C), device=dev, dtype=F32)
+        wsb = lib.ia_gap_workspace_bytes(B, HW, C)
+        ws = _ws(dev, wsb)
+        check(lib.ia_eca_fwd(x.data_ptr(), conv_w.data_ptr(), k, shortcut.data_ptr(), out.data_ptr(), pooled.data_ptr(), gate.data_ptr(), B, HW, C,
+                             coef, ws.data_ptr(), wsb, stream_ptr()), "ia_eca_fwd")
+        ctx.eca, ctx.saved, ctx.dims = eca, (x, pooled, gate), (B, HW, C, k, coef)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, pooled, gate = ctx.saved
+        B, HW, C, k, coef = ctx.dims
+        w = ctx.eca.conv.weight
+        dout = dout.contiguous()
+        dx = torch.empty_like(x)
+        wsb = lib.ia_eca_bwd_workspace_bytes(B, HW, C)
+        ws = _ws(dout.device, wsb)
+        check(lib.ia_eca_bwd(dout.data_ptr(), x.data_ptr(), w.data_ptr(), k, pooled.data_ptr(), gate.data_ptr(), dx.data_ptr(),
+                             w.grad.data_ptr() if w.requires_grad else None, B, HW, C, coef, ws.data_ptr(), wsb, stream_ptr()), "ia_eca_bwd")
+        Fn._notify([w])
+        ctx.saved = None
+        return dx, dout, None, None, None, None, None
+
+
+class GapFn(torch.autograd.Function):
+    """[B*HW, C] bf16 -> mean over HW -> [B, C] fp32 (SelectAdaptivePool2d('avg', flatten=True))."""
+
+    @staticmethod
+    def forward(ctx, x, B, HW):
+        lib = _lib.load()
+        x = x.contiguous()
+        C = x.shape[1]
+        pooled = torch.empty((B, C), device=x.device, dtype=F32)
+        wsb = lib.ia_gap_workspace_bytes(B, HW, C)
+        ws = _ws(x.device, wsb)
+        check(lib.ia_gap_fwd(x.data_ptr(), pooled.data_ptr(), B, HW, C, ws.data_ptr(), wsb, stream_ptr()), "ia_gap_fwd")
+        ctx.dims = (B, HW, C)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dp):
+        lib = _lib.load()
+        B, HW, C = ctx.dims
+        dx = torch.empty((B * HW, C), device=dp.device, dtype=BF16)
+        check(lib.ia_gap_bwd(dp.contiguous().to(F32).data_ptr(), dx.data_ptr(), B, HW, C, stream_ptr()), "ia_gap_bwd")
+        return dx, None, None
+
+
+# ---------------------------------------------------------------------------------------------- modules
+class FeatureMap:
+    """NHWC feature map handed between the tower's modules: rows [B*H*W, C] bf16 + its geometry."""
+    __slots__ = ("t", "B", "H", "W")
+
+    def __init__(self, t, B, H, W):
+        self.t, self.B, self.H, self.W = t, B, H, W
+
+    @property
+    def shape(self):
+        return (self.B, self.H, self.W, self.t.shape[1])
+
+
+class ScaledStdConv2d(nn.Module):
+    """timm layers/std_conv.py ScaledStdConv2d (gamma folded into the weight scale, eps 1e-5, bias on)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, groups=1, gamma=NONLIN_GAMMA_SILU, eps=1e-5, gain_init=1.0):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size, self.stride, self.groups, self.eps = in_channels, out_channels, kernel_size, stride, groups, eps
+        self.in_pad = max(8, in_channels) if groups == 1 else in_channels      # the 3-channel image is zero-padded to 8
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels // groups, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        self.gain = nn.Parameter(torch.full((out_channels, 1, 1, 1), gain_init))
+        self.scale = gamma * self.weight[0].numel() ** -0.5
+        nn.init.kaiming_normal_(self.weight, mode="fan_in", nonlinearity="linear")       # reference image.py:156
+
+    def forward(self, f):
+        y = StdConvFn.apply(f.t, self.weight, self, f.B, f.H, f.W)
+        k, s = self.kernel_size, self.stride
+        Ho, Wo = (f.H, f.W) if k == 1 else ((f.H - 1) // s + 1, (f.W - 1) // s + 1)
+        return FeatureMap(y, f.B, Ho, Wo)
+
+
+class EcaModule(nn.Module):
+    """timm layers/eca.py EcaModule: kernel size from the channel count (gamma 2, beta 1)."""
+
+    def __init__(self, channels, gamma=2, beta=1):
+        super().__init__()
+        t = int(abs(math.log(channels, 2) + beta) / gamma)
+        k = max(t if t % 2 else t + 1, 3)
+        self.conv = nn.Conv1d(1, 1, kernel_size=k, padding=(k - 1) // 2, bias=False)
+
+
+class DownsampleAvg(nn.Module):
+    """timm nfnet.py DownsampleAvg: 2x2 average pool (stride > 1 only) then a 1x1 ScaledStdConv2d."""
+
+    def __init__(self, in_chs, out_chs, stride=1):
+        super().__init__()
+        self.stride = stride
+        self.pool = nn.AvgPool2d(2, stride, ceil_mode=True, count_include_pad=False) if stride > 1 else nn.Identity()
+        self.conv = ScaledStdConv2d(in_chs, out_chs, 1)
+
+    def forward(self, f):
+        if self.stride > 1:
+            f = FeatureMap(AvgPool2Fn.apply(f.t, f.B, f.H, f.W), f.B, (f.H + 1) // 2, (f.W + 1) // 2)
+        return self.conv(f)
+
+
+class NormFreeBlock(nn.Module):
+    """timm nfnet.py NormFreeBlock (reg=False, extra_conv=True, skipinit off, eca as attn_last, no drop path)."""
+
+    def __init__(self, in_chs, out_chs, stride=1, alpha=0.2, beta=1.0, bottle_ratio=0.25, group_size=64, ch_div=8, attn_gain=2.0):
+        super().__init__()
+        mid_chs = make_divisible(out_chs * bottle_ratio, ch_div)
+        groups = mid_chs // group_size
+        mid_chs = group_size * groups
+        self.alpha, self.beta, self.attn_gain = alpha, beta, attn_gain
+        self.downsample = DownsampleAvg(in_chs, out_chs, stride=stride) if (in_chs != out_chs or stride != 1) else None
+        self.conv1 = ScaledStdConv2d(in_chs, mid_chs, 1)
+        self.conv2 = ScaledStdConv2d(mid_chs, mid_chs, 3, stride=stride, groups=groups)
+        self.conv2b = ScaledStdConv2d(mid_chs, mid_chs, 3, stride=1, groups=groups)
+        self.conv3 = ScaledStdConv2d(mid_chs, out_chs, 1, gain_init=0.0)       # timm: gain_init = 1 if skipinit else 0
+        self.attn_last = EcaModule(out_chs)
+
+    def forward(self, f):
+        act = lambda g: FeatureMap(SiluFn.apply(g.t, 1.0, False), g.B, g.H, g.W)
+        if self.downsample is not None:
+            out = FeatureMap(SiluFn.apply(f.t, self.beta, False), f.B, f.H, f.W)
+            shortcut = self.downsample(out).t
+        else:
+            o, shortcut = SiluFn.apply(f.t, self.beta, True)
+            out = FeatureMap(o, f.B, f.H, f.W)
+        out = self.conv1(out)
+        out = self.conv2(act(out))
+        out = self.conv2b(act(out))
+        out = self.conv3(act(out))
+        y = EcaResidualFn.apply(out.t, shortcut, self.attn_last.conv.weight, self.attn_last, out.B, out.H * out.W, self.attn_gain * self.alpha)
+        return FeatureMap(y, out.B, out.H, out.W)
+
+
+class _GlobalPool(nn.Module):
+    def forward(self, f):
+        return GapFn.apply(f.t, f.B, f.H * f.W)
+
+
+class _Head(nn.Module):
+    """timm ClassifierHead: only `global_pool` is on the item-alignment path (reference image.py:255); `fc` is kept for
+    state_dict parity with timm checkpoints."""
+
+    def __init__(self, num_features, num_classes=1000):
+        super().__init__()
+        self.global_pool = _GlobalPool()
+        self.fc = nn.Linear(num_features, num_classes)
+
+
+class NormFreeNet(HipModule):
+    """reference image.py:40-199.  forward_features(images [B,3,S,S] fp32) -> FeatureMap ([B, S/32, S/32, num_features] NHWC
+    bf16); head.global_pool(map) -> [B, num_features] fp32."""
+
+    def __init__(self, depths, channels, feat_mult, stem_chs=128, group_size=64, bottle_ratio=0.25, alpha=0.2, attn_gain=2.0, num_classes=1000):
+        super().__init__()
+        chs = (stem_chs // 8, stem_chs // 4, stem_chs // 2, stem_chs)
+        stem, cin = [], 3
+        for i, (c, s) in enumerate(zip(chs, (2, 1, 1, 2))):                       # timm create_stem('deep_quad')
+            stem.append((f"conv{i + 1}", ScaledStdConv2d(cin, c, 3, stride=s)))
+            if i != 3:
+                stem.append((f"act{i + 2}", nn.SiLU()))
+            cin = c
+        from collections import OrderedDict
+        self.stem = nn.Sequential(OrderedDict(stem))
+        prev, expected_var, stages = stem_chs, 1.0, []
+        for si, depth in enumerate(depths):                                        # reference image.py:98-137
+            stride = 1 if si == 0 else 2
+            blocks = []
+            for bi in range(depth):
+                out_chs = make_divisible(channels[si], 8)
+                blocks.append(NormFreeBlock(prev, out_chs, stride=stride if bi == 0 else 1, alpha=alpha, beta=1.0 / expected_var ** 0.5,
+                                            bottle_ratio=bottle_ratio, group_size=group_size, attn_gain=attn_gain))
+                if bi == 0:
+                    expected_var = 1.0
+                expected_var += alpha ** 2
+                prev = out_chs
+            stages.append(nn.Sequential(*blocks))
+        self.stages = nn.Sequential(*stages)
+        self.num_features = make_divisible(int(channels[-1] * feat_mult), 8)
+        self.final_conv = ScaledStdConv2d(prev, self.num_features, 1)
+        self.final_act = nn.SiLU()
+        self.head = _Head(self.num_features, num_classes)
+        nn.init.normal_(self.head.fc.weight, 0.0, 0.01)
+        nn.init.zeros_(self.head.fc.bias)
+
+    def forward_features(self, images):
+        (self._root if "_root" in self.__dict__ else self).ensure_arena()
+        lib = _lib.load()
+        Fn._need_gpu(images, "images")
+        images = images.contiguous().to(F32)
+        B, C, H, W = images.shape
+        x = torch.empty((B * H * W, 8), device=images.device, dtype=BF16)
+        check(lib.ia_nchw_to_nhwc_bf16(images.data_ptr(), x.data_ptr(), B, C, H, W, 8, stream_ptr()), "ia_nchw_to_nhwc_bf16")
+        f = FeatureMap(x, B, H, W)
+        for name, m in self.stem.named_children():
+            f = m(f) if isinstance(m, ScaledStdConv2d) else FeatureMap(SiluFn.apply(f.t, 1.0, False), f.B, f.H, f.W)
+        for stage in self.stages:
+            for blk in stage:
+                f = blk(f)
+        f = self.final_conv(f)
+        return FeatureMap(SiluFn.apply(f.t, 1.0, False), f.B, f.H, f.W)
+
+    def forward(self, images):
+        return self.head.global_pool(self.forward_features(images))
+
+
+def create_nfnet(model_name, **kwargs):
+    depths, channels, feat_mult = NFNET_CONFIGS[model_name]
+    return NormFreeNet(depths, channels, feat_mult)

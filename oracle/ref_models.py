@@ -498,6 +498,158 @@ def image_two_tower(sd, cfg, feats1, feats2, labels=None, training=False):
     return _out(loss, logits, probs, src, tgt)
 
 
+# ----------------------------------------------------------------------------------------------- NF-Net
+# timm==0.6.5 `models/nfnet.py` + `layers/std_conv.py` + `layers/eca.py` restated from their published definitions
+# (timm is pinned by requirements.txt:13 but absent offline: PARITY UNPINNED by the reference for this tower).
+# The stage / stride / beta / expected-variance bookkeeping is the part the reference mirrors in-tree
+# (src/models/image.py:81-142) and is followed literally.
+
+NONLIN_GAMMA_SILU = 1.7881293296813965      # timm nfnet.py _nonlin_gamma['silu']
+
+
+def make_divisible(v, divisor=8, min_value=None, round_limit=0.9):
+    min_value = min_value or divisor
+    new_v = max(min_value, int(v + divisor / 2) // divisor * divisor)
+    if new_v < round_limit * v:
+        new_v += divisor
+    return new_v
+
+
+def nfnet_cfg(name="eca_nfnet_l0"):
+    """timm nfnet.py model_cfgs via _nfnet_cfg: deep_quad stem 128, group_size 64, bottle_ratio 0.25, extra_conv,
+    num_features = channels[-1] * feat_mult, act silu, attn eca, alpha 0.2, attn_gain 2.0, std_conv_eps 1e-5."""
+    from types import SimpleNamespace
+    table = {
+        "eca_nfnet_l0": dict(depths=(1, 2, 6, 3), channels=(256, 512, 1536, 1536), feat_mult=1.5),
+        "eca_nfnet_l1": dict(depths=(2, 4, 12, 6), channels=(256, 512, 1536, 1536), feat_mult=2.0),
+        "eca_nfnet_l2": dict(depths=(3, 6, 18, 9), channels=(256, 512, 1536, 1536), feat_mult=2.0),
+    }
+    t = table[name]
+    return SimpleNamespace(depths=t["depths"], channels=t["channels"], stem_chs=128, group_size=64, bottle_ratio=0.25,
+                           num_features=int(t["channels"][-1] * t["feat_mult"]), alpha=0.2, attn_gain=2.0, eps=1e-5, ch_div=8)
+
+
+def nfnet_plan(cfg):
+    """Per-block geometry exactly as reference image.py:98-137 derives it (output_stride 32, dilation 1 throughout):
+    list of stages, each a list of dicts(in_chs, out_chs, mid_chs, groups, stride, beta, downsample)."""
+    prev, expected_var, stages = cfg.stem_chs, 1.0, []
+    for si, depth in enumerate(cfg.depths):
+        stride = 1 if si == 0 else 2                       # stem stride 4 > 2 (image.py:99)
+        blocks = []
+        for bi in range(depth):
+            out_chs = make_divisible(cfg.channels[si], cfg.ch_div)
+            mid = make_divisible(out_chs * cfg.bottle_ratio, cfg.ch_div)        # reg=False: from out_chs (timm NormFreeBlock)
+            groups = mid // cfg.group_size
+            mid = cfg.group_size * groups
+            s = stride if bi == 0 else 1
+            blocks.append(dict(in_chs=prev, out_chs=out_chs, mid_chs=mid, groups=groups, stride=s, beta=1.0 / expected_var ** 0.5,
+                               downsample=(prev != out_chs or s != 1)))
+            if bi == 0:
+                expected_var = 1.0
+            expected_var += cfg.alpha ** 2
+            prev = out_chs
+        stages.append(blocks)
+    return stages
+
+
+def eca_kernel_size(channels, gamma=2, beta=1):
+    """timm layers/eca.py EcaModule."""
+    t = int(abs(math.log(channels, 2) + beta) / gamma)
+    return max(t if t % 2 else t + 1, 3)
+
+
+def scaled_std_conv(x, sd, p, stride=1, groups=1, eps=1e-5, gamma=NONLIN_GAMMA_SILU):
+    """timm layers/std_conv.py ScaledStdConv2d.forward: weight standardised per output channel over its fan-in
+    (biased variance, eps inside the sqrt) times gain * gamma * fan_in^-0.5; padding = get_padding(k, stride)."""
+    w = sd[p + ".weight"]
+    k = w.shape[-1]
+    scale = gamma * w[0].numel() ** -0.5
+    wf = w.reshape(w.shape[0], -1)
+    mu = wf.mean(dim=1, keepdim=True)
+    var = wf.var(dim=1, unbiased=False, keepdim=True)
+    what = ((wf - mu) / torch.sqrt(var + eps) * (sd[p + ".gain"].reshape(-1, 1) * scale)).reshape_as(w)
+    pad = ((stride - 1) + (k - 1)) // 2
+    return F.conv2d(x, what, sd[p + ".bias"], stride, pad, 1, groups)
+
+
+def eca(x, sd, p):
+    """timm EcaModule.forward: GAP -> conv1d over channels -> sigmoid -> scale."""
+    w = sd[p + ".conv.weight"]
+    y = x.mean((2, 3)).unsqueeze(1)
+    y = F.conv1d(y, w, padding=(w.shape[-1] - 1) // 2)
+    return x * torch.sigmoid(y).reshape(x.shape[0], -1, 1, 1)
+
+
+def nf_block(x, sd, p, blk, cfg):
+    """timm NormFreeBlock.forward (reg=False, extra_conv=True, skipinit off, no drop path)."""
+    out = F.silu(x) * blk["beta"]
+    shortcut = x
+    if blk["downsample"]:
+        sc = out
+        if blk["stride"] > 1:
+            sc = F.avg_pool2d(sc, 2, blk["stride"], ceil_mode=True, count_include_pad=False)      # DownsampleAvg
+        shortcut = scaled_std_conv(sc, sd, p + ".downsample.conv", eps=cfg.eps)
+    out = scaled_std_conv(out, sd, p + ".conv1", eps=cfg.eps)
+    out = scaled_std_conv(F.silu(out), sd, p + ".conv2", stride=blk["stride"], groups=blk["groups"], eps=cfg.eps)
+    out = scaled_std_conv(F.silu(out), sd, p + ".conv2b", groups=blk["groups"], eps=cfg.eps)
+    out = scaled_std_conv(F.silu(out), sd, p + ".conv3", eps=cfg.eps)
+    out = cfg.attn_gain * eca(out, sd, p + ".attn_last")
+    return out * cfg.alpha + shortcut
+
+
+def nfnet_forward_features(sd, p, cfg, images):
+    """reference image.py:191-199 NormFreeNet.forward_features: deep_quad stem (3x3 convs, strides 2,1,1,2, SiLU between),
+    stages, final 1x1 conv, final SiLU.  images: [B, 3, S, S] fp32 -> [B, num_features, S/32, S/32]."""
+    x = images
+    chs = (cfg.stem_chs // 8, cfg.stem_chs // 4, cfg.stem_chs // 2, cfg.stem_chs)
+    for i, s in enumerate((2, 1, 1, 2)):
+        x = scaled_std_conv(x, sd, f"{p}.stem.conv{i + 1}", stride=s, eps=cfg.eps)
+        if i != 3:
+            x = F.silu(x)
+    for si, blocks in enumerate(nfnet_plan(cfg)):
+        for bi, blk in enumerate(blocks):
+            x = nf_block(x, sd, f"{p}.stages.{si}.{bi}", blk, cfg)
+    x = scaled_std_conv(x, sd, p + ".final_conv", eps=cfg.eps)
+    return F.silu(x)
+
+
+def nfnet_global_pool(x):
+    """head.global_pool = SelectAdaptivePool2d('avg', flatten=True)."""
+    return x.mean((2, 3))
+
+
+def nfnet_state_spec(cfg, prefix="img_encoder"):
+    """(key, shape) list with timm's NormFreeNet key names (conv weight / bias / gain; ECA conv.weight)."""
+    spec = []
+
+    def conv(name, cin, cout, k, groups=1):
+        spec.extend([(f"{name}.weight", (cout, cin // groups, k, k)), (f"{name}.bias", (cout,)), (f"{name}.gain", (cout, 1, 1, 1))])
+    chs = (cfg.stem_chs // 8, cfg.stem_chs // 4, cfg.stem_chs // 2, cfg.stem_chs)
+    cin = 3
+    for i, c in enumerate(chs):
+        conv(f"{prefix}.stem.conv{i + 1}", cin, c, 3)
+        cin = c
+    for si, blocks in enumerate(nfnet_plan(cfg)):
+        for bi, b in enumerate(blocks):
+            q = f"{prefix}.stages.{si}.{bi}"
+            if b["downsample"]:
+                conv(q + ".downsample.conv", b["in_chs"], b["out_chs"], 1)
+            conv(q + ".conv1", b["in_chs"], b["mid_chs"], 1)
+            conv(q + ".conv2", b["mid_chs"], b["mid_chs"], 3, b["groups"])
+            conv(q + ".conv2b", b["mid_chs"], b["mid_chs"], 3, b["groups"])
+            conv(q + ".conv3", b["mid_chs"], b["out_chs"], 1)
+            spec.append((q + ".attn_last.conv.weight", (1, 1, eca_kernel_size(b["out_chs"]))))
+    conv(prefix + ".final_conv", cfg.channels[-1], cfg.num_features, 1)
+    return spec
+
+
+def nfnet_two_tower(sd, cfg, ncfg, images_1, images_2, labels=None, training=False):
+    """reference image.py:253-294 NFNetTwoTower.forward."""
+    f1 = nfnet_global_pool(nfnet_forward_features(sd, "img_encoder", ncfg, images_1))
+    f2 = nfnet_global_pool(nfnet_forward_features(sd, "img_encoder", ncfg, images_2))
+    return image_two_tower(sd, cfg, f1, f2, labels, training)
+
+
 # ---------------------------------------------------------------------------------------- optimiser step
 
 

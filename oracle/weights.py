@@ -14,7 +14,7 @@ def _kind(key):
     k = key.lower()
     if k.endswith("position_ids") or k.endswith("token_type_ids") or "inv_freq" in k:
         return "buffer"
-    if k.endswith("layernorm.weight") or k.endswith(".gamma") or ".norm" in k and k.endswith(".weight") or k.endswith("norm.weight"):
+    if k.endswith("layernorm.weight") or k.endswith(".gamma") or k.endswith(".gain") or ".norm" in k and k.endswith(".weight") or k.endswith("norm.weight"):
         return "gain"
     if k.endswith(".beta") and "norm" in k:
         return "zero_buffer"      # CoCa LayerNorm.beta is a zero buffer (reference multimodal.py:479)

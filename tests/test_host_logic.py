@@ -107,3 +107,38 @@ def test_textcnn_plumbing_model_matches_reference():
     p = dict(model.named_parameters())
     for k, want in case.grads.items():
         assert torch.allclose(p[k].grad, want, atol=1e-5, rtol=1e-4), k
+
+
+def test_nfnet_oracle_structure():
+    """The NF-Net restatement (timm is absent: parity unpinned) must at least reproduce the published structure of
+    eca_nfnet_l0: 24.14 M parameters with the 1000-way fc (timm model card), 2304 features, ECA kernel sizes from the channel
+    count, and the stage bookkeeping the reference mirrors in-tree (image.py:98-137)."""
+    import torch
+    from oracle import ref_models as O
+    cfg = O.nfnet_cfg("eca_nfnet_l0")
+    spec = O.nfnet_state_spec(cfg)
+    n = sum(int(torch.tensor(s).prod()) for _, s in spec) + 2304 * 1000 + 1000
+    assert abs(n / 1e6 - 24.14) < 0.01, n
+    assert cfg.num_features == 2304
+    plan = O.nfnet_plan(cfg)
+    assert [len(s) for s in plan] == [1, 2, 6, 3]
+    assert [s[0]["stride"] for s in plan] == [1, 2, 2, 2] and all(b["stride"] == 1 for s in plan for b in s[1:])
+    assert [s[0]["mid_chs"] for s in plan] == [64, 128, 384, 384] and [s[0]["groups"] for s in plan] == [1, 2, 6, 6]
+    assert plan[0][0]["beta"] == 1.0 and abs(plan[1][1]["beta"] - 1 / (1 + 0.04) ** 0.5) < 1e-12
+    assert abs(plan[2][5]["beta"] - 1 / (1 + 5 * 0.04) ** 0.5) < 1e-12
+    assert [O.eca_kernel_size(c) for c in (256, 512, 1536)] == [5, 5, 5]
+    x = torch.randn(1, 3, 64, 64)
+    from oracle.weights import seeded_state_dict
+    y = O.nfnet_forward_features(seeded_state_dict(spec, 1), "img_encoder", cfg, x)
+    assert tuple(y.shape) == (1, 2304, 2, 2) and torch.isfinite(y).all()
+
+
+def test_nfnet_module_matches_timm_names():
+    from item_alignment_amd.models import create_model
+    from oracle import ref_models as O
+    net = create_model("eca_nfnet_l0")
+    want = {k[len("img_encoder."):]: s for k, s in O.nfnet_state_spec(O.nfnet_cfg("eca_nfnet_l0"))}
+    have = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert set(want) | {"head.fc.weight", "head.fc.bias"} == set(have)
+    assert all(have[k] == tuple(s) for k, s in want.items())
+    assert sum(p.numel() for p in net.parameters()) == 24143924
