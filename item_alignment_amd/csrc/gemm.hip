@@ -545,10 +545,19 @@ Plan make_plan(int M, int N, int K, bool f32_out) {
   const int smax = f32_out ? (nk / 8 > 32 ? 32 : (nk / 8 < 1 ? 1 : nk / 8)) : 1;
   pl.big = M >= 256 && N >= 256 && (N & 7) == 0 && t256n * smax >= 160;
   const long tiles = pl.big ? t256n : (long)((M + 127) / 128) * ((N + 127) / 128);
-  const int target = pl.big ? 256 : 512;
-  int s = (int)((target + tiles - 1) / tiles);
-  if (s > smax) s = smax;
-  pl.splits = s < 1 ? 1 : s;
+  // Pick the cut that minimises the makespan: ceil(workgroups / resident slots) rounds of (k-tiles per workgroup + a fixed
+  // prologue/epilogue cost), plus the fixed-order reduction that reads one fp32 copy of C per split.  Overshooting the
+  // slot count by a few workgroups (36 tiles x 8 = 288 on 256 CUs) would cost a whole extra round.
+  const long slots = pl.big ? 256 : 512;
+  const double reduce_per_split = (double)tiles * (pl.big ? 0.0244 : 0.0061);   // in k-tile times of one workgroup
+  int best = 1;
+  double best_cost = 1e30;
+  for (int s = 1; s <= smax; ++s) {
+    const long rounds = (tiles * s + slots - 1) / slots;
+    const double cost = (double)rounds * ((nk + s - 1) / s + 6) + (s > 1 ? s * reduce_per_split : 0.0);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
+  }
+  pl.splits = best;
   return pl;
 }
 
