@@ -83,6 +83,19 @@ IA_DEV void epi_store4(const GemmArgs& p, int m, int n, f32x4 v) {
   }
 }
 
+// One 16-byte global store as exactly one VMEM instruction.  The persistent T256 kernel leaves a tile's output stores in
+// flight while the next tile's main loop starts and waits with a COUNTED s_waitcnt vmcnt(N) for the k-tile DMA issued
+// before them (vmcnt retires in issue order), so the number of store instructions per epilogue must be known exactly.
+template <typename V>
+IA_DEV void gstore16(void* ptr, V v) {
+  static_assert(sizeof(V) == 16, "16-byte store");
+  // s_nop 1: a store of more than 8 bytes reads its data registers over several cycles; a VALU write to them in the next
+  // two wait states corrupts the stored value (the compiler pads its own stores, it cannot see inside an asm statement)
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(ptr), "v"(v) : "memory");
+}
+template <int EPI, bool OUTF32>
+constexpr int epi_stores_per_call() { return OUTF32 ? 2 : (EPI == EPI_BIAS_GELU ? 2 : 1); }
+
 // v = 8 consecutive output columns n..n+7 of row m (row-coalesced epilogue of the T256 kernel)
 template <int EPI, bool OUTF32>
 IA_DEV void epi_store8(const GemmArgs& p, int m, int n, f32x4 lo, f32x4 hi) {
@@ -96,7 +109,7 @@ IA_DEV void epi_store8(const GemmArgs& p, int m, int n, f32x4 lo, f32x4 hi) {
     bf16x8 pre;
 #pragma unroll
     for (int r = 0; r < 8; ++r) pre[r] = f2bf(v[r]);
-    *reinterpret_cast<bf16x8*>(p.C2 + (size_t)m * p.ldc + n) = pre;
+    gstore16(p.C2 + (size_t)m * p.ldc + n, pre);
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = gelu_erf(bf2f(pre[r]));
   }
@@ -112,13 +125,13 @@ IA_DEV void epi_store8(const GemmArgs& p, int m, int n, f32x4 lo, f32x4 hi) {
     float* c = p.splits > 1 ? p.ws + ((size_t)blockIdx.y * p.M + m) * p.N + n : reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
     f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
     if (p.splits <= 1 && p.accumulate) { o0 += *reinterpret_cast<const f32x4*>(c); o1 += *reinterpret_cast<const f32x4*>(c + 4); }
-    *reinterpret_cast<f32x4*>(c) = o0;
-    *reinterpret_cast<f32x4*>(c + 4) = o1;
+    gstore16(c, o0);
+    gstore16(c + 4, o1);
   } else {
     bf16x8 o;
 #pragma unroll
     for (int r = 0; r < 8; ++r) o[r] = f2bf(v[r]);
-    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n) = o;
+    gstore16(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n, o);
   }
 }
 
@@ -260,8 +273,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 // ============================================================================== T256 (8 waves, 32x32x16)
 namespace t256 {
 constexpr int BM = 256, BN = 256, TILE_BYTES = 32768;
-constexpr int EPI_ROW = 260;                               // floats per staged output row (256 + 4 pad: conflict-free 16 B writes)
-constexpr int LDS_BYTES = 2 * 64 * EPI_ROW * 4;           // 133,120 B: >= the 128 KiB k-tile double buffer
+constexpr int STAGE_BYTES = 16 * 64 * 4;                   // per-wave epilogue slot: 16 rows x 64 columns fp32
+constexpr int LDS_BYTES = 2 * 2 * TILE_BYTES + 8 * STAGE_BYTES;   // 128 KiB k-tile double buffer + 32 KiB = all 160 KiB of the CU
 
 template <bool KS>
 IA_DEV void stage_tile(__amdgpu_buffer_rsrc_t rs, char* s, int kt, int x0, int ld, int K, int tid, int wave) {
@@ -309,9 +322,9 @@ IA_DEV bf16x8 frag_ks(const char* s, int k0, int col0, int lane) {
 
 // Ping-pong main loop of one wave group (GRP 0: rows 0..127 of the block tile and the A-operand DMA;
 // GRP 1: rows 128..255 and the B-operand DMA).  See the schedule comment in gemm_kernel.
-template <int GRP, bool AKS, bool BKS>
+template <int GRP, bool AKS, bool BKS, int PEND>
 IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][2], __amdgpu_buffer_rsrc_t rs, int x0, int ld, int kt0,
-                      int n_tiles, int nk_all, int wn, int lane, bool prologue_only) {
+                      int n_tiles, int nk_all, int wn, int lane, bool prologue_only, bool stores_in_flight) {
   constexpr bool MYKS = GRP ? BKS : AKS;            // layout of the operand this group streams
   const int hh = lane >> 5, li = lane & 31;
   const int gt = wn * 64 + lane;                    // thread index inside the group (0..255)
@@ -353,7 +366,10 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][2], __amdg
     }
     return;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prologue DMA (and the previous tile's stores)
+  // the prologue DMA of this tile.  After a full-tile epilogue exactly PEND store instructions were issued behind it and
+  // may stay in flight (vmcnt retires in order: at most PEND outstanding <=> every older DMA piece has landed).
+  if (stores_in_flight) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PEND) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (GRP == 1) __builtin_amdgcn_s_barrier();      // G1 idles through phase 0
 
@@ -384,7 +400,8 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][2], __amdg
         else bfr[ks][ni] = frag_kc(sB, wn * 64 + ni * 32 + nperm, ks * 2 + hh);
       }
     }
-    if (GRP == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // G1's DMA issued in its previous COMPUTE
+    // G1's DMA issued in its previous COMPUTE (none yet at u == 0: do not drain the previous tile's stores there)
+    if (GRP == 1 && u >= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     if (!(p.dbg & 16)) __builtin_amdgcn_s_barrier();
@@ -403,7 +420,7 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][2], __amdg
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][ni], af[ks][mi], acc[mi][ni], 0, 0, 0);
       }
     __builtin_amdgcn_s_setprio(0);
-    if (GRP == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // G0's DMA issued in this iteration's LOAD
+    if (GRP == 0 && u >= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // G0's DMA issued in this iteration's LOAD (u >= 1)
     __builtin_amdgcn_sched_barrier(0);
     if (!(p.dbg & 16)) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -433,22 +450,25 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs p) {
   // each waits for its own DMA one phase later, i.e. before the barrier that ends phase 2u+3.
   //
   // The workgroup is persistent over output tiles (one workgroup per CU): the DMA of the NEXT tile's first two
-  // k-tiles is issued before the current tile's epilogue, so the ~2 us HBM round trip of a tile prologue hides
-  // behind the epilogue's stores instead of idling the CU.
-  auto run = [&](int tile, bool prologue_only, f32x16 (&acc)[4][2]) {
+  // k-tiles is issued before the current tile's epilogue (which stages through LDS outside the k-tile buffers), so the
+  // ~2 us HBM round trip of a tile prologue hides behind the epilogue instead of idling the CU.
+  constexpr int PEND = 16 * epi_stores_per_call<EPI, OUTF32>();   // store instructions of one full-tile epilogue, per wave
+  static_assert(PEND < 60, "vmcnt is a 6-bit counter");
+  auto run = [&](int tile, bool prologue_only, f32x16 (&acc)[4][2], bool stores_in_flight) {
     int bm, bn;
     tile_of_index(p, tile, total_tiles, bm, bn);
     // keep per-lane address arithmetic from being hoisted out of the tile loop (it would stay live across the
     // epilogue and push the 256-register kernel into scratch): every call derives it afresh from an opaque lane id
     int lane = lane0;
     asm volatile("" : "+v"(lane));
-    if (wm == 0) main_loop<0, AKS, BKS>(p, smem, acc, ia_rsrc(p.A, p.a_bytes), bm * BM, p.lda, kt0, n_tiles, nk_all, wn, lane, prologue_only);
-    else         main_loop<1, AKS, BKS>(p, smem, acc, ia_rsrc(p.B, p.b_bytes), bn * BN, p.ldb, kt0, n_tiles, nk_all, wn, lane, prologue_only);
+    if (wm == 0) main_loop<0, AKS, BKS, PEND>(p, smem, acc, ia_rsrc(p.A, p.a_bytes), bm * BM, p.lda, kt0, n_tiles, nk_all, wn, lane, prologue_only, stores_in_flight);
+    else         main_loop<1, AKS, BKS, PEND>(p, smem, acc, ia_rsrc(p.B, p.b_bytes), bn * BN, p.ldb, kt0, n_tiles, nk_all, wn, lane, prologue_only, stores_in_flight);
   };
 
   f32x16 acc[4][2];
   int tile = blockIdx.x;
-  run(tile, true, acc);
+  run(tile, true, acc, false);
+  bool stores_in_flight = false;
   while (true) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -456,54 +476,59 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs p) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    run(tile, false, acc);
+    run(tile, false, acc, stores_in_flight);
     const int next = tile + gridDim.x;
 
-    // Epilogue through LDS (free once the main loop's last barrier has passed): the MFMA C^T fragments give each lane
-    // 4-element runs scattered over 32 rows, which as direct global stores cost ~11 us per tile (64 separate
-    // segments per store instruction).  Instead each group stages 64 rows x 256 columns of fp32 at a time, then
-    // every wave streams whole 1 KiB rows: bias / residual / GELU inputs are read and all outputs written fully
-    // coalesced (16 B per lane, 512 B runs).  C^T fragment: lane (m = li, half hh) register r <-> fragment row
-    // i = (r&3) + 8*(r>>2) + 4*hh; k-contiguous B: n = hh*16 + r; k-strided B: n = i.
+    // The k-tile buffers are free once the main loop's last barrier has passed: start the NEXT tile's first two k-tiles
+    // now, so their HBM round trip (~2 us) runs under this tile's epilogue.
+    if (next < total_tiles) run(next, true, acc, false);
+
+    // Epilogue through a wave-private LDS slot outside the k-tile buffers (no workgroup barrier).  The MFMA C^T fragments
+    // give each lane 4-element runs scattered over 32 rows, which as direct global stores cost ~11 us per tile (64 separate
+    // segments per store instruction).  Instead a wave stages 16 rows x 64 columns of fp32 (4 KiB, 16-byte chunks XOR-swizzled
+    // by row: conflict-free both ways), then streams them out: bias / residual / GELU inputs are read and all outputs written
+    // as full 128-byte row segments, 8 rows per instruction.  C^T fragment: lane (m = li, half hh) register r <-> fragment
+    // row i = (r&3) + 8*(r>>2) + 4*hh; k-contiguous B: n = hh*16 + r; k-strided B: n = i.
     int bm, bn;
     tile_of_index(p, tile, total_tiles, bm, bn);
-    const int m0 = bm * BM, n0 = bn * BN;
+    const int m0 = bm * BM + wm * 128, n0 = bn * BN + wn * 64;
     int lane_e = lane0;
     asm volatile("" : "+v"(lane_e));
     const int hh = lane_e >> 5, li = lane_e & 31;
-    float* gbuf = reinterpret_cast<float*>(smem) + wm * (64 * EPI_ROW);
+    char* stg = smem + 2 * 2 * TILE_BYTES + wave * STAGE_BYTES;
+    const int wrow = li & 15, rrow = lane_e >> 3, c8 = lane_e & 7;
+    if (!(p.dbg & 32))
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
+    for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
-      for (int mh = 0; mh < 2; ++mh) {
-        const int mi = ps * 2 + mh;
+      for (int h16 = 0; h16 < 2; ++h16) {
+        if ((li >> 4) == h16) {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
+          for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-          for (int rg = 0; rg < 4; ++rg) {
-            const int ncol = wn * 64 + ni * 32 + (BKS ? rg * 8 + hh * 4 : hh * 16 + rg * 4);
-            const f32x4 v = {acc[mi][ni][rg * 4], acc[mi][ni][rg * 4 + 1], acc[mi][ni][rg * 4 + 2], acc[mi][ni][rg * 4 + 3]};
-            *reinterpret_cast<f32x4*>(gbuf + (mh * 32 + li) * EPI_ROW + ncol) = v;
-          }
+            for (int rg = 0; rg < 4; ++rg) {
+              const int chunk = (ni * 32 + (BKS ? rg * 8 + hh * 4 : hh * 16 + rg * 4)) >> 2;
+              const f32x4 v = {acc[mi][ni][rg * 4], acc[mi][ni][rg * 4 + 1], acc[mi][ni][rg * 4 + 2], acc[mi][ni][rg * 4 + 3]};
+              *reinterpret_cast<f32x4*>(stg + wrow * 256 + ((chunk ^ wrow) << 4)) = v;
+            }
         }
-      }
-      __syncthreads();
-      // wave wn streams rows wn*16 .. wn*16+15 of the staged 64; a half-wave covers one row (32 lanes x 8 columns)
-#pragma unroll 2
-      for (int st = 0; st < 8; ++st) {
-        const int rl = wn * 16 + st * 2 + hh;
-        const int m = m0 + wm * 128 + ps * 64 + rl;
-        const int n = n0 + li * 8;
-        if (m < p.M && n < p.N) {
-          const f32x4 lo = *reinterpret_cast<const f32x4*>(gbuf + rl * EPI_ROW + li * 8);
-          const f32x4 hi = *reinterpret_cast<const f32x4*>(gbuf + rl * EPI_ROW + li * 8 + 4);
-          epi_store8<EPI, OUTF32>(p, m, n, lo, hi);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int row = it * 8 + rrow;
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + row * 256 + (((2 * c8) ^ row) << 4));
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * 256 + (((2 * c8 + 1) ^ row) << 4));
+          const int m = m0 + mi * 32 + h16 * 16 + row, n = n0 + c8 * 8;
+          if (m < p.M && n < p.N && !(p.dbg & 64)) epi_store8<EPI, OUTF32>(p, m, n, lo, hi);
+          if (p.dbg & 64) asm volatile("" : : "v"(lo), "v"(hi));
         }
+        __builtin_amdgcn_wave_barrier();
       }
-      __syncthreads();
     }
-    if (next < total_tiles) run(next, true, acc);     // start the next tile's first two k-tiles right away
     if (next >= total_tiles) break;
+    // a wave whose 128 x 64 part of the tile was clipped by M or N issued fewer stores than PEND: drain instead of counting
+    stores_in_flight = !(p.dbg & 96) && m0 + 128 <= p.M && n0 + 64 <= p.N;
+    if (!stores_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     tile = next;
   }
 }
