@@ -123,20 +123,38 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
 #pragma unroll
     for (int j = 0; j < 8; ++j) gm[i][j] = (col < H) ? gamma[col + j] : 0.f;
   }
-  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
-    const float mu = mean[row], rs = rstd[row];
+  // Rows are software-pipelined: the 16-byte loads of the wave's next row are in flight while the current row goes
+  // through its two reductions (one row alone leaves HBM idle for the whole reduce -> normalise -> store chain).
+  const int row0 = blockIdx.x * 4 + wave, rstep = gridDim.x * 4;
+  bf16x8 dv[NV], zv[NV], rv[NV];
+  float mu = 0.f, rs = 0.f;
+  auto fetch = [&](int row, bf16x8 (&d)[NV], bf16x8 (&z_)[NV], bf16x8 (&r)[NV], float& m_, float& s_) {
+    m_ = mean[row]; s_ = rstd[row];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int col = i * 512 + lane * 8;
+      if (col < H) {
+        d[i] = *reinterpret_cast<const bf16x8*>(dy + (size_t)row * H + col);
+        z_[i] = *reinterpret_cast<const bf16x8*>(z + (size_t)row * H + col);
+        if (dres) r[i] = *reinterpret_cast<const bf16x8*>(dres + (size_t)row * H + col);
+      }
+    }
+  };
+  if (row0 < M) fetch(row0, dv, zv, rv, mu, rs);
+  for (int row = row0; row < M; row += rstep) {
+    bf16x8 ndv[NV], nzv[NV], nrv[NV];
+    float nmu = 0.f, nrs = 0.f;
+    if (row + rstep < M) fetch(row + rstep, ndv, nzv, nrv, nmu, nrs);
     float g[NV][8], xh[NV][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int col = i * 512 + lane * 8;
       if (col < H) {
-        const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dy + (size_t)row * H + col);
-        const bf16x8 zv = *reinterpret_cast<const bf16x8*>(z + (size_t)row * H + col);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float d = bf2f(dv[j]);
-          const float xhat = (bf2f(zv[j]) - mu) * rs;
+          const float d = bf2f(dv[i][j]);
+          const float xhat = (bf2f(zv[i][j]) - mu) * rs;
           xh[i][j] = xhat;
           ag[i][j] += d * xhat;
           ab[i][j] += d;
@@ -160,9 +178,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = rs * (g[i][j] - s1 - xh[i][j] * s2);
         if (dres) {
-          const bf16x8 rv = *reinterpret_cast<const bf16x8*>(dres + (size_t)row * H + col);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] += bf2f(rv[j]);
+          for (int j = 0; j < 8; ++j) o[j] += bf2f(rv[i][j]);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) ov[j] = f2bf(o[j]);
@@ -185,6 +202,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
         }
       }
     }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { dv[i] = ndv[i]; zv[i] = nzv[i]; rv[i] = nrv[i]; }
+    mu = nmu; rs = nrs;
   }
   // cross-wave reduction, 512 columns at a time
 #pragma unroll
