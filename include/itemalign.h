@@ -140,9 +140,10 @@ int ia_conv_nhwc_fwd(const void* x, const void* what, const float* bias, void* y
                      int groups, void* workspace, size_t workspace_bytes, ia_stream_t stream);
 int ia_conv_nhwc_bwd_data(const void* dy, const void* what, void* dx, int B, int H, int W, int C, int Cout, int k, int stride, int groups,
                           void* workspace, size_t workspace_bytes, ia_stream_t stream);
-/* dwhat [Cout][k*k*C/groups] fp32 is overwritten; dbias [Cout] (may be NULL) is accumulated */
+/* dwhat [Cout][k*k*C/groups] fp32 is overwritten; dbias [Cout] (may be NULL) is accumulated.  cols_valid != 0: the workspace
+ * is the one ia_conv_nhwc_fwd used for the same x / geometry and still holds its patch matrix (skips the gather). */
 int ia_conv_nhwc_bwd_weight(const void* x, const void* dy, float* dwhat, float* dbias, int B, int H, int W, int C, int Cout, int k,
-                            int stride, int groups, void* workspace, size_t workspace_bytes, ia_stream_t stream);
+                            int stride, int groups, int cols_valid, void* workspace, size_t workspace_bytes, ia_stream_t stream);
 /* ScaledStdConv2d weight: what[o][t*Cgp + c] = (w[o][c][t] - mean_o) * rstd_o * gain[o] * scale (statistics over the
  * Cg*kk fan-in, biased variance, eps inside the sqrt; channels Cg..Cgp-1 zero).  bwd accumulates into dw / dgain. */
 int ia_ws_conv_weight_fwd(const float* w, const float* gain, void* what, float* mean, float* rstd, int Cout, int Cg, int kk, int Cgp,

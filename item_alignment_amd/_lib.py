@@ -59,7 +59,7 @@ SIGNATURES = {
     "ia_conv_nhwc_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32, i32, i32]),
     "ia_conv_nhwc_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "ia_conv_nhwc_bwd_data": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
-    "ia_conv_nhwc_bwd_weight": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "ia_conv_nhwc_bwd_weight": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "ia_ws_conv_weight_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, vp]),
     "ia_ws_conv_weight_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     "ia_silu_fwd": (i32, [vp, vp, sz, f32, vp]),

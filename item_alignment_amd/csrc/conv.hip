@@ -275,22 +275,24 @@ __global__ __launch_bounds__(256) void eca_gate_bwd_kernel(const float* __restri
   dpooled[idx] = s;
 }
 
-// dw[j] += sum_{b, c} ds[b, c] * pooled[b, c + j - pad]     (one block, k <= 16 taps)
-__global__ __launch_bounds__(256) void eca_gate_wgrad_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
-                                                             const float* __restrict__ pooled, float* __restrict__ dw, int B, int C, int k) {
-  __shared__ float red[4];
-  const int pad = (k - 1) / 2;
-  for (int j = 0; j < k; ++j) {
-    float s = 0.f;
-    for (int idx = threadIdx.x; idx < B * C; idx += 256) {
-      const int b = idx / C, c = idx % C, cc = c + j - pad;
-      if (cc >= 0 && cc < C) { const float gt = gate[idx]; s += dgate[idx] * gt * (1.f - gt) * pooled[b * C + cc]; }
-    }
-    s = wave_sum(s);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) dw[j] += red[0] + red[1] + red[2] + red[3];
+// dw[j] += sum_{b, c} ds[b, c] * pooled[b, c + j - pad]     (one 1024-thread block per tap j)
+__global__ __launch_bounds__(1024) void eca_gate_wgrad_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
+                                                              const float* __restrict__ pooled, float* __restrict__ dw, int B, int C, int k) {
+  __shared__ float red[16];
+  const int j = blockIdx.x, pad = (k - 1) / 2;
+  float s = 0.f;
+  for (int idx = threadIdx.x; idx < B * C; idx += 1024) {
+    const int b = idx / C, c = idx % C, cc = c + j - pad;
+    if (cc >= 0 && cc < C) { const float gt = gate[idx]; s += dgate[idx] * gt * (1.f - gt) * pooled[b * C + cc]; }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tot += red[i];
+    dw[j] += tot;
   }
 }
 
@@ -406,8 +408,10 @@ extern "C" int ia_conv_nhwc_bwd_data(const void* dy, const void* what, void* dx,
 }
 
 // dwhat [Cout][k*k*Cg] fp32 (overwritten) and dbias [Cout] (+=, may be NULL) from x and dy
+// cols_valid != 0: the workspace still holds the patch matrix ia_conv_nhwc_fwd left there for the same x and geometry
+// (the caller kept that buffer), so the gather is not repeated
 extern "C" int ia_conv_nhwc_bwd_weight(const void* x, const void* dy, float* dwhat, float* dbias, int B, int H, int W, int C, int Cout, int k,
-                                       int stride, int groups, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                                       int stride, int groups, int cols_valid, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   (void)hipGetLastError();
   ConvGeom g;
   int rc = geom(g, B, H, W, C, Cout, k, stride, groups);
@@ -421,9 +425,11 @@ extern "C" int ia_conv_nhwc_bwd_weight(const void* x, const void* dy, float* dwh
   int lda = C;
   if (k == 3) {
     bf16* cols = (bf16*)workspace;
-    const size_t total = g.M * 9 * (size_t)(C >> 3);
-    hipLaunchKernelGGL(im2col3_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)x, cols, H, W, C, g.Cg, g.Ho, g.Wo, stride, total);
-    rc = ia_check_launch();
+    if (!cols_valid) {
+      const size_t total = g.M * 9 * (size_t)(C >> 3);
+      hipLaunchKernelGGL(im2col3_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)x, cols, H, W, C, g.Cg, g.Ho, g.Wo, stride, total);
+      rc = ia_check_launch();
+    }
     a = cols; lda = 9 * C;
   }
   void* gws = need > cols_bytes ? (char*)workspace + cols_bytes : nullptr;
@@ -538,7 +544,7 @@ extern "C" int ia_eca_bwd(const void* dout, const void* x, const float* conv_w, 
   hipLaunchKernelGGL(spatial_sum_kernel, dim3(ns, B), dim3(256), 0, stream, (const bf16*)dout, (const bf16*)x, part, HW, C, ns);
   hipLaunchKernelGGL(spatial_finish_kernel, dim3((B * C + 255) / 256), dim3(256), 0, stream, (const float*)part, dgate, C, ns, coef, B * C);
   hipLaunchKernelGGL(eca_gate_bwd_kernel, dim3((B * C + 255) / 256), dim3(256), 0, stream, (const float*)dgate, gate, conv_w, dpooled, C, k, B * C);
-  if (dconv_w) hipLaunchKernelGGL(eca_gate_wgrad_kernel, dim3(1), dim3(256), 0, stream, (const float*)dgate, gate, pooled, dconv_w, B, C, k);
+  if (dconv_w) hipLaunchKernelGGL(eca_gate_wgrad_kernel, dim3(k), dim3(1024), 0, stream, (const float*)dgate, gate, pooled, dconv_w, B, C, k);
   const size_t total = (size_t)B * HW * (C >> 3);
   hipLaunchKernelGGL(scale_residual_bwd_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)dout, gate, (const float*)dpooled,
                      (bf16*)dx, HW, C, coef, total);

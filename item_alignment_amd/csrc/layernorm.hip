@@ -331,10 +331,20 @@ extern "C" int ia_ln_bwd(const void* dy, const void* dres, const void* z, const 
   return ia_check_launch();
 }
 
+// Narrow matrices (N < 512 dividing 512, rows contiguous: conv-tower bias gradients with 16..256 channels) are summed as
+// [M*N/512, 512]: every lane of the column-sum kernel stays busy, and the 512/N column groups fold for free because the
+// partial buffer [rows][512] read as [rows * 512/N][N] is exactly what the second stage sums over.
+static int colsum_fold(int M, int N, int ld) {
+  if (ld != N || N >= 512 || (512 % N)) return 1;
+  const int f = 512 / N;
+  return (M % f) ? 1 : f;
+}
+
 extern "C" size_t ia_colsum_workspace_bytes(int M, int N) {
   (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   int rb = (M + 3) / 4; if (rb > 256) rb = 256;
-  return (size_t)rb * N * sizeof(float);
+  const int W = N < 512 ? 512 : N;
+  return (size_t)rb * W * sizeof(float);
 }
 
 extern "C" int ia_colsum(const void* x, int ld, int M, int N, float* out, int accumulate, void* workspace,
@@ -342,9 +352,11 @@ extern "C" int ia_colsum(const void* x, int ld, int M, int N, float* out, int ac
   (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!x || !out || M <= 0 || N <= 0 || (N & 7) || (ld & 7)) return IA_ERR_ARG;
   if (!workspace || workspace_bytes < ia_colsum_workspace_bytes(M, N)) return IA_ERR_WORKSPACE;
-  int rb = (M + 3) / 4; if (rb > 256) rb = 256;
-  hipLaunchKernelGGL(colsum_kernel, dim3((N + 511) / 512, rb), dim3(256), 0, stream, (const bf16*)x, (float*)workspace, M, N, ld);
+  const int fold = colsum_fold(M, N, ld);
+  const int Mw = M / fold, Nw = N * fold, ldw = fold > 1 ? Nw : ld;
+  int rb = (Mw + 3) / 4; if (rb > 256) rb = 256;
+  hipLaunchKernelGGL(colsum_kernel, dim3((Nw + 511) / 512, rb), dim3(256), 0, stream, (const bf16*)x, (float*)workspace, Mw, Nw, ldw);
   ReduceOuts outs{{out, nullptr, nullptr}};
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 31) / 32), dim3(1024), 0, stream, (const float*)workspace, rb, 1, N, outs, accumulate);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 31) / 32), dim3(1024), 0, stream, (const float*)workspace, rb * fold, 1, N, outs, accumulate);
   return ia_check_launch();
 }

@@ -65,6 +65,9 @@ class StdConvFn(torch.autograd.Function):
                                    stream_ptr()), "ia_conv_nhwc_fwd")
         ctx.conv, ctx.saved, ctx.dims = conv, (x, what, mean, rstd), (B, H, W, C, Cout, k, s, g, Cg, Cgp, kk)
         ctx.need_dx = ctx.needs_input_grad[0]
+        # keep the 3x3 patch matrix for the weight gradient (9x the input, a few GB per step on 288 GB of HBM) instead of
+        # gathering it again in backward
+        ctx.cols_ws = ws if (k == 3 and conv.weight.requires_grad and conv.keep_cols) else None
         return y
 
     @staticmethod
@@ -76,7 +79,7 @@ class StdConvFn(torch.autograd.Function):
         dy = dy.contiguous()
         dev = dy.device
         wsb = lib.ia_conv_nhwc_workspace_bytes(B, H, W, C, Cout, k, s, g)
-        ws = _ws(dev, wsb)
+        ws = _ws(dev, wsb)                 # scratch of the data gradient (it overwrites the patch area)
         dx = None
         if ctx.need_dx:
             dx = torch.empty_like(x)
@@ -85,8 +88,10 @@ class StdConvFn(torch.autograd.Function):
         if conv.weight.requires_grad:
             dwhat = torch.empty((Cout, kk * Cgp), device=dev, dtype=F32)
             bg = conv.bias.grad.data_ptr() if conv.bias is not None and conv.bias.requires_grad else None
-            check(lib.ia_conv_nhwc_bwd_weight(x.data_ptr(), dy.data_ptr(), dwhat.data_ptr(), bg, B, H, W, C, Cout, k, s, g, ws.data_ptr(), wsb,
-                                              stream_ptr()), "ia_conv_nhwc_bwd_weight")
+            wws = ctx.cols_ws if ctx.cols_ws is not None else ws
+            check(lib.ia_conv_nhwc_bwd_weight(x.data_ptr(), dy.data_ptr(), dwhat.data_ptr(), bg, B, H, W, C, Cout, k, s, g,
+                                              int(ctx.cols_ws is not None), wws.data_ptr(), wsb, stream_ptr()), "ia_conv_nhwc_bwd_weight")
+            ctx.cols_ws = None
             check(lib.ia_ws_conv_weight_bwd(dwhat.data_ptr(), conv.weight.data_ptr(), conv.gain.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                             conv.weight.grad.data_ptr(), conv.gain.grad.data_ptr(), Cout, Cg, kk, Cgp, conv.scale, stream_ptr()),
                   "ia_ws_conv_weight_bwd")
@@ -227,6 +232,7 @@ class ScaledStdConv2d(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_channels))
         self.gain = nn.Parameter(torch.full((out_channels, 1, 1, 1), gain_init))
         self.scale = gamma * self.weight[0].numel() ** -0.5
+        self.keep_cols = True              # stash the 3x3 patch matrix from forward for the weight gradient
         nn.init.kaiming_normal_(self.weight, mode="fan_in", nonlinearity="linear")       # reference image.py:156
 
     def forward(self, f):
