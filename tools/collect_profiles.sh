@@ -1,0 +1,23 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats of the default bench workload plus the PMC passes behind
+# bench.py's roofline object (separate --pmc passes, as the guide prescribes).  Output: gpurun_out/profiles/<tag>_*.
+# usage: tools/collect_profiles.sh <tag>      e.g. r01
+TAG=${1:-r01}
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/profiles
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $OUT/kt -o b --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof.json 2> /dev/null
+cp $OUT/kt/b_kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv
+python3 $R/tools/prof_summary.py $OUT/kt/b_kernel_stats.csv 7 40 > $OUT/${TAG}_bench_kernel_stats_summary.txt
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA"; do
+  i=$((i+1))
+  rocprofv3 --pmc $set -d $OUT/pmc$i -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  python3 $R/tools/pmc_summary.py $(ls $OUT/pmc$i/*counter_collection.csv | head -1) > $OUT/${TAG}_pmc_$i.csv
+done
+mv $OUT/${TAG}_pmc_1.csv $OUT/${TAG}_pmc_fetch_size.csv
+mv $OUT/${TAG}_pmc_2.csv $OUT/${TAG}_pmc_write_size.csv
+cat $OUT/${TAG}_pmc_3.csv > $OUT/${TAG}_pmc_mfma.csv; tail -n +2 $OUT/${TAG}_pmc_4.csv >> $OUT/${TAG}_pmc_mfma.csv; rm -f $OUT/${TAG}_pmc_3.csv $OUT/${TAG}_pmc_4.csv
+rm -rf $OUT/kt $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4
+ls -la $OUT
