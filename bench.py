@@ -154,7 +154,7 @@ def main():
         return out.loss
 
     def barrier():
-        if world > 1:
+        if world > 1 or iadist.FORCE:
             torch.distributed.barrier()
 
     for i in range(args.warmup):
@@ -173,10 +173,10 @@ def main():
     ms, fl, nl = C.c_double(), C.c_double(), C.c_int()
     _lib.check(lib.ia_prof_end(C.byref(ms), C.byref(fl), C.byref(nl)), "ia_prof_end")
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if world > 1 or iadist.FORCE:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = tmax.item()
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     if rank == 0:
         pairs = B * world * args.steps
@@ -203,7 +203,7 @@ def main():
             except Exception as e:  # the baseline must never take the GPU number down with it
                 res["cpu_baseline"] = {"value": None, "unit": "item-pairs/sec", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -19,13 +19,17 @@ import os
 import torch
 import torch.distributed as dist
 
+FORCE = os.environ.get("IA_DP_FORCE_COLLECTIVES") == "1"
+
 
 def init_from_env(device_type="cuda"):
     """RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the launcher (torch.distributed.run).  Returns (rank, world, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # IA_DP_FORCE_COLLECTIVES=1: initialise RCCL and issue every bucket all-reduce even with one rank (lets a 1-GPU box
+    # exercise the exact multi-GPU code path: process group, stream hand-over, async bucket launches)
+    if (world > 1 or FORCE) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = "nccl" if device_type == "cuda" else "gloo"
@@ -87,7 +91,7 @@ class GradBucketReducer:
     def _launch(self, i):
         s, e = self.buckets[i]
         self.launched[i] = True
-        if self.world > 1:
+        if self.world > 1 or (FORCE and dist.is_initialized()):
             self.works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def grads_ready(self, params):
@@ -116,7 +120,7 @@ class GradBucketReducer:
 
 def broadcast_arena(arena, src=0):
     """Identical replicas: rank `src`'s master weights (and its bf16 shadow) everywhere."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized() and (dist.get_world_size() > 1 or FORCE):
         dist.broadcast(arena.master, src=src)
         arena.refresh_shadow()
 
