@@ -235,3 +235,80 @@ def test_pair_sim_head(gpu, measure):
     ((s * w1).sum() + (p * w2).sum()).backward()
     assert rel_err(sim, s) < 1e-4 and rel_err(probs, p) < 1e-4
     assert rel_err(x.grad, xr.grad) < 1e-4 and rel_err(y.grad, yr.grad) < 1e-4
+
+
+# ------------------------------------------------------------------ full-size properties and edge shapes
+def test_gemm_full_size_checksum(gpu):
+    """BASELINE-size GEMM (ffn1 of the C5 text tower: 32640 x 4096 x 1024) through a size-independent property:
+    sum_mn C[m,n] == sum_k (sum_m A[m,k]) (sum_n W[n,k])  — a checksum of checksums, fp32 output, 1e-3 relative
+    (the sum runs over 1.3e8 products of bf16 inputs; both sides are accumulated in fp64 on the host side of the check)."""
+    from item_alignment_amd import ops
+    M, N, K = 32640, 4096, 1024
+    a, w = rnd((M, K), gpu, 1.0, 11), rnd((N, K), gpu, 0.05, 12)
+    c = ops.gemm(a, w, out_f32=True)
+    want = (a.double().sum(0) * w.double().sum(0)).sum()
+    got = c.double().sum()
+    scale = (a.double().abs().sum(0) * w.double().abs().sum(0)).sum()
+    assert abs(got - want) / scale < 1e-6, (got.item(), want.item())
+    # and one bf16-output row block against fp32 matmul
+    cb = ops.gemm(a, w)
+    assert rel_err(cb[-300:], a[-300:].float() @ w.float().t()) < 2e-2
+
+
+@pytest.mark.parametrize("B,L,nh,masked", [(16, 577, 12, False), (32, 255, 16, True), (4, 510, 16, True)])
+def test_attention_full_size_rows_sum_to_one(gpu, B, L, nh, masked):
+    """Full-size attention through softmax's defining property: with V == 1 every output element is exactly the row sum
+    of P, i.e. 1 (bf16: 1 +- 2^-8), for any mask that leaves a query at least one key; and dV = P^T dO column sums give
+    sum(dV) == sum(dO) on attended keys (sum over keys of P is 1 per query)."""
+    from item_alignment_amd import ops
+    H = nh * 64
+    qkv = rnd((B * L, 3 * H), gpu, 1.0, 21)
+    qkv[:, 2 * H:] = 1.0
+    mask = None
+    if masked:
+        g = torch.Generator().manual_seed(3)
+        lens = torch.randint(1, L + 1, (B,), generator=g)
+        mask = (torch.arange(L)[None, :] < lens[:, None]).to(torch.uint8).to(gpu)
+    ctx, lse = ops.attn_fwd(qkv, B, L, nh, key_mask=mask)
+    assert (ctx.float() - 1.0).abs().max().item() <= 2 ** -7
+    d = rnd((B * L, H), gpu, 1.0, 22)
+    dqkv = ops.attn_bwd(qkv, ctx, d, lse, B, L, nh, key_mask=mask)
+    dv = dqkv[:, 2 * H:].float().view(B, L, nh, 64)
+    want = d.float().view(B, L, nh, 64).sum(1)
+    got = dv.sum(1)
+    assert rel_err(got, want) < 2e-2
+    if masked:   # keys outside the mask receive exactly zero gradient
+        dead = (mask == 0).view(B, L, 1, 1)
+        assert (dqkv.float().view(B, L, 3, nh, 64)[:, :, 1:] * dead.unsqueeze(2)).abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("B,L,nh", [(1, 1, 1), (2, 64, 2), (3, 65, 1), (1, 129, 3)])
+def test_attention_edge_lengths(gpu, B, L, nh):
+    """tile-boundary sequence lengths (1, exactly one tile, one past a tile, one past two tiles) incl. a key mask that
+    leaves only the first token attendable in sequence 0."""
+    from item_alignment_amd import ops
+    H = nh * 64
+    qkv = rnd((B * L, 3 * H), gpu, 1.0, 31)
+    mask = torch.ones((B, L), dtype=torch.uint8, device=gpu)
+    mask[0, 1:] = 0
+    dctx = rnd((B * L, H), gpu, 1.0, 32)
+    ctx, lse = ops.attn_fwd(qkv, B, L, nh, key_mask=mask)
+    dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, B, L, nh, key_mask=mask)
+    ref, rgrad = attn_ref(qkv, B, L, nh, mask, dctx)
+    assert rel_err(ctx, ref) < 2e-2
+    got = dqkv.float().view(B * L, 3, nh, 64)
+    want = rgrad.view(B * L, 3, nh, 64)
+    for i in range(3):   # a sequence whose only attendable key is token 0 has dq == dk == 0: compare on an absolute floor
+        assert (got[:, i] - want[:, i]).abs().max().item() < 3e-2 * max(want[:, i].abs().max().item(), 1e-2), i
+
+
+def test_layernorm_full_size_statistics(gpu):
+    """Full-size LayerNorm (32640 x 1024): with gamma = 1, beta = 0 every output row has mean 0 and variance 1."""
+    from item_alignment_amd import ops
+    M, H = 32640, 1024
+    x = rnd((M, H), gpu, 3.0, 41)
+    y, _, mean, rstd = ops.ln_fwd(x, torch.ones(H, device=gpu), torch.zeros(H, device=gpu), 1e-12, write_z=False)
+    yf = y.float()
+    assert yf.mean(1).abs().max().item() < 2e-2
+    assert (yf.var(1, unbiased=False) - 1).abs().max().item() < 3e-2
+    assert rel_err(mean, x.float().mean(1)) < 1e-4
