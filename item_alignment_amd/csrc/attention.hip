@@ -317,25 +317,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   }
 }
 
-// ------------------------------------------------------------------------------- delta = rowsum(dO*O)
-__global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs p) {
-  // one 8-lane group per (token, head): 64 columns = 8 lanes x 8 bf16
-  const int gid = (blockIdx.x * 256 + threadIdx.x) >> 3, sub = threadIdx.x & 7;
-  const int total = p.B * p.Lq * p.nh;
-  if (gid >= total) return;
-  const int tok = gid / p.nh, h = gid % p.nh;
-  const bf16x8 a = *reinterpret_cast<const bf16x8*>(p.o + (size_t)tok * p.ld_o + h * 64 + sub * 8);
-  const bf16x8 g = *reinterpret_cast<const bf16x8*>(p.d_o + (size_t)tok * p.ld_o + h * 64 + sub * 8);
-  float s = 0.f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) s += bf2f(a[j]) * bf2f(g[j]);
-  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-  if (sub == 0) {
-    const int b = tok / p.Lq, l = tok % p.Lq;
-    p.delta[((size_t)b * p.nh + h) * p.Lq + l] = s;
-  }
-}
-
 // ------------------------------------------------------------------------------------- backward: dQ
 // One 64-key tile for this wave's 32 queries: dQ^T += K^T dS^T with dS^T = P^T (dP^T - delta) (the softmax scale is
 // applied once, when dQ is stored).
@@ -436,7 +417,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
   }
   const size_t sidx = ((size_t)b * p.nh + h) * Lq + qc;
   const float lse = p.lse2[sidx];
-  const float dlt = p.delta[sidx];
+  // delta = rowsum(dO * O) of this lane's query: each lane of the pair (lane, lane^32) holds half of the 64 columns.
+  // Written out for the dK/dV kernel, which runs after this one on the same stream.
+  float dlt = 0.f;
+  {
+    const bf16* op = p.o + (qbase + qc) * p.ld_o + h * 64 + hh * 8;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const bf16x8 ov = *reinterpret_cast<const bf16x8*>(op + kb * 16);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dlt += bf2f(ov[j]) * bf2f(gf[kb][j]);
+    }
+    dlt += __shfl_xor(dlt, 32, 64);
+    if (active && hh == 0 && q < Lq) p.delta[sidx] = dlt;
+  }
   const __amdgpu_buffer_rsrc_t rsK = ia_rsrc(p.k, p.kv_bytes);
   const __amdgpu_buffer_rsrc_t rsV = ia_rsrc(p.v, p.kv_bytes);
   const uint32_t stream_id = (uint32_t)(b * p.nh + h);
@@ -665,7 +659,7 @@ extern "C" int ia_attn_fwd_x(const void* q, int ld_q, const void* k, const void*
   return ia_check_launch();
 }
 
-// delta: caller-provided scratch of B*nh*Lq floats.
+// delta: caller-provided scratch of B*nh*Lq floats (filled by the dQ kernel, read by the dK/dV kernel).
 extern "C" int ia_attn_bwd_x(const void* q, int ld_q, const void* k, const void* v, int ld_kv, const uint8_t* key_mask,
                              const void* out, const void* d_out, int ld_o, const float* lse2, float* delta, void* dq, int ld_dq,
                              void* dk, void* dv, int ld_dkv, int B, int nh, int Lq, int Lk, float scale, float drop_p, uint32_t seed,
@@ -679,8 +673,6 @@ extern "C" int ia_attn_bwd_x(const void* q, int ld_q, const void* k, const void*
   a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.o = (const bf16*)out; a.d_o = (const bf16*)d_out;
   a.mask = key_mask; a.lse2 = const_cast<float*>(lse2); a.delta = delta;
   a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.ld_dq = ld_dq; a.ld_dkv = ld_dkv;
-  const int total = B * Lq * nh;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((total * 8 + 255) / 256), dim3(256), 0, stream, a);
   dim3 gq(((Lq + 127) / 128) * nh * B), gk(((Lk + 127) / 128) * nh * B), blk(256);
   if (a.thr16) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gq, blk, 0, stream, a);
