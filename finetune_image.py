@@ -76,7 +76,7 @@ def main():
     train_data, valid_data, test_data = load_raw_data(args)
     logger.info(f"# train samples: {len(train_data)}, # valid samples: {len(valid_data)}, # test samples: {len(test_data)}")
     is_training = False if "vit" in args.model_name else True          # quirk A16 (reference :246)
-    make = lambda data, tr: PairedImageDataset(data, args.image_size, tr, args.hflip, args.color_jitter)
+    make = lambda data, tr: PairedImageDataset(data, args.image_size, tr, args.hflip, args.color_jitter, raw=args.gpu_preproc)
     device = pick_device(model)
     model.to(device)
     args.interaction_type = "two_tower"

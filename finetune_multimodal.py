@@ -102,7 +102,7 @@ def main():
         if coca:
             return PairedMultimodalDataset(data, ensemble=args.ensemble, image_size=args.image_size, is_training=training,
                                            text_tokenizer=tokenizer, max_seq_len=args.max_seq_len, max_seq_len_pv=args.max_seq_len_pv,
-                                           hflip=args.hflip, color_jitter=args.color_jitter)
+                                           hflip=args.hflip, color_jitter=args.color_jitter, raw=args.gpu_preproc)
         cls = RobertaImageOneTowerDataset if one else RobertaImageTwoTowerDataset
         return cls(data, tokenizer, max_seq_len=args.max_seq_len, max_seq_len_pv=args.max_seq_len_pv, ensemble=args.ensemble)
 

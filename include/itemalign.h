@@ -168,6 +168,19 @@ size_t ia_eca_bwd_workspace_bytes(int B, int HW, int C);
 int ia_eca_bwd(const void* dout, const void* x, const float* conv_w, int k, const float* pooled, const float* gate, void* dx,
                float* dconv_w, int B, int HW, int C, float coef, void* workspace, size_t workspace_bytes, ia_stream_t stream);
 
+/* ---- image input pipeline on the GPU (src/data/data.py:838-866: timm create_transform(is_training=False) = PIL bicubic
+ * resize -> ToTensor -> Normalize).  ia_resize_pass_u8 is one separable pass of Pillow's 8-bit resampler (Resample.c) over
+ * a batch of equally sized uint8 RGB frames: horizontal != 0: src [B, other_len, in_len, 3] -> dst [B, other_len, out_len, 3];
+ * else src [B, in_len, other_len, 3] -> dst [B, out_len, other_len, 3].  bounds [out_len][2] (first tap, tap count) and
+ * coeffs [out_len][ksize] (int32, 8.22 fixed point) are Pillow's precompute_coeffs / normalize_coeffs_8bpc tables, built
+ * by the host (item_alignment_amd/data/gpu_preproc.py): results are bit-identical to Image.resize(size, BICUBIC). */
+int ia_resize_pass_u8(const uint8_t* src, uint8_t* dst, const int* bounds, const int* coeffs, int ksize, int B, int in_len, int out_len,
+                      int other_len, int horizontal, ia_stream_t stream);
+/* uint8 [B,S0,S1,3] -> fp32 [B,3,S0,S1] = (x/255 - mean)/std with IEEE fp32 division (ToTensor + Normalize), optional
+ * per-image horizontal flip (flip: [B] device bytes or NULL); mean3 / std3: HOST arrays of 3 floats */
+int ia_u8_to_nchw_normalized(const uint8_t* src, const uint8_t* flip, float* out, int B, int S0, int S1, const float* mean3,
+                             const float* std3, ia_stream_t stream);
+
 /* ---- embeddings (src/models/base.py:238-279, :501-556, :394-442) */
 int ia_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const int32_t* extra_idx, const float* word,
                     const float* type, const float* pos, const float* extra, const float* gamma, const float* beta, void* z_out,

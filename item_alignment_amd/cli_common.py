@@ -36,6 +36,10 @@ def add_common_flags(parser, config_required=True):
     a("--adam_epsilon", default=1e-8, type=float)
     a("--fp16", action="store_true", help="kept for CLI compatibility: the HIP engine always computes in bf16 with fp32 master weights")
     a("--margin", default=1.0, type=float)
+    # not in the reference (its DataLoader has 0 workers and transforms run inside __getitem__): host-side decode workers and
+    # the GPU resize / normalise kernels of SURVEY §8(f) rank 1.  Defaults keep the reference behaviour.
+    a("--num_workers", default=0, type=int, help="DataLoader worker processes for decode / tokenisation")
+    a("--gpu_preproc", action="store_true", help="decode images to uint8 on the host, resize + normalise on the GPU (bit-identical to PIL bicubic)")
 
 
 def load_config(path, **overrides):

@@ -65,8 +65,8 @@ def collate_two_tower(inputs):
 def collate_image(inputs):
     """reference data.py:77-95: samples whose image failed to load are dropped."""
     keep = [i for i in inputs if "src_input" in i and "tgt_input" in i]
-    return ([i["src_item_id"] for i in keep], [i["tgt_item_id"] for i in keep], torch.stack([i["src_input"] for i in keep]),
-            torch.stack([i["tgt_input"] for i in keep]), _t([i["labels"] for i in keep]))
+    return ([i["src_item_id"] for i in keep], [i["tgt_item_id"] for i in keep], stack_images([i["src_input"] for i in keep]),
+            stack_images([i["tgt_input"] for i in keep]), _t([i["labels"] for i in keep]))
 
 
 def collate_multimodal(inputs):
@@ -94,9 +94,9 @@ def collate_coca_pair(inputs):
     tpos = [i["tgt_position_ids"] for i in keep if "tgt_position_ids" in i]
     return ([i["src_item_id"] for i in keep], [i["tgt_item_id"] for i in keep],
             _t([i["src_input_ids"] for i in keep]), _t([i["src_attention_mask"] for i in keep]), _t([i["src_token_type_ids"] for i in keep]),
-            _t(spos) if spos else None, torch.stack([i["src_image"] for i in keep]),
+            _t(spos) if spos else None, stack_images([i["src_image"] for i in keep]),
             _t([i["tgt_input_ids"] for i in keep]), _t([i["tgt_attention_mask"] for i in keep]), _t([i["tgt_token_type_ids"] for i in keep]),
-            _t(tpos) if tpos else None, torch.stack([i["tgt_image"] for i in keep]), _t([i["labels"] for i in keep]))
+            _t(tpos) if tpos else None, stack_images([i["tgt_image"] for i in keep]), _t([i["labels"] for i in keep]))
 
 
 # ------------------------------------------------------------------------------------------------ datasets
@@ -270,13 +270,43 @@ IMAGENET_MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32)
 IMAGENET_STD = np.array([0.229, 0.224, 0.225], dtype=np.float32)
 
 
-def load_image(path, size, is_training=False, hflip=0.5, rng=None):
+class RawImage:
+    """Decoded but unprocessed frame for the GPU pipeline (data/gpu_preproc.py): uint8 [H, W, 3] + the flip decision."""
+    __slots__ = ("u8", "flip")
+
+    def __init__(self, u8, flip):
+        self.u8, self.flip = u8, bool(flip)
+
+
+class RawImageBatch:
+    """What a collate function emits for RawImage samples: the frames stay a list (their sizes differ)."""
+
+    def __init__(self, items):
+        self.items = items
+
+    def __len__(self):
+        return len(self.items)
+
+
+def stack_images(items):
+    """torch.stack for processed [3,S,S] tensors (the reference path), RawImageBatch for RawImage samples."""
+    if items and isinstance(items[0], RawImage):
+        return RawImageBatch(items)
+    return torch.stack(items)
+
+
+def load_image(path, size, is_training=False, hflip=0.5, rng=None, raw=False):
     """PIL open -> RGB -> bicubic resize to size x size -> (train: random horizontal flip) -> ImageNet mean/std,
-    CHW fp32: the tensor layout timm's create_transform yields (reference data.py:838-866)."""
+    CHW fp32: the tensor layout timm's create_transform yields (reference data.py:838-866).  raw=True stops after the
+    decode and returns a RawImage: the resize / flip / normalisation then run on the GPU (same arithmetic, gpu_preproc.py)."""
     from PIL import Image
-    img = Image.open(path).convert("RGB").resize((size, size), Image.BICUBIC)
+    img = Image.open(path).convert("RGB")
+    flip = bool(is_training and hflip and (rng or np.random).random() < hflip)
+    if raw:
+        return RawImage(torch.from_numpy(np.ascontiguousarray(np.asarray(img, dtype=np.uint8))), flip)
+    img = img.resize((size, size), Image.BICUBIC)
     a = np.asarray(img, dtype=np.float32) / 255.0
-    if is_training and hflip and (rng or np.random).random() < hflip:
+    if flip:
         a = a[:, ::-1]
     a = (a - IMAGENET_MEAN) / IMAGENET_STD
     return torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))
@@ -285,8 +315,8 @@ def load_image(path, size, is_training=False, hflip=0.5, rng=None):
 class PairedImageDataset(Dataset):
     """reference data.py:835-869."""
 
-    def __init__(self, data, input_size, is_training, hflip=0.5, color_jitter=None):
-        self.data, self.size, self.train, self.hflip = data, input_size, is_training, hflip
+    def __init__(self, data, input_size, is_training, hflip=0.5, color_jitter=None, raw=False):
+        self.data, self.size, self.train, self.hflip, self.raw = data, input_size, is_training, hflip, raw
 
     def __len__(self):
         return len(self.data)
@@ -295,8 +325,8 @@ class PairedImageDataset(Dataset):
         label, src_id, src_path, tgt_id, tgt_path = self.data[item]
         rec = {"labels": int(label), "src_item_id": src_id, "tgt_item_id": tgt_id}
         try:
-            rec["src_input"] = load_image(src_path, self.size, self.train, self.hflip)
-            rec["tgt_input"] = load_image(tgt_path, self.size, self.train, self.hflip)
+            rec["src_input"] = load_image(src_path, self.size, self.train, self.hflip, raw=self.raw)
+            rec["tgt_input"] = load_image(tgt_path, self.size, self.train, self.hflip, raw=self.raw)
         except Exception:
             pass                        # the collate drops samples without images (reference data.py:848-860, :84)
         return rec
@@ -306,8 +336,8 @@ class PairedMultimodalDataset(Dataset):
     """reference data.py:918-989 (CoCa pairs: text ids with explicit position ids 0..L-1 + two images)."""
 
     def __init__(self, data, ensemble, image_size, is_training, text_tokenizer, max_seq_len, max_seq_len_pv=None, hflip=0.5,
-                 color_jitter=None):
-        self.data, self.ensemble, self.size, self.train, self.hflip = data, ensemble, image_size, is_training, hflip
+                 color_jitter=None, raw=False):
+        self.data, self.ensemble, self.size, self.train, self.hflip, self.raw = data, ensemble, image_size, is_training, hflip, raw
         self.tk, self.max_seq_len, self.max_seq_len_pv = text_tokenizer, max_seq_len, max_seq_len_pv
 
     def __len__(self):
@@ -327,8 +357,8 @@ class PairedMultimodalDataset(Dataset):
                "tgt_input_ids": t["input_ids"], "tgt_token_type_ids": t["token_type_ids"], "tgt_attention_mask": t["attention_mask"],
                "tgt_position_ids": list(range(len(t["input_ids"])))}
         try:
-            rec["src_image"] = load_image(src_path, self.size, self.train, self.hflip)
-            rec["tgt_image"] = load_image(tgt_path, self.size, self.train, self.hflip)
+            rec["src_image"] = load_image(src_path, self.size, self.train, self.hflip, raw=self.raw)
+            rec["tgt_image"] = load_image(tgt_path, self.size, self.train, self.hflip, raw=self.raw)
         except Exception:
             pass
         return rec

@@ -85,8 +85,33 @@ def run(args, model, datasets, collate_fn, call_model, checkpoint_name, path_fie
     if rank == 0:
         os.makedirs(out_dir, exist_ok=True)
 
+    pipelines = {}
+
+    def gpu_images(raw_batch):
+        """RawImageBatch -> normalised [B, 3, S, S] on the device (data/gpu_preproc.py); frames are grouped by size so each
+        group is one batched launch."""
+        from .data.gpu_preproc import GpuImagePipeline
+        size = int(getattr(args, "image_size", 0) or 0)
+        pipe = pipelines.get(size)
+        if pipe is None:
+            pipe = pipelines[size] = GpuImagePipeline(size, device)
+        items = raw_batch.items
+        out = torch.empty((len(items), 3, size, size), device=device, dtype=torch.float32)
+        groups = {}
+        for i, it in enumerate(items):
+            groups.setdefault(tuple(it.u8.shape), []).append(i)
+        for idxs in groups.values():
+            frames = torch.stack([items[i].u8 for i in idxs])
+            out[torch.as_tensor(idxs, device=device)] = pipe(frames, flip=[int(items[i].flip) for i in idxs])
+        return out
+
     def to_dev(batch):
-        return tuple(t.to(device=device, non_blocking=True) if torch.is_tensor(t) else t for t in batch)
+        from .data.datasets import RawImageBatch
+        return tuple(gpu_images(t) if isinstance(t, RawImageBatch) else (t.to(device=device, non_blocking=True) if torch.is_tensor(t) else t)
+                     for t in batch)
+
+    nw = int(getattr(args, "num_workers", 0) or 0)
+    dl_kw = dict(num_workers=nw, pin_memory=(device.type == "cuda"), persistent_workers=False)
 
     def evaluate(loader, tag):
         model.eval()
@@ -132,7 +157,7 @@ def run(args, model, datasets, collate_fn, call_model, checkpoint_name, path_fie
         for epoch in range(int(args.start_epoch), int(args.num_train_epochs)):
             model.train()
             idx = iadist.shard_indices(len(train_ds), rank, world, args.seed + epoch, shuffle=True)
-            loader = DataLoader(Subset(train_ds, idx.tolist()), batch_size=per_rank, shuffle=False, collate_fn=collate_fn)
+            loader = DataLoader(Subset(train_ds, idx.tolist()), batch_size=per_rank, shuffle=False, collate_fn=collate_fn, **dl_kw)
             opt.zero_grad()
             for step, batch in enumerate(loader):
                 b = to_dev(batch[2:])
@@ -151,19 +176,19 @@ def run(args, model, datasets, collate_fn, call_model, checkpoint_name, path_fie
                     global_step += 1
             if args.do_eval and datasets.get("valid") is not None and rank == 0:
                 logger.info(f"[Epoch-{epoch}] Starting evaluation ...")
-                evaluate(DataLoader(datasets["valid"], batch_size=args.eval_batch_size, shuffle=False, collate_fn=collate_fn), f"Epoch-{epoch}")
+                evaluate(DataLoader(datasets["valid"], batch_size=args.eval_batch_size, shuffle=False, collate_fn=collate_fn, **dl_kw), f"Epoch-{epoch}")
             if rank == 0:
                 logger.info(f"[Epoch-{epoch}] saving model")
                 torch.save(model.state_dict(), os.path.join(out_dir, f"{checkpoint_name}_epoch-{epoch}.bin"))
     elif args.do_eval and datasets.get("valid") is not None:
-        evaluate(DataLoader(datasets["valid"], batch_size=args.eval_batch_size, shuffle=False, collate_fn=collate_fn), "Eval")
+        evaluate(DataLoader(datasets["valid"], batch_size=args.eval_batch_size, shuffle=False, collate_fn=collate_fn, **dl_kw), "Eval")
 
     if args.do_pred and datasets.get("test") is not None and rank == 0:
         model.eval()
         head = model.classifier.out_proj
         json.dump({"w": head.weight.detach().cpu().numpy().tolist(), "b": head.bias.detach().cpu().numpy().tolist()},
                   open(os.path.join(out_dir, "weights.json"), "w", encoding="utf-8"), ensure_ascii=False)
-        loader = DataLoader(datasets["test"], batch_size=args.eval_batch_size, shuffle=False, collate_fn=collate_fn)
+        loader = DataLoader(datasets["test"], batch_size=args.eval_batch_size, shuffle=False, collate_fn=collate_fn, **dl_kw)
         with open(os.path.join(out_dir, f"deepAI_result_threshold={args.threshold}.jsonl"), "w", encoding="utf-8") as w, torch.no_grad():
             for step, batch in enumerate(loader):
                 src_ids, tgt_ids = batch[:2]

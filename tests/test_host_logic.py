@@ -142,3 +142,28 @@ def test_nfnet_module_matches_timm_names():
     assert set(want) | {"head.fc.weight", "head.fc.bias"} == set(have)
     assert all(have[k] == tuple(s) for k, s in want.items())
     assert sum(p.numel() for p in net.parameters()) == 24143924
+
+
+def test_resize_tables_reproduce_pillow_bit_exact():
+    """The host-built resampling tables (data/gpu_preproc.py: Pillow Resample.c precompute_coeffs + normalize_coeffs_8bpc) and
+    the 8.22 fixed-point two-pass arithmetic the GPU kernels implement reproduce PIL Image.resize(..., BICUBIC) bit for bit
+    (numpy emulation of csrc/image.hip here; the kernels themselves are checked in test_kernels_gpu.py)."""
+    import numpy as np
+    from PIL import Image
+    from item_alignment_amd.data.gpu_preproc import PRECISION_BITS, precompute_coeffs
+
+    def one_pass(x, n_out, axis):
+        b, k, _ = precompute_coeffs(x.shape[axis], n_out)
+        x = np.moveaxis(x.astype(np.int64), axis, 0)
+        out = np.zeros((n_out,) + x.shape[1:], dtype=np.int64)
+        for i in range(n_out):
+            lo, n = b[i]
+            acc = (1 << (PRECISION_BITS - 1)) + np.tensordot(k[i, :n].astype(np.int64), x[lo:lo + n], axes=(0, 0))
+            out[i] = np.clip(acc >> PRECISION_BITS, 0, 255)
+        return np.moveaxis(out, 0, axis)
+    rs = np.random.RandomState(0)
+    for H, W, S in [(800, 800, 384), (333, 517, 384), (90, 70, 224), (801, 640, 800)]:
+        img = rs.randint(0, 256, size=(H, W, 3)).astype(np.uint8)
+        ref = np.asarray(Image.fromarray(img).resize((S, S), Image.BICUBIC))
+        got = one_pass(one_pass(img, S, 1), S, 0)          # Pillow: horizontal pass first
+        assert np.array_equal(ref, got.astype(np.uint8)), (H, W, S)

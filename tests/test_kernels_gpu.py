@@ -312,3 +312,27 @@ def test_layernorm_full_size_statistics(gpu):
     assert yf.mean(1).abs().max().item() < 2e-2
     assert (yf.var(1, unbiased=False) - 1).abs().max().item() < 3e-2
     assert rel_err(mean, x.float().mean(1)) < 1e-4
+
+
+@pytest.mark.parametrize("H,W,S", [(800, 800, 384), (600, 811, 384), (96, 130, 224), (801, 640, 800)])
+def test_gpu_image_pipeline_bit_exact(gpu, tmp_path, H, W, S):
+    """ia_resize_pass_u8 + ia_u8_to_nchw_normalized against the host path the reference uses (PIL
+    bicubic resize -> /255 -> mean/std, data.py:838-866): integer pixels bit-exact, normalised fp32 tensor bit-exact."""
+    import numpy as np
+    from PIL import Image
+    from item_alignment_amd.data.datasets import load_image
+    from item_alignment_amd.data.gpu_preproc import GpuImagePipeline
+    rs = np.random.RandomState(H + W)
+    frames = rs.randint(0, 256, size=(3, H, W, 3)).astype(np.uint8)
+    pipe = GpuImagePipeline(S, gpu)
+    got_u8 = pipe.resize(torch.from_numpy(frames)).cpu().numpy()
+    for i in range(3):
+        assert np.array_equal(got_u8[i], np.asarray(Image.fromarray(frames[i]).resize((S, S), Image.BICUBIC))), i
+    out = pipe(torch.from_numpy(frames), flip=[0, 1, 0]).cpu()
+    for i in range(3):
+        path = tmp_path / f"f{i}.png"
+        Image.fromarray(frames[i]).save(path)
+        want = load_image(str(path), S)
+        if i == 1:
+            want = want.flip(-1)
+        assert torch.equal(out[i], want), i

@@ -1,5 +1,5 @@
 """Micro-benchmarks of the hot kernels on one MI355X (random data, HIP-event timing).
-usage: python tools/kbench.py [gemm] [attn] [ln]"""
+usage: python tools/kbench.py [gemm] [attn] [ln] [img]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -67,8 +67,19 @@ def bench_ln():
         print(f"ln bwd M={M} H={H}: {t*1e6:7.1f} us  {M*H*2*3/t/1e9:7.0f} GB/s (dy,z read; dz write)")
 
 
+def bench_img():
+    from item_alignment_amd.data.gpu_preproc import GpuImagePipeline
+    for B, H, S in [(128, 800, 384), (16, 800, 800)]:
+        frames = torch.randint(0, 256, (B, H, H, 3), dtype=torch.uint8, device=dev)
+        pipe = GpuImagePipeline(S, dev)
+        t = timeit(lambda: pipe(frames))
+        print(f"image pipeline {B} x {H}x{H} uint8 -> {S}x{S} fp32 normalised: {t*1e6:8.1f} us  {B/t:9.0f} images/s  "
+              f"{(B*H*H*3 + B*S*S*3*4)/t/1e9:6.0f} GB/s (in + out)")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "attn", "ln"]
     if "gemm" in which: bench_gemm()
     if "attn" in which: bench_attn()
     if "ln" in which: bench_ln()
+    if "img" in which: bench_img()
