@@ -121,6 +121,10 @@ def run(args, model, datasets, collate_fn, call_model, checkpoint_name, path_fie
                 b = to_dev(batch[2:])
                 out = call_model(model, b)
                 probs, labels = out.probs.float().cpu().numpy(), b[-1].cpu().numpy()
+                if probs.ndim == 2:
+                    # RobertaTwoTower / PKGMTwoTower / RobertaImageTwoTower hand back softmax probs [B, 2] (quirk A3); the
+                    # reference appends them flat and its sklearn call then fails on 2B vs B samples: score P(match) instead
+                    probs = probs[:, 1]
                 probs_all = probs if probs_all is None else np.append(probs_all, probs)
                 labels_all = labels if labels_all is None else np.append(labels_all, labels)
         from sklearn.metrics import f1_score, precision_score, recall_score

@@ -1,0 +1,112 @@
+"""End-to-end runs of the kept CLIs on the GPU with the HIP engine (synthetic files written to a temp dir): data loading,
+tokenisation, collate order, train loop with the fused AdamW, eval sweep, checkpoint + prediction files — the drop-in
+surface of SURVEY §8(b)(i).  finetune_multimodal.py (CoCa sum, roberta-shaped tiny text tower + vit_base_patch16_224) and
+finetune_image.py (eca_nfnet_l0 two-tower, with the GPU input pipeline and decode workers)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from test_cli_textcnn import ROOT, WORDS, make_data
+
+pytestmark = pytest.mark.gpu
+
+
+def _images(directory, names, size, seed=0):
+    from PIL import Image
+    rs = np.random.RandomState(seed)
+    os.makedirs(directory, exist_ok=True)
+    for i, n in enumerate(names):
+        h, w = (size, size) if i % 3 else (size + 13, size - 7)            # a few frames of another size
+        Image.fromarray(rs.randint(0, 256, size=(h, w, 3)).astype(np.uint8)).save(os.path.join(directory, n), quality=90)
+
+
+def _run(cmd, timeout=900):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    return r
+
+
+def test_finetune_multimodal_coca_gpu(gpu, tmp_path):
+    root = str(tmp_path)
+    pre = make_data(root, n_train=16, n_test=8)
+    _images(os.path.join(root, "raw", "item_images"), [f"i{k}.jpg" for k in range(40)], 96)
+    vocab_size = len(open(os.path.join(pre, "vocab.txt"), encoding="utf-8").read().split("\n")) - 1
+    cfg = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=vocab_size,
+               max_position_embeddings=64, type_vocab_size=2, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    json.dump(cfg, open(os.path.join(root, "coca_tiny.json"), "w"))
+    out = os.path.join(root, "out")
+    os.makedirs(out)
+    cmd = [sys.executable, os.path.join(ROOT, "finetune_multimodal.py"), "--data_dir", root, "--output_dir", out, "--config_file",
+           os.path.join(root, "coca_tiny.json"), "--model_name", "coca_tiny", "--data_version", "v1", "--interaction_type", "two_tower",
+           "--classification_method", "cls", "--ensemble", "sum", "--loss_type", "ce", "--do_train", "--do_eval", "--do_pred",
+           "--train_batch_size", "8", "--eval_batch_size", "4", "--num_train_epochs", "1", "--learning_rate", "1e-4", "--log_steps", "1",
+           "--pretrained_model_path", pre, "--max_seq_len", "8", "--max_seq_len_pv", "12", "--max_position_embeddings", "64",
+           "--image_size", "224", "--image_model_name", "vit_base_patch16_224", "--gpu_preproc", "--num_workers", "2", "--fp16"]
+    r = _run(cmd)
+    dirs = [d for d in os.listdir(out) if d.startswith("coca_tiny")]
+    assert len(dirs) == 1, os.listdir(out)
+    d = os.path.join(out, dirs[0])
+    files = os.listdir(d)
+    assert any(f.endswith("epoch-0.bin") for f in files), files
+    assert "weights.json" in files and "hyperparamter.txt" in files
+    pred = [f for f in files if f.endswith(".jsonl")]
+    assert pred, files
+    lines = [json.loads(l) for l in open(os.path.join(d, pred[0]))]
+    assert len(lines) == 8 and set(lines[0]) == {"src_item_id", "src_item_emb", "tgt_item_id", "tgt_item_emb", "threshold"}
+    assert "f1=" in r.stderr and "loss:" in r.stderr
+
+
+def test_finetune_image_nfnet_gpu(gpu, tmp_path):
+    root = str(tmp_path)
+    rs = np.random.RandomState(1)
+    items = [f"i{k}" for k in range(12)]
+    with open(os.path.join(root, "item_info.jsonl"), "w", encoding="utf-8") as w:
+        for it in items:
+            w.write(json.dumps({"item_id": it, "item_image_name": it + ".jpg"}) + "\n")
+    _images(os.path.join(root, "item_images"), [it + ".jpg" for it in items], 80)
+    for name, n in (("item_train_pair.jsonl", 8), ("item_valid_pair.jsonl", 4), ("item_test_pair.jsonl", 4)):
+        with open(os.path.join(root, name), "w", encoding="utf-8") as w:
+            for _ in range(n):
+                a, b = rs.choice(items, 2, replace=False)
+                w.write(json.dumps({"src_item_id": a, "tgt_item_id": b, "item_label": str(rs.randint(2))}) + "\n")
+    json.dump(dict(hidden_dropout_prob=0.1, num_labels=2), open(os.path.join(root, "eca_nfnet_l0.json"), "w"))
+    out = os.path.join(root, "out")
+    os.makedirs(out)
+    cmd = [sys.executable, os.path.join(ROOT, "finetune_image.py"), "--data_dir", root, "--output_dir", out, "--config_file",
+           os.path.join(root, "eca_nfnet_l0.json"), "--model_name", "eca_nfnet_l0", "--data_version", "v1", "--do_train", "--do_eval", "--do_pred",
+           "--train_batch_size", "4", "--eval_batch_size", "4", "--num_train_epochs", "1", "--learning_rate", "1e-4", "--log_steps", "1",
+           "--image_size", "64", "--gpu_preproc", "--num_workers", "2"]
+    r = _run(cmd)
+    dirs = os.listdir(out)
+    assert len(dirs) == 1, dirs
+    files = os.listdir(os.path.join(out, dirs[0]))
+    assert any(f.endswith("epoch-0.bin") for f in files) and "weights.json" in files, files
+    assert "f1=" in r.stderr and "loss:" in r.stderr
+
+
+@pytest.mark.parametrize("interaction,method,measure,loss", [("one_tower", "cls", "NA", "ce"), ("two_tower", "vec_sim", "cosine", "cosine")])
+def test_finetune_text_roberta_gpu(gpu, tmp_path, interaction, method, measure, loss):
+    root = str(tmp_path)
+    pre = make_data(root, n_train=16, n_test=8)
+    vocab_size = len(open(os.path.join(pre, "vocab.txt"), encoding="utf-8").read().split("\n")) - 1
+    cfg = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=vocab_size,
+               max_position_embeddings=64, type_vocab_size=2, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    json.dump(cfg, open(os.path.join(root, "roberta_tiny.json"), "w"))
+    out = os.path.join(root, "out")
+    os.makedirs(out)
+    cmd = [sys.executable, os.path.join(ROOT, "finetune_text.py"), "--data_dir", root, "--output_dir", out, "--config_file",
+           os.path.join(root, "roberta_tiny.json"), "--model_name", "roberta_tiny", "--data_version", "v1", "--interaction_type", interaction,
+           "--classification_method", method, "--similarity_measure", measure, "--loss_type", loss, "--do_train", "--do_eval", "--do_pred",
+           "--train_batch_size", "8", "--eval_batch_size", "4", "--num_train_epochs", "1", "--learning_rate", "1e-4", "--log_steps", "1",
+           "--pretrained_model_path", pre, "--max_seq_len", "8", "--max_seq_len_pv", "12", "--max_position_embeddings", "64", "--fp16"]
+    r = _run(cmd)
+    dirs = os.listdir(out)
+    assert len(dirs) == 1, dirs
+    files = os.listdir(os.path.join(out, dirs[0]))
+    assert any(f.endswith("epoch-0.bin") for f in files) and "hyperparamter.txt" in files, files
+    assert "f1=" in r.stderr and "loss:" in r.stderr
