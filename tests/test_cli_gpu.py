@@ -110,3 +110,34 @@ def test_finetune_text_roberta_gpu(gpu, tmp_path, interaction, method, measure, 
     files = os.listdir(os.path.join(out, dirs[0]))
     assert any(f.endswith("epoch-0.bin") for f in files) and "hyperparamter.txt" in files, files
     assert "f1=" in r.stderr and "loss:" in r.stderr
+
+
+@pytest.mark.parametrize("interaction", ["one_tower", "two_tower"])
+def test_finetune_text_pkgm_gpu(gpu, tmp_path, interaction):
+    """pkgm_* through finetune_text.py: entity / relation id files, KG rows spliced into the sequence (ia_kg_* kernels)."""
+    root = str(tmp_path)
+    pre = make_data(root, n_train=16, n_test=8)
+    with open(os.path.join(root, "processed", "entity2id.txt"), "w", encoding="utf-8") as w:
+        for k in range(40):
+            w.write(f"/item/i{k}\t{k + 1}\n")
+    with open(os.path.join(root, "processed", "relation2id.txt"), "w", encoding="utf-8") as w:
+        for k, word in enumerate(WORDS):
+            w.write(f"{word}\t{k + 1}\n")
+    vocab_size = len(open(os.path.join(pre, "vocab.txt"), encoding="utf-8").read().split("\n")) - 1
+    cfg = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=vocab_size,
+               max_position_embeddings=64, type_vocab_size=2, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
+               num_entities=41, num_relations=len(WORDS) + 1, kg_embedding_dim=128, entity_projection_bias=False)
+    json.dump(cfg, open(os.path.join(root, "pkgm_tiny.json"), "w"))
+    out = os.path.join(root, "out")
+    os.makedirs(out)
+    cmd = [sys.executable, os.path.join(ROOT, "finetune_text.py"), "--data_dir", root, "--output_dir", out, "--config_file",
+           os.path.join(root, "pkgm_tiny.json"), "--model_name", "pkgm_tiny", "--data_version", "v1", "--interaction_type", interaction,
+           "--classification_method", "cls", "--similarity_measure", "NA", "--loss_type", "ce", "--do_train", "--do_eval", "--do_pred",
+           "--train_batch_size", "8", "--eval_batch_size", "4", "--num_train_epochs", "1", "--learning_rate", "1e-4", "--log_steps", "1",
+           "--pretrained_model_path", pre, "--max_seq_len", "8", "--max_pvs", "4", "--max_position_embeddings", "64", "--fp16"]
+    r = _run(cmd)
+    dirs = os.listdir(out)
+    assert len(dirs) == 1, dirs
+    files = os.listdir(os.path.join(out, dirs[0]))
+    assert any(f.endswith("epoch-0.bin") for f in files), files
+    assert "f1=" in r.stderr and "loss:" in r.stderr
