@@ -141,3 +141,25 @@ def test_finetune_text_pkgm_gpu(gpu, tmp_path, interaction):
     files = os.listdir(os.path.join(out, dirs[0]))
     assert any(f.endswith("epoch-0.bin") for f in files), files
     assert "f1=" in r.stderr and "loss:" in r.stderr
+
+
+def test_finetune_multimodal_coca_cross_attn_gpu(gpu, tmp_path):
+    """--ensemble cross_attn through the CLI: a 768-wide 2-layer text tower + vit_base_patch16_224 + one multimodal layer."""
+    root = str(tmp_path)
+    pre = make_data(root, n_train=8, n_test=4)
+    _images(os.path.join(root, "raw", "item_images"), [f"i{k}.jpg" for k in range(40)], 64)
+    vocab_size = len(open(os.path.join(pre, "vocab.txt"), encoding="utf-8").read().split("\n")) - 1
+    cfg = dict(hidden_size=768, num_hidden_layers=2, num_attention_heads=12, intermediate_size=1024, vocab_size=vocab_size,
+               max_position_embeddings=64, type_vocab_size=2, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
+               num_hidden_layers_multimodal=1, num_attention_heads_multimodal=12, feedforward_multiplication_multimodal=2)
+    json.dump(cfg, open(os.path.join(root, "coca_x.json"), "w"))
+    out = os.path.join(root, "out")
+    os.makedirs(out)
+    cmd = [sys.executable, os.path.join(ROOT, "finetune_multimodal.py"), "--data_dir", root, "--output_dir", out, "--config_file",
+           os.path.join(root, "coca_x.json"), "--model_name", "coca_x", "--data_version", "v1", "--interaction_type", "two_tower",
+           "--classification_method", "cls", "--ensemble", "cross_attn", "--loss_type", "ce", "--do_train", "--do_eval",
+           "--train_batch_size", "4", "--eval_batch_size", "4", "--num_train_epochs", "1", "--learning_rate", "1e-4", "--log_steps", "1",
+           "--pretrained_model_path", pre, "--max_seq_len", "8", "--max_seq_len_pv", "12", "--max_position_embeddings", "64",
+           "--image_size", "224", "--image_model_name", "vit_base_patch16_224", "--fp16"]
+    r = _run(cmd)
+    assert "f1=" in r.stderr and "loss:" in r.stderr
