@@ -336,3 +336,26 @@ def test_gpu_image_pipeline_bit_exact(gpu, tmp_path, H, W, S):
         if i == 1:
             want = want.flip(-1)
         assert torch.equal(out[i], want), i
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(8200, 2056, 256, "none"), (8200, 2056, 320, "bias_gelu"), (16500, 1032, 192, "add")])
+def test_gemm_persistent_rounds_with_clipped_tiles(gpu, M, N, K, epi):
+    """More than 256 output tiles (the T256 kernel loops over tiles per workgroup, keeps the previous tile's stores in
+    flight behind a counted wait) with both M and N clipping the last tiles: the whole output against fp32 matmul."""
+    from item_alignment_amd import ops
+    a, w = rnd((M, K), gpu, 1.0, 51), rnd((N, K), gpu, 0.1, 52)
+    ref = a.float() @ w.float().t()
+    if epi == "none":
+        assert rel_err(ops.gemm(a, w), ref) < 2e-2
+    elif epi == "bias_gelu":
+        bias = torch.randn(N, device=gpu)
+        act, pre = ops.gemm(a, w, epilogue=ops.EPI_BIAS_GELU, bias=bias)
+        assert rel_err(pre, ref + bias) < 2e-2
+        assert rel_err(act, torch.nn.functional.gelu(pre.float())) < 2e-2
+    else:
+        aux = rnd((M, N), gpu, 1.0, 53)
+        assert rel_err(ops.gemm(a, w, epilogue=ops.EPI_ADD, aux=aux), ref + aux.float()) < 2e-2
+    # run it again right behind itself: stores of the first launch's last tiles must not be disturbed by the second
+    out1 = ops.gemm(a, w)
+    out2 = ops.gemm(a, w)
+    assert torch.equal(out1, out2)
