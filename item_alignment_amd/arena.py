@@ -27,6 +27,7 @@ def _round_up(n, a):
 
 class ParamArena:
     def __init__(self, model, device, frozen_ok=True):
+        self.side_streams = []
         self.device = torch.device(device)
         named = [(n, p) for n, p in model.named_parameters()]
         by_id = {id(p): n for n, p in named}
@@ -102,7 +103,16 @@ class ParamArena:
         lib = _lib.load()
         check(lib.ia_cast_f32_to_bf16(self.master.data_ptr(), self.shadow.data_ptr(), self.numel, stream_ptr()), "ia_cast_f32_to_bf16")
 
+    def join_side_streams(self):
+        """Models that run independent towers on extra HIP streams register them in `side_streams`: everything that reads or
+        rewrites the arenas on the current stream (optimiser step, zero_grad) first waits for those streams."""
+        if self.side_streams:
+            cur = torch.cuda.current_stream()
+            for s in self.side_streams:
+                cur.wait_stream(s)
+
     def zero_grad(self):
+        self.join_side_streams()
         self.grad.zero_()
 
     def reattach(self):
@@ -115,6 +125,7 @@ class ParamArena:
         """One fused AdamW update over the whole arena + bf16 shadow refresh (single launch)."""
         lib = _lib.load()
         self.step_count += 1
+        self.join_side_streams()
         check(lib.ia_adamw_flat(self.master.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                                 self.shadow.data_ptr(), self.chunk_table.data_ptr(), self.n_chunks, lr, betas[0], betas[1], eps,
                                 weight_decay, self.step_count, grad_scale, stream_ptr()), "ia_adamw_flat")

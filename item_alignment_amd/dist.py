@@ -80,7 +80,16 @@ class GradBucketReducer:
 
     @classmethod
     def for_arena(cls, arena, **kw):
-        return cls(arena.grad, [(p, o, p.numel()) for p, o in zip(arena.params, arena.offsets)], **kw)
+        r = cls(arena.grad, [(p, o, p.numel()) for p, o in zip(arena.params, arena.offsets)], **kw)
+        r.arena = arena
+        r.main_stream = torch.cuda.current_stream() if arena.grad.is_cuda else None
+        return r
+
+    def streams(self):
+        """the stream the reducer was created on + the side streams the model registered in its arena"""
+        a = getattr(self, "arena", None)
+        main = getattr(self, "main_stream", None)
+        return ([main] if main is not None else []) + (list(a.side_streams) if a is not None else [])
 
     def reset(self):
         self.left = list(self.need)
@@ -92,6 +101,12 @@ class GradBucketReducer:
         s, e = self.buckets[i]
         self.launched[i] = True
         if self.world > 1 or (FORCE and dist.is_initialized()):
+            # gradients of one bucket may have been produced on several HIP streams (models that run independent towers
+            # concurrently): the stream the collective is ordered after must have seen all of them
+            cur = torch.cuda.current_stream() if self.flat.is_cuda else None
+            for st in self.streams():
+                if cur is not None and st != cur:
+                    cur.wait_stream(st)
             self.works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def grads_ready(self, params):

@@ -112,6 +112,9 @@ def run(args, model, datasets, collate_fn, call_model, checkpoint_name, path_fie
 
     nw = int(getattr(args, "num_workers", 0) or 0)
     dl_kw = dict(num_workers=nw, pin_memory=(device.type == "cuda"), persistent_workers=False)
+    if nw > 0:
+        # never fork() a process that owns HIP streams: workers come from a clean fork server and only see the pickled dataset
+        dl_kw["multiprocessing_context"] = "forkserver"
 
     def evaluate(loader, tag):
         model.eval()
