@@ -47,16 +47,37 @@ IA_DEV __amdgpu_buffer_rsrc_t ia_rsrc(const void* p, uint32_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
 
-// wave-wide reductions (64 lanes)
-IA_DEV float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// wave-wide reductions (64 lanes) on DPP (no LDS round trips: __shfl_xor lowers to ds_bpermute_b32, ~100 cycles a step):
+// four in-row butterfly steps leave every lane with the total of its 16-lane row, the four row totals are then combined
+// through scalar registers.  The result is wave-uniform.
+template <int CTRL>
+IA_DEV float ia_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+IA_DEV float ia_lane(float v, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane)); }
+IA_DEV float row16_sum(float v) {
+  v += ia_dpp<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += ia_dpp<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += ia_dpp<0x141>(v);   // row_half_mirror
+  v += ia_dpp<0x140>(v);   // row_mirror
   return v;
 }
+IA_DEV float wave_sum(float v) {
+  v = row16_sum(v);
+  return (ia_lane(v, 0) + ia_lane(v, 16)) + (ia_lane(v, 32) + ia_lane(v, 48));
+}
+// sums over lanes 0..31 and 32..63 separately
+IA_DEV void half_wave_sums(float v, float& lo, float& hi) {
+  v = row16_sum(v);
+  lo = ia_lane(v, 0) + ia_lane(v, 16);
+  hi = ia_lane(v, 32) + ia_lane(v, 48);
+}
 IA_DEV float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, ia_dpp<0xB1>(v));
+  v = fmaxf(v, ia_dpp<0x4E>(v));
+  v = fmaxf(v, ia_dpp<0x141>(v));
+  v = fmaxf(v, ia_dpp<0x140>(v));
+  return fmaxf(fmaxf(ia_lane(v, 0), ia_lane(v, 16)), fmaxf(ia_lane(v, 32), ia_lane(v, 48)));
 }
 
 // Counter-based dropout RNG: one 32-bit mix per (seed, stream, index) -> two 16-bit uniforms.
