@@ -167,3 +167,28 @@ def test_resize_tables_reproduce_pillow_bit_exact():
         ref = np.asarray(Image.fromarray(img).resize((S, S), Image.BICUBIC))
         got = one_pass(one_pass(img, S, 1), S, 0)          # Pillow: horizontal pass first
         assert np.array_equal(ref, got.astype(np.uint8)), (H, W, S)
+
+
+def test_raw_image_mode_collates_without_resizing(tmp_path):
+    """--gpu_preproc host side: datasets hand decoded uint8 frames (any size) + the flip decision to the collate functions,
+    which keep them as a RawImageBatch (no stacking of unequal sizes); the default path still yields [B,3,S,S] fp32."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    from item_alignment_amd.data.datasets import PairedImageDataset, RawImage, RawImageBatch, collate_image
+    rs = np.random.RandomState(0)
+    paths = []
+    for i, (h, w) in enumerate([(40, 50), (33, 71), (64, 64), (20, 90)]):
+        p = tmp_path / f"{i}.png"
+        Image.fromarray(rs.randint(0, 256, size=(h, w, 3)).astype(np.uint8)).save(p)
+        paths.append(str(p))
+    data = [(1, "a", paths[0], "b", paths[1]), (0, "c", paths[2], "d", paths[3]), (1, "e", paths[0], "f", str(tmp_path / "missing.png"))]
+    raw = PairedImageDataset(data, 32, True, hflip=0.5, raw=True)
+    src_ids, tgt_ids, a, b, labels = collate_image([raw[i] for i in range(3)])
+    assert src_ids == ["a", "c"] and labels.tolist() == [1, 0]                 # the sample with a missing image is dropped
+    assert isinstance(a, RawImageBatch) and isinstance(b, RawImageBatch) and len(a) == 2
+    assert isinstance(a.items[0], RawImage) and a.items[0].u8.dtype == torch.uint8 and tuple(a.items[0].u8.shape) == (40, 50, 3)
+    assert tuple(b.items[1].u8.shape) == (20, 90, 3)
+    std = PairedImageDataset(data, 32, False)
+    _, _, a2, b2, _ = collate_image([std[i] for i in range(2)])
+    assert tuple(a2.shape) == (2, 3, 32, 32) and a2.dtype == torch.float32
