@@ -218,6 +218,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   __syncthreads();
 
   const int g = lane >> 4, li = lane & 15;
+  // a wave whose 64 x 64 quadrant lies entirely outside C (M or N <= 64: conv groups, heads) only helps with the staging
+  const bool quadrant_live = m0 + wm * 64 < p.M && n0 + wn * 64 < p.N;
   for (int kt = kt0; kt < nk; ++kt) {
     const int buf = (kt - kt0) & 1;
     if (kt + 1 < nk) {
@@ -227,6 +229,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     }
     const char* sA = smem + buf * 2 * TILE_BYTES;
     const char* sB = sA + TILE_BYTES;
+    if (quadrant_live)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[4], bfr[4];
