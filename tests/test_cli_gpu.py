@@ -163,3 +163,34 @@ def test_finetune_multimodal_coca_cross_attn_gpu(gpu, tmp_path):
            "--image_size", "224", "--image_model_name", "vit_base_patch16_224", "--fp16"]
     r = _run(cmd)
     assert "f1=" in r.stderr and "loss:" in r.stderr
+
+
+@pytest.mark.parametrize("interaction,ensemble", [("one_tower", "begin"), ("two_tower", "begin"), ("one_tower", "end")])
+def test_finetune_multimodal_roberta_image_gpu(gpu, tmp_path, interaction, ensemble):
+    """roberta_image_* through finetune_multimodal.py: rows carry pre-extracted image embeddings (JSON lists), spliced in as
+    tokens (`begin`) or fed to the head (`end`)."""
+    root = str(tmp_path)
+    pre = make_data(root, n_train=16, n_test=8)
+    rs = np.random.RandomState(3)
+    D = 64
+    for name in ("finetune_train.tsv", "finetune_test.tsv"):       # add the two embedding columns
+        path = os.path.join(root, "processed", "v1", name)
+        rows = [l.rstrip("\n").split("\t") for l in open(path, encoding="utf-8")]
+        with open(path, "w", encoding="utf-8") as w:
+            for label, a, at, ap, b, bt, bp in rows:
+                ea, eb = (json.dumps([round(float(x), 4) for x in rs.standard_normal(D)]) for _ in range(2))
+                w.write("\t".join([label, a, at, ap, ea, b, bt, bp, eb]) + "\n")
+    vocab_size = len(open(os.path.join(pre, "vocab.txt"), encoding="utf-8").read().split("\n")) - 1
+    cfg = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=vocab_size,
+               max_position_embeddings=64, type_vocab_size=2, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    json.dump(cfg, open(os.path.join(root, "ri.json"), "w"))
+    out = os.path.join(root, "out")
+    os.makedirs(out)
+    cmd = [sys.executable, os.path.join(ROOT, "finetune_multimodal.py"), "--data_dir", root, "--output_dir", out, "--config_file",
+           os.path.join(root, "ri.json"), "--model_name", "roberta_image_tiny", "--data_version", "v1", "--interaction_type", interaction,
+           "--classification_method", "cls", "--ensemble", ensemble, "--loss_type", "ce", "--do_train", "--do_eval",
+           "--train_batch_size", "8", "--eval_batch_size", "4", "--num_train_epochs", "1", "--learning_rate", "1e-4", "--log_steps", "1",
+           "--pretrained_model_path", pre, "--max_seq_len", "8", "--max_seq_len_pv", "12", "--max_position_embeddings", "64",
+           "--image_hidden_size", str(D), "--fp16"]
+    r = _run(cmd)
+    assert "f1=" in r.stderr and "loss:" in r.stderr
