@@ -61,7 +61,8 @@ def test_finetune_multimodal_coca_gpu(gpu, tmp_path):
     assert "f1=" in r.stderr and "loss:" in r.stderr
 
 
-def test_finetune_image_nfnet_gpu(gpu, tmp_path):
+@pytest.mark.parametrize("model_name,size", [("eca_nfnet_l0", 64), ("vit_base_patch16_224", 224)])
+def test_finetune_image_gpu(gpu, tmp_path, model_name, size):
     root = str(tmp_path)
     rs = np.random.RandomState(1)
     items = [f"i{k}" for k in range(12)]
@@ -74,13 +75,13 @@ def test_finetune_image_nfnet_gpu(gpu, tmp_path):
             for _ in range(n):
                 a, b = rs.choice(items, 2, replace=False)
                 w.write(json.dumps({"src_item_id": a, "tgt_item_id": b, "item_label": str(rs.randint(2))}) + "\n")
-    json.dump(dict(hidden_dropout_prob=0.1, num_labels=2), open(os.path.join(root, "eca_nfnet_l0.json"), "w"))
+    json.dump(dict(hidden_dropout_prob=0.1, num_labels=2), open(os.path.join(root, "img.json"), "w"))
     out = os.path.join(root, "out")
     os.makedirs(out)
     cmd = [sys.executable, os.path.join(ROOT, "finetune_image.py"), "--data_dir", root, "--output_dir", out, "--config_file",
-           os.path.join(root, "eca_nfnet_l0.json"), "--model_name", "eca_nfnet_l0", "--data_version", "v1", "--do_train", "--do_eval", "--do_pred",
+           os.path.join(root, "img.json"), "--model_name", model_name, "--data_version", "v1", "--do_train", "--do_eval", "--do_pred",
            "--train_batch_size", "4", "--eval_batch_size", "4", "--num_train_epochs", "1", "--learning_rate", "1e-4", "--log_steps", "1",
-           "--image_size", "64", "--gpu_preproc", "--num_workers", "2"]
+           "--image_size", str(size), "--gpu_preproc", "--num_workers", "2"]
     r = _run(cmd)
     dirs = os.listdir(out)
     assert len(dirs) == 1, dirs
