@@ -195,3 +195,28 @@ def test_finetune_multimodal_roberta_image_gpu(gpu, tmp_path, interaction, ensem
            "--image_hidden_size", str(D), "--fp16"]
     r = _run(cmd)
     assert "f1=" in r.stderr and "loss:" in r.stderr
+
+
+def test_finetune_text_under_torchrun_rccl(gpu, tmp_path):
+    """The CLI under torch.distributed.run with the RCCL process group live (one rank, IA_DP_FORCE_COLLECTIVES=1 makes the
+    bucket all-reduces, the arena broadcast and the barriers actually run): the multi-GPU train loop on a 1-GPU box."""
+    root = str(tmp_path)
+    pre = make_data(root, n_train=16, n_test=8)
+    vocab_size = len(open(os.path.join(pre, "vocab.txt"), encoding="utf-8").read().split("\n")) - 1
+    cfg = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=vocab_size,
+               max_position_embeddings=64, type_vocab_size=2, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    json.dump(cfg, open(os.path.join(root, "roberta_tiny.json"), "w"))
+    out = os.path.join(root, "out")
+    os.makedirs(out)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port",
+           "29533", os.path.join(ROOT, "finetune_text.py"), "--data_dir", root, "--output_dir", out, "--config_file",
+           os.path.join(root, "roberta_tiny.json"), "--model_name", "roberta_tiny", "--data_version", "v1", "--interaction_type", "two_tower",
+           "--classification_method", "cls", "--similarity_measure", "NA", "--loss_type", "ce", "--do_train", "--do_eval",
+           "--train_batch_size", "8", "--eval_batch_size", "4", "--num_train_epochs", "1", "--learning_rate", "1e-4", "--log_steps", "1",
+           "--pretrained_model_path", pre, "--max_seq_len", "8", "--max_seq_len_pv", "12", "--max_position_embeddings", "64", "--fp16"]
+    env = dict(os.environ, PYTHONPATH=ROOT, IA_DP_FORCE_COLLECTIVES="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    dirs = os.listdir(out)
+    assert len(dirs) == 1 and any(f.endswith("epoch-0.bin") for f in os.listdir(os.path.join(out, dirs[0])))
+    assert "f1=" in r.stderr and "loss:" in r.stderr
