@@ -327,6 +327,62 @@ __global__ __launch_bounds__(256) void scale_residual_bwd_kernel(const bf16* __r
   *reinterpret_cast<bf16x8*>(dx + idx * 8) = o;
 }
 
+// --------------------------------------------------------------------------- SiLU between padded / compact layouts
+// The patch-matrix-free 3x3 convolution (ia_conv3x3_padded_*) reads [B, H+2, W+2, C] with a zero border and produces its
+// output on the same padded domain (border rows hold garbage).  These SiLU kernels move between that domain and the
+// compact [B, H, W, C] one: the border of a padded output is written as zero, the border of a padded input is ignored.
+IA_DEV size_t pad_row(size_t b, int y, int x, int H, int W) { return (b * (H + 2) + y + 1) * (size_t)(W + 2) + x + 1; }
+
+__global__ __launch_bounds__(256) void silu_pad_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, int H, int W, int C, float scale,
+                                                           int in_padded, int out_padded, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;      // over output rows x C/8
+  if (idx >= total) return;
+  const int c8n = C >> 3, c = (int)(idx % c8n) * 8;
+  const size_t row = idx / c8n;
+  const int OW = out_padded ? W + 2 : W, OH = out_padded ? H + 2 : H;
+  const int ox = (int)(row % OW), oy = (int)((row / OW) % OH);
+  const size_t b = row / ((size_t)OW * OH);
+  const int yy = out_padded ? oy - 1 : oy, xx = out_padded ? ox - 1 : ox;
+  bf16x8 o;
+  if (yy < 0 || yy >= H || xx < 0 || xx >= W) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf(0.f);
+  } else {
+    const size_t irow = in_padded ? pad_row(b, yy, xx, H, W) : (b * H + yy) * (size_t)W + xx;
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + irow * C + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float a = bf2f(v[j]); o[j] = f2bf(a / (1.f + __expf(-a)) * scale); }
+  }
+  *reinterpret_cast<bf16x8*>(y + row * C + c) = o;
+}
+
+// dx (layout of x) = dy (layout of y) * scale * silu'(x); the border of a padded dx is zero
+__global__ __launch_bounds__(256) void silu_pad_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x, bf16* __restrict__ dx, int H,
+                                                           int W, int C, float scale, int in_padded, int out_padded, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;      // over rows of x (its own layout) x C/8
+  if (idx >= total) return;
+  const int c8n = C >> 3, c = (int)(idx % c8n) * 8;
+  const size_t row = idx / c8n;
+  const int IW = in_padded ? W + 2 : W, IH = in_padded ? H + 2 : H;
+  const int ix = (int)(row % IW), iy = (int)((row / IW) % IH);
+  const size_t b = row / ((size_t)IW * IH);
+  const int yy = in_padded ? iy - 1 : iy, xx = in_padded ? ix - 1 : ix;
+  bf16x8 o;
+  if (yy < 0 || yy >= H || xx < 0 || xx >= W) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf(0.f);
+  } else {
+    const size_t orow = out_padded ? pad_row(b, yy, xx, H, W) : (b * H + yy) * (size_t)W + xx;
+    const bf16x8 g = *reinterpret_cast<const bf16x8*>(dy + orow * C + c), v = *reinterpret_cast<const bf16x8*>(x + row * C + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float a = bf2f(v[j]), sg = 1.f / (1.f + __expf(-a));
+      o[j] = f2bf(bf2f(g[j]) * scale * sg * (1.f + a * (1.f - sg)));
+    }
+  }
+  *reinterpret_cast<bf16x8*>(dx + row * C + c) = o;
+}
+
 inline unsigned blocks_of(size_t total) { return (unsigned)((total + 255) / 256); }
 inline int nsplit_of(int HW) { int n = HW / 64; return n < 1 ? 1 : (n > 64 ? 64 : n); }
 
@@ -548,5 +604,88 @@ extern "C" int ia_eca_bwd(const void* dout, const void* x, const float* conv_w, 
   const size_t total = (size_t)B * HW * (C >> 3);
   hipLaunchKernelGGL(scale_residual_bwd_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)dout, gate, (const float*)dpooled,
                      (bf16*)dx, HW, C, coef, total);
+  return ia_check_launch();
+}
+
+// ------------------------------------------------------------------------ 3x3 stride-1 convolution without a patch matrix
+// xp / yp / dxp / dyp: [B, H+2, W+2, C] bf16 ("padded domain"); inputs (xp, dyp) must have a ZERO border, outputs carry garbage
+// in their border rows.  Channel groups of exactly 64 in and 64 out channels (ECA-NFNet group_size 64): tap t of a group is
+// k-tile t of a GEMM whose A rows are the tensor itself shifted by (t/3-1)(W+2) + (t%3-1) rows (ia_gemm_bf16_view), so the
+// activations are read in place (9 shifted reads served by L2) instead of through a 9x larger gathered matrix.
+static int padded_ok(int B, int H, int W, int C, int groups) {
+  if (B <= 0 || H <= 0 || W <= 0 || groups <= 0 || C != groups * 64) return IA_ERR_UNSUPPORTED;
+  if ((size_t)B * (H + 2) * (W + 2) * C * 2 >= 0x7FFFFFFFull) return IA_ERR_ARG;
+  return IA_OK;
+}
+
+extern "C" int ia_conv3x3_padded_fwd(const void* xp, const void* what, const float* bias, void* yp, int B, int H, int W, int C, int groups,
+                                     hipStream_t stream) {
+  (void)hipGetLastError();
+  int rc = padded_ok(B, H, W, C, groups);
+  if (rc) return rc;
+  if (!xp || !what || !yp) return IA_ERR_ARG;
+  const size_t Mp = (size_t)B * (H + 2) * (W + 2);
+  for (int g = 0; g < groups && !rc; ++g)
+    rc = ia_gemm_bf16_view((const bf16*)xp + g * 64, 0, C, (const bf16*)what + (size_t)g * 64 * 576, 0, 576, (bf16*)yp + g * 64, 0, C, (int)Mp, 64,
+                           576, bias ? IA_EPI_BIAS : IA_EPI_NONE, bias ? bias + g * 64 : nullptr, 0, nullptr, 0, 1, 0, W + 2,
+                           (Mp * C - (size_t)g * 64) * 2, 0, stream);
+  return rc;
+}
+
+extern "C" int ia_conv3x3_padded_bwd_data(const void* dyp, const void* what, void* dxp, int B, int H, int W, int C, int groups, hipStream_t stream) {
+  (void)hipGetLastError();
+  int rc = padded_ok(B, H, W, C, groups);
+  if (rc) return rc;
+  if (!dyp || !what || !dxp) return IA_ERR_ARG;
+  const size_t Mp = (size_t)B * (H + 2) * (W + 2);
+  for (int g = 0; g < groups && !rc; ++g)
+    rc = ia_gemm_bf16_view((const bf16*)dyp + g * 64, 0, C, (const bf16*)what + (size_t)g * 64 * 576, 1, 576, (bf16*)dxp + g * 64, 0, C, (int)Mp, 64,
+                           576, IA_EPI_NONE, nullptr, 0, nullptr, 0, -1, 1, W + 2, (Mp * C - (size_t)g * 64) * 2,
+                           ((size_t)(groups - g) * 64 * 576) * 2, stream);
+  return rc;
+}
+
+extern "C" size_t ia_conv3x3_padded_workspace_bytes(int B, int H, int W, int C) {
+  const size_t Mp = (size_t)B * (H + 2) * (W + 2);
+  const size_t gw = ia_gemm_workspace_bytes(64, 576, (int)Mp, 1), cs = ia_colsum_workspace_bytes((int)Mp, C);
+  return gw > cs ? gw : cs;
+}
+
+// dwhat [C][576] fp32 overwritten, dbias [C] accumulated (may be NULL)
+extern "C" int ia_conv3x3_padded_bwd_weight(const void* xp, const void* dyp, float* dwhat, float* dbias, int B, int H, int W, int C, int groups,
+                                            void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  (void)hipGetLastError();
+  int rc = padded_ok(B, H, W, C, groups);
+  if (rc) return rc;
+  if (!xp || !dyp || !dwhat) return IA_ERR_ARG;
+  if (!workspace || workspace_bytes < ia_conv3x3_padded_workspace_bytes(B, H, W, C)) return IA_ERR_WORKSPACE;
+  const size_t Mp = (size_t)B * (H + 2) * (W + 2);
+  for (int g = 0; g < groups && !rc; ++g)
+    rc = ia_gemm_bf16_view((const bf16*)dyp + g * 64, 1, C, (const bf16*)xp + g * 64, 1, C, dwhat + (size_t)g * 64 * 576, 1, 576, 64, 576, (int)Mp,
+                           IA_EPI_NONE, nullptr, 0, workspace, workspace_bytes, 0, 2, W + 2, 0, (Mp * C - (size_t)g * 64) * 2, stream);
+  if (rc || !dbias) return rc;
+  return ia_colsum(dyp, C, (int)Mp, C, dbias, 1, workspace, workspace_bytes, stream);
+}
+
+// y = silu(x) * scale moving between the compact [B,H,W,C] and the zero-bordered [B,H+2,W+2,C] layouts (flags per side)
+extern "C" int ia_silu_pad_fwd(const void* x, void* y, int B, int H, int W, int C, float scale, int in_padded, int out_padded, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7)) return IA_ERR_ARG;
+  const size_t rows = out_padded ? (size_t)B * (H + 2) * (W + 2) : (size_t)B * H * W;
+  const size_t total = rows * (C >> 3);
+  hipLaunchKernelGGL(silu_pad_fwd_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, H, W, C, scale, in_padded,
+                     out_padded, total);
+  return ia_check_launch();
+}
+
+// dx (layout of x: in_padded) = dy (layout of y: out_padded) * scale * silu'(x)
+extern "C" int ia_silu_pad_bwd(const void* dy, const void* x, void* dx, int B, int H, int W, int C, float scale, int in_padded, int out_padded,
+                               hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dy || !x || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7)) return IA_ERR_ARG;
+  const size_t rows = in_padded ? (size_t)B * (H + 2) * (W + 2) : (size_t)B * H * W;
+  const size_t total = rows * (C >> 3);
+  hipLaunchKernelGGL(silu_pad_bwd_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)x, (bf16*)dx, H, W, C, scale,
+                     in_padded, out_padded, total);
   return ia_check_launch();
 }

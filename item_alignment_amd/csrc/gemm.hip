@@ -41,7 +41,15 @@ struct GemmArgs {
   int splits, nk_per_split;   // split-K (fp32 output only): blockIdx.y owns k-tiles [y*nk_per_split, ...)
   float* ws;                  // [splits][M][N] fp32 partials when splits > 1
   int dbg;                    // ablation switches for tuning runs (IA_GEMM_DBG env): results are WRONG when non-zero
+  // Shifted operand views (T128 only) that turn the GEMM into a 3x3 convolution over a zero-padded NHWC tensor
+  // [B, H+2, W+2, C] without a patch matrix: tap t = k-tile t of a 64-channel group, i.e. the same rows shifted by
+  // tap_delta(t) = (t/3 - 1) * pw + (t%3 - 1).  a_view: 1 = A rows + delta(k-tile), -1 = rows - delta(k-tile) (k-contiguous A,
+  // k-local column = channel).  b_view: 1 = k-strided B with k-local rows and a column shift of 64 per k-tile (data gradient:
+  // B[k=(t,n)][c] = W[n][t*64+c]); 2 = k-strided B whose 64-column block j reads rows + delta(j) (weight gradient).
+  int a_view, b_view, pw;
 };
+
+IA_DEV int tap_delta(int t, int pw) { return (t / 3 - 1) * pw + (t % 3 - 1); }
 
 // ---------------------------------------------------------------------------------- shared epilogue
 // v = 4 consecutive output columns n..n+3 of row m
@@ -156,7 +164,7 @@ constexpr int BM = 128, BN = 128, TILE_BYTES = 16384;
 IA_DEV int ks_swz(int k) { return ((k & 3) | (((k >> 3) & 1) << 2)) << 1; }
 
 template <bool KS>
-IA_DEV void stage_tile(__amdgpu_buffer_rsrc_t rs, char* s, int kt, int x0, int ld, int K, int tid, int wave) {
+IA_DEV void stage_tile(__amdgpu_buffer_rsrc_t rs, char* s, int kt, int x0, int ld, int K, int tid, int wave, int view = 0, int pw = 0) {
 #pragma unroll
   for (int issue = 0; issue < 4; ++issue) {
     uint32_t off;
@@ -164,13 +172,16 @@ IA_DEV void stage_tile(__amdgpu_buffer_rsrc_t rs, char* s, int kt, int x0, int l
       const int row = issue * 32 + (tid >> 3);
       const int c = (tid & 7) ^ (row & 7);
       const int k = kt * BK + c * 8;
-      off = (uint32_t)(((x0 + row) * ld + k) * 2);
+      if (view == 0) off = (uint32_t)(((x0 + row) * ld + k) * 2);
+      else off = (uint32_t)(((x0 + row + view * tap_delta(kt, pw)) * ld + c * 8) * 2);   // rows before the tensor wrap to out-of-range
       if (k >= K) off = OOB;
     } else {
       const int row = issue * 16 + (tid >> 4);
       const int c = (tid & 15) ^ ks_swz(row);
       const int k = kt * BK + row;
-      off = (uint32_t)((k * ld + x0 + c * 8) * 2);
+      if (view == 0) off = (uint32_t)((k * ld + x0 + c * 8) * 2);
+      else if (view == 1) off = (uint32_t)((row * ld + kt * BK + x0 + c * 8) * 2);
+      else { const int col = x0 + c * 8; off = (uint32_t)(((k + tap_delta(col >> 6, pw)) * ld + (col & 63)) * 2); }
       if (k >= K) off = OOB;
     }
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, IA_LDS(s + issue * 4096 + wave * 1024), 16, off, 0, 0, 0);
@@ -212,8 +223,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   const int nk_all = (p.K + BK - 1) / BK;
   const int kt0 = blockIdx.y * p.nk_per_split;
   const int nk = min(nk_all, kt0 + p.nk_per_split);
-  stage_tile<AKS>(rsA, smem, kt0, m0, p.lda, p.K, tid, wave);
-  stage_tile<BKS>(rsB, smem + TILE_BYTES, kt0, n0, p.ldb, p.K, tid, wave);
+  stage_tile<AKS>(rsA, smem, kt0, m0, p.lda, p.K, tid, wave, p.a_view, p.pw);
+  stage_tile<BKS>(rsB, smem + TILE_BYTES, kt0, n0, p.ldb, p.K, tid, wave, p.b_view, p.pw);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -224,8 +235,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     const int buf = (kt - kt0) & 1;
     if (kt + 1 < nk) {
       char* nb = smem + (buf ^ 1) * 2 * TILE_BYTES;
-      stage_tile<AKS>(rsA, nb, kt + 1, m0, p.lda, p.K, tid, wave);
-      stage_tile<BKS>(rsB, nb + TILE_BYTES, kt + 1, n0, p.ldb, p.K, tid, wave);
+      stage_tile<AKS>(rsA, nb, kt + 1, m0, p.lda, p.K, tid, wave, p.a_view, p.pw);
+      stage_tile<BKS>(rsB, nb + TILE_BYTES, kt + 1, n0, p.ldb, p.K, tid, wave, p.b_view, p.pw);
     }
     const char* sA = smem + buf * 2 * TILE_BYTES;
     const char* sB = sA + TILE_BYTES;
@@ -630,10 +641,34 @@ extern "C" size_t ia_gemm_workspace_bytes(int M, int N, int K, int c_is_f32) {
   return pl.splits > 1 ? (size_t)pl.splits * M * N * sizeof(float) : 0;
 }
 
+static int gemm_core(const void* A, int a_kstrided, int lda, const void* B, int b_kstrided, int ldb, void* C, int c_is_f32, int ldc, int M,
+                     int N, int K, int epilogue, const float* bias, const void* aux, int ldaux, void* C2, int accumulate, void* workspace,
+                     size_t workspace_bytes, int a_view, int b_view, int pw, uint64_t a_window, uint64_t b_window, hipStream_t stream);
+
 extern "C" int ia_gemm_bf16(const void* A, int a_kstrided, int lda, const void* B, int b_kstrided, int ldb,
                             void* C, int c_is_f32, int ldc, int M, int N, int K, int epilogue,
                             const float* bias, const void* aux, int ldaux, void* C2, int accumulate, void* workspace,
                             size_t workspace_bytes, hipStream_t stream) {
+  return gemm_core(A, a_kstrided, lda, B, b_kstrided, ldb, C, c_is_f32, ldc, M, N, K, epilogue, bias, aux, ldaux, C2, accumulate, workspace,
+                   workspace_bytes, 0, 0, 0, 0, 0, stream);
+}
+
+// ia_gemm_bf16 with shifted operand views (see GemmArgs): the building block of the patch-matrix-free 3x3 convolution in
+// conv.hip.  a_window / b_window: bytes addressable from A / B (rows shifted outside the window read as zero).
+extern "C" int ia_gemm_bf16_view(const void* A, int a_kstrided, int lda, const void* B, int b_kstrided, int ldb, void* C, int c_is_f32,
+                                 int ldc, int M, int N, int K, int epilogue, const float* bias, int accumulate, void* workspace,
+                                 size_t workspace_bytes, int a_view, int b_view, int pw, size_t a_window, size_t b_window,
+                                 hipStream_t stream) {
+  if ((a_view && (a_kstrided || (a_view != 1 && a_view != -1))) || (b_view && (!b_kstrided || b_view < 1 || b_view > 2)) || pw <= 2)
+    return IA_ERR_ARG;
+  if (!a_view && !b_view) return IA_ERR_ARG;
+  return gemm_core(A, a_kstrided, lda, B, b_kstrided, ldb, C, c_is_f32, ldc, M, N, K, epilogue, bias, nullptr, 0, nullptr, accumulate,
+                   workspace, workspace_bytes, a_view, b_view, pw, a_window, b_window, stream);
+}
+
+static int gemm_core(const void* A, int a_kstrided, int lda, const void* B, int b_kstrided, int ldb, void* C, int c_is_f32, int ldc, int M,
+                     int N, int K, int epilogue, const float* bias, const void* aux, int ldaux, void* C2, int accumulate, void* workspace,
+                     size_t workspace_bytes, int a_view, int b_view, int pw, uint64_t a_window, uint64_t b_window, hipStream_t stream) {
   (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return IA_ERR_ARG;
   if ((lda & 7) || (ldb & 7) || (ldc & 3) || (N & 3)) return IA_ERR_ARG;
@@ -641,8 +676,9 @@ extern "C" int ia_gemm_bf16(const void* A, int a_kstrided, int lda, const void* 
   GemmArgs g;
   g.A = (const bf16*)A; g.B = (const bf16*)B; g.C = C; g.C2 = (bf16*)C2; g.bias = bias; g.aux = (const bf16*)aux;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux; g.accumulate = accumulate;
-  const uint64_t ab = a_kstrided ? ((uint64_t)(K - 1) * lda + M) * 2 : ((uint64_t)(M - 1) * lda + K) * 2;
-  const uint64_t bb = b_kstrided ? ((uint64_t)(K - 1) * ldb + N) * 2 : ((uint64_t)(N - 1) * ldb + K) * 2;
+  const uint64_t ab = a_window ? a_window : (a_kstrided ? ((uint64_t)(K - 1) * lda + M) * 2 : ((uint64_t)(M - 1) * lda + K) * 2);
+  const uint64_t bb = b_window ? b_window : (b_kstrided ? ((uint64_t)(K - 1) * ldb + N) * 2 : ((uint64_t)(N - 1) * ldb + K) * 2);
+  g.a_view = a_view; g.b_view = b_view; g.pw = pw;
   if (ab >= 0x7FFFFFFFull || bb >= 0x7FFFFFFFull) return IA_ERR_ARG;
   if (!a_kstrided && (K & 7)) return IA_ERR_ARG;
   g.a_bytes = (uint32_t)ab; g.b_bytes = (uint32_t)bb;
@@ -661,7 +697,7 @@ extern "C" int ia_gemm_bf16(const void* A, int a_kstrided, int lda, const void* 
   if (needs_bias && !bias) return IA_ERR_ARG;
   if (needs_aux && (!aux || (ldaux & 3))) return IA_ERR_ARG;
   if (epilogue == EPI_BIAS_GELU && !C2) return IA_ERR_ARG;
-  const bool big = pl.big;
+  const bool big = pl.big && !a_view && !b_view;     // the shifted views live in the T128 staging only
 
   if (!a_kstrided && !b_kstrided && !c_is_f32) {
     switch (epilogue) {

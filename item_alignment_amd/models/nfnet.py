@@ -8,6 +8,7 @@ gather + one GEMM per group (csrc/conv.hip).  Module / parameter names are timm'
 `stages.{s}.{b}.attn_last.conv.weight`, `final_conv.*`, `head.fc.*`.
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -19,6 +20,9 @@ from .base import HipModule
 
 BF16, F32 = torch.bfloat16, torch.float32
 NONLIN_GAMMA_SILU = 1.7881293296813965          # timm nfnet.py _nonlin_gamma['silu']
+# stride-1 grouped 3x3 convolutions run as shifted-view GEMMs over a zero-bordered tensor; IA_CONV_PATCH_MATRIX=1 keeps the
+# gathered patch matrix for them too (A/B measurement switch, tools/config_bench.py)
+PADDED_CONV = os.environ.get("IA_CONV_PATCH_MATRIX", "0") != "1"
 
 NFNET_CONFIGS = {   # timm nfnet.py model_cfgs (_nfnet_cfg): depths, channels, feat_mult
     "eca_nfnet_l0": ((1, 2, 6, 3), (256, 512, 1536, 1536), 1.5),
@@ -98,6 +102,86 @@ class StdConvFn(torch.autograd.Function):
             Fn._notify([p for p in (conv.weight, conv.bias, conv.gain) if p is not None])
         ctx.saved = None
         return dx, None, None, None, None, None
+
+
+class PaddedStdConvFn(torch.autograd.Function):
+    """ScaledStdConv2d, 3x3 / stride 1 / groups of 64 channels, on the zero-bordered domain [B*(H+2)*(W+2), C]: no patch
+    matrix — every tap is a k-tile of a GEMM over the input shifted by whole rows (ia_conv3x3_padded_*).  The input must
+    carry a zero border (SiluPadFn writes it); the output's border rows are garbage and are only ever read by SiluPadFn,
+    which ignores them.  The incoming gradient needs a zero border too: SiluPadFn.backward provides it."""
+
+    @staticmethod
+    def forward(ctx, xp, weight, conv, B, H, W):
+        lib = _lib.load()
+        Fn._need_gpu(xp, "feature map")
+        C, g = conv.out_channels, conv.groups
+        dev = xp.device
+        what = torch.empty((C, 576), device=dev, dtype=BF16)
+        mean = torch.empty(C, device=dev, dtype=F32)
+        rstd = torch.empty(C, device=dev, dtype=F32)
+        check(lib.ia_ws_conv_weight_fwd(conv.weight.data_ptr(), conv.gain.data_ptr(), what.data_ptr(), mean.data_ptr(), rstd.data_ptr(), C, 64, 9, 64,
+                                        conv.scale, conv.eps, stream_ptr()), "ia_ws_conv_weight_fwd")
+        yp = torch.empty_like(xp)
+        check(lib.ia_conv3x3_padded_fwd(xp.data_ptr(), what.data_ptr(), ptr(conv.bias), yp.data_ptr(), B, H, W, C, g, stream_ptr()),
+              "ia_conv3x3_padded_fwd")
+        ctx.conv, ctx.saved, ctx.dims = conv, (xp, what, mean, rstd), (B, H, W, C, g)
+        ctx.need_dx = ctx.needs_input_grad[0]
+        return yp
+
+    @staticmethod
+    def backward(ctx, dyp):
+        lib = _lib.load()
+        conv = ctx.conv
+        xp, what, mean, rstd = ctx.saved
+        B, H, W, C, g = ctx.dims
+        dyp = dyp.contiguous()
+        dev = dyp.device
+        dxp = None
+        if ctx.need_dx:
+            dxp = torch.empty_like(xp)
+            check(lib.ia_conv3x3_padded_bwd_data(dyp.data_ptr(), what.data_ptr(), dxp.data_ptr(), B, H, W, C, g, stream_ptr()),
+                  "ia_conv3x3_padded_bwd_data")
+        if conv.weight.requires_grad:
+            dwhat = torch.empty((C, 576), device=dev, dtype=F32)
+            bg = conv.bias.grad.data_ptr() if conv.bias is not None and conv.bias.requires_grad else None
+            wsb = lib.ia_conv3x3_padded_workspace_bytes(B, H, W, C)
+            ws = _ws(dev, wsb)
+            check(lib.ia_conv3x3_padded_bwd_weight(xp.data_ptr(), dyp.data_ptr(), dwhat.data_ptr(), bg, B, H, W, C, g, ws.data_ptr(), wsb,
+                                                   stream_ptr()), "ia_conv3x3_padded_bwd_weight")
+            check(lib.ia_ws_conv_weight_bwd(dwhat.data_ptr(), conv.weight.data_ptr(), conv.gain.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                            conv.weight.grad.data_ptr(), conv.gain.grad.data_ptr(), C, 64, 9, 64, conv.scale, stream_ptr()),
+                  "ia_ws_conv_weight_bwd")
+            Fn._notify([p for p in (conv.weight, conv.bias, conv.gain) if p is not None])
+        ctx.saved = None
+        return dxp, None, None, None, None, None
+
+
+class SiluPadFn(torch.autograd.Function):
+    """y = silu(x) * scale while moving between the compact [B*H*W, C] rows and the zero-bordered [B*(H+2)*(W+2), C] rows
+    that PaddedStdConvFn works on (one flag per side; ia_silu_pad_*).  A padded output gets its border written as zero, a
+    padded input's border is never read; the same holds for the gradients in backward."""
+
+    @staticmethod
+    def forward(ctx, x, scale, B, H, W, in_padded, out_padded):
+        lib = _lib.load()
+        x = x.contiguous()
+        C = x.shape[1]
+        rows = B * (H + 2) * (W + 2) if out_padded else B * H * W
+        y = torch.empty((rows, C), device=x.device, dtype=BF16)
+        check(lib.ia_silu_pad_fwd(x.data_ptr(), y.data_ptr(), B, H, W, C, scale, int(in_padded), int(out_padded), stream_ptr()), "ia_silu_pad_fwd")
+        ctx.x, ctx.args = x, (B, H, W, C, scale, int(in_padded), int(out_padded))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x = ctx.x
+        B, H, W, C, scale, in_p, out_p = ctx.args
+        dx = torch.empty_like(x)
+        check(lib.ia_silu_pad_bwd(dy.contiguous().data_ptr(), x.data_ptr(), dx.data_ptr(), B, H, W, C, scale, in_p, out_p, stream_ptr()),
+              "ia_silu_pad_bwd")
+        ctx.x = None
+        return dx, None, None, None, None, None, None
 
 
 class SiluFn(torch.autograd.Function):
@@ -235,6 +319,12 @@ class ScaledStdConv2d(nn.Module):
         self.keep_cols = True              # stash the 3x3 patch matrix from forward for the weight gradient
         nn.init.kaiming_normal_(self.weight, mode="fan_in", nonlinearity="linear")       # reference image.py:156
 
+    @property
+    def shifted_views(self):
+        """3x3 / stride 1 / 64-channel groups: runs without a patch matrix on the zero-bordered domain (PaddedStdConvFn)"""
+        return (PADDED_CONV and self.kernel_size == 3 and self.stride == 1 and self.in_channels == self.out_channels
+                and self.in_channels == 64 * self.groups)
+
     def forward(self, f):
         y = StdConvFn.apply(f.t, self.weight, self, f.B, f.H, f.W)
         k, s = self.kernel_size, self.stride
@@ -292,9 +382,24 @@ class NormFreeBlock(nn.Module):
             o, shortcut = SiluFn.apply(f.t, self.beta, True)
             out = FeatureMap(o, f.B, f.H, f.W)
         out = self.conv1(out)
-        out = self.conv2(act(out))
-        out = self.conv2b(act(out))
-        out = self.conv3(act(out))
+        B, H, W = out.B, out.H, out.W
+        if self.conv2.shifted_views and self.conv2b.shifted_views:
+            # conv1 -> [silu -> padded] conv2 [silu, padded -> padded] conv2b [silu -> compact] -> conv3
+            t = SiluPadFn.apply(out.t, 1.0, B, H, W, False, True)
+            t = PaddedStdConvFn.apply(t, self.conv2.weight, self.conv2, B, H, W)
+            t = SiluPadFn.apply(t, 1.0, B, H, W, True, True)
+            t = PaddedStdConvFn.apply(t, self.conv2b.weight, self.conv2b, B, H, W)
+            out = FeatureMap(SiluPadFn.apply(t, 1.0, B, H, W, True, False), B, H, W)
+        elif self.conv2b.shifted_views:
+            out = self.conv2(act(out))                       # the strided 3x3 keeps the patch-matrix path
+            B, H, W = out.B, out.H, out.W
+            t = SiluPadFn.apply(out.t, 1.0, B, H, W, False, True)
+            t = PaddedStdConvFn.apply(t, self.conv2b.weight, self.conv2b, B, H, W)
+            out = FeatureMap(SiluPadFn.apply(t, 1.0, B, H, W, True, False), B, H, W)
+        else:
+            out = self.conv2(act(out))
+            out = act(self.conv2b(act(out)))
+        out = self.conv3(out)
         y = EcaResidualFn.apply(out.t, shortcut, self.attn_last.conv.weight, self.attn_last, out.B, out.H * out.W, self.attn_gain * self.alpha)
         return FeatureMap(y, out.B, out.H, out.W)
 

@@ -359,3 +359,81 @@ def test_gemm_persistent_rounds_with_clipped_tiles(gpu, M, N, K, epi):
     out1 = ops.gemm(a, w)
     out2 = ops.gemm(a, w)
     assert torch.equal(out1, out2)
+
+
+def _pad_nhwc(t):
+    """[B,H,W,C] -> zero-bordered [B,H+2,W+2,C]"""
+    return torch.nn.functional.pad(t, (0, 0, 1, 1, 1, 1)).contiguous()
+
+
+@pytest.mark.parametrize("B,H,W,groups", [(2, 7, 9, 1), (3, 25, 25, 2), (1, 50, 50, 6), (2, 13, 200, 1)])
+def test_conv3x3_padded_domain(gpu, B, H, W, groups):
+    """Patch-matrix-free grouped 3x3 convolution (shifted-view GEMMs over the zero-bordered NHWC tensor) against
+    torch conv2d in fp32 on the same bf16-rounded inputs: forward, data gradient, weight + bias gradient."""
+    from item_alignment_amd import _lib
+    from item_alignment_amd.ops import check, stream_ptr
+    lib = _lib.load()
+    C = groups * 64
+    x = rnd((B, H, W, C), gpu, 1.0, 11)
+    w = rnd((C, 64, 3, 3), gpu, 0.05, 12)                                 # torch layout [Cout][Cg][ky][kx]
+    bias = torch.randn(C, device=gpu)
+    dy = rnd((B, H, W, C), gpu, 1.0, 13)
+    what = w.permute(0, 2, 3, 1).reshape(C, 576).contiguous()             # [o][t*64 + c]
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.float().requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(xr, wr, br, padding=1, groups=groups)
+    ref.backward(dy.float().permute(0, 3, 1, 2))
+
+    xp, dyp = _pad_nhwc(x), _pad_nhwc(dy)
+    yp = torch.empty_like(xp)
+    check(lib.ia_conv3x3_padded_fwd(xp.data_ptr(), what.data_ptr(), bias.data_ptr(), yp.data_ptr(), B, H, W, C, groups, stream_ptr()), "fwd")
+    assert rel_err(yp[:, 1:-1, 1:-1], ref.permute(0, 2, 3, 1)) < 2e-2
+    dxp = torch.empty_like(xp)
+    check(lib.ia_conv3x3_padded_bwd_data(dyp.data_ptr(), what.data_ptr(), dxp.data_ptr(), B, H, W, C, groups, stream_ptr()), "bwd_data")
+    assert rel_err(dxp[:, 1:-1, 1:-1], xr.grad.permute(0, 2, 3, 1)) < 2e-2
+    wsb = lib.ia_conv3x3_padded_workspace_bytes(B, H, W, C)
+    ws = torch.empty(max(wsb, 16), device=gpu, dtype=torch.uint8)
+    dwhat = torch.empty((C, 576), device=gpu, dtype=torch.float32)
+    dbias = torch.zeros(C, device=gpu)
+    check(lib.ia_conv3x3_padded_bwd_weight(xp.data_ptr(), dyp.data_ptr(), dwhat.data_ptr(), dbias.data_ptr(), B, H, W, C, groups, ws.data_ptr(),
+                                           wsb, stream_ptr()), "bwd_weight")
+    assert rel_err(dwhat.view(C, 3, 3, 64).permute(0, 3, 1, 2), wr.grad) < 2e-3
+    assert rel_err(dbias, br.grad) < 2e-3
+
+
+def test_silu_between_padded_and_compact_layouts(gpu):
+    from item_alignment_amd import _lib
+    from item_alignment_amd.ops import check, stream_ptr
+    lib = _lib.load()
+    B, H, W, C = 2, 6, 5, 64
+    x = rnd((B, H, W, C), gpu, 2.0, 21)
+    xp = _pad_nhwc(x)
+    xp_dirty = xp.clone()
+    xp_dirty[:, 0], xp_dirty[:, -1], xp_dirty[:, :, 0], xp_dirty[:, :, -1] = 7.0, -7.0, 3.0, -3.0     # garbage border of a conv output
+    xr = x.float().requires_grad_(True)
+    ref = torch.nn.functional.silu(xr) * 1.7
+    dy = rnd((B, H, W, C), gpu, 1.0, 22)
+    ref.backward(dy.float())
+    dyp = _pad_nhwc(dy)
+    for in_p, out_p in ((0, 1), (1, 1), (1, 0)):
+        src = xp_dirty if in_p else x
+        y = torch.full_like(xp if out_p else x, 9.0)
+        check(lib.ia_silu_pad_fwd(src.data_ptr(), y.data_ptr(), B, H, W, C, 1.7, in_p, out_p, stream_ptr()), "silu_pad_fwd")
+        if out_p:
+            assert rel_err(y[:, 1:-1, 1:-1], ref) < 1e-2
+            inner = y.clone()
+            inner[:, 1:-1, 1:-1] = 0
+            assert inner.abs().max().item() == 0.0                        # the border is written as zero
+        else:
+            assert rel_err(y, ref) < 1e-2
+        g = dyp if out_p else dy
+        dx = torch.full_like(src, 9.0)
+        check(lib.ia_silu_pad_bwd(g.data_ptr(), src.data_ptr(), dx.data_ptr(), B, H, W, C, 1.7, in_p, out_p, stream_ptr()), "silu_pad_bwd")
+        if in_p:
+            assert rel_err(dx[:, 1:-1, 1:-1], xr.grad) < 1e-2
+            inner = dx.clone()
+            inner[:, 1:-1, 1:-1] = 0
+            assert inner.abs().max().item() == 0.0
+        else:
+            assert rel_err(dx, xr.grad) < 1e-2
