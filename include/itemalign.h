@@ -168,18 +168,17 @@ size_t ia_eca_bwd_workspace_bytes(int B, int HW, int C);
 int ia_eca_bwd(const void* dout, const void* x, const float* conv_w, int k, const float* pooled, const float* gate, void* dx,
                float* dconv_w, int B, int HW, int C, float coef, void* workspace, size_t workspace_bytes, ia_stream_t stream);
 
-/* ---- 3x3 stride-1 grouped convolution without a patch matrix (groups of exactly 64 in / 64 out channels).  Tensors live on
- * the "padded domain" [B, H+2, W+2, C] bf16: inputs (xp, dyp) with a ZERO border, outputs with garbage in their border rows.
- * Tap t of a group is k-tile t of a GEMM over the tensor shifted by (t/3-1)(W+2) + (t%3-1) rows (ia_gemm_bf16_view). */
-int ia_gemm_bf16_view(const void* A, int a_kstrided, int lda, const void* B, int b_kstrided, int ldb, void* C, int c_is_f32, int ldc, int M,
-                      int N, int K, int epilogue, const float* bias, int accumulate, void* workspace, size_t workspace_bytes, int a_view,
-                      int b_view, int pw, size_t a_window, size_t b_window, ia_stream_t stream);
-int ia_conv3x3_padded_fwd(const void* xp, const void* what, const float* bias, void* yp, int B, int H, int W, int C, int groups,
+/* ---- 3x3 stride-1 (grouped) convolution without a patch matrix.  Tensors live on the "padded domain": xp / dxp
+ * [B, H+2, W+2, Cin], yp / dyp [B, H+2, W+2, Cout] bf16; inputs (xp, dyp) need a ZERO border, outputs carry garbage in their
+ * border rows.  Cin/groups and Cout/groups must be powers of two >= 8.  what [Cout][9 * Cin/groups] (tap-major, as
+ * ia_ws_conv_weight_fwd writes it).  Tap t is read as the tensor shifted by (t/3-1)(W+2) + (t%3-1) rows inside the GEMM. */
+int ia_conv3x3_padded_fwd(const void* xp, const void* what, const float* bias, void* yp, int B, int H, int W, int Cin, int Cout, int groups,
                           ia_stream_t stream);
-int ia_conv3x3_padded_bwd_data(const void* dyp, const void* what, void* dxp, int B, int H, int W, int C, int groups, ia_stream_t stream);
-size_t ia_conv3x3_padded_workspace_bytes(int B, int H, int W, int C);
-int ia_conv3x3_padded_bwd_weight(const void* xp, const void* dyp, float* dwhat, float* dbias, int B, int H, int W, int C, int groups,
-                                 void* workspace, size_t workspace_bytes, ia_stream_t stream);
+int ia_conv3x3_padded_bwd_data(const void* dyp, const void* what, void* dxp, int B, int H, int W, int Cin, int Cout, int groups,
+                               ia_stream_t stream);
+size_t ia_conv3x3_padded_workspace_bytes(int B, int H, int W, int Cin, int Cout, int groups);
+int ia_conv3x3_padded_bwd_weight(const void* xp, const void* dyp, float* dwhat, float* dbias, int B, int H, int W, int Cin, int Cout,
+                                 int groups, void* workspace, size_t workspace_bytes, ia_stream_t stream);
 /* y = silu(x) * scale between the compact [B,H,W,C] and the zero-bordered [B,H+2,W+2,C] layouts (one flag per side); the
  * backward call produces dx in x's layout from dy in y's layout */
 int ia_silu_pad_fwd(const void* x, void* y, int B, int H, int W, int C, float scale, int in_padded, int out_padded, ia_stream_t stream);

@@ -72,11 +72,10 @@ SIGNATURES = {
     "ia_eca_fwd": (i32, [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, sz, vp]),
     "ia_eca_bwd_workspace_bytes": (sz, [i32, i32, i32]),
     "ia_eca_bwd": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, sz, vp]),
-    "ia_gemm_bf16_view": (i32, [vp, i32, i32, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, sz, i32, i32, i32, sz, sz, vp]),
-    "ia_conv3x3_padded_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
-    "ia_conv3x3_padded_bwd_data": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
-    "ia_conv3x3_padded_workspace_bytes": (sz, [i32, i32, i32, i32]),
-    "ia_conv3x3_padded_bwd_weight": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "ia_conv3x3_padded_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "ia_conv3x3_padded_bwd_data": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "ia_conv3x3_padded_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
+    "ia_conv3x3_padded_bwd_weight": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "ia_silu_pad_fwd": (i32, [vp, vp, i32, i32, i32, i32, f32, i32, i32, vp]),
     "ia_silu_pad_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, vp]),
     "ia_resize_pass_u8": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),

@@ -112,3 +112,20 @@ static inline int ia_check_launch() {
   if (e != hipSuccess) g_ia_last_hip_error = e;
   return e == hipSuccess ? IA_OK : IA_ERR_LAUNCH;
 }
+
+// Library-internal GEMM with shifted operand views + channel groups batched in one launch (gemm.hip; used by the
+// patch-matrix-free 3x3 convolution in conv.hip).  Fields as in ia_gemm_bf16; the view fields are described at GemmArgs.
+struct IaViewGemm {
+  const void* A; int a_kstrided, lda;
+  const void* B; int b_kstrided, ldb;
+  void* C; int c_is_f32, ldc;
+  int M, N, K;
+  const float* bias;                 // NULL = no bias
+  void* workspace; size_t workspace_bytes;
+  int a_view, b_view, pw, lca, lcbk, lcbn;
+  size_t a_window, b_window;         // bytes addressable from A / B of group 0 (to the end of the tensor)
+  int groups; long ga, gb, gc, gbias;   // per-group element strides of A, B, C, bias
+};
+__attribute__((visibility("hidden"))) int ia_gemm_view(const IaViewGemm& v, hipStream_t stream);
+__attribute__((visibility("hidden"))) size_t ia_gemm_view_workspace_bytes(int M, int N, int K, int groups);
+

@@ -608,63 +608,80 @@ extern "C" int ia_eca_bwd(const void* dout, const void* x, const float* conv_w, 
 }
 
 // ------------------------------------------------------------------------ 3x3 stride-1 convolution without a patch matrix
-// xp / yp / dxp / dyp: [B, H+2, W+2, C] bf16 ("padded domain"); inputs (xp, dyp) must have a ZERO border, outputs carry garbage
-// in their border rows.  Channel groups of exactly 64 in and 64 out channels (ECA-NFNet group_size 64): tap t of a group is
-// k-tile t of a GEMM whose A rows are the tensor itself shifted by (t/3-1)(W+2) + (t%3-1) rows (ia_gemm_bf16_view), so the
-// activations are read in place (9 shifted reads served by L2) instead of through a 9x larger gathered matrix.
-static int padded_ok(int B, int H, int W, int C, int groups) {
-  if (B <= 0 || H <= 0 || W <= 0 || groups <= 0 || C != groups * 64) return IA_ERR_UNSUPPORTED;
-  if ((size_t)B * (H + 2) * (W + 2) * C * 2 >= 0x7FFFFFFFull) return IA_ERR_ARG;
+// xp / dxp: [B, H+2, W+2, Cin], yp / dyp: [B, H+2, W+2, Cout] bf16 ("padded domain"); inputs (xp, dyp) must have a ZERO border,
+// outputs carry garbage in their border rows.  Channels per group (Cin/groups, Cout/groups) must be powers of two >= 8.  The
+// k axis of the GEMMs is (tap, channel): tap t reads the tensor itself shifted by (t/3-1)(W+2) + (t%3-1) rows (ia_gemm_view), so
+// the activations are read in place (9 shifted reads served by L2) instead of through a 9x larger gathered matrix, and all
+// channel groups run in one launch.
+static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+static int padded_ok(int B, int H, int W, int Cin, int Cout, int groups) {
+  if (B <= 0 || H <= 0 || W <= 0 || groups <= 0 || Cin <= 0 || Cout <= 0 || Cin % groups || Cout % groups) return IA_ERR_ARG;
+  const int ci = Cin / groups, co = Cout / groups;
+  if (ci < 8 || co < 8 || (ci & (ci - 1)) || (co & (co - 1))) return IA_ERR_UNSUPPORTED;
+  if ((size_t)B * (H + 2) * (W + 2) * (Cin > Cout ? Cin : Cout) * 2 >= 0x7FFFFFFFull) return IA_ERR_ARG;
   return IA_OK;
 }
 
-extern "C" int ia_conv3x3_padded_fwd(const void* xp, const void* what, const float* bias, void* yp, int B, int H, int W, int C, int groups,
-                                     hipStream_t stream) {
+extern "C" int ia_conv3x3_padded_fwd(const void* xp, const void* what, const float* bias, void* yp, int B, int H, int W, int Cin, int Cout,
+                                     int groups, hipStream_t stream) {
   (void)hipGetLastError();
-  int rc = padded_ok(B, H, W, C, groups);
+  const int rc = padded_ok(B, H, W, Cin, Cout, groups);
   if (rc) return rc;
   if (!xp || !what || !yp) return IA_ERR_ARG;
   const size_t Mp = (size_t)B * (H + 2) * (W + 2);
-  for (int g = 0; g < groups && !rc; ++g)
-    rc = ia_gemm_bf16_view((const bf16*)xp + g * 64, 0, C, (const bf16*)what + (size_t)g * 64 * 576, 0, 576, (bf16*)yp + g * 64, 0, C, (int)Mp, 64,
-                           576, bias ? IA_EPI_BIAS : IA_EPI_NONE, bias ? bias + g * 64 : nullptr, 0, nullptr, 0, 1, 0, W + 2,
-                           (Mp * C - (size_t)g * 64) * 2, 0, stream);
-  return rc;
+  const int ci = Cin / groups, co = Cout / groups;
+  IaViewGemm v{};
+  v.A = xp; v.lda = Cin; v.B = what; v.ldb = 9 * ci; v.C = yp; v.ldc = Cout;
+  v.M = (int)Mp; v.N = co; v.K = 9 * ci; v.bias = bias;
+  v.a_view = 1; v.pw = W + 2; v.lca = ilog2(ci); v.lcbk = v.lcbn = 6;
+  v.a_window = Mp * Cin * 2; v.b_window = (size_t)Cout * 9 * ci * 2;
+  v.groups = groups; v.ga = ci; v.gb = (long)co * 9 * ci; v.gc = co; v.gbias = co;
+  return ia_gemm_view(v, stream);
 }
 
-extern "C" int ia_conv3x3_padded_bwd_data(const void* dyp, const void* what, void* dxp, int B, int H, int W, int C, int groups, hipStream_t stream) {
+extern "C" int ia_conv3x3_padded_bwd_data(const void* dyp, const void* what, void* dxp, int B, int H, int W, int Cin, int Cout, int groups,
+                                          hipStream_t stream) {
   (void)hipGetLastError();
-  int rc = padded_ok(B, H, W, C, groups);
+  const int rc = padded_ok(B, H, W, Cin, Cout, groups);
   if (rc) return rc;
   if (!dyp || !what || !dxp) return IA_ERR_ARG;
   const size_t Mp = (size_t)B * (H + 2) * (W + 2);
-  for (int g = 0; g < groups && !rc; ++g)
-    rc = ia_gemm_bf16_view((const bf16*)dyp + g * 64, 0, C, (const bf16*)what + (size_t)g * 64 * 576, 1, 576, (bf16*)dxp + g * 64, 0, C, (int)Mp, 64,
-                           576, IA_EPI_NONE, nullptr, 0, nullptr, 0, -1, 1, W + 2, (Mp * C - (size_t)g * 64) * 2,
-                           ((size_t)(groups - g) * 64 * 576) * 2, stream);
-  return rc;
+  const int ci = Cin / groups, co = Cout / groups;
+  IaViewGemm v{};
+  v.A = dyp; v.lda = Cout; v.B = what; v.b_kstrided = 1; v.ldb = 9 * ci; v.C = dxp; v.ldc = Cin;
+  v.M = (int)Mp; v.N = ci; v.K = 9 * co;
+  v.a_view = -1; v.b_view = 1; v.pw = W + 2; v.lca = v.lcbk = ilog2(co); v.lcbn = ilog2(ci);
+  v.a_window = Mp * Cout * 2; v.b_window = (size_t)Cout * 9 * ci * 2;
+  v.groups = groups; v.ga = co; v.gb = (long)co * 9 * ci; v.gc = ci;
+  return ia_gemm_view(v, stream);
 }
 
-extern "C" size_t ia_conv3x3_padded_workspace_bytes(int B, int H, int W, int C) {
+extern "C" size_t ia_conv3x3_padded_workspace_bytes(int B, int H, int W, int Cin, int Cout, int groups) {
+  if (padded_ok(B, H, W, Cin, Cout, groups)) return 0;
   const size_t Mp = (size_t)B * (H + 2) * (W + 2);
-  const size_t gw = ia_gemm_workspace_bytes(64, 576, (int)Mp, 1), cs = ia_colsum_workspace_bytes((int)Mp, C);
+  const size_t gw = ia_gemm_view_workspace_bytes(Cout / groups, 9 * (Cin / groups), (int)Mp, groups), cs = ia_colsum_workspace_bytes((int)Mp, Cout);
   return gw > cs ? gw : cs;
 }
 
-// dwhat [C][576] fp32 overwritten, dbias [C] accumulated (may be NULL)
-extern "C" int ia_conv3x3_padded_bwd_weight(const void* xp, const void* dyp, float* dwhat, float* dbias, int B, int H, int W, int C, int groups,
-                                            void* workspace, size_t workspace_bytes, hipStream_t stream) {
+// dwhat [Cout][9 * Cin/groups] fp32 overwritten, dbias [Cout] accumulated (may be NULL)
+extern "C" int ia_conv3x3_padded_bwd_weight(const void* xp, const void* dyp, float* dwhat, float* dbias, int B, int H, int W, int Cin, int Cout,
+                                            int groups, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   (void)hipGetLastError();
-  int rc = padded_ok(B, H, W, C, groups);
+  int rc = padded_ok(B, H, W, Cin, Cout, groups);
   if (rc) return rc;
   if (!xp || !dyp || !dwhat) return IA_ERR_ARG;
-  if (!workspace || workspace_bytes < ia_conv3x3_padded_workspace_bytes(B, H, W, C)) return IA_ERR_WORKSPACE;
+  if (!workspace || workspace_bytes < ia_conv3x3_padded_workspace_bytes(B, H, W, Cin, Cout, groups)) return IA_ERR_WORKSPACE;
   const size_t Mp = (size_t)B * (H + 2) * (W + 2);
-  for (int g = 0; g < groups && !rc; ++g)
-    rc = ia_gemm_bf16_view((const bf16*)dyp + g * 64, 1, C, (const bf16*)xp + g * 64, 1, C, dwhat + (size_t)g * 64 * 576, 1, 576, 64, 576, (int)Mp,
-                           IA_EPI_NONE, nullptr, 0, workspace, workspace_bytes, 0, 2, W + 2, 0, (Mp * C - (size_t)g * 64) * 2, stream);
+  const int ci = Cin / groups, co = Cout / groups;
+  IaViewGemm v{};
+  v.A = dyp; v.a_kstrided = 1; v.lda = Cout; v.B = xp; v.b_kstrided = 1; v.ldb = Cin; v.C = dwhat; v.c_is_f32 = 1; v.ldc = 9 * ci;
+  v.M = co; v.N = 9 * ci; v.K = (int)Mp; v.workspace = workspace; v.workspace_bytes = workspace_bytes;
+  v.b_view = 2; v.pw = W + 2; v.lca = v.lcbk = 6; v.lcbn = ilog2(ci);
+  v.a_window = Mp * Cout * 2; v.b_window = Mp * Cin * 2;
+  v.groups = groups; v.ga = co; v.gb = ci; v.gc = (long)co * 9 * ci;
+  rc = ia_gemm_view(v, stream);
   if (rc || !dbias) return rc;
-  return ia_colsum(dyp, C, (int)Mp, C, dbias, 1, workspace, workspace_bytes, stream);
+  return ia_colsum(dyp, Cout, (int)Mp, Cout, dbias, 1, workspace, workspace_bytes, stream);
 }
 
 // y = silu(x) * scale moving between the compact [B,H,W,C] and the zero-bordered [B,H+2,W+2,C] layouts (flags per side)

@@ -41,12 +41,16 @@ struct GemmArgs {
   int splits, nk_per_split;   // split-K (fp32 output only): blockIdx.y owns k-tiles [y*nk_per_split, ...)
   float* ws;                  // [splits][M][N] fp32 partials when splits > 1
   int dbg;                    // ablation switches for tuning runs (IA_GEMM_DBG env): results are WRONG when non-zero
-  // Shifted operand views (T128 only) that turn the GEMM into a 3x3 convolution over a zero-padded NHWC tensor
-  // [B, H+2, W+2, C] without a patch matrix: tap t = k-tile t of a 64-channel group, i.e. the same rows shifted by
-  // tap_delta(t) = (t/3 - 1) * pw + (t%3 - 1).  a_view: 1 = A rows + delta(k-tile), -1 = rows - delta(k-tile) (k-contiguous A,
-  // k-local column = channel).  b_view: 1 = k-strided B with k-local rows and a column shift of 64 per k-tile (data gradient:
-  // B[k=(t,n)][c] = W[n][t*64+c]); 2 = k-strided B whose 64-column block j reads rows + delta(j) (weight gradient).
-  int a_view, b_view, pw;
+  // Shifted operand views (T128 only) that turn the GEMM into a 3x3 convolution over a zero-bordered NHWC tensor
+  // [B, H+2, W+2, C] without a patch matrix: the k axis is (tap, channel) with a power-of-two channel count per tap, and tap t
+  // reads the same rows shifted by tap_delta(t) = (t/3 - 1) * pw + (t%3 - 1).
+  //   a_view +1 / -1 (k-contiguous A): k = (tap << lca) + ch reads row + / - tap_delta(tap), column ch        (forward / data grad)
+  //   b_view 1 (k-strided B = W[o][(tap << lcbn) + c]): k = (tap << lcbk) + o, column n reads W[o][(tap << lcbn) + n]   (data grad)
+  //   b_view 2 (k-strided B = the activations): column n = (tap << lcbn) + ch reads row k + tap_delta(tap), column ch  (weight grad)
+  int a_view, b_view, pw, lca, lcbk, lcbn;
+  // blockIdx.z = channel group: operands advance by ga / gb / gc / gbias elements per group (all groups in one launch)
+  int groups;
+  long ga, gb, gc, gbias;
 };
 
 IA_DEV int tap_delta(int t, int pw) { return (t / 3 - 1) * pw + (t % 3 - 1); }
@@ -164,7 +168,8 @@ constexpr int BM = 128, BN = 128, TILE_BYTES = 16384;
 IA_DEV int ks_swz(int k) { return ((k & 3) | (((k >> 3) & 1) << 2)) << 1; }
 
 template <bool KS>
-IA_DEV void stage_tile(__amdgpu_buffer_rsrc_t rs, char* s, int kt, int x0, int ld, int K, int tid, int wave, int view = 0, int pw = 0) {
+IA_DEV void stage_tile(__amdgpu_buffer_rsrc_t rs, char* s, int kt, int x0, int ld, int K, int tid, int wave, int view = 0, int pw = 0,
+                       int lck = 6, int lcn = 6) {
 #pragma unroll
   for (int issue = 0; issue < 4; ++issue) {
     uint32_t off;
@@ -173,15 +178,15 @@ IA_DEV void stage_tile(__amdgpu_buffer_rsrc_t rs, char* s, int kt, int x0, int l
       const int c = (tid & 7) ^ (row & 7);
       const int k = kt * BK + c * 8;
       if (view == 0) off = (uint32_t)(((x0 + row) * ld + k) * 2);
-      else off = (uint32_t)(((x0 + row + view * tap_delta(kt, pw)) * ld + c * 8) * 2);   // rows before the tensor wrap to out-of-range
+      else off = (uint32_t)(((x0 + row + view * tap_delta(k >> lck, pw)) * ld + (k & ((1 << lck) - 1))) * 2);   // rows before the tensor wrap to out-of-range
       if (k >= K) off = OOB;
     } else {
       const int row = issue * 16 + (tid >> 4);
       const int c = (tid & 15) ^ ks_swz(row);
       const int k = kt * BK + row;
       if (view == 0) off = (uint32_t)((k * ld + x0 + c * 8) * 2);
-      else if (view == 1) off = (uint32_t)((row * ld + kt * BK + x0 + c * 8) * 2);
-      else { const int col = x0 + c * 8; off = (uint32_t)(((k + tap_delta(col >> 6, pw)) * ld + (col & 63)) * 2); }
+      else if (view == 1) off = (uint32_t)(((k & ((1 << lck) - 1)) * ld + ((k >> lck) << lcn) + x0 + c * 8) * 2);
+      else { const int col = x0 + c * 8; off = (uint32_t)(((k + tap_delta(col >> lcn, pw)) * ld + (col & ((1 << lcn) - 1))) * 2); }
       if (k >= K) off = OOB;
     }
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, IA_LDS(s + issue * 4096 + wave * 1024), 16, off, 0, 0, 0);
@@ -211,6 +216,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   int bm, bn;
   tile_of_index(p, blockIdx.x, gridDim.x, bm, bn);
   const int m0 = bm * BM, n0 = bn * BN;
+  if (p.groups > 1) {                  // uniform: the kernel argument copy is ours to edit
+    const long z = blockIdx.z;
+    p.A += z * p.ga; p.B += z * p.gb;
+    p.a_bytes -= (uint32_t)(z * p.ga * 2); p.b_bytes -= (uint32_t)(z * p.gb * 2);     // the windows end where the tensors end
+    p.C = reinterpret_cast<char*>(p.C) + z * p.gc * (OUTF32 ? 4 : 2);
+    if (p.bias) p.bias += z * p.gbias;
+    if (p.ws) p.ws += z * (long)p.splits * p.M * p.N;
+  }
   const __amdgpu_buffer_rsrc_t rsA = ia_rsrc(p.A, p.a_bytes);
   const __amdgpu_buffer_rsrc_t rsB = ia_rsrc(p.B, p.b_bytes);
 
@@ -223,8 +236,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   const int nk_all = (p.K + BK - 1) / BK;
   const int kt0 = blockIdx.y * p.nk_per_split;
   const int nk = min(nk_all, kt0 + p.nk_per_split);
-  stage_tile<AKS>(rsA, smem, kt0, m0, p.lda, p.K, tid, wave, p.a_view, p.pw);
-  stage_tile<BKS>(rsB, smem + TILE_BYTES, kt0, n0, p.ldb, p.K, tid, wave, p.b_view, p.pw);
+  stage_tile<AKS>(rsA, smem, kt0, m0, p.lda, p.K, tid, wave, p.a_view, p.pw, p.lca, 0);
+  stage_tile<BKS>(rsB, smem + TILE_BYTES, kt0, n0, p.ldb, p.K, tid, wave, p.b_view, p.pw, p.lcbk, p.lcbn);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -235,8 +248,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     const int buf = (kt - kt0) & 1;
     if (kt + 1 < nk) {
       char* nb = smem + (buf ^ 1) * 2 * TILE_BYTES;
-      stage_tile<AKS>(rsA, nb, kt + 1, m0, p.lda, p.K, tid, wave, p.a_view, p.pw);
-      stage_tile<BKS>(rsB, nb + TILE_BYTES, kt + 1, n0, p.ldb, p.K, tid, wave, p.b_view, p.pw);
+      stage_tile<AKS>(rsA, nb, kt + 1, m0, p.lda, p.K, tid, wave, p.a_view, p.pw, p.lca, 0);
+      stage_tile<BKS>(rsB, nb + TILE_BYTES, kt + 1, n0, p.ldb, p.K, tid, wave, p.b_view, p.pw, p.lcbk, p.lcbn);
     }
     const char* sA = smem + buf * 2 * TILE_BYTES;
     const char* sB = sA + TILE_BYTES;
@@ -560,7 +573,9 @@ GemmProf g_prof;
 
 // C[m][n] (+)= sum_s ws[s][m][n]
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int M, int N, int ldc,
-                                                            int splits, int accumulate) {
+                                                            int splits, int accumulate, long gc) {
+  ws += (size_t)blockIdx.y * splits * M * N;       // blockIdx.y = channel group of a batched convolution GEMM
+  C += (size_t)blockIdx.y * gc;
   const size_t total4 = (size_t)M * N / 4;
   for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total4; t += (size_t)gridDim.x * 256) {
     const size_t e = t * 4;
@@ -577,13 +592,14 @@ struct Plan { bool big; int splits; };
 
 // Tile choice + split-K factor.  Weight-gradient GEMMs have outputs of only a few dozen tiles (1024x1024 ->
 // 16 tiles of 256x256) while K = #tokens is tens of thousands, so K is cut until every CU has a workgroup.
-Plan make_plan(int M, int N, int K, bool f32_out) {
+Plan make_plan(int M, int N, int K, bool f32_out, int groups = 1) {
   Plan pl;
   const int nk = (K + BK - 1) / BK;
   const long t256n = (long)((M + 255) / 256) * ((N + 255) / 256);
   const int smax = f32_out ? (nk / 8 > 32 ? 32 : (nk / 8 < 1 ? 1 : nk / 8)) : 1;
   pl.big = M >= 256 && N >= 256 && (N & 7) == 0 && t256n * smax >= 160;
-  const long tiles = pl.big ? t256n : (long)((M + 127) / 128) * ((N + 127) / 128);
+  if (groups > 1) pl.big = false;
+  const long tiles = pl.big ? t256n : (long)((M + 127) / 128) * ((N + 127) / 128) * groups;
   // Pick the cut that minimises the makespan: ceil(workgroups / resident slots) rounds of (k-tiles per workgroup + a fixed
   // prologue/epilogue cost), plus the fixed-order reduction that reads one fp32 copy of C per split.  Overshooting the
   // slot count by a few workgroups (36 tiles x 8 = 288 on 256 CUs) would cost a whole extra round.
@@ -618,11 +634,12 @@ int launch(GemmArgs a, bool big, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(gx, a.splits), dim3(512), t256::LDS_BYTES, st, a);
   } else {
     a.tiles_m = (a.M + t128::BM - 1) / t128::BM; a.tiles_n = (a.N + t128::BN - 1) / t128::BN;
-    hipLaunchKernelGGL((t128::gemm_kernel<AKS, BKS, EPI, OUTF32>), dim3(a.tiles_m * a.tiles_n, a.splits), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((t128::gemm_kernel<AKS, BKS, EPI, OUTF32>), dim3(a.tiles_m * a.tiles_n, a.splits, a.groups), dim3(256), 0, st, a);
   }
   if (OUTF32 && a.splits > 1) {
     size_t g = ((size_t)a.M * a.N / 4 + 255) / 256; if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)g), dim3(256), 0, st, a.ws, (float*)a.C, a.M, a.N, a.ldc, a.splits, a.accumulate);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)g, a.groups), dim3(256), 0, st, a.ws, (float*)a.C, a.M, a.N, a.ldc, a.splits, a.accumulate,
+                       a.gc);
   }
   if (rec) {
     (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st);
@@ -643,32 +660,37 @@ extern "C" size_t ia_gemm_workspace_bytes(int M, int N, int K, int c_is_f32) {
 
 static int gemm_core(const void* A, int a_kstrided, int lda, const void* B, int b_kstrided, int ldb, void* C, int c_is_f32, int ldc, int M,
                      int N, int K, int epilogue, const float* bias, const void* aux, int ldaux, void* C2, int accumulate, void* workspace,
-                     size_t workspace_bytes, int a_view, int b_view, int pw, uint64_t a_window, uint64_t b_window, hipStream_t stream);
+                     size_t workspace_bytes, const IaViewGemm* view, hipStream_t stream);
 
 extern "C" int ia_gemm_bf16(const void* A, int a_kstrided, int lda, const void* B, int b_kstrided, int ldb,
                             void* C, int c_is_f32, int ldc, int M, int N, int K, int epilogue,
                             const float* bias, const void* aux, int ldaux, void* C2, int accumulate, void* workspace,
                             size_t workspace_bytes, hipStream_t stream) {
   return gemm_core(A, a_kstrided, lda, B, b_kstrided, ldb, C, c_is_f32, ldc, M, N, K, epilogue, bias, aux, ldaux, C2, accumulate, workspace,
-                   workspace_bytes, 0, 0, 0, 0, 0, stream);
+                   workspace_bytes, nullptr, stream);
 }
 
-// ia_gemm_bf16 with shifted operand views (see GemmArgs): the building block of the patch-matrix-free 3x3 convolution in
-// conv.hip.  a_window / b_window: bytes addressable from A / B (rows shifted outside the window read as zero).
-extern "C" int ia_gemm_bf16_view(const void* A, int a_kstrided, int lda, const void* B, int b_kstrided, int ldb, void* C, int c_is_f32,
-                                 int ldc, int M, int N, int K, int epilogue, const float* bias, int accumulate, void* workspace,
-                                 size_t workspace_bytes, int a_view, int b_view, int pw, size_t a_window, size_t b_window,
-                                 hipStream_t stream) {
-  if ((a_view && (a_kstrided || (a_view != 1 && a_view != -1))) || (b_view && (!b_kstrided || b_view < 1 || b_view > 2)) || pw <= 2)
+// GEMM with shifted operand views and channel groups batched into one launch (see GemmArgs): the building block of the
+// patch-matrix-free 3x3 convolution in conv.hip (library-internal, declared in common.h).
+int ia_gemm_view(const IaViewGemm& v, hipStream_t stream) {
+  if ((v.a_view && (v.a_kstrided || (v.a_view != 1 && v.a_view != -1))) || (v.b_view && (!v.b_kstrided || v.b_view < 1 || v.b_view > 2)) ||
+      v.pw <= 2 || (!v.a_view && !v.b_view) || v.groups < 1 || v.lca < 3 || v.lcbk < 3 || v.lcbn < 3)
     return IA_ERR_ARG;
-  if (!a_view && !b_view) return IA_ERR_ARG;
-  return gemm_core(A, a_kstrided, lda, B, b_kstrided, ldb, C, c_is_f32, ldc, M, N, K, epilogue, bias, nullptr, 0, nullptr, accumulate,
-                   workspace, workspace_bytes, a_view, b_view, pw, a_window, b_window, stream);
+  return gemm_core(v.A, v.a_kstrided, v.lda, v.B, v.b_kstrided, v.ldb, v.C, v.c_is_f32, v.ldc, v.M, v.N, v.K, v.bias ? EPI_BIAS : EPI_NONE,
+                   v.bias, nullptr, 0, nullptr, 0, v.workspace, v.workspace_bytes, &v, stream);
+}
+
+size_t ia_gemm_view_workspace_bytes(int M, int N, int K, int groups) {
+  if (M <= 0 || N <= 0 || K <= 0 || groups <= 0) return 0;
+  const Plan pl = make_plan(M, N, K, true, groups);
+  return pl.splits > 1 ? (size_t)groups * pl.splits * M * N * sizeof(float) : 0;
 }
 
 static int gemm_core(const void* A, int a_kstrided, int lda, const void* B, int b_kstrided, int ldb, void* C, int c_is_f32, int ldc, int M,
                      int N, int K, int epilogue, const float* bias, const void* aux, int ldaux, void* C2, int accumulate, void* workspace,
-                     size_t workspace_bytes, int a_view, int b_view, int pw, uint64_t a_window, uint64_t b_window, hipStream_t stream) {
+                     size_t workspace_bytes, const IaViewGemm* view, hipStream_t stream) {
+  const uint64_t a_window = view ? view->a_window : 0, b_window = view ? view->b_window : 0;
+  const int groups = view ? view->groups : 1;
   (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return IA_ERR_ARG;
   if ((lda & 7) || (ldb & 7) || (ldc & 3) || (N & 3)) return IA_ERR_ARG;
@@ -678,16 +700,21 @@ static int gemm_core(const void* A, int a_kstrided, int lda, const void* B, int 
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux; g.accumulate = accumulate;
   const uint64_t ab = a_window ? a_window : (a_kstrided ? ((uint64_t)(K - 1) * lda + M) * 2 : ((uint64_t)(M - 1) * lda + K) * 2);
   const uint64_t bb = b_window ? b_window : (b_kstrided ? ((uint64_t)(K - 1) * ldb + N) * 2 : ((uint64_t)(N - 1) * ldb + K) * 2);
-  g.a_view = a_view; g.b_view = b_view; g.pw = pw;
+  g.a_view = g.b_view = g.pw = 0; g.lca = g.lcbk = g.lcbn = 6;
+  g.groups = 1; g.ga = g.gb = g.gc = g.gbias = 0;
+  if (view) {
+    g.a_view = view->a_view; g.b_view = view->b_view; g.pw = view->pw; g.lca = view->lca; g.lcbk = view->lcbk; g.lcbn = view->lcbn;
+    g.groups = groups; g.ga = view->ga; g.gb = view->gb; g.gc = view->gc; g.gbias = view->gbias;
+  }
   if (ab >= 0x7FFFFFFFull || bb >= 0x7FFFFFFFull) return IA_ERR_ARG;
   if (!a_kstrided && (K & 7)) return IA_ERR_ARG;
   g.a_bytes = (uint32_t)ab; g.b_bytes = (uint32_t)bb;
   g.tiles_m = g.tiles_n = 0;
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("IA_GEMM_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
   const int nk = (K + BK - 1) / BK;
-  Plan pl = make_plan(M, N, K, c_is_f32 != 0);
+  Plan pl = make_plan(M, N, K, c_is_f32 != 0, groups);
   g.splits = 1; g.nk_per_split = nk; g.ws = nullptr;
-  if (c_is_f32 && pl.splits > 1 && workspace && workspace_bytes >= (size_t)pl.splits * M * N * sizeof(float)) {
+  if (c_is_f32 && pl.splits > 1 && workspace && workspace_bytes >= (size_t)groups * pl.splits * M * N * sizeof(float)) {
     g.nk_per_split = (nk + pl.splits - 1) / pl.splits;
     g.splits = (nk + g.nk_per_split - 1) / g.nk_per_split;
     g.ws = (float*)workspace;
@@ -697,7 +724,7 @@ static int gemm_core(const void* A, int a_kstrided, int lda, const void* B, int 
   if (needs_bias && !bias) return IA_ERR_ARG;
   if (needs_aux && (!aux || (ldaux & 3))) return IA_ERR_ARG;
   if (epilogue == EPI_BIAS_GELU && !C2) return IA_ERR_ARG;
-  const bool big = pl.big && !a_view && !b_view;     // the shifted views live in the T128 staging only
+  const bool big = pl.big && !view;     // the shifted views and the group batching live in the T128 kernel only
 
   if (!a_kstrided && !b_kstrided && !c_is_f32) {
     switch (epilogue) {

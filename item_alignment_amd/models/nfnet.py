@@ -105,26 +105,28 @@ class StdConvFn(torch.autograd.Function):
 
 
 class PaddedStdConvFn(torch.autograd.Function):
-    """ScaledStdConv2d, 3x3 / stride 1 / groups of 64 channels, on the zero-bordered domain [B*(H+2)*(W+2), C]: no patch
-    matrix — every tap is a k-tile of a GEMM over the input shifted by whole rows (ia_conv3x3_padded_*).  The input must
-    carry a zero border (SiluPadFn writes it); the output's border rows are garbage and are only ever read by SiluPadFn,
-    which ignores them.  The incoming gradient needs a zero border too: SiluPadFn.backward provides it."""
+    """ScaledStdConv2d, 3x3 / stride 1 (power-of-two channels per group), on the zero-bordered domain [B*(H+2)*(W+2), C]: no
+    patch matrix — every tap is read as the input shifted by whole rows inside the GEMM, all groups in one launch
+    (ia_conv3x3_padded_*).  The input must carry a zero border (SiluPadFn writes it); the output's border rows are garbage
+    and are only ever read by SiluPadFn, which ignores them.  The incoming gradient needs a zero border too:
+    SiluPadFn.backward provides it."""
 
     @staticmethod
     def forward(ctx, xp, weight, conv, B, H, W):
         lib = _lib.load()
         Fn._need_gpu(xp, "feature map")
-        C, g = conv.out_channels, conv.groups
+        Cin, Cout, g = conv.in_channels, conv.out_channels, conv.groups
+        ci = Cin // g
         dev = xp.device
-        what = torch.empty((C, 576), device=dev, dtype=BF16)
-        mean = torch.empty(C, device=dev, dtype=F32)
-        rstd = torch.empty(C, device=dev, dtype=F32)
-        check(lib.ia_ws_conv_weight_fwd(conv.weight.data_ptr(), conv.gain.data_ptr(), what.data_ptr(), mean.data_ptr(), rstd.data_ptr(), C, 64, 9, 64,
-                                        conv.scale, conv.eps, stream_ptr()), "ia_ws_conv_weight_fwd")
-        yp = torch.empty_like(xp)
-        check(lib.ia_conv3x3_padded_fwd(xp.data_ptr(), what.data_ptr(), ptr(conv.bias), yp.data_ptr(), B, H, W, C, g, stream_ptr()),
+        what = torch.empty((Cout, 9 * ci), device=dev, dtype=BF16)
+        mean = torch.empty(Cout, device=dev, dtype=F32)
+        rstd = torch.empty(Cout, device=dev, dtype=F32)
+        check(lib.ia_ws_conv_weight_fwd(conv.weight.data_ptr(), conv.gain.data_ptr(), what.data_ptr(), mean.data_ptr(), rstd.data_ptr(), Cout, ci, 9,
+                                        ci, conv.scale, conv.eps, stream_ptr()), "ia_ws_conv_weight_fwd")
+        yp = torch.empty((xp.shape[0], Cout), device=dev, dtype=BF16)
+        check(lib.ia_conv3x3_padded_fwd(xp.data_ptr(), what.data_ptr(), ptr(conv.bias), yp.data_ptr(), B, H, W, Cin, Cout, g, stream_ptr()),
               "ia_conv3x3_padded_fwd")
-        ctx.conv, ctx.saved, ctx.dims = conv, (xp, what, mean, rstd), (B, H, W, C, g)
+        ctx.conv, ctx.saved, ctx.dims = conv, (xp, what, mean, rstd), (B, H, W, Cin, Cout, g, ci)
         ctx.need_dx = ctx.needs_input_grad[0]
         return yp
 
@@ -133,23 +135,23 @@ class PaddedStdConvFn(torch.autograd.Function):
         lib = _lib.load()
         conv = ctx.conv
         xp, what, mean, rstd = ctx.saved
-        B, H, W, C, g = ctx.dims
+        B, H, W, Cin, Cout, g, ci = ctx.dims
         dyp = dyp.contiguous()
         dev = dyp.device
         dxp = None
         if ctx.need_dx:
             dxp = torch.empty_like(xp)
-            check(lib.ia_conv3x3_padded_bwd_data(dyp.data_ptr(), what.data_ptr(), dxp.data_ptr(), B, H, W, C, g, stream_ptr()),
+            check(lib.ia_conv3x3_padded_bwd_data(dyp.data_ptr(), what.data_ptr(), dxp.data_ptr(), B, H, W, Cin, Cout, g, stream_ptr()),
                   "ia_conv3x3_padded_bwd_data")
         if conv.weight.requires_grad:
-            dwhat = torch.empty((C, 576), device=dev, dtype=F32)
+            dwhat = torch.empty((Cout, 9 * ci), device=dev, dtype=F32)
             bg = conv.bias.grad.data_ptr() if conv.bias is not None and conv.bias.requires_grad else None
-            wsb = lib.ia_conv3x3_padded_workspace_bytes(B, H, W, C)
+            wsb = lib.ia_conv3x3_padded_workspace_bytes(B, H, W, Cin, Cout, g)
             ws = _ws(dev, wsb)
-            check(lib.ia_conv3x3_padded_bwd_weight(xp.data_ptr(), dyp.data_ptr(), dwhat.data_ptr(), bg, B, H, W, C, g, ws.data_ptr(), wsb,
+            check(lib.ia_conv3x3_padded_bwd_weight(xp.data_ptr(), dyp.data_ptr(), dwhat.data_ptr(), bg, B, H, W, Cin, Cout, g, ws.data_ptr(), wsb,
                                                    stream_ptr()), "ia_conv3x3_padded_bwd_weight")
             check(lib.ia_ws_conv_weight_bwd(dwhat.data_ptr(), conv.weight.data_ptr(), conv.gain.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                            conv.weight.grad.data_ptr(), conv.gain.grad.data_ptr(), C, 64, 9, 64, conv.scale, stream_ptr()),
+                                            conv.weight.grad.data_ptr(), conv.gain.grad.data_ptr(), Cout, ci, 9, ci, conv.scale, stream_ptr()),
                   "ia_ws_conv_weight_bwd")
             Fn._notify([p for p in (conv.weight, conv.bias, conv.gain) if p is not None])
         ctx.saved = None
@@ -321,9 +323,13 @@ class ScaledStdConv2d(nn.Module):
 
     @property
     def shifted_views(self):
-        """3x3 / stride 1 / 64-channel groups: runs without a patch matrix on the zero-bordered domain (PaddedStdConvFn)"""
-        return (PADDED_CONV and self.kernel_size == 3 and self.stride == 1 and self.in_channels == self.out_channels
-                and self.in_channels == 64 * self.groups)
+        """3x3 / stride 1 / power-of-two channels per group: runs without a patch matrix on the zero-bordered domain"""
+        ci, co = self.in_channels // self.groups, self.out_channels // self.groups
+        return (PADDED_CONV and self.kernel_size == 3 and self.stride == 1 and ci >= 8 and co >= 8 and not (ci & (ci - 1)) and not (co & (co - 1)))
+
+    def fits_padded(self, B, H, W):
+        """the shifted-view GEMMs address the padded tensor with 32-bit byte offsets"""
+        return B * (H + 2) * (W + 2) * max(self.in_channels, self.out_channels) * 2 < 0x7FFFFFFF
 
     def forward(self, f):
         y = StdConvFn.apply(f.t, self.weight, self, f.B, f.H, f.W)
@@ -383,14 +389,15 @@ class NormFreeBlock(nn.Module):
             out = FeatureMap(o, f.B, f.H, f.W)
         out = self.conv1(out)
         B, H, W = out.B, out.H, out.W
-        if self.conv2.shifted_views and self.conv2b.shifted_views:
+        fits = self.conv2b.fits_padded(B, H, W)
+        if self.conv2.shifted_views and self.conv2b.shifted_views and fits:
             # conv1 -> [silu -> padded] conv2 [silu, padded -> padded] conv2b [silu -> compact] -> conv3
             t = SiluPadFn.apply(out.t, 1.0, B, H, W, False, True)
             t = PaddedStdConvFn.apply(t, self.conv2.weight, self.conv2, B, H, W)
             t = SiluPadFn.apply(t, 1.0, B, H, W, True, True)
             t = PaddedStdConvFn.apply(t, self.conv2b.weight, self.conv2b, B, H, W)
             out = FeatureMap(SiluPadFn.apply(t, 1.0, B, H, W, True, False), B, H, W)
-        elif self.conv2b.shifted_views:
+        elif self.conv2b.shifted_views and fits:
             out = self.conv2(act(out))                       # the strided 3x3 keeps the patch-matrix path
             B, H, W = out.B, out.H, out.W
             t = SiluPadFn.apply(out.t, 1.0, B, H, W, False, True)
@@ -464,8 +471,26 @@ class NormFreeNet(HipModule):
         x = torch.empty((B * H * W, 8), device=images.device, dtype=BF16)
         check(lib.ia_nchw_to_nhwc_bf16(images.data_ptr(), x.data_ptr(), B, C, H, W, 8, stream_ptr()), "ia_nchw_to_nhwc_bf16")
         f = FeatureMap(x, B, H, W)
-        for name, m in self.stem.named_children():
-            f = m(f) if isinstance(m, ScaledStdConv2d) else FeatureMap(SiluFn.apply(f.t, 1.0, False), f.B, f.H, f.W)
+        # deep_quad stem: conv1 (s2) act conv2 act conv3 act conv4 (s2).  The stride-1 convs run on the zero-bordered domain,
+        # the SiLU in front of each one also converts the layout (compact -> padded -> padded -> compact).
+        mods = list(self.stem.children())
+        padded, i = False, 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, ScaledStdConv2d):
+                if padded:
+                    f = FeatureMap(PaddedStdConvFn.apply(f.t, m.weight, m, f.B, f.H, f.W), f.B, f.H, f.W)
+                else:
+                    f = m(f)
+            else:
+                nxt = mods[i + 1] if i + 1 < len(mods) else None
+                to_padded = isinstance(nxt, ScaledStdConv2d) and nxt.shifted_views and nxt.fits_padded(f.B, f.H, f.W)
+                if padded or to_padded:
+                    f = FeatureMap(SiluPadFn.apply(f.t, 1.0, f.B, f.H, f.W, padded, to_padded), f.B, f.H, f.W)
+                else:
+                    f = FeatureMap(SiluFn.apply(f.t, 1.0, False), f.B, f.H, f.W)
+                padded = to_padded
+            i += 1
         for stage in self.stages:
             for blk in stage:
                 f = blk(f)

@@ -366,19 +366,21 @@ def _pad_nhwc(t):
     return torch.nn.functional.pad(t, (0, 0, 1, 1, 1, 1)).contiguous()
 
 
-@pytest.mark.parametrize("B,H,W,groups", [(2, 7, 9, 1), (3, 25, 25, 2), (1, 50, 50, 6), (2, 13, 200, 1)])
-def test_conv3x3_padded_domain(gpu, B, H, W, groups):
-    """Patch-matrix-free grouped 3x3 convolution (shifted-view GEMMs over the zero-bordered NHWC tensor) against
-    torch conv2d in fp32 on the same bf16-rounded inputs: forward, data gradient, weight + bias gradient."""
+@pytest.mark.parametrize("B,H,W,Cin,Cout,groups", [(2, 7, 9, 64, 64, 1), (3, 25, 25, 128, 128, 2), (1, 50, 50, 384, 384, 6), (2, 13, 200, 64, 64, 1),
+                                                   (2, 30, 21, 16, 32, 1), (1, 40, 40, 32, 64, 1), (2, 12, 12, 256, 256, 1), (1, 9, 10, 128, 64, 1),
+                                                   (2, 11, 8, 64, 32, 2)])
+def test_conv3x3_padded_domain(gpu, B, H, W, Cin, Cout, groups):
+    """Patch-matrix-free (grouped) 3x3 convolution (shifted-view GEMMs over the zero-bordered NHWC tensor, all groups in one
+    launch) against torch conv2d in fp32 on the same bf16-rounded inputs: forward, data gradient, weight + bias gradient."""
     from item_alignment_amd import _lib
     from item_alignment_amd.ops import check, stream_ptr
     lib = _lib.load()
-    C = groups * 64
-    x = rnd((B, H, W, C), gpu, 1.0, 11)
-    w = rnd((C, 64, 3, 3), gpu, 0.05, 12)                                 # torch layout [Cout][Cg][ky][kx]
-    bias = torch.randn(C, device=gpu)
-    dy = rnd((B, H, W, C), gpu, 1.0, 13)
-    what = w.permute(0, 2, 3, 1).reshape(C, 576).contiguous()             # [o][t*64 + c]
+    ci = Cin // groups
+    x = rnd((B, H, W, Cin), gpu, 1.0, 11)
+    w = rnd((Cout, ci, 3, 3), gpu, 0.05, 12)                              # torch layout [Cout][Cin/groups][ky][kx]
+    bias = torch.randn(Cout, device=gpu)
+    dy = rnd((B, H, W, Cout), gpu, 1.0, 13)
+    what = w.permute(0, 2, 3, 1).reshape(Cout, 9 * ci).contiguous()      # [o][t*ci + c]
     xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
     wr = w.float().requires_grad_(True)
     br = bias.clone().requires_grad_(True)
@@ -386,19 +388,19 @@ def test_conv3x3_padded_domain(gpu, B, H, W, groups):
     ref.backward(dy.float().permute(0, 3, 1, 2))
 
     xp, dyp = _pad_nhwc(x), _pad_nhwc(dy)
-    yp = torch.empty_like(xp)
-    check(lib.ia_conv3x3_padded_fwd(xp.data_ptr(), what.data_ptr(), bias.data_ptr(), yp.data_ptr(), B, H, W, C, groups, stream_ptr()), "fwd")
+    yp = torch.empty_like(dyp)
+    check(lib.ia_conv3x3_padded_fwd(xp.data_ptr(), what.data_ptr(), bias.data_ptr(), yp.data_ptr(), B, H, W, Cin, Cout, groups, stream_ptr()), "fwd")
     assert rel_err(yp[:, 1:-1, 1:-1], ref.permute(0, 2, 3, 1)) < 2e-2
     dxp = torch.empty_like(xp)
-    check(lib.ia_conv3x3_padded_bwd_data(dyp.data_ptr(), what.data_ptr(), dxp.data_ptr(), B, H, W, C, groups, stream_ptr()), "bwd_data")
+    check(lib.ia_conv3x3_padded_bwd_data(dyp.data_ptr(), what.data_ptr(), dxp.data_ptr(), B, H, W, Cin, Cout, groups, stream_ptr()), "bwd_data")
     assert rel_err(dxp[:, 1:-1, 1:-1], xr.grad.permute(0, 2, 3, 1)) < 2e-2
-    wsb = lib.ia_conv3x3_padded_workspace_bytes(B, H, W, C)
+    wsb = lib.ia_conv3x3_padded_workspace_bytes(B, H, W, Cin, Cout, groups)
     ws = torch.empty(max(wsb, 16), device=gpu, dtype=torch.uint8)
-    dwhat = torch.empty((C, 576), device=gpu, dtype=torch.float32)
-    dbias = torch.zeros(C, device=gpu)
-    check(lib.ia_conv3x3_padded_bwd_weight(xp.data_ptr(), dyp.data_ptr(), dwhat.data_ptr(), dbias.data_ptr(), B, H, W, C, groups, ws.data_ptr(),
-                                           wsb, stream_ptr()), "bwd_weight")
-    assert rel_err(dwhat.view(C, 3, 3, 64).permute(0, 3, 1, 2), wr.grad) < 2e-3
+    dwhat = torch.empty((Cout, 9 * ci), device=gpu, dtype=torch.float32)
+    dbias = torch.zeros(Cout, device=gpu)
+    check(lib.ia_conv3x3_padded_bwd_weight(xp.data_ptr(), dyp.data_ptr(), dwhat.data_ptr(), dbias.data_ptr(), B, H, W, Cin, Cout, groups,
+                                           ws.data_ptr(), wsb, stream_ptr()), "bwd_weight")
+    assert rel_err(dwhat.view(Cout, 3, 3, ci).permute(0, 3, 1, 2), wr.grad) < 2e-3
     assert rel_err(dbias, br.grad) < 2e-3
 
 

@@ -32,14 +32,14 @@ for (H, groups) in ((200, 1), (100, 2), (50, 6), (25, 6)):
     dwhat = torch.empty((C, 576), device=dev, dtype=torch.float32)
     wsb = lib.ia_conv_nhwc_workspace_bytes(N, H, W, C, C, 3, 1, groups)
     ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
-    wsb2 = lib.ia_conv3x3_padded_workspace_bytes(N, H, W, C)
+    wsb2 = lib.ia_conv3x3_padded_workspace_bytes(N, H, W, C, C, groups)
     ws2 = torch.empty(max(wsb2, 16), device=dev, dtype=torch.uint8)
     s = stream_ptr()
     flops = 2.0 * N * H * W * C * 576
     old = [timed(lambda: check(lib.ia_conv_nhwc_fwd(x.data_ptr(), what.data_ptr(), None, y.data_ptr(), N, H, W, C, C, 3, 1, groups, ws.data_ptr(), wsb, s), "f")),
            timed(lambda: check(lib.ia_conv_nhwc_bwd_data(dy.data_ptr(), what.data_ptr(), dx.data_ptr(), N, H, W, C, C, 3, 1, groups, ws.data_ptr(), wsb, s), "d")),
            timed(lambda: check(lib.ia_conv_nhwc_bwd_weight(x.data_ptr(), dy.data_ptr(), dwhat.data_ptr(), None, N, H, W, C, C, 3, 1, groups, 0, ws.data_ptr(), wsb, s), "w"))]
-    new = [timed(lambda: check(lib.ia_conv3x3_padded_fwd(xp.data_ptr(), what.data_ptr(), None, yp.data_ptr(), N, H, W, C, groups, s), "f")),
-           timed(lambda: check(lib.ia_conv3x3_padded_bwd_data(dyp.data_ptr(), what.data_ptr(), dxp.data_ptr(), N, H, W, C, groups, s), "d")),
-           timed(lambda: check(lib.ia_conv3x3_padded_bwd_weight(xp.data_ptr(), dyp.data_ptr(), dwhat.data_ptr(), None, N, H, W, C, groups, ws2.data_ptr(), wsb2, s), "w"))]
+    new = [timed(lambda: check(lib.ia_conv3x3_padded_fwd(xp.data_ptr(), what.data_ptr(), None, yp.data_ptr(), N, H, W, C, C, groups, s), "f")),
+           timed(lambda: check(lib.ia_conv3x3_padded_bwd_data(dyp.data_ptr(), what.data_ptr(), dxp.data_ptr(), N, H, W, C, C, groups, s), "d")),
+           timed(lambda: check(lib.ia_conv3x3_padded_bwd_weight(xp.data_ptr(), dyp.data_ptr(), dwhat.data_ptr(), None, N, H, W, C, C, groups, ws2.data_ptr(), wsb2, s), "w"))]
     print(f"H={H} C={C} groups={groups}: " + "  ".join(f"{n} {o:.3f}->{v:.3f} ms ({flops / v / 1e9:.0f} TF)" for n, o, v in zip(("fwd", "dgrad", "wgrad"), old, new)), flush=True)
