@@ -604,10 +604,14 @@ Plan make_plan(int M, int N, int K, bool f32_out, int groups = 1) {
   // prologue/epilogue cost), plus the fixed-order reduction that reads one fp32 copy of C per split.  Overshooting the
   // slot count by a few workgroups (36 tiles x 8 = 288 on 256 CUs) would cost a whole extra round.
   const long slots = pl.big ? 256 : 512;
+  // outputs of one or two tiles under a huge K (convolution weight gradients: 64 x 576 over millions of pixels) are pure
+  // streaming reads: cut K until the resident slots are full, the partials are a few KB each
+  int smax2 = smax;
+  if (f32_out && slots / tiles > smax2) { smax2 = (int)(slots / tiles); if (smax2 > nk / 8) smax2 = nk / 8 < 1 ? 1 : nk / 8; if (smax2 < smax) smax2 = smax; }
   const double reduce_per_split = (double)tiles * (pl.big ? 0.0244 : 0.0061);   // in k-tile times of one workgroup
   int best = 1;
   double best_cost = 1e30;
-  for (int s = 1; s <= smax; ++s) {
+  for (int s = 1; s <= smax2; ++s) {
     const long rounds = (tiles * s + slots - 1) / slots;
     const double cost = (double)rounds * ((nk + s - 1) / s + 6) + (s > 1 ? s * reduce_per_split : 0.0);
     if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
