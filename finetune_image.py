@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Image-only two-tower pair matching (ViT / ECA-NFNet / ResNetV2 through `create_model`): CLI-compatible with
-the reference's finetune_image.py (flags :17-74, dispatch :192-218, loop :310-348).  The ViT family and eca_nfnet_l0/l1/l2
-have HIP encoders; resnetv2 (BatchNorm) raises NotImplementedError."""
+the reference's finetune_image.py (flags :17-74, dispatch :192-218, loop :310-348).  The ViT family, eca_nfnet_l0/l1/l2
+and resnetv2_50/101/152 (BatchNorm) have HIP encoders; the BiT resnetv2_*_bitm variants raise NotImplementedError."""
 import argparse
 import json
 import os

@@ -182,8 +182,38 @@ int ia_conv3x3_padded_bwd_weight(const void* xp, const void* dyp, float* dwhat, 
 /* y = silu(x) * scale between the compact [B,H,W,C] and the zero-bordered [B,H+2,W+2,C] layouts (one flag per side); the
  * backward call produces dx in x's layout from dy in y's layout */
 int ia_silu_pad_fwd(const void* x, void* y, int B, int H, int W, int C, float scale, int in_padded, int out_padded, ia_stream_t stream);
+int ia_pad_rows(const void* x, void* y, int B, int H, int W, int C, int in_padded, int out_padded, ia_stream_t stream);   /* plain copy */
 int ia_silu_pad_bwd(const void* dy, const void* x, void* dx, int B, int H, int W, int C, float scale, int in_padded, int out_padded,
                     ia_stream_t stream);
+
+/* ---- pre-activation ResNetV2 tower pieces (reference src/models/image.py:298-378 ResNetTwoTower -> timm 0.6.5 resnetv2.py
+ * with norm_layer=BatchNormAct2d; README.md:187-197 `--model_name resnetv2_50`).  NHWC rows [B*H*W, C] bf16 as above. */
+/* BatchNorm2d + ReLU.  The rows are `segments` equal consecutive runs, each normalised with its own batch statistics (the
+ * reference runs the two towers as two forward calls: image.py:337-341).  training: batch statistics, running_mean/var [C]
+ * (NULL allowed) updated with `momentum` segment by segment; else the running statistics are used.  mean / rstd
+ * [segments][C] fp32 are saved for the backward call. */
+size_t ia_bn_act_workspace_bytes(int rows, int C, int segments);
+int ia_bn_act_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, void* y, float* mean,
+                  float* rstd, int rows, int C, int segments, float eps, float momentum, int training, int relu, void* workspace,
+                  size_t workspace_bytes, ia_stream_t stream);
+/* dx (+ extra [rows, C] bf16 when not NULL: a second gradient reaching x), dgamma / dbeta [C] accumulated (NULL allowed) */
+int ia_bn_act_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                  const void* extra, void* dx, float* dgamma, float* dbeta, int rows, int C, int segments, int training, int relu,
+                  void* workspace, size_t workspace_bytes, ia_stream_t stream);
+/* cols [B*Ho*Wo, Kp] bf16: patch matrix of a k x k / stride / pad convolution read from NCHW fp32 images; column
+ * (ky*k + kx)*C + c, columns >= k*k*C zero, Kp % 8 == 0 (the 7x7 stem, timm resnetv2.py create_resnetv2_stem) */
+int ia_patches_nchw(const float* images, void* cols, int B, int C, int H, int W, int k, int stride, int pad, int Kp, ia_stream_t stream);
+/* MaxPool2d(3, stride 2, padding 1): y [B*Ho*Wo, C] bf16, arg [B*Ho*Wo, C] u8 = window position of the first maximum */
+int ia_maxpool3s2_fwd(const void* x, void* y, uint8_t* arg, int B, int H, int W, int C, ia_stream_t stream);
+int ia_maxpool3s2_bwd(const void* dy, const uint8_t* arg, void* dx, int B, int H, int W, int C, ia_stream_t stream);
+/* rows read by a strided 1x1 convolution: y [B*Ho*Wo, C] = x[b, oy*stride, ox*stride, :]; the backward call writes
+ * dx = base (NULL = zeros; may alias dx) + dy scattered onto the stride grid */
+int ia_rows_subsample_fwd(const void* x, void* y, int B, int H, int W, int C, int stride, ia_stream_t stream);
+int ia_rows_subsample_bwd(const void* dy, const void* base, void* dx, int B, int H, int W, int C, int stride, ia_stream_t stream);
+/* plain convolution weight: what [Cout][ldw] bf16 (tap-major, channels padded to Cgp, row padded with zeros to ldw) from the
+ * PyTorch layout w [Cout][Cg][kk] fp32; the grad call does dw += dwhat in the inverse mapping */
+int ia_conv_weight_pack(const float* w, void* what, int Cout, int Cg, int kk, int Cgp, int ldw, ia_stream_t stream);
+int ia_conv_weight_unpack_grad(const float* dwhat, float* dw, int Cout, int Cg, int kk, int Cgp, int ldw, ia_stream_t stream);
 
 /* ---- image input pipeline on the GPU (src/data/data.py:838-866: timm create_transform(is_training=False) = PIL bicubic
  * resize -> ToTensor -> Normalize).  ia_resize_pass_u8 is one separable pass of Pillow's 8-bit resampler (Resample.c) over

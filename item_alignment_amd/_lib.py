@@ -76,8 +76,19 @@ SIGNATURES = {
     "ia_conv3x3_padded_bwd_data": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "ia_conv3x3_padded_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
     "ia_conv3x3_padded_bwd_weight": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "ia_pad_rows": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "ia_silu_pad_fwd": (i32, [vp, vp, i32, i32, i32, i32, f32, i32, i32, vp]),
     "ia_silu_pad_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, vp]),
+    "ia_bn_act_workspace_bytes": (sz, [i32, i32, i32]),
+    "ia_bn_act_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, i32, i32, vp, sz, vp]),
+    "ia_bn_act_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "ia_patches_nchw": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "ia_maxpool3s2_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "ia_maxpool3s2_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "ia_rows_subsample_fwd": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "ia_rows_subsample_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "ia_conv_weight_pack": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "ia_conv_weight_unpack_grad": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "ia_resize_pass_u8": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "ia_u8_to_nchw_normalized": (i32, [vp, vp, vp, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp]),
     "ia_embed_ln_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, u32, u32, vp]),

@@ -201,25 +201,43 @@ __global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const bf16* __restric
 // part[b][s][c] = sum over the s-th slice of HW of x[b, hw, c] (* y[b, hw, c] if y); fixed slice order -> deterministic
 __global__ __launch_bounds__(256) void spatial_sum_kernel(const bf16* __restrict__ x, const bf16* __restrict__ y, float* __restrict__ part,
                                                           int HW, int C, int nsplit) {
+  // C/8 column threads x as many row lanes as fit in the block; row lanes are folded through LDS in a fixed order
+  __shared__ float red[256 * 8];
   const int b = blockIdx.y, s = blockIdx.x;
   const int per = (HW + nsplit - 1) / nsplit, h0 = s * per, h1 = min(HW, h0 + per);
-  for (int c = threadIdx.x * 8; c < C; c += 256 * 8) {
+  const int c8n = C >> 3;
+  const int ncol = c8n < 256 ? c8n : 256, nlane = 256 / ncol;
+  const int col = threadIdx.x % ncol, lane = threadIdx.x / ncol;
+  for (int c0 = 0; c0 < c8n; c0 += ncol) {
+    const int c = (c0 + col) * 8;
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    for (int hw = h0; hw < h1; ++hw) {
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + ((size_t)b * HW + hw) * C + c);
-      if (y) {
-        const bf16x8 u = *reinterpret_cast<const bf16x8*>(y + ((size_t)b * HW + hw) * C + c);
+    if (lane < nlane && c0 + col < c8n)
+      for (int hw = h0 + lane; hw < h1; hw += nlane) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + ((size_t)b * HW + hw) * C + c);
+        if (y) {
+          const bf16x8 u = *reinterpret_cast<const bf16x8*>(y + ((size_t)b * HW + hw) * C + c);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += bf2f(v[j]) * bf2f(u[j]);
-      } else {
+          for (int j = 0; j < 8; ++j) acc[j] += bf2f(v[j]) * bf2f(u[j]);
+        } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += bf2f(v[j]);
+          for (int j = 0; j < 8; ++j) acc[j] += bf2f(v[j]);
+        }
       }
-    }
+    if (nlane > 1) {
+      __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 8; ++j) part[((size_t)b * nsplit + s) * C + c + j] = acc[j];
+      for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = acc[j];
+      __syncthreads();
+      if (lane == 0)
+        for (int l = 1; l < nlane; ++l)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += red[(l * ncol + col) * 8 + j];
+    }
+    if (lane == 0 && c0 + col < c8n)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) part[((size_t)b * nsplit + s) * C + c + j] = acc[j];
   }
 }
 
@@ -333,6 +351,7 @@ __global__ __launch_bounds__(256) void scale_residual_bwd_kernel(const bf16* __r
 // compact [B, H, W, C] one: the border of a padded output is written as zero, the border of a padded input is ignored.
 IA_DEV size_t pad_row(size_t b, int y, int x, int H, int W) { return (b * (H + 2) + y + 1) * (size_t)(W + 2) + x + 1; }
 
+template <bool ACT>
 __global__ __launch_bounds__(256) void silu_pad_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, int H, int W, int C, float scale,
                                                            int in_padded, int out_padded, size_t total) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;      // over output rows x C/8
@@ -351,7 +370,7 @@ __global__ __launch_bounds__(256) void silu_pad_fwd_kernel(const bf16* __restric
     const size_t irow = in_padded ? pad_row(b, yy, xx, H, W) : (b * H + yy) * (size_t)W + xx;
     const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + irow * C + c);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { const float a = bf2f(v[j]); o[j] = f2bf(a / (1.f + __expf(-a)) * scale); }
+    for (int j = 0; j < 8; ++j) { const float a = bf2f(v[j]); o[j] = ACT ? f2bf(a / (1.f + __expf(-a)) * scale) : v[j]; }
   }
   *reinterpret_cast<bf16x8*>(y + row * C + c) = o;
 }
@@ -690,7 +709,19 @@ extern "C" int ia_silu_pad_fwd(const void* x, void* y, int B, int H, int W, int 
   if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7)) return IA_ERR_ARG;
   const size_t rows = out_padded ? (size_t)B * (H + 2) * (W + 2) : (size_t)B * H * W;
   const size_t total = rows * (C >> 3);
-  hipLaunchKernelGGL(silu_pad_fwd_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, H, W, C, scale, in_padded,
+  hipLaunchKernelGGL(silu_pad_fwd_kernel<true>, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, H, W, C, scale, in_padded,
+                     out_padded, total);
+  return ia_check_launch();
+}
+
+// plain copy between the compact [B,H,W,C] and the zero-bordered [B,H+2,W+2,C] layouts (a padded output gets a zero border,
+// a padded input's border is ignored)
+extern "C" int ia_pad_rows(const void* x, void* y, int B, int H, int W, int C, int in_padded, int out_padded, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7)) return IA_ERR_ARG;
+  const size_t rows = out_padded ? (size_t)B * (H + 2) * (W + 2) : (size_t)B * H * W;
+  const size_t total = rows * (C >> 3);
+  hipLaunchKernelGGL(silu_pad_fwd_kernel<false>, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, H, W, C, 1.f, in_padded,
                      out_padded, total);
   return ia_check_launch();
 }

@@ -1,0 +1,455 @@
+// Pieces of the pre-activation ResNetV2 image tower (reference src/models/image.py:298-378 ResNetTwoTower -> timm 0.6.5
+// resnetv2.py ResNetV2 / PreActBottleneck with norm_layer=BatchNormAct2d, conv_layer=create_conv2d, stem_type ''): activations are
+// NHWC rows [B*H*W, C] bf16 as in conv.hip, so the 1x1 / 3x3 convolutions are the GEMMs of gemm.hip / conv.hip.  What is new
+// here: training-mode BatchNorm + ReLU with per-call batch statistics (the reference runs the two towers as two separate
+// forward calls, so a batch of 2B images is normalised in two segments of B), the 7x7 stem patch gather straight from the
+// NCHW fp32 images, MaxPool 3x3/2, the row subsampling of a strided 1x1 convolution and the plain (unstandardised) weight
+// re-layout.  All HBM-bound kernels with 16-byte accesses; reductions have a fixed order (deterministic).
+#include "common.h"
+#include "../../include/itemalign.h"
+
+namespace {
+
+inline unsigned blocks_of(size_t total) { return (unsigned)((total + 255) / 256); }
+
+// --------------------------------------------------------------------------------------- BatchNorm statistics
+// part[(seg * nsplit + s) * C + c] (two planes: plane 0 = sum a, plane 1 = sum b) over rows of slice s of segment seg:
+//   MODE 0 (forward):  a = x,           b = x*x
+//   MODE 1 (backward): a = g,           b = g * xhat      with g = dy * [act > 0] (relu) and xhat = (x - mean) * rstd
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ part, int rows_per_seg, int C,
+                                                         int nsplit, int relu, size_t plane) {
+  __shared__ float red[256 * 16];
+  const int seg = blockIdx.y, s = blockIdx.x;
+  const int per = (rows_per_seg + nsplit - 1) / nsplit, r0 = s * per, r1 = min(rows_per_seg, r0 + per);
+  const int c8n = C >> 3;
+  const int ncol = c8n < 256 ? c8n : 256, nlane = 256 / ncol;
+  const int col = threadIdx.x % ncol, lane = threadIdx.x / ncol;
+  const size_t base = (size_t)seg * rows_per_seg;
+  for (int c0 = 0; c0 < c8n; c0 += ncol) {
+    const int c = (c0 + col) * 8;
+    const bool live = lane < nlane && c0 + col < c8n;
+    float a[8], b[8], mu[8], rs[8], ga[8], be[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a[j] = b[j] = 0.f; mu[j] = rs[j] = ga[j] = be[j] = 0.f; }
+    if (MODE == 1 && live) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { mu[j] = mean[seg * C + c + j]; rs[j] = rstd[seg * C + c + j]; ga[j] = gamma[c + j]; be[j] = beta[c + j]; }
+    }
+    if (live)
+      for (int r = r0 + lane; r < r1; r += nlane) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (base + r) * C + c);
+        if (MODE == 0) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const float f = bf2f(v[j]); a[j] += f; b[j] += f * f; }
+        } else {
+          const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(dy + (base + r) * C + c);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float xh = (bf2f(v[j]) - mu[j]) * rs[j];
+            float g = bf2f(g8[j]);
+            if (relu && xh * ga[j] + be[j] <= 0.f) g = 0.f;
+            a[j] += g; b[j] += g * xh;
+          }
+        }
+      }
+    if (nlane > 1) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { red[threadIdx.x * 16 + j] = a[j]; red[threadIdx.x * 16 + 8 + j] = b[j]; }
+      __syncthreads();
+      if (lane == 0)
+        for (int l = 1; l < nlane; ++l)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { a[j] += red[(l * ncol + col) * 16 + j]; b[j] += red[(l * ncol + col) * 16 + 8 + j]; }
+    }
+    if (lane == 0 && c0 + col < c8n)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        part[((size_t)seg * nsplit + s) * C + c + j] = a[j];
+        part[plane + ((size_t)seg * nsplit + s) * C + c + j] = b[j];
+      }
+  }
+}
+
+// forward finish: mean / rstd per (segment, channel) from the partial sums; running statistics follow nn.BatchNorm2d (momentum
+// update with the unbiased variance), one segment after the other exactly as two consecutive forward calls would do
+__global__ __launch_bounds__(256) void bn_finish_fwd_kernel(const float* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd,
+                                                            float* __restrict__ running_mean, float* __restrict__ running_var, int C, int nsplit,
+                                                            int segments, int rows_per_seg, float eps, float momentum, size_t plane) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
+  for (int seg = 0; seg < segments; ++seg) {
+    float s = 0.f, q = 0.f;
+    for (int i = 0; i < nsplit; ++i) { s += part[((size_t)seg * nsplit + i) * C + c]; q += part[plane + ((size_t)seg * nsplit + i) * C + c]; }
+    const float n = (float)rows_per_seg, mu = s / n;
+    float var = q / n - mu * mu;
+    var = var < 0.f ? 0.f : var;
+    mean[seg * C + c] = mu;
+    rstd[seg * C + c] = rsqrtf(var + eps);
+    rm = (1.f - momentum) * rm + momentum * mu;
+    rv = (1.f - momentum) * rv + momentum * var * (n > 1.f ? n / (n - 1.f) : 1.f);
+  }
+  if (running_mean) running_mean[c] = rm;
+  if (running_var) running_var[c] = rv;
+}
+
+// eval mode: mean / rstd from the running statistics (every segment alike)
+__global__ __launch_bounds__(256) void bn_running_kernel(const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                                         float* __restrict__ mean, float* __restrict__ rstd, int C, int segments, float eps) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  for (int seg = 0; seg < segments; ++seg) { mean[seg * C + c] = running_mean[c]; rstd[seg * C + c] = rsqrtf(running_var[c] + eps); }
+}
+
+// y = act((x - mean) * rstd * gamma + beta)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, bf16* __restrict__ y,
+                                                       int rows_per_seg, int C, int relu, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c8n = C >> 3, c = (int)(idx % c8n) * 8;
+  const size_t row = idx / c8n;
+  const int seg = (int)(row / rows_per_seg);
+  const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + row * C + c);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float f = (bf2f(v[j]) - mean[seg * C + c + j]) * rstd[seg * C + c + j] * gamma[c + j] + beta[c + j];
+    if (relu && f < 0.f) f = 0.f;
+    o[j] = f2bf(f);
+  }
+  *reinterpret_cast<bf16x8*>(y + row * C + c) = o;
+}
+
+// backward finish: sums[seg][c] = (sum g, sum g*xhat); dgamma += sum over segments of sum g*xhat, dbeta += sum g
+__global__ __launch_bounds__(256) void bn_finish_bwd_kernel(const float* __restrict__ part, float* __restrict__ sums, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int C, int nsplit, int segments, size_t plane) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float dg = 0.f, db = 0.f;
+  for (int seg = 0; seg < segments; ++seg) {
+    float s = 0.f, q = 0.f;
+    for (int i = 0; i < nsplit; ++i) { s += part[((size_t)seg * nsplit + i) * C + c]; q += part[plane + ((size_t)seg * nsplit + i) * C + c]; }
+    sums[(seg * 2) * C + c] = s;
+    sums[(seg * 2 + 1) * C + c] = q;
+    db += s; dg += q;
+  }
+  if (dgamma) dgamma[c] += dg;
+  if (dbeta) dbeta[c] += db;
+}
+
+// dx = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat))  [training]   or   gamma * rstd * g  [eval: statistics are constants]
+// (+ extra: a second gradient reaching x, e.g. the identity shortcut of a pre-activation block)
+__global__ __launch_bounds__(256) void bn_dx_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x, const float* __restrict__ mean,
+                                                    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    const float* __restrict__ sums, const bf16* __restrict__ extra, bf16* __restrict__ dx,
+                                                    int rows_per_seg, int C, int relu, int training, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c8n = C >> 3, c = (int)(idx % c8n) * 8;
+  const size_t row = idx / c8n;
+  const int seg = (int)(row / rows_per_seg);
+  const float inv_n = 1.f / (float)rows_per_seg;
+  const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + row * C + c), g8 = *reinterpret_cast<const bf16x8*>(dy + row * C + c);
+  bf16x8 e8;
+  if (extra) e8 = *reinterpret_cast<const bf16x8*>(extra + row * C + c);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float rs = rstd[seg * C + c + j], ga = gamma[c + j];
+    const float xh = (bf2f(v[j]) - mean[seg * C + c + j]) * rs;
+    float g = bf2f(g8[j]);
+    if (relu && xh * ga + beta[c + j] <= 0.f) g = 0.f;
+    float d = training ? ga * rs * (g - sums[(seg * 2) * C + c + j] * inv_n - xh * sums[(seg * 2 + 1) * C + c + j] * inv_n) : ga * rs * g;
+    if (extra) d += bf2f(e8[j]);
+    o[j] = f2bf(d);
+  }
+  *reinterpret_cast<bf16x8*>(dx + row * C + c) = o;
+}
+
+// ------------------------------------------------------------------------------------------ stem patch gather
+// cols[m][(ky*k + kx)*C + c] = images[b, c, oy*stride + ky - pad, ox*stride + kx - pad] (fp32 NCHW -> bf16), zero outside the
+// image and in the padding columns [k*k*C, Kp)
+__global__ __launch_bounds__(256) void patches_nchw_kernel(const float* __restrict__ img, bf16* __restrict__ cols, int C, int H, int W, int Ho,
+                                                           int Wo, int k, int stride, int pad, int Kp, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;      // over m * Kp
+  if (idx >= total) return;
+  const int kk = (int)(idx % Kp);
+  const size_t m = idx / Kp;
+  float v = 0.f;
+  if (kk < k * k * C) {
+    const int c = kk % C, t = kk / C, ky = t / k, kx = t % k;
+    const int ox = (int)(m % Wo), oy = (int)((m / Wo) % Ho);
+    const size_t b = m / ((size_t)Wo * Ho);
+    const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = img[((b * C + c) * H + iy) * (size_t)W + ix];
+  }
+  cols[idx] = f2bf(v);
+}
+
+// ------------------------------------------------------------------------------------------- MaxPool 3x3 / 2 / pad 1
+// y[b, oy, ox, c] = max over the 3x3 window at (2oy-1, 2ox-1); arg = window position (ky*3+kx) of the FIRST maximum in scan
+// order (the element PyTorch's max_pool2d backward routes the gradient to)
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, uint8_t* __restrict__ arg, int H, int W,
+                                                          int C, int Ho, int Wo, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c8n = C >> 3, c = (int)(idx % c8n) * 8;
+  const size_t m = idx / c8n;
+  const int ox = (int)(m % Wo), oy = (int)((m / Wo) % Ho);
+  const size_t b = m / ((size_t)Wo * Ho);
+  float best[8];
+  int at[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { best[j] = -INFINITY; at[j] = 0; }
+  bool first = true;
+  for (int t = 0; t < 9; ++t) {
+    const int iy = 2 * oy + t / 3 - 1, ix = 2 * ox + t % 3 - 1;
+    if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + ((b * H + iy) * W + ix) * C + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float f = bf2f(v[j]);
+      if (first || f > best[j] || f != f) { best[j] = f; at[j] = t; }
+    }
+    first = false;
+  }
+  bf16x8 o;
+  uint8_t a8[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { o[j] = f2bf(best[j]); a8[j] = (uint8_t)at[j]; }
+  *reinterpret_cast<bf16x8*>(y + m * C + c) = o;
+  *reinterpret_cast<uint2*>(arg + m * C + c) = *reinterpret_cast<const uint2*>(a8);
+}
+
+// dx[b, iy, ix, c] = sum of dy over the (at most 4) windows whose recorded maximum is this pixel (gather form)
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16* __restrict__ dy, const uint8_t* __restrict__ arg, bf16* __restrict__ dx, int H,
+                                                          int W, int C, int Ho, int Wo, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c8n = C >> 3, c = (int)(idx % c8n) * 8;
+  const size_t pix = idx / c8n;
+  const int ix = (int)(pix % W), iy = (int)((pix / W) % H);
+  const size_t b = pix / ((size_t)W * H);
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int t = 0; t < 9; ++t) {
+    const int ny = iy + 1 - t / 3, nx = ix + 1 - t % 3;          // 2*oy = ny, 2*ox = nx
+    if (ny < 0 || nx < 0 || (ny & 1) || (nx & 1)) continue;
+    const int oy = ny >> 1, ox = nx >> 1;
+    if (oy >= Ho || ox >= Wo) continue;
+    const size_t m = (b * Ho + oy) * Wo + ox;
+    const bf16x8 g = *reinterpret_cast<const bf16x8*>(dy + m * C + c);
+    const uint2 a2 = *reinterpret_cast<const uint2*>(arg + m * C + c);
+    const uint8_t* a8 = reinterpret_cast<const uint8_t*>(&a2);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (a8[j] == t) acc[j] += bf2f(g[j]);
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = f2bf(acc[j]);
+  *reinterpret_cast<bf16x8*>(dx + pix * C + c) = o;
+}
+
+// ---------------------------------------------------------------------------------- strided 1x1 convolution rows
+// y[b, oy, ox, :] = x[b, oy*s, ox*s, :]
+__global__ __launch_bounds__(256) void subsample_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, int H, int W, int C, int Ho, int Wo,
+                                                            int stride, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c8n = C >> 3, c = (int)(idx % c8n) * 8;
+  const size_t m = idx / c8n;
+  const int ox = (int)(m % Wo), oy = (int)((m / Wo) % Ho);
+  const size_t b = m / ((size_t)Wo * Ho);
+  *reinterpret_cast<bf16x8*>(y + m * C + c) = *reinterpret_cast<const bf16x8*>(x + ((b * H + oy * stride) * W + ox * stride) * C + c);
+}
+
+// dx[b, iy, ix, :] = (base ? base[b, iy, ix, :] : 0) + (iy, ix on the stride grid ? dy[b, iy/s, ix/s, :] : 0)
+__global__ __launch_bounds__(256) void subsample_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ base, bf16* __restrict__ dx, int H,
+                                                            int W, int C, int Ho, int Wo, int stride, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c8n = C >> 3, c = (int)(idx % c8n) * 8;
+  const size_t pix = idx / c8n;
+  const int ix = (int)(pix % W), iy = (int)((pix / W) % H);
+  const size_t b = pix / ((size_t)W * H);
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  if (base) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(base + pix * C + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = bf2f(v[j]);
+  }
+  if (iy % stride == 0 && ix % stride == 0 && iy / stride < Ho && ix / stride < Wo) {
+    const bf16x8 g = *reinterpret_cast<const bf16x8*>(dy + ((b * Ho + iy / stride) * Wo + ix / stride) * C + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += bf2f(g[j]);
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = f2bf(acc[j]);
+  *reinterpret_cast<bf16x8*>(dx + pix * C + c) = o;
+}
+
+// ------------------------------------------------------------------------------------- plain weight re-layout
+// what[o][t*Cgp + c] = w[o][c][t] (c < Cg) else 0, columns [kk*Cgp, ldw) zero      (PyTorch conv weight -> tap-major bf16)
+__global__ __launch_bounds__(256) void weight_pack_kernel(const float* __restrict__ w, bf16* __restrict__ what, int Cg, int kk, int Cgp, int ldw,
+                                                          size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int i = (int)(idx % ldw);
+  const size_t o = idx / ldw;
+  float v = 0.f;
+  if (i < kk * Cgp) {
+    const int t = i / Cgp, c = i % Cgp;
+    if (c < Cg) v = w[(o * Cg + c) * kk + t];
+  }
+  what[idx] = f2bf(v);
+}
+
+// dw[o][c][t] += dwhat[o][t*Cgp + c]
+__global__ __launch_bounds__(256) void weight_unpack_grad_kernel(const float* __restrict__ dwhat, float* __restrict__ dw, int Cg, int kk, int Cgp,
+                                                                 int ldw, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;      // over Cout * Cg * kk
+  if (idx >= total) return;
+  const int t = (int)(idx % kk), c = (int)((idx / kk) % Cg);
+  const size_t o = idx / ((size_t)kk * Cg);
+  dw[idx] += dwhat[o * ldw + t * Cgp + c];
+}
+
+inline int bn_nsplit(int rows_per_seg) { int n = rows_per_seg / 64; return n < 1 ? 1 : (n > 128 ? 128 : n); }
+
+}  // namespace
+
+// workspace of ia_bn_act_fwd / ia_bn_act_bwd: two planes of [segments][nsplit][C] partial sums + [segments][2][C] finished sums
+extern "C" size_t ia_bn_act_workspace_bytes(int rows, int C, int segments) {
+  if (rows <= 0 || C <= 0 || segments <= 0 || rows % segments) return 0;
+  const int ns = bn_nsplit(rows / segments);
+  return ((size_t)2 * segments * ns * C + (size_t)2 * segments * C) * sizeof(float);
+}
+
+// BatchNormAct2d (timm layers/norm_act.py: nn.BatchNorm2d followed by ReLU) over NHWC rows x [rows, C] bf16.  The rows are
+// `segments` equal consecutive runs, each normalised with its own batch statistics (= that many separate forward calls).
+// training != 0: batch statistics; running_mean / running_var [C] (may be NULL) are updated in place with `momentum`, segment
+// by segment.  training == 0: the running statistics are used.  mean / rstd [segments][C] fp32 are written for the backward.
+extern "C" int ia_bn_act_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, void* y, float* mean,
+                             float* rstd, int rows, int C, int segments, float eps, float momentum, int training, int relu, void* workspace,
+                             size_t workspace_bytes, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || C <= 0 || (C & 7) || segments <= 0 || rows % segments) return IA_ERR_ARG;
+  const int rps = rows / segments;
+  if (training) {
+    if (!workspace || workspace_bytes < ia_bn_act_workspace_bytes(rows, C, segments)) return IA_ERR_WORKSPACE;
+    const int ns = bn_nsplit(rps);
+    const size_t plane = (size_t)segments * ns * C;
+    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(ns, segments), dim3(256), 0, stream, (const bf16*)x, (const bf16*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)workspace, rps, C, ns, 0, plane);
+    hipLaunchKernelGGL(bn_finish_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)workspace, mean, rstd, running_mean,
+                       running_var, C, ns, segments, rps, eps, momentum, plane);
+  } else {
+    if (!running_mean || !running_var) return IA_ERR_ARG;
+    hipLaunchKernelGGL(bn_running_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)running_mean, (const float*)running_var, mean,
+                       rstd, C, segments, eps);
+  }
+  const size_t total = (size_t)rows * (C >> 3);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)x, (const float*)mean, (const float*)rstd, gamma,
+                     beta, (bf16*)y, rps, C, relu, total);
+  return ia_check_launch();
+}
+
+// dx [rows, C] bf16 (+ extra [rows, C] bf16 if not NULL), dgamma / dbeta [C] fp32 accumulated (either may be NULL)
+extern "C" int ia_bn_act_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                             const void* extra, void* dx, float* dgamma, float* dbeta, int rows, int C, int segments, int training, int relu,
+                             void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dy || !x || !gamma || !beta || !mean || !rstd || !dx || rows <= 0 || C <= 0 || (C & 7) || segments <= 0 || rows % segments) return IA_ERR_ARG;
+  if (!workspace || workspace_bytes < ia_bn_act_workspace_bytes(rows, C, segments)) return IA_ERR_WORKSPACE;
+  const int rps = rows / segments, ns = bn_nsplit(rps);
+  const size_t plane = (size_t)segments * ns * C;
+  float* sums = (float*)workspace + 2 * plane;
+  hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(ns, segments), dim3(256), 0, stream, (const bf16*)x, (const bf16*)dy, mean, rstd, gamma, beta,
+                     (float*)workspace, rps, C, ns, relu, plane);
+  hipLaunchKernelGGL(bn_finish_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)workspace, sums, dgamma, dbeta, C, ns, segments,
+                     plane);
+  const size_t total = (size_t)rows * (C >> 3);
+  hipLaunchKernelGGL(bn_dx_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)x, mean, rstd, gamma, beta,
+                     (const float*)sums, (const bf16*)extra, (bf16*)dx, rps, C, relu, training, total);
+  return ia_check_launch();
+}
+
+// cols [B*Ho*Wo, Kp] bf16 patch matrix of a k x k / stride / pad convolution read straight from NCHW fp32 images
+// (Ho = (H + 2 pad - k) / stride + 1); column (ky*k + kx)*C + c, columns >= k*k*C zero.  Kp % 8 == 0.
+extern "C" int ia_patches_nchw(const float* images, void* cols, int B, int C, int H, int W, int k, int stride, int pad, int Kp, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!images || !cols || B <= 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0 || stride <= 0 || pad < 0 || Kp < k * k * C || (Kp & 7)) return IA_ERR_ARG;
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  if (Ho <= 0 || Wo <= 0) return IA_ERR_ARG;
+  const size_t total = (size_t)B * Ho * Wo * Kp;
+  hipLaunchKernelGGL(patches_nchw_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, images, (bf16*)cols, C, H, W, Ho, Wo, k, stride, pad, Kp, total);
+  return ia_check_launch();
+}
+
+// MaxPool2d(3, stride 2, padding 1) on NHWC rows: y [B*Ho*Wo, C] bf16, arg [B*Ho*Wo, C] u8 (window position of the maximum)
+extern "C" int ia_maxpool3s2_fwd(const void* x, void* y, uint8_t* arg, int B, int H, int W, int C, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!x || !y || !arg || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7)) return IA_ERR_ARG;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const size_t total = (size_t)B * Ho * Wo * (C >> 3);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, arg, H, W, C, Ho, Wo, total);
+  return ia_check_launch();
+}
+
+extern "C" int ia_maxpool3s2_bwd(const void* dy, const uint8_t* arg, void* dx, int B, int H, int W, int C, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dy || !arg || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7)) return IA_ERR_ARG;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const size_t total = (size_t)B * H * W * (C >> 3);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)dy, arg, (bf16*)dx, H, W, C, Ho, Wo, total);
+  return ia_check_launch();
+}
+
+// rows of a strided 1x1 convolution: y [B*Ho*Wo, C] = x[b, oy*stride, ox*stride, :], Ho = (H-1)/stride + 1
+extern "C" int ia_rows_subsample_fwd(const void* x, void* y, int B, int H, int W, int C, int stride, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || stride < 1) return IA_ERR_ARG;
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const size_t total = (size_t)B * Ho * Wo * (C >> 3);
+  hipLaunchKernelGGL(subsample_fwd_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, H, W, C, Ho, Wo, stride, total);
+  return ia_check_launch();
+}
+
+// dx [B*H*W, C] = base (may be NULL = zeros; may alias dx) + dy scattered onto the stride grid
+extern "C" int ia_rows_subsample_bwd(const void* dy, const void* base, void* dx, int B, int H, int W, int C, int stride, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dy || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || stride < 1) return IA_ERR_ARG;
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const size_t total = (size_t)B * H * W * (C >> 3);
+  hipLaunchKernelGGL(subsample_bwd_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)base, (bf16*)dx, H, W, C, Ho, Wo,
+                     stride, total);
+  return ia_check_launch();
+}
+
+// what [Cout][ldw] bf16 (tap-major, channels padded to Cgp, row padded to ldw) from the PyTorch weight w [Cout][Cg][kk] fp32
+extern "C" int ia_conv_weight_pack(const float* w, void* what, int Cout, int Cg, int kk, int Cgp, int ldw, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!w || !what || Cout <= 0 || Cg <= 0 || kk <= 0 || Cgp < Cg || ldw < kk * Cgp) return IA_ERR_ARG;
+  const size_t total = (size_t)Cout * ldw;
+  hipLaunchKernelGGL(weight_pack_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, w, (bf16*)what, Cg, kk, Cgp, ldw, total);
+  return ia_check_launch();
+}
+
+// dw [Cout][Cg][kk] fp32 += dwhat [Cout][ldw] fp32 (same layout as ia_conv_weight_pack writes)
+extern "C" int ia_conv_weight_unpack_grad(const float* dwhat, float* dw, int Cout, int Cg, int kk, int Cgp, int ldw, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dwhat || !dw || Cout <= 0 || Cg <= 0 || kk <= 0 || Cgp < Cg || ldw < kk * Cgp) return IA_ERR_ARG;
+  const size_t total = (size_t)Cout * Cg * kk;
+  hipLaunchKernelGGL(weight_unpack_grad_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, dwhat, dw, Cg, kk, Cgp, ldw, total);
+  return ia_check_launch();
+}

@@ -119,8 +119,11 @@ def create_model(model_name, pretrained=False, **kwargs):
     from .nfnet import NFNET_CONFIGS, create_nfnet
     if model_name in NFNET_CONFIGS:
         return create_nfnet(model_name, **kwargs)
-    raise NotImplementedError(f"image encoder {model_name!r}: the ViT family and eca_nfnet_l0/l1/l2 run on the HIP engine "
-                              "(resnetv2 towers are not built, DESIGN.md)")
+    from .resnetv2 import RESNETV2_CONFIGS, create_resnetv2
+    if model_name in RESNETV2_CONFIGS:
+        return create_resnetv2(model_name, **kwargs)
+    raise NotImplementedError(f"image encoder {model_name!r}: the ViT family, eca_nfnet_l0/l1/l2 and resnetv2_50/101/152 run on the HIP "
+                              "engine (the BiT resnetv2_*_bitm variants are not built, DESIGN.md)")
 
 
 class _ImageTwoTower(HipModule):
@@ -176,4 +179,16 @@ class NFNetTwoTower(_ImageTwoTower):
 
 
 class ResNetTwoTower(NFNetTwoTower):
-    pass
+    """reference image.py:298-378.  The reference calls the encoder once per tower, so its BatchNorm layers see two batches of
+    B images; here both towers are one 2B batch normalised in two segments (models/resnetv2.py)."""
+
+    def _embed(self, images):
+        enc = self.img_encoder
+        had = getattr(enc, "bn_segments", None)
+        if had is not None:
+            enc.bn_segments = 2
+        try:
+            return enc.head.global_pool(enc.forward_features(images)).flatten(1)
+        finally:
+            if had is not None:
+                enc.bn_segments = had

@@ -650,6 +650,104 @@ def nfnet_two_tower(sd, cfg, ncfg, images_1, images_2, labels=None, training=Fal
     return image_two_tower(sd, cfg, f1, f2, labels, training)
 
 
+# ------------------------------------------------------------------------------------- ResNetV2 (pre-activation, BatchNorm)
+# timm 0.6.5 resnetv2.py, `resnetv2_50` = ResNetV2(layers=[3, 4, 6, 3], conv_layer=create_conv2d, norm_layer=BatchNormAct2d):
+# third-party, absent offline -> restated from the published definitions (parity unpinned, like the NFNet tower).  Called by
+# the reference at finetune_image.py:191,215-216 and image.py:337-341.
+
+
+def resnetv2_cfg(name="resnetv2_50"):
+    from types import SimpleNamespace
+    layers = {"resnetv2_50": (3, 4, 6, 3), "resnetv2_101": (3, 4, 23, 3), "resnetv2_152": (3, 8, 36, 3)}[name]
+    return SimpleNamespace(layers=layers, channels=(256, 512, 1024, 2048), stem_chs=64, bottle_ratio=0.25, eps=1e-5, momentum=0.1,
+                           num_features=2048)
+
+
+def resnetv2_plan(cfg):
+    """ResNetV2.__init__ / ResNetStage: the first block of every stage projects (DownsampleConv, preact=True -> no norm) and
+    carries the stage stride (1 for stage 0, 2 after)."""
+    stages, prev = [], cfg.stem_chs
+    for si, (depth, c) in enumerate(zip(cfg.layers, cfg.channels)):
+        blocks = []
+        for bi in range(depth):
+            blocks.append(dict(in_chs=prev, out_chs=c, mid_chs=make_divisible(c * cfg.bottle_ratio), stride=(1 if si == 0 else 2) if bi == 0 else 1,
+                               downsample=bi == 0))
+            prev = c
+        stages.append(blocks)
+    return stages
+
+
+def bn_act(x, sd, p, cfg, training, stats=None):
+    """BatchNormAct2d = nn.BatchNorm2d + ReLU.  training: batch statistics (biased variance) and, when `stats` (a dict of
+    running buffers) is given, the momentum update with the unbiased variance."""
+    w, b = sd[p + ".weight"], sd[p + ".bias"]
+    if training:
+        rm = stats[p + ".running_mean"] if stats is not None else None
+        rv = stats[p + ".running_var"] if stats is not None else None
+        return F.relu(F.batch_norm(x, rm, rv, w, b, True, cfg.momentum, cfg.eps))
+    return F.relu(F.batch_norm(x, stats[p + ".running_mean"], stats[p + ".running_var"], w, b, False, cfg.momentum, cfg.eps))
+
+
+def preact_bottleneck(x, sd, p, blk, cfg, training, stats):
+    """timm resnetv2.py PreActBottleneck.forward"""
+    pre = bn_act(x, sd, p + ".norm1", cfg, training, stats)
+    shortcut = x
+    if blk["downsample"]:
+        shortcut = F.conv2d(pre, sd[p + ".downsample.conv.weight"], None, stride=blk["stride"])
+    out = F.conv2d(pre, sd[p + ".conv1.weight"])
+    out = F.conv2d(bn_act(out, sd, p + ".norm2", cfg, training, stats), sd[p + ".conv2.weight"], None, stride=blk["stride"], padding=1)
+    out = F.conv2d(bn_act(out, sd, p + ".norm3", cfg, training, stats), sd[p + ".conv3.weight"])
+    return out + shortcut
+
+
+def resnetv2_forward_features(sd, p, cfg, images, training=True, stats=None):
+    """ResNetV2.forward_features: stem (7x7/2 conv, MaxPool 3/2/1), stages, final BatchNormAct2d."""
+    x = F.conv2d(images, sd[p + ".stem.conv.weight"], None, stride=2, padding=3)
+    x = F.max_pool2d(x, 3, 2, 1)
+    for si, blocks in enumerate(resnetv2_plan(cfg)):
+        for bi, blk in enumerate(blocks):
+            x = preact_bottleneck(x, sd, f"{p}.stages.{si}.blocks.{bi}", blk, cfg, training, stats)
+    return bn_act(x, sd, p + ".norm", cfg, training, stats)
+
+
+def resnetv2_state_spec(cfg, prefix="img_encoder"):
+    spec = [(prefix + ".stem.conv.weight", (cfg.stem_chs, 3, 7, 7))]
+
+    def norm(name, c):
+        spec.extend([(name + ".weight", (c,)), (name + ".bias", (c,))])
+    for si, blocks in enumerate(resnetv2_plan(cfg)):
+        for bi, b in enumerate(blocks):
+            q = f"{prefix}.stages.{si}.blocks.{bi}"
+            if b["downsample"]:
+                spec.append((q + ".downsample.conv.weight", (b["out_chs"], b["in_chs"], 1, 1)))
+            norm(q + ".norm1", b["in_chs"])
+            spec.append((q + ".conv1.weight", (b["mid_chs"], b["in_chs"], 1, 1)))
+            norm(q + ".norm2", b["mid_chs"])
+            spec.append((q + ".conv2.weight", (b["mid_chs"], b["mid_chs"], 3, 3)))
+            norm(q + ".norm3", b["mid_chs"])
+            spec.append((q + ".conv3.weight", (b["out_chs"], b["mid_chs"], 1, 1)))
+    norm(prefix + ".norm", cfg.channels[-1])
+    return spec
+
+
+def resnetv2_running_stats(cfg, prefix="img_encoder"):
+    """fresh running buffers (mean 0, var 1) keyed like the state_dict"""
+    st = {}
+    for k, shape in resnetv2_state_spec(cfg, prefix):
+        if ".norm" in k and k.endswith(".weight"):
+            st[k[:-7] + ".running_mean"] = torch.zeros(shape)
+            st[k[:-7] + ".running_var"] = torch.ones(shape)
+    return st
+
+
+def resnetv2_two_tower(sd, cfg, rcfg, images_1, images_2, labels=None, training=False, stats=None):
+    """reference image.py:337-378 ResNetTwoTower.forward: the two towers are two separate forward calls (their BatchNorm
+    statistics are per call), global average pool, flatten, pair head."""
+    f1 = resnetv2_forward_features(sd, "img_encoder", rcfg, images_1, training, stats).mean((2, 3))
+    f2 = resnetv2_forward_features(sd, "img_encoder", rcfg, images_2, training, stats).mean((2, 3))
+    return image_two_tower(sd, cfg, f1, f2, labels, training)
+
+
 # ---------------------------------------------------------------------------------------- optimiser step
 
 

@@ -439,3 +439,89 @@ def test_silu_between_padded_and_compact_layouts(gpu):
             assert inner.abs().max().item() == 0.0
         else:
             assert rel_err(dx, xr.grad) < 1e-2
+
+
+@pytest.mark.parametrize("rows,C,segments", [(64, 64, 1), (2 * 1000, 256, 2), (3 * 77, 16, 3), (4096, 2048, 1)])
+def test_batchnorm_relu_fwd_bwd(gpu, rows, C, segments):
+    """ia_bn_act_* (BatchNorm2d + ReLU on NHWC rows, per-segment batch statistics) against torch batch_norm in fp32 on the same
+    bf16-rounded input, one call per segment as the reference's two tower calls do; running statistics included."""
+    from item_alignment_amd import _lib
+    from item_alignment_amd.ops import check, stream_ptr
+    lib = _lib.load()
+    x = rnd((rows, C), gpu, 1.5, 31) + 0.4
+    dy = rnd((rows, C), gpu, 1.0, 32)
+    extra = rnd((rows, C), gpu, 1.0, 33)
+    gamma = (1 + 0.2 * torch.randn(C, device=gpu)).contiguous()
+    beta = (0.1 * torch.randn(C, device=gpu)).contiguous()
+    rm, rv = torch.zeros(C, device=gpu), torch.ones(C, device=gpu)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    xr = x.float().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rps = rows // segments
+    ys = [torch.relu(torch.nn.functional.batch_norm(xr[s * rps:(s + 1) * rps].t().reshape(1, C, rps), rm_ref, rv_ref, gr, br, True, 0.1, 1e-5))
+          for s in range(segments)]
+    ref = torch.cat([y.reshape(C, rps).t() for y in ys])
+    ref.backward(dy.float())
+
+    y = torch.empty_like(x)
+    mean = torch.empty((segments, C), device=gpu)
+    rstd = torch.empty((segments, C), device=gpu)
+    wsb = lib.ia_bn_act_workspace_bytes(rows, C, segments)
+    ws = torch.empty(wsb, device=gpu, dtype=torch.uint8)
+    check(lib.ia_bn_act_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                            rstd.data_ptr(), rows, C, segments, 1e-5, 0.1, 1, 1, ws.data_ptr(), wsb, stream_ptr()), "bn_fwd")
+    assert rel_err(y, ref) < 1e-2
+    assert rel_err(rm, rm_ref) < 1e-3 and rel_err(rv, rv_ref) < 1e-3
+    dx = torch.empty_like(x)
+    dg, db = torch.zeros(C, device=gpu), torch.zeros(C, device=gpu)
+    check(lib.ia_bn_act_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(), extra.data_ptr(),
+                            dx.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, C, segments, 1, 1, ws.data_ptr(), wsb, stream_ptr()), "bn_bwd")
+    assert rel_err(dx, xr.grad + extra.float()) < 2e-2
+    assert rel_err(dg, gr.grad) < 5e-3 and rel_err(db, br.grad) < 5e-3
+    # eval mode: running statistics
+    check(lib.ia_bn_act_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                            rstd.data_ptr(), rows, C, segments, 1e-5, 0.1, 0, 1, ws.data_ptr(), wsb, stream_ptr()), "bn_eval")
+    ref_ev = torch.relu((x.float() - rm) * torch.rsqrt(rv + 1e-5) * gamma + beta)
+    assert rel_err(y, ref_ev) < 1e-2
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 9, 12, 16), (1, 32, 32, 64), (2, 7, 7, 8)])
+def test_maxpool_stem_patches_and_subsample(gpu, B, H, W, C):
+    """MaxPool 3/2/1 (ties go to the first maximum, as PyTorch routes the gradient), the strided-row gather of a 1x1/2
+    convolution and the 7x7/2 stem patch matrix, each against the torch op."""
+    from item_alignment_amd import _lib
+    from item_alignment_amd.ops import check, stream_ptr
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randint(-3, 4, (B, H, W, C), generator=g).float() * 0.5).to(gpu).bfloat16()      # coarse values: many ties
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    ref = torch.nn.functional.max_pool2d(xr, 3, 2, 1)
+    dy = rnd((B, Ho, Wo, C), gpu, 1.0, 5)
+    ref.backward(dy.float().permute(0, 3, 1, 2))
+    y = torch.empty((B, Ho, Wo, C), device=gpu, dtype=torch.bfloat16)
+    arg = torch.empty((B, Ho, Wo, C), device=gpu, dtype=torch.uint8)
+    check(lib.ia_maxpool3s2_fwd(x.data_ptr(), y.data_ptr(), arg.data_ptr(), B, H, W, C, stream_ptr()), "maxpool_fwd")
+    assert torch.equal(y.float(), ref.permute(0, 2, 3, 1))
+    dx = torch.empty_like(x)
+    check(lib.ia_maxpool3s2_bwd(dy.data_ptr(), arg.data_ptr(), dx.data_ptr(), B, H, W, C, stream_ptr()), "maxpool_bwd")
+    assert rel_err(dx, xr.grad.permute(0, 2, 3, 1)) < 1e-2
+
+    sub = torch.empty((B, Ho, Wo, C), device=gpu, dtype=torch.bfloat16)
+    check(lib.ia_rows_subsample_fwd(x.data_ptr(), sub.data_ptr(), B, H, W, C, 2, stream_ptr()), "subsample_fwd")
+    assert torch.equal(sub, x[:, ::2, ::2].contiguous())
+    base = rnd((B, H, W, C), gpu, 1.0, 6)
+    back = torch.empty_like(x)
+    check(lib.ia_rows_subsample_bwd(dy.data_ptr(), base.data_ptr(), back.data_ptr(), B, H, W, C, 2, stream_ptr()), "subsample_bwd")
+    want = base.float().clone()
+    want[:, ::2, ::2] += dy.float()
+    assert rel_err(back, want) < 1e-2
+
+    img = torch.randn((B, 3, H * 4, W * 4), generator=g).to(gpu)
+    Hs, Ws = (H * 4 + 6 - 7) // 2 + 1, (W * 4 + 6 - 7) // 2 + 1
+    cols = torch.empty((B * Hs * Ws, 152), device=gpu, dtype=torch.bfloat16)
+    check(lib.ia_patches_nchw(img.data_ptr(), cols.data_ptr(), B, 3, H * 4, W * 4, 7, 2, 3, 152, stream_ptr()), "patches")
+    unf = torch.nn.functional.unfold(img, 7, padding=3, stride=2)                        # [B, 3*49 (c, ky, kx), L]
+    want = unf.view(B, 3, 49, Hs * Ws).permute(0, 3, 2, 1).reshape(B * Hs * Ws, 147)      # column (ky*7+kx)*3 + c
+    assert torch.equal(cols[:, :147].float(), want.bfloat16().float())
+    assert cols[:, 147:].abs().max().item() == 0.0

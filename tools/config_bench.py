@@ -67,6 +67,17 @@ def c3(pairs=8, S=800):
     run(f"C3 eca_nfnet_l0 two_tower {S}x{S}", M.NFNetTwoTower(cfg, M.create_model("eca_nfnet_l0")), lambda m: m(im1, im2, labels), pairs, 6.49e11)
 
 
+def c3r(pairs=8, S=800):
+    """resnetv2_50 two_tower (reference README.md:187-197): 4.1 GMAC @224 (timm model table) -> 52.3 GMAC / image @800"""
+    from types import SimpleNamespace
+    cfg = SimpleNamespace(num_labels=2, hidden_dropout_prob=0.1, loss_type="ce", loss_margin=0.0, classification_method="cls", hidden_size=2048)
+    g = torch.Generator().manual_seed(0)
+    im1, im2 = torch.randn((pairs, 3, S, S), generator=g).to(dev), torch.randn((pairs, 3, S, S), generator=g).to(dev)
+    labels = torch.randint(0, 2, (pairs,), generator=g).to(dev)
+    torch.manual_seed(2345)
+    run(f"C3r resnetv2_50 two_tower {S}x{S}", M.ResNetTwoTower(cfg, M.create_model("resnetv2_50")), lambda m: m(im1, im2, labels), pairs, 6.28e11)
+
+
 def c4(pairs=128):
     S, P = 50, 30
     cfg = roberta_large_config(interaction_type="one_tower", max_seq_len=S, max_seq_len_pv=None, max_pvs=P, num_entities=258211,
