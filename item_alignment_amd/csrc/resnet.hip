@@ -74,17 +74,35 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const bf16* __restrict_
   }
 }
 
+// sum over the nsplit partials of (segment, channel): 16 lanes take every 16th partial, then lane 0 folds the 16 lane sums in
+// order (fixed order -> deterministic).  Block = 16 channels x 16 lanes.
+IA_DEV void fold_partials(const float* __restrict__ part, size_t plane, int seg, int nsplit, int C, int c, int lane, float* red, float& s, float& q) {
+  s = 0.f; q = 0.f;
+  if (c < C)
+    for (int i = lane; i < nsplit; i += 16) { s += part[((size_t)seg * nsplit + i) * C + c]; q += part[plane + ((size_t)seg * nsplit + i) * C + c]; }
+  __syncthreads();
+  red[threadIdx.x * 2] = s; red[threadIdx.x * 2 + 1] = q;
+  __syncthreads();
+  if (lane == 0) {
+    const int ch = threadIdx.x >> 4;
+    s = 0.f; q = 0.f;
+    for (int l = 0; l < 16; ++l) { s += red[(ch * 16 + l) * 2]; q += red[(ch * 16 + l) * 2 + 1]; }
+  }
+}
+
 // forward finish: mean / rstd per (segment, channel) from the partial sums; running statistics follow nn.BatchNorm2d (momentum
 // update with the unbiased variance), one segment after the other exactly as two consecutive forward calls would do
 __global__ __launch_bounds__(256) void bn_finish_fwd_kernel(const float* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd,
                                                             float* __restrict__ running_mean, float* __restrict__ running_var, int C, int nsplit,
                                                             int segments, int rows_per_seg, float eps, float momentum, size_t plane) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
+  __shared__ float red[512];
+  const int c = blockIdx.x * 16 + (threadIdx.x >> 4), lane = threadIdx.x & 15;
+  const bool owner = lane == 0 && c < C;
+  float rm = (owner && running_mean) ? running_mean[c] : 0.f, rv = (owner && running_var) ? running_var[c] : 0.f;
   for (int seg = 0; seg < segments; ++seg) {
-    float s = 0.f, q = 0.f;
-    for (int i = 0; i < nsplit; ++i) { s += part[((size_t)seg * nsplit + i) * C + c]; q += part[plane + ((size_t)seg * nsplit + i) * C + c]; }
+    float s, q;
+    fold_partials(part, plane, seg, nsplit, C, c, lane, red, s, q);
+    if (!owner) continue;
     const float n = (float)rows_per_seg, mu = s / n;
     float var = q / n - mu * mu;
     var = var < 0.f ? 0.f : var;
@@ -93,8 +111,8 @@ __global__ __launch_bounds__(256) void bn_finish_fwd_kernel(const float* __restr
     rm = (1.f - momentum) * rm + momentum * mu;
     rv = (1.f - momentum) * rv + momentum * var * (n > 1.f ? n / (n - 1.f) : 1.f);
   }
-  if (running_mean) running_mean[c] = rm;
-  if (running_var) running_var[c] = rv;
+  if (owner && running_mean) running_mean[c] = rm;
+  if (owner && running_var) running_var[c] = rv;
 }
 
 // eval mode: mean / rstd from the running statistics (every segment alike)
@@ -105,41 +123,65 @@ __global__ __launch_bounds__(256) void bn_running_kernel(const float* __restrict
   for (int seg = 0; seg < segments; ++seg) { mean[seg * C + c] = running_mean[c]; rstd[seg * C + c] = rsqrtf(running_var[c] + eps); }
 }
 
+// Row-slab layout shared by the element-wise passes: blockIdx.y = segment, blockIdx.x = slab of `per` rows; the block is
+// (C/8 column threads) x (row lanes), so a thread keeps its 8 channels for the whole slab and loads their statistics once.
+struct Slab { int r0, r1, ncol, nlane, col, lane, c8n; size_t base; };
+IA_DEV Slab slab_of(int rows_per_seg, int C, int per) {
+  Slab t;
+  t.r0 = blockIdx.x * per; t.r1 = min(rows_per_seg, t.r0 + per);
+  t.c8n = C >> 3;
+  t.ncol = t.c8n < 256 ? t.c8n : 256; t.nlane = 256 / t.ncol;
+  t.col = threadIdx.x % t.ncol; t.lane = threadIdx.x / t.ncol;
+  t.base = (size_t)blockIdx.y * rows_per_seg;
+  return t;
+}
+IA_DEV void load8(const float* __restrict__ p, float* v) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+
 // y = act((x - mean) * rstd * gamma + beta)
 __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, bf16* __restrict__ y,
-                                                       int rows_per_seg, int C, int relu, size_t total) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int c8n = C >> 3, c = (int)(idx % c8n) * 8;
-  const size_t row = idx / c8n;
-  const int seg = (int)(row / rows_per_seg);
-  const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + row * C + c);
-  bf16x8 o;
+                                                       int rows_per_seg, int C, int relu, int per) {
+  const Slab t = slab_of(rows_per_seg, C, per);
+  const int seg = blockIdx.y;
+  for (int c0 = 0; c0 < t.c8n; c0 += t.ncol) {
+    if (t.lane >= t.nlane || c0 + t.col >= t.c8n) continue;
+    const int c = (c0 + t.col) * 8;
+    float mu[8], sc[8], sh[8], ga[8];
+    load8(mean + seg * C + c, mu); load8(rstd + seg * C + c, sc); load8(gamma + c, ga); load8(beta + c, sh);
+    for (int r = t.r0 + t.lane; r < t.r1; r += t.nlane) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (t.base + r) * C + c);
+      bf16x8 o;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    float f = (bf2f(v[j]) - mean[seg * C + c + j]) * rstd[seg * C + c + j] * gamma[c + j] + beta[c + j];
-    if (relu && f < 0.f) f = 0.f;
-    o[j] = f2bf(f);
+      for (int j = 0; j < 8; ++j) {
+        float f = (bf2f(v[j]) - mu[j]) * sc[j] * ga[j] + sh[j];
+        if (relu && f < 0.f) f = 0.f;
+        o[j] = f2bf(f);
+      }
+      *reinterpret_cast<bf16x8*>(y + (t.base + r) * C + c) = o;
+    }
   }
-  *reinterpret_cast<bf16x8*>(y + row * C + c) = o;
 }
 
 // backward finish: sums[seg][c] = (sum g, sum g*xhat); dgamma += sum over segments of sum g*xhat, dbeta += sum g
 __global__ __launch_bounds__(256) void bn_finish_bwd_kernel(const float* __restrict__ part, float* __restrict__ sums, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, int C, int nsplit, int segments, size_t plane) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float red[512];
+  const int c = blockIdx.x * 16 + (threadIdx.x >> 4), lane = threadIdx.x & 15;
+  const bool owner = lane == 0 && c < C;
   float dg = 0.f, db = 0.f;
   for (int seg = 0; seg < segments; ++seg) {
-    float s = 0.f, q = 0.f;
-    for (int i = 0; i < nsplit; ++i) { s += part[((size_t)seg * nsplit + i) * C + c]; q += part[plane + ((size_t)seg * nsplit + i) * C + c]; }
+    float s, q;
+    fold_partials(part, plane, seg, nsplit, C, c, lane, red, s, q);
+    if (!owner) continue;
     sums[(seg * 2) * C + c] = s;
     sums[(seg * 2 + 1) * C + c] = q;
     db += s; dg += q;
   }
-  if (dgamma) dgamma[c] += dg;
-  if (dbeta) dbeta[c] += db;
+  if (owner && dgamma) dgamma[c] += dg;
+  if (owner && dbeta) dbeta[c] += db;
 }
 
 // dx = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat))  [training]   or   gamma * rstd * g  [eval: statistics are constants]
@@ -147,28 +189,41 @@ __global__ __launch_bounds__(256) void bn_finish_bwd_kernel(const float* __restr
 __global__ __launch_bounds__(256) void bn_dx_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x, const float* __restrict__ mean,
                                                     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     const float* __restrict__ sums, const bf16* __restrict__ extra, bf16* __restrict__ dx,
-                                                    int rows_per_seg, int C, int relu, int training, size_t total) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int c8n = C >> 3, c = (int)(idx % c8n) * 8;
-  const size_t row = idx / c8n;
-  const int seg = (int)(row / rows_per_seg);
+                                                    int rows_per_seg, int C, int relu, int training, int per) {
+  const Slab t = slab_of(rows_per_seg, C, per);
+  const int seg = blockIdx.y;
   const float inv_n = 1.f / (float)rows_per_seg;
-  const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + row * C + c), g8 = *reinterpret_cast<const bf16x8*>(dy + row * C + c);
-  bf16x8 e8;
-  if (extra) e8 = *reinterpret_cast<const bf16x8*>(extra + row * C + c);
-  bf16x8 o;
+  for (int c0 = 0; c0 < t.c8n; c0 += t.ncol) {
+    if (t.lane >= t.nlane || c0 + t.col >= t.c8n) continue;
+    const int c = (c0 + t.col) * 8;
+    float mu[8], rs[8], ga[8], be[8], k1[8], k2[8], k3[8];
+    load8(mean + seg * C + c, mu); load8(rstd + seg * C + c, rs); load8(gamma + c, ga); load8(beta + c, be);
+    load8(sums + (seg * 2) * C + c, k2); load8(sums + (seg * 2 + 1) * C + c, k3);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float rs = rstd[seg * C + c + j], ga = gamma[c + j];
-    const float xh = (bf2f(v[j]) - mean[seg * C + c + j]) * rs;
-    float g = bf2f(g8[j]);
-    if (relu && xh * ga + beta[c + j] <= 0.f) g = 0.f;
-    float d = training ? ga * rs * (g - sums[(seg * 2) * C + c + j] * inv_n - xh * sums[(seg * 2 + 1) * C + c + j] * inv_n) : ga * rs * g;
-    if (extra) d += bf2f(e8[j]);
-    o[j] = f2bf(d);
+    for (int j = 0; j < 8; ++j) {
+      k1[j] = ga[j] * rs[j];
+      k2[j] = training ? k2[j] * inv_n : 0.f;          // mean(g)
+      k3[j] = training ? k3[j] * inv_n : 0.f;          // mean(g * xhat)
+    }
+    for (int r = t.r0 + t.lane; r < t.r1; r += t.nlane) {
+      const size_t off = (t.base + r) * C + c;
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + off);
+      const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(dy + off);
+      bf16x8 e8;
+      if (extra) e8 = *reinterpret_cast<const bf16x8*>(extra + off);
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = (bf2f(v[j]) - mu[j]) * rs[j];
+        float g = bf2f(g8[j]);
+        if (relu && xh * ga[j] + be[j] <= 0.f) g = 0.f;
+        float d = k1[j] * (g - k2[j] - xh * k3[j]);
+        if (extra) d += bf2f(e8[j]);
+        o[j] = f2bf(d);
+      }
+      *reinterpret_cast<bf16x8*>(dx + off) = o;
+    }
   }
-  *reinterpret_cast<bf16x8*>(dx + row * C + c) = o;
 }
 
 // ------------------------------------------------------------------------------------------ stem patch gather
@@ -176,19 +231,25 @@ __global__ __launch_bounds__(256) void bn_dx_kernel(const bf16* __restrict__ dy,
 // image and in the padding columns [k*k*C, Kp)
 __global__ __launch_bounds__(256) void patches_nchw_kernel(const float* __restrict__ img, bf16* __restrict__ cols, int C, int H, int W, int Ho,
                                                            int Wo, int k, int stride, int pad, int Kp, size_t total) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;      // over m * Kp
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;      // over m * Kp/8: one 16-byte store of 8 columns per thread
   if (idx >= total) return;
-  const int kk = (int)(idx % Kp);
-  const size_t m = idx / Kp;
-  float v = 0.f;
-  if (kk < k * k * C) {
-    const int c = kk % C, t = kk / C, ky = t / k, kx = t % k;
-    const int ox = (int)(m % Wo), oy = (int)((m / Wo) % Ho);
-    const size_t b = m / ((size_t)Wo * Ho);
-    const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
-    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = img[((b * C + c) * H + iy) * (size_t)W + ix];
+  const int k8n = Kp >> 3, kk0 = (int)(idx % k8n) * 8;
+  const size_t m = idx / k8n;
+  const int ox = (int)(m % Wo), oy = (int)((m / Wo) % Ho);
+  const size_t b = m / ((size_t)Wo * Ho);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int kk = kk0 + j;
+    float v = 0.f;
+    if (kk < k * k * C) {
+      const int c = kk % C, t = kk / C, ky = t / k, kx = t % k;
+      const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = img[((b * C + c) * H + iy) * (size_t)W + ix];
+    }
+    o[j] = f2bf(v);
   }
-  cols[idx] = f2bf(v);
+  *reinterpret_cast<bf16x8*>(cols + m * Kp + kk0) = o;
 }
 
 // ------------------------------------------------------------------------------------------- MaxPool 3x3 / 2 / pad 1
@@ -324,6 +385,8 @@ __global__ __launch_bounds__(256) void weight_unpack_grad_kernel(const float* __
   dw[idx] += dwhat[o * ldw + t * Cgp + c];
 }
 
+// rows per block of the element-wise passes: 16 rows per row lane
+inline int slab_rows(int C) { const int c8n = C >> 3, ncol = c8n < 256 ? c8n : 256; return (256 / ncol) * 16; }
 inline int bn_nsplit(int rows_per_seg) { int n = rows_per_seg / 64; return n < 1 ? 1 : (n > 128 ? 128 : n); }
 
 }  // namespace
@@ -351,16 +414,16 @@ extern "C" int ia_bn_act_fwd(const void* x, const float* gamma, const float* bet
     const size_t plane = (size_t)segments * ns * C;
     hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(ns, segments), dim3(256), 0, stream, (const bf16*)x, (const bf16*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)workspace, rps, C, ns, 0, plane);
-    hipLaunchKernelGGL(bn_finish_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)workspace, mean, rstd, running_mean,
+    hipLaunchKernelGGL(bn_finish_fwd_kernel, dim3((C + 15) / 16), dim3(256), 0, stream, (const float*)workspace, mean, rstd, running_mean,
                        running_var, C, ns, segments, rps, eps, momentum, plane);
   } else {
     if (!running_mean || !running_var) return IA_ERR_ARG;
     hipLaunchKernelGGL(bn_running_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)running_mean, (const float*)running_var, mean,
                        rstd, C, segments, eps);
   }
-  const size_t total = (size_t)rows * (C >> 3);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)x, (const float*)mean, (const float*)rstd, gamma,
-                     beta, (bf16*)y, rps, C, relu, total);
+  const int per = slab_rows(C);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((rps + per - 1) / per, segments), dim3(256), 0, stream, (const bf16*)x, (const float*)mean,
+                     (const float*)rstd, gamma, beta, (bf16*)y, rps, C, relu, per);
   return ia_check_launch();
 }
 
@@ -376,11 +439,11 @@ extern "C" int ia_bn_act_bwd(const void* dy, const void* x, const float* gamma, 
   float* sums = (float*)workspace + 2 * plane;
   hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(ns, segments), dim3(256), 0, stream, (const bf16*)x, (const bf16*)dy, mean, rstd, gamma, beta,
                      (float*)workspace, rps, C, ns, relu, plane);
-  hipLaunchKernelGGL(bn_finish_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)workspace, sums, dgamma, dbeta, C, ns, segments,
+  hipLaunchKernelGGL(bn_finish_bwd_kernel, dim3((C + 15) / 16), dim3(256), 0, stream, (const float*)workspace, sums, dgamma, dbeta, C, ns, segments,
                      plane);
-  const size_t total = (size_t)rows * (C >> 3);
-  hipLaunchKernelGGL(bn_dx_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)x, mean, rstd, gamma, beta,
-                     (const float*)sums, (const bf16*)extra, (bf16*)dx, rps, C, relu, training, total);
+  const int per = slab_rows(C);
+  hipLaunchKernelGGL(bn_dx_kernel, dim3((rps + per - 1) / per, segments), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)x, mean, rstd, gamma,
+                     beta, (const float*)sums, (const bf16*)extra, (bf16*)dx, rps, C, relu, training, per);
   return ia_check_launch();
 }
 
@@ -391,7 +454,7 @@ extern "C" int ia_patches_nchw(const float* images, void* cols, int B, int C, in
   if (!images || !cols || B <= 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0 || stride <= 0 || pad < 0 || Kp < k * k * C || (Kp & 7)) return IA_ERR_ARG;
   const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
   if (Ho <= 0 || Wo <= 0) return IA_ERR_ARG;
-  const size_t total = (size_t)B * Ho * Wo * Kp;
+  const size_t total = (size_t)B * Ho * Wo * (Kp >> 3);
   hipLaunchKernelGGL(patches_nchw_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, images, (bf16*)cols, C, H, W, Ho, Wo, k, stride, pad, Kp, total);
   return ia_check_launch();
 }
