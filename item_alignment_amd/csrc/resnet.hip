@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void weight_unpack_grad_kernel(const float* __
 
 // rows per block of the element-wise passes: 16 rows per row lane
 inline int slab_rows(int C) { const int c8n = C >> 3, ncol = c8n < 256 ? c8n : 256; return (256 / ncol) * 16; }
-inline int bn_nsplit(int rows_per_seg) { int n = rows_per_seg / 64; return n < 1 ? 1 : (n > 128 ? 128 : n); }
+inline int bn_nsplit(int rows_per_seg) { int n = rows_per_seg / 64; return n < 1 ? 1 : (n > 512 ? 512 : n); }   // >= 1024 blocks on big maps
 
 }  // namespace
 
