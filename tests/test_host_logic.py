@@ -144,6 +144,35 @@ def test_nfnet_module_matches_timm_names():
     assert sum(p.numel() for p in net.parameters()) == 24143924
 
 
+def test_resnetv2_structure_and_timm_names():
+    """The ResNetV2 restatement (timm is absent: parity unpinned) reproduces the published structure of resnetv2_50: 25.55 M
+    parameters with the 1000-way fc (timm model table), 2048 features, the first block of every stage projecting and carrying
+    the stride; the HIP module has timm's state_dict keys (BatchNorm buffers included)."""
+    import torch
+    from item_alignment_amd.models import create_model
+    from oracle import ref_models as O
+    cfg = O.resnetv2_cfg("resnetv2_50")
+    spec = O.resnetv2_state_spec(cfg)
+    n = sum(int(torch.tensor(s).prod()) for _, s in spec) + 2048 * 1000 + 1000
+    assert abs(n / 1e6 - 25.55) < 0.01, n
+    plan = O.resnetv2_plan(cfg)
+    assert [len(s) for s in plan] == [3, 4, 6, 3]
+    assert [s[0]["stride"] for s in plan] == [1, 2, 2, 2] and all(b["stride"] == 1 and not b["downsample"] for s in plan for b in s[1:])
+    assert [s[0]["mid_chs"] for s in plan] == [64, 128, 256, 512] and all(s[0]["downsample"] for s in plan)
+    net = create_model("resnetv2_50")
+    want = {k[len("img_encoder."):]: s for k, s in spec}
+    have = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    extra = set(have) - set(want)
+    assert set(want) <= set(have)
+    assert all(k.startswith("head.fc") or k.endswith(("running_mean", "running_var", "num_batches_tracked")) for k in extra), extra
+    assert all(have[k] == tuple(s) for k, s in want.items())
+    assert sum(p.numel() for p in net.parameters()) == n
+    x = torch.randn(2, 3, 64, 64)
+    from oracle.weights import seeded_state_dict
+    y = O.resnetv2_forward_features(seeded_state_dict(spec, 1), "img_encoder", cfg, x, True, O.resnetv2_running_stats(cfg))
+    assert tuple(y.shape) == (2, 2048, 2, 2) and torch.isfinite(y).all()
+
+
 def test_resize_tables_reproduce_pillow_bit_exact():
     """The host-built resampling tables (data/gpu_preproc.py: Pillow Resample.c precompute_coeffs + normalize_coeffs_8bpc) and
     the 8.22 fixed-point two-pass arithmetic the GPU kernels implement reproduce PIL Image.resize(..., BICUBIC) bit for bit

@@ -1,5 +1,6 @@
+"""BatchNorm+ReLU forward / backward (ia_bn_act_*) bandwidth on the resnetv2_50 @800x800 activation shapes: python tools/bn_bench.py"""
 import sys, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from item_alignment_amd import _lib
 from item_alignment_amd._lib import check, stream_ptr
@@ -24,4 +25,4 @@ for rows, C in [(640000, 256), (640000, 64), (160000, 512), (40000, 1024), (1000
     f = timed(lambda: check(lib.ia_bn_act_fwd(x.data_ptr(), ga.data_ptr(), be.data_ptr(), rm.data_ptr(), rv.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, C, seg, 1e-5, 0.1, 1, 1, ws.data_ptr(), wsb, stream_ptr()), "f"))
     b = timed(lambda: check(lib.ia_bn_act_bwd(dy.data_ptr(), x.data_ptr(), ga.data_ptr(), be.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ex.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, C, seg, 1, 1, ws.data_ptr(), wsb, stream_ptr()), "b"))
     mb = rows * C * 2 / 1e6
-    print(f"rows {rows} C {C}: fwd {f*1e3:.0f} us ({3*mb/f/1e3:.0f} GB/s)  bwd {b*1e3:.0f} us ({6*mb/b/1e3:.0f} GB/s)", flush=True)
+    print(f"rows {rows} C {C}: fwd {f*1e3:.0f} us ({3*mb/f/1e6:.1f} TB/s)  bwd {b*1e3:.0f} us ({6*mb/b/1e6:.1f} TB/s)", flush=True)
