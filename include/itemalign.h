@@ -263,6 +263,13 @@ int ia_pair_head_ce_fwd(const float* x, const float* y, const float* W, const fl
 int ia_pair_head_ce_bwd(const float* probs, const int64_t* labels, const float* dloss, const float* x, const float* y, const float* W,
                         float* dx, float* dy, float* dW, float* db, int B, int D, int C, ia_stream_t stream);
 
+/* span means of the auxiliary attribute-pair task (reference text.py:66-102 AuxiliaryTaskPair: mean of the token rows of a
+ * key:value span, for the source and the target item; the pair head + CE above finishes it).  spans [S][2] int32 = absolute
+ * (first row, end row) into seq [rows, ld] bf16; out [S][H] fp32.  Backward: dseq [B*L, H] bf16 overwritten; span_ptr [B+1]
+ * delimits the spans of each sample. */
+int ia_span_mean_fwd(const void* seq, int ld, const int* spans, float* out, int S, int H, ia_stream_t stream);
+int ia_span_mean_bwd(const float* dout, const int* spans, const int* span_ptr, void* dseq, int B, int L, int H, ia_stream_t stream);
+
 /* ---- optimiser (torch.optim.AdamW, finetune_multimodal.py:296-308,460-468) */
 int ia_adamw_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, const void* chunk_table,
                   int n_chunks, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,

@@ -103,6 +103,8 @@ SIGNATURES = {
     "ia_linear_small_fwd": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "ia_linear_small_bwd": (i32, [vp, vp, vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
     "ia_pair_head_ce_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "ia_span_mean_fwd": (i32, [vp, i32, vp, vp, i32, i32, vp]),
+    "ia_span_mean_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "ia_pair_head_ce_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "ia_adamw_flat": (i32, [vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, i32, f32, vp]),
     "ia_cast_f32_to_bf16": (i32, [vp, vp, sz, vp]),

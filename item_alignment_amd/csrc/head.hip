@@ -138,6 +138,50 @@ __global__ __launch_bounds__(256) void pair_head_bwd_dw_kernel(const float* __re
   if (db && k == 0) db[c] += sb;
 }
 
+// ---- span means of the auxiliary attribute-pair task (reference text.py:66-102 AuxiliaryTaskPair.forward)
+// out[s][h] = mean over rows [spans[s][0], spans[s][1]) of seq[row][h]   (an empty span gives NaN, like torch's mean of nothing)
+__global__ __launch_bounds__(256) void span_mean_fwd_kernel(const bf16* __restrict__ seq, int ld, const int* __restrict__ spans,
+                                                            float* __restrict__ out, int H, int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;       // over S * H/8
+  if (idx >= total) return;
+  const int h8n = H >> 3, h = (idx % h8n) * 8, sp = idx / h8n;
+  const int r0 = spans[2 * sp], r1 = spans[2 * sp + 1];
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(seq + (size_t)r * ld + h);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += bf2f(v[j]);
+  }
+  const float inv = 1.f / (float)(r1 - r0);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) out[(size_t)sp * H + h + j] = acc[j] * inv;
+}
+
+// dseq[row][h] = sum over the spans of this row's sample that contain the row of dout[s][h] / len(s)   (gather form, fixed
+// order -> deterministic; rows outside every span get zero).  span_ptr[b] .. span_ptr[b+1] = spans of sample b.
+__global__ __launch_bounds__(256) void span_mean_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ spans,
+                                                            const int* __restrict__ span_ptr, bf16* __restrict__ dseq, int L, int H, int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;       // over B*L * H/8
+  if (idx >= total) return;
+  const int h8n = H >> 3, h = (idx % h8n) * 8, row = idx / h8n, b = row / L;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int sp = span_ptr[b]; sp < span_ptr[b + 1]; ++sp) {
+    const int r0 = spans[2 * sp], r1 = spans[2 * sp + 1];
+    if (row < r0 || row >= r1) continue;
+    const float inv = 1.f / (float)(r1 - r0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += dout[(size_t)sp * H + h + j] * inv;
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = f2bf(acc[j]);
+  *reinterpret_cast<bf16x8*>(dseq + (size_t)row * H + h) = o;
+}
+
 }  // namespace
 
 extern "C" int ia_linear_small_fwd(const float* x, int ldx, const float* W, const float* bias, float* y, int B, int N, int K, int act,
@@ -180,5 +224,25 @@ extern "C" int ia_pair_head_ce_bwd(const float* probs, const int64_t* labels, co
   const int F = two ? 2 * D : D;
   hipLaunchKernelGGL(pair_head_bwd_dxy_kernel, dim3((B * F + 255) / 256), dim3(256), 0, stream, probs, labels, dloss, W, dx, dy, B, D, C, two);
   if (dW) hipLaunchKernelGGL(pair_head_bwd_dw_kernel, dim3((C * F + 255) / 256), dim3(256), 0, stream, probs, labels, dloss, x, y, dW, db, B, D, C, two);
+  return ia_check_launch();
+}
+
+
+// Span means over token rows (auxiliary attribute-pair task, reference text.py:79-86): seq [rows, ld] bf16, spans [S][2] int32
+// = absolute (first row, end row) of each span, out [S][H] fp32.
+extern "C" int ia_span_mean_fwd(const void* seq, int ld, const int* spans, float* out, int S, int H, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!seq || !spans || !out || S <= 0 || H <= 0 || (H & 7) || (ld & 7)) return IA_ERR_ARG;
+  const int total = S * (H >> 3);
+  hipLaunchKernelGGL(span_mean_fwd_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, (const bf16*)seq, ld, spans, out, H, total);
+  return ia_check_launch();
+}
+
+// dseq [B*L, H] bf16 (overwritten) from dout [S][H] fp32; span_ptr [B+1] int32: spans of sample b are span_ptr[b]..span_ptr[b+1]
+extern "C" int ia_span_mean_bwd(const float* dout, const int* spans, const int* span_ptr, void* dseq, int B, int L, int H, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dout || !spans || !span_ptr || !dseq || B <= 0 || L <= 0 || H <= 0 || (H & 7)) return IA_ERR_ARG;
+  const int total = B * L * (H >> 3);
+  hipLaunchKernelGGL(span_mean_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, dout, spans, span_ptr, (bf16*)dseq, L, H, total);
   return ia_check_launch();
 }

@@ -100,14 +100,54 @@ def collate_coca_pair(inputs):
 
 
 # ------------------------------------------------------------------------------------------------ datasets
+COLON_ID, SEMICOLON_ID = 131, 132        # ":" and ";" in the BERT-zh vocabulary (reference data.py:11-12)
+
+
+def _next_attribute(ids, p, colon, semicolon):
+    """Scan ids[p:] up to the next ";".  Returns (found, p', colon, prev_semicolon, semicolon): the last ":" seen so far (kept
+    from earlier attributes when this one has none, as the reference's running variables do), the previous and the new ";"."""
+    while p < len(ids):
+        if ids[p] == COLON_ID:
+            colon = p
+        elif ids[p] == SEMICOLON_ID:
+            return True, p + 1, colon, semicolon, p
+        p += 1
+    return False, p, colon, None, semicolon
+
+
+def attribute_pair_indices(input_ids, sep_token_id):
+    """reference data.py:568-612 (`--auxiliary_task`): walk the `key:value;` attributes of the source and the target item in
+    step while their keys agree; one row (src start, src end, tgt start, tgt end, values equal) per aligned attribute, positions
+    in the one-tower sequence [CLS] title [SEP] attributes [SEP] title [SEP] attributes [SEP]."""
+    seps = [i for i, t in enumerate(input_ids) if t == sep_token_id]
+    src_off, tgt_off = seps[0] + 1, seps[2] + 1
+    src, tgt = input_ids[seps[0] + 1:seps[1]], input_ids[seps[2] + 1:seps[3]]
+    out = []
+    sp = tp = 0
+    s_colon = t_colon = None
+    s_semi = t_semi = -1
+    while sp < len(src) and tp < len(tgt):
+        ok, sp, s_colon, s_prev, s_semi = _next_attribute(src, sp, s_colon, s_semi)
+        if not ok:
+            break
+        ok, tp, t_colon, t_prev, t_semi = _next_attribute(tgt, tp, t_colon, t_semi)
+        if not ok:
+            break
+        # values are sliced before the keys are compared, as in the reference: an attribute without any ':' so far raises here
+        same = src[s_colon + 1:s_semi] == tgt[t_colon + 1:t_semi]
+        if src[s_prev + 1:s_colon] != tgt[t_prev + 1:t_colon]:          # keys differ: stop
+            break
+        out.append([s_prev + 1 + src_off, s_semi + src_off, t_prev + 1 + tgt_off, t_semi + tgt_off, 1 if same else 0])
+    return out
+
+
 class RobertaOneTowerDataset(Dataset):
-    """reference data.py:519-620 (auxiliary_task pair indices are out of scope)."""
+    """reference data.py:519-620 (with `auxiliary_task`, records also carry `pair_indices`, :568-612)."""
 
     def __init__(self, data, text_tokenizer, max_seq_len, classification_method, max_seq_len_pv=None, auxiliary_task=False):
-        if auxiliary_task:
-            raise NotImplementedError("auxiliary_task is outside the hot path (DESIGN.md)")
         self.data, self.tk = data, text_tokenizer
         self.max_seq_len, self.max_seq_len_pv, self.method = max_seq_len, max_seq_len_pv, classification_method
+        self.auxiliary_task = auxiliary_task
 
     def __len__(self):
         return len(self.data)
@@ -124,6 +164,8 @@ class RobertaOneTowerDataset(Dataset):
         else:
             rec = dict(_tok(self.tk, src_text, 2 * L, text_pair=tgt_text))
         rec.update(labels=int(label), src_item_id=src_id, tgt_item_id=tgt_id)
+        if self.auxiliary_task:
+            rec["pair_indices"] = attribute_pair_indices(rec["input_ids"], self.tk.sep_token_id)
         return rec
 
 

@@ -183,6 +183,30 @@ class GatherRowsFn(torch.autograd.Function):
         return dsrc, None, None, None, None
 
 
+class SpanMeanFn(torch.autograd.Function):
+    """Mean of the token rows of each span, fp32 [S, H] (reference text.py:82-83: sequence_output[i, a:b, :].mean(axis=0))."""
+
+    @staticmethod
+    def forward(ctx, hidden, anchor, spans, span_ptr, B, L):
+        lib = _lib.load()
+        _need_gpu(hidden, "hidden states")
+        hidden = hidden.contiguous()
+        S, H = spans.shape[0], hidden.shape[-1]
+        out = torch.empty((S, H), device=hidden.device, dtype=F32)
+        check(lib.ia_span_mean_fwd(hidden.data_ptr(), H, spans.data_ptr(), out.data_ptr(), S, H, stream_ptr()), "ia_span_mean_fwd")
+        ctx.spans, ctx.span_ptr, ctx.dims, ctx.shape = spans, span_ptr, (B, L, H), hidden.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        B, L, H = ctx.dims
+        dsrc = torch.empty(ctx.shape, device=dout.device, dtype=BF16)
+        check(lib.ia_span_mean_bwd(dout.contiguous().to(F32).data_ptr(), ctx.spans.data_ptr(), ctx.span_ptr.data_ptr(), dsrc.data_ptr(), B, L, H,
+                                   stream_ptr()), "ia_span_mean_bwd")
+        return dsrc, None, None, None, None, None
+
+
 class LinearSmallFn(torch.autograd.Function):
     """y = act(x W^T + b) on a few rows, fp32 (dense+tanh of the heads, img2txt; reference base.py:142-143,530)."""
 

@@ -43,6 +43,7 @@ class RobertaImageModel(HipModule, PretrainedMixin):
 
 class RobertaImageOneTower(RobertaOneTower):
     """reference multimodal.py:213-320."""
+    supports_auxiliary = False
 
     def _make_backbone(self, config):
         return RobertaImageModel(config, add_pooling_layer=False)

@@ -105,8 +105,48 @@ class _PairTowerBase(HipModule, PretrainedMixin):
         return SequenceClassifierOutput(loss=loss, logits=logits, probs=probs, src_embeds=src, tgt_embeds=tgt, hidden_states=hidden_states)
 
 
+class AuxiliaryTaskPair(nn.Module):
+    """reference text.py:66-102: for every (source attribute, target attribute) pair with the same key, the mean token vector of
+    each `key:value` span -> dropout -> Linear(2H -> num_labels); labels say whether the values are equal.  `pair_indices` is
+    the per-sample list the dataset builds (data.py:568-612): rows of (src start, src end, tgt start, tgt end, label).
+    Returns the mean cross-entropy over all pairs of the batch (what `self.loss_fct(logits2, labels2)` adds at :1478-1480)."""
+
+    def __init__(self, config):
+        super().__init__()
+        drop = getattr(config, "classifier_dropout", None)
+        self.drop_p = float(drop if drop is not None else config.hidden_dropout_prob)
+        self.out_proj = nn.Linear(config.hidden_size * 2, config.num_labels)
+
+    def forward(self, taps, pair_indices, anchor, B, L, training):
+        import numpy as np
+        rows, ptr_, labels = [], [0], []
+        for i, pi in enumerate(pair_indices):
+            pi = pi.detach().cpu().numpy() if torch.is_tensor(pi) else np.asarray(pi)
+            for j in range(pi.shape[0] if pi.ndim == 2 else 0):
+                a0, a1, b0, b1, lab = (int(v) for v in pi[j])
+                rows += [(i * L + a0, i * L + a1), (i * L + b0, i * L + b1)]
+                labels.append(lab)
+            ptr_.append(len(rows))
+        ptr_ += [len(rows)] * (B + 1 - len(ptr_))
+        if not labels:
+            raise RuntimeError("auxiliary_task: no attribute pairs in this batch (the reference's torch.stack of an empty list fails likewise)")
+        dev = taps[0].device
+        spans = torch.tensor(rows, dtype=torch.int32, device=dev)
+        span_ptr = torch.tensor(ptr_, dtype=torch.int32, device=dev)
+        labels2 = torch.tensor(labels, dtype=torch.int64, device=dev)
+        H = taps[0].shape[-1]
+        means = [Fn.SpanMeanFn.apply(t.reshape(B * L, H), anchor, spans, span_ptr, B, L) for t in taps]
+        m = means[0] if len(means) == 1 else torch.stack(means).mean(dim=0)
+        x, y = m[0::2], m[1::2]
+        if training and self.drop_p > 0:
+            x, y = F.dropout(x, self.drop_p, True), F.dropout(y, self.drop_p, True)
+        _logits, _probs, loss = Fn.PairHeadCEFn.apply(x, y, self.out_proj, labels2)
+        return loss
+
+
 class RobertaOneTower(_PairTowerBase):
     """reference text.py:1379-1492."""
+    supports_auxiliary = True          # only this class builds AuxiliaryTaskPair in the reference (text.py:1412-1413)
 
     def __init__(self, config):
         super().__init__()
@@ -125,10 +165,16 @@ class RobertaOneTower(_PairTowerBase):
         else:
             self.classifier = RobertaClassificationHead(config)
         self.loss_fct = make_loss(config)
-        if getattr(config, "auxiliary_task", False):
-            raise NotImplementedError("auxiliary_task (reference text.py:66-102) is outside the MI355X hot path (DESIGN.md, out of scope)")
+        if getattr(config, "auxiliary_task", False) and type(self).supports_auxiliary:
+            self._build_auxiliary(config)
         init_bert_weights(self, getattr(config, "initializer_range", 0.02))
         adopt(self, self.roberta)
+
+    def _build_auxiliary(self, config):
+        if config.cls_pool != "avg" and len(self.cls_layers) > 1:
+            raise ValueError("auxiliary_task needs a hidden_size-wide sequence output: one cls layer or cls_pool='avg' "
+                             "(reference text.py:77: out_proj is Linear(2 * hidden_size, num_labels))")
+        self.auxiliary_task = AuxiliaryTaskPair(config)
 
     def _make_backbone(self, config):
         return RobertaModel(config, add_pooling_layer=False)
@@ -168,7 +214,13 @@ class RobertaOneTower(_PairTowerBase):
             logits, probs2, loss = self.classifier(pick(0, 0), labels if ce else None, inputs_embeds=inputs_embeds,
                                                    differentiable_logits=(labels is not None and not ce))
             src, tgt, probs = probs2[:, 0], probs2[:, 1], probs2[:, 1]
-        return self._finish(logits, probs, loss, src, tgt, labels, hidden_states=hs if output_hidden_states else None)
+        out = self._finish(logits, probs, loss, src, tgt, labels, hidden_states=hs if output_hidden_states else None)
+        if labels is not None and hasattr(self, "auxiliary_task"):
+            if self.config.loss_type != "ce":
+                raise ValueError("auxiliary_task adds self.loss_fct(logits2 [P, 2], labels2 [P]) (reference text.py:1478-1480): only "
+                                 "--loss_type ce has that signature")
+            out.loss = out.loss + self.auxiliary_task(taps, image_indices, self.anchor, B, L, training)
+        return out
 
 
 class RobertaTwoTower(_PairTowerBase):
@@ -245,6 +297,7 @@ class RobertaPKGMModel(HipModule, PretrainedMixin):
 
 class PKGMOneTower(RobertaOneTower):
     """reference text.py:691-783 (+ two-file from_pretrained :785-1080)."""
+    supports_auxiliary = False
     weight_files = (ROBERTA_WEIGHTS_NAME, KG_WEIGHTS_NAME)
 
     def __init__(self, config):

@@ -91,9 +91,37 @@ def t(x):
     return None if x is None else torch.from_numpy(np.asarray(x))
 
 
+def aux_case(M):
+    """RobertaOneTower with --auxiliary_task (reference text.py:1412-1413,1478-1480): ragged pair lists incl. a sample with
+    no aligned attribute.  Own RandomState so the other fixtures keep their draws."""
+    rs = np.random.RandomState(777)
+    B = 3
+    cfg = reference_config(**TINY, interaction_type="one_tower", max_seq_len=8, max_seq_len_pv=12, auxiliary_task=True)
+    model = M.RobertaOneTower(cfg).eval()
+    seed = 18
+    spec = load_weights(model, seed)
+    ids, mask, tt = text_batch(rs, B, 40, cfg.vocab_size)
+    labels = np.array([1, 0, 1], dtype=np.int64)
+    pairs = [[[9, 12, 29, 31, 1], [12, 16, 31, 36, 0]], [], [[10, 11, 28, 30, 0], [11, 15, 30, 31, 1], [15, 19, 31, 34, 1]]]
+    pi = [torch.tensor(p, dtype=torch.long) for p in pairs]
+    out = model(input_ids=t(ids), attention_mask=t(mask), token_type_ids=t(tt), position_ids=None, labels=t(labels),
+                output_hidden_states=True, image_indices=pi)
+    out.loss.backward()
+    padded = -np.ones((B, 3, 5), dtype=np.int64)
+    for i, p in enumerate(pairs):
+        for j, r in enumerate(p):
+            padded[i, j] = r
+    save("roberta_one_tower_aux", cfg, seed, spec, dict(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, pair_indices=padded),
+         out, grads_of(model, ["classifier.out_proj.weight", "auxiliary_task.out_proj.weight", "auxiliary_task.out_proj.bias",
+                               "roberta.encoder.layer.1.output.LayerNorm.weight", "roberta.encoder.layer.0.attention.self.query.weight",
+                               "roberta.embeddings.word_embeddings.weight"]))
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     M = load_reference()
+    if "--only-aux" in sys.argv:          # added after the other fixtures were captured: does not disturb their random draws
+        return aux_case(M)
     rs = np.random.RandomState(2345)
     B = 3
 
@@ -326,6 +354,7 @@ def main():
     from types import SimpleNamespace as NS
     save("roberta_large_one_layer", cfg, seed, spec, dict(input_ids=ids, attention_mask=mask, token_type_ids=tt), NS(),
          None, extra=dict(h0_sub=hs[0][0, ::16, ::16], h1_sub=hs[1][0, ::16, ::16], h1_norm=hs[1].norm(), h1_rows=hs[1][0, :4, :]))
+    aux_case(M)
 
 
 if __name__ == "__main__":

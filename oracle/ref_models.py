@@ -201,10 +201,36 @@ def _max_seq_len(cfg):
     return cfg.max_seq_len + cfg.max_seq_len_pv
 
 
-def roberta_one_tower(sd, cfg, input_ids, attention_mask, token_type_ids, position_ids=None, labels=None, training=False):
-    """text.py:1417-1492 RobertaOneTower.forward."""
+def auxiliary_task_pair(sd, p, cfg, sequence_output, pair_indices, training=False):
+    """text.py:79-102 AuxiliaryTaskPair.forward: span means of the (source, target) attribute of every pair row
+    (src start, src end, tgt start, tgt end, label) -> dropout -> Linear(2H -> num_labels).  Returns (logits, labels)."""
+    x, y, labels = [], [], []
+    for i, rows in enumerate(pair_indices):
+        for r in rows:
+            a0, a1, b0, b1, lab = (int(v) for v in r)
+            x.append(sequence_output[i, a0:a1, :].mean(dim=0))
+            y.append(sequence_output[i, b0:b1, :].mean(dim=0))
+            labels.append(lab)
+    x, y = torch.stack(x), torch.stack(y)
+    drop = getattr(cfg, "classifier_dropout", None)
+    drop = drop if drop is not None else cfg.hidden_dropout_prob
+    x, y = dropout(x, drop, training), dropout(y, drop, training)
+    logits = F.linear(torch.cat((x, y), dim=1), sd[p + ".out_proj.weight"], sd[p + ".out_proj.bias"])
+    return logits, torch.tensor(labels, dtype=torch.long)
+
+
+def roberta_one_tower(sd, cfg, input_ids, attention_mask, token_type_ids, position_ids=None, labels=None, training=False,
+                      pair_indices=None):
+    """text.py:1417-1492 RobertaOneTower.forward (with `auxiliary_task`, :1478-1480: + CE over the attribute pairs)."""
     hs = roberta_model(sd, "roberta", cfg, input_ids, attention_mask, token_type_ids, position_ids, training)
-    return _one_tower_tail(sd, cfg, hs, labels, _max_seq_len(cfg), training)
+    out = _one_tower_tail(sd, cfg, hs, labels, _max_seq_len(cfg), training)
+    if labels is not None and getattr(cfg, "auxiliary_task", False):
+        cls_layers = [-int(i) for i in cfg.cls_layers.split(",")]
+        seqs = [hs[i] for i in cls_layers]
+        seq = torch.stack(seqs).mean(dim=0) if cfg.cls_pool == "avg" else torch.cat(seqs, dim=-1)
+        logits2, labels2 = auxiliary_task_pair(sd, "auxiliary_task", cfg, seq, pair_indices, training)
+        out.loss = out.loss + F.cross_entropy(logits2.view(-1, cfg.num_labels), labels2.view(-1))
+    return out
 
 
 def roberta_two_tower(sd, cfg, ids1, mask1, tt1, pos1, ids2, mask2, tt2, pos2, labels=None, training=False):

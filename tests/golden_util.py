@@ -40,6 +40,14 @@ def vit_cfg(case):
     return SimpleNamespace(embed_dim=v[0], depth=v[1], num_heads=v[2], patch_size=v[3], image_size=v[4], eps=1e-6)
 
 
+def pair_list(case):
+    """the fixture stores the ragged `pair_indices` list padded with -1 rows: back to a list of [n_i, 5] tensors (n_i may be 0)"""
+    p = case.inputs.get("pair_indices")
+    if p is None:
+        return None
+    return [rows[(rows[:, 0] >= 0)] for rows in p]
+
+
 def run_oracle(case, sd, training=False):
     """Dispatch a fixture to the oracle function that restates the reference class it was captured from."""
     from oracle import ref_models as O
@@ -47,7 +55,8 @@ def run_oracle(case, sd, training=False):
     g = i.get
     if n.startswith("roberta_one_tower"):
         lab = i["labels"].float() if cfg.loss_type == "bce" else i["labels"]
-        return O.roberta_one_tower(sd, cfg, i["input_ids"], i["attention_mask"], i["token_type_ids"], None, lab, training)
+        return O.roberta_one_tower(sd, cfg, i["input_ids"], i["attention_mask"], i["token_type_ids"], None, lab, training,
+                                   pair_indices=pair_list(case))
     if n.startswith("roberta_two_tower"):
         return O.roberta_two_tower(sd, cfg, i["input_ids_1"], i["attention_mask_1"], i["token_type_ids_1"], None, i["input_ids_2"],
                                    i["attention_mask_2"], i["token_type_ids_2"], None, i["labels"], training)

@@ -113,6 +113,40 @@ def test_finetune_text_roberta_gpu(gpu, tmp_path, interaction, method, measure, 
     assert "f1=" in r.stderr and "loss:" in r.stderr
 
 
+def test_finetune_text_auxiliary_task_gpu(gpu, tmp_path):
+    """`--auxiliary_task` (reference finetune_text.py:82, text.py:66-102,1478-1480): the dataset aligns the `key:value;` attributes
+    of both items, the model adds the attribute-pair cross-entropy (span means -> pair head) to the loss."""
+    root = str(tmp_path)
+    pre = make_data(root, n_train=16, n_test=8)
+    rs = np.random.RandomState(3)
+    for name, n in (("finetune_train.tsv", 16), ("finetune_test.tsv", 8)):
+        with open(os.path.join(root, "processed", "v1", name), "w", encoding="utf-8") as w:
+            for _ in range(n):
+                a, b = rs.choice(40, 2, replace=False)
+                keys = list(rs.choice(WORDS, 3, replace=False))
+                pv = lambda: "".join(f"{k}:{rs.choice(WORDS[:3])};" for k in keys)
+                w.write("\t".join([str(rs.randint(2)), f"i{a}", " ".join(rs.choice(WORDS, 3)), pv(), f"i{b}", " ".join(rs.choice(WORDS, 3)), pv()]) + "\n")
+    vocab_size = len(open(os.path.join(pre, "vocab.txt"), encoding="utf-8").read().split("\n")) - 1
+    cfg = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=vocab_size,
+               max_position_embeddings=64, type_vocab_size=2, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    json.dump(cfg, open(os.path.join(root, "roberta_tiny.json"), "w"))
+    out = os.path.join(root, "out")
+    os.makedirs(out)
+    cmd = [sys.executable, os.path.join(ROOT, "finetune_text.py"), "--data_dir", root, "--output_dir", out, "--config_file",
+           os.path.join(root, "roberta_tiny.json"), "--model_name", "roberta_tiny", "--data_version", "v1", "--interaction_type", "one_tower",
+           "--classification_method", "cls", "--similarity_measure", "NA", "--loss_type", "ce", "--do_train", "--do_eval", "--auxiliary_task",
+           "--train_batch_size", "8", "--eval_batch_size", "4", "--num_train_epochs", "1", "--learning_rate", "1e-4", "--log_steps", "1",
+           "--pretrained_model_path", pre, "--max_seq_len", "8", "--max_seq_len_pv", "16", "--max_position_embeddings", "64", "--fp16"]
+    r = _run(cmd)
+    dirs = os.listdir(out)
+    files = os.listdir(os.path.join(out, dirs[0]))
+    assert any(f.endswith("epoch-0.bin") for f in files), files
+    import torch
+    sd = torch.load(os.path.join(out, dirs[0], [f for f in files if f.endswith("epoch-0.bin")][0]), map_location="cpu")
+    assert tuple(sd["auxiliary_task.out_proj.weight"].shape) == (2, 256)
+    assert "f1=" in r.stderr and "loss:" in r.stderr
+
+
 @pytest.mark.parametrize("interaction", ["one_tower", "two_tower"])
 def test_finetune_text_pkgm_gpu(gpu, tmp_path, interaction):
     """pkgm_* through finetune_text.py: entity / relation id files, KG rows spliced into the sequence (ia_kg_* kernels)."""

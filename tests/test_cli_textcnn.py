@@ -33,7 +33,9 @@ def make_data(root, n_train=48, n_test=16, seed=0):
                 w.write("\t".join([str(rs.randint(2)), a, text(4), pvs(), b, text(4), pvs()]) + "\n")
     pre = os.path.join(root, "pretrained")
     os.makedirs(pre, exist_ok=True)
-    vocab = ["[PAD]"] + [f"[unused{i}]" for i in range(1, 100)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]", "<S>", ":", ";"] + WORDS
+    # ":" / ";" sit at ids 131 / 132 as in the BERT-zh vocabulary (reference data.py:11-12 COLON_ID / SEMICOLON_ID)
+    vocab = ["[PAD]"] + [f"[unused{i}]" for i in range(1, 100)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]", "<S>"] + [f"[fill{i}]" for i in range(26)] + [":", ";"] + WORDS
+    assert vocab.index(":") == 131 and vocab.index(";") == 132
     open(os.path.join(pre, "vocab.txt"), "w", encoding="utf-8").write("\n".join(vocab) + "\n")
     cfg = dict(hidden_size=32, num_hidden_layers=1, num_attention_heads=1, intermediate_size=64, vocab_size=len(vocab),
                max_position_embeddings=64, type_vocab_size=2, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)

@@ -221,3 +221,24 @@ def test_raw_image_mode_collates_without_resizing(tmp_path):
     std = PairedImageDataset(data, 32, False)
     _, _, a2, b2, _ = collate_image([std[i] for i in range(2)])
     assert tuple(a2.shape) == (2, 3, 32, 32) and a2.dtype == torch.float32
+
+
+def test_attribute_pair_indices_match_reference_vectors():
+    """`--auxiliary_task` attribute alignment (data/datasets.py attribute_pair_indices) against vectors captured from the
+    reference's RobertaOneTowerDataset.__getitem__ (oracle/gen_pair_indices.py; data.py:568-612): aligned keys, a key mismatch
+    part-way, truncated last attributes, attributes without ':' (stale-colon behaviour and the TypeError of a leading one)."""
+    import json
+    import os
+    from item_alignment_amd.data import datasets as DS
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "pair_indices.json")))
+    assert (fx["colon_id"], fx["semicolon_id"]) == (DS.COLON_ID, DS.SEMICOLON_ID)
+    n_pairs = 0
+    for c in fx["cases"]:
+        if "error" in c:
+            with pytest.raises(Exception) as e:
+                DS.attribute_pair_indices(c["input_ids"], fx["sep_token_id"])
+            assert type(e.value).__name__ == c["error"]
+        else:
+            assert DS.attribute_pair_indices(c["input_ids"], fx["sep_token_id"]) == c["pair_indices"]
+            n_pairs += len(c["pair_indices"])
+    assert n_pairs > 20

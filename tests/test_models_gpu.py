@@ -64,15 +64,19 @@ def g(case, k):
 
 
 @pytest.mark.parametrize("name", ["roberta_one_tower_cls_ce", "roberta_one_tower_cls12_cat", "roberta_one_tower_cls12_avg",
-                                  "roberta_one_tower_vecsim_cosine", "roberta_one_tower_vecsim_l2_bce", "roberta_one_tower_vecsim_ip_hinge"])
+                                  "roberta_one_tower_vecsim_cosine", "roberta_one_tower_vecsim_l2_bce", "roberta_one_tower_vecsim_ip_hinge",
+                                  "roberta_one_tower_aux"])
 def test_roberta_one_tower(gpu, name):
+    from golden_util import pair_list
     case = load_case(name)
     model = build(case, "RobertaOneTower")
     labels = g(case, "labels").float() if case.cfg.loss_type == "bce" else g(case, "labels")
     out = model(input_ids=g(case, "input_ids"), attention_mask=g(case, "attention_mask"), token_type_ids=g(case, "token_type_ids"),
-                position_ids=None, labels=labels, output_hidden_states=True)
+                position_ids=None, labels=labels, output_hidden_states=True, image_indices=pair_list(case))
     check(case, out, model)
     for k, idx in (("hidden0", 0), ("hidden1", 1), ("hidden_last", -1)):
+        if k not in case.extra:
+            continue
         m = g(case, "attention_mask").bool().cpu()
         got, want = out.hidden_states[idx].float().cpu(), case.extra[k]
         assert rel(got[m], want[m]) < TOL, (k, rel(got[m], want[m]))
