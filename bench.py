@@ -110,7 +110,11 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=2)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--full-length", action="store_true", help="all sequences at the full 255 tokens (mask all ones)")
+    ap.add_argument("--unpad", action="store_true", help="text towers on the valid tokens only (IA_UNPAD=1, DESIGN.md 4.8); off by "
+                    "default: the reference computes densely on the padding and the headline number keeps that workload")
     args = ap.parse_args()
+    if args.unpad:
+        os.environ["IA_UNPAD"] = "1"
 
     from item_alignment_amd import _lib
     from item_alignment_amd import dist as iadist
@@ -188,10 +192,11 @@ def main():
             "config": {"workload": "coca(roberta_large + vit_base_patch16_384) two_tower cls/ce, ensemble=sum, seq 50+205, img 384, "
                                    "dropout 0.1, fused AdamW; train step = fwd+bwd+allreduce+optimizer",
                        "pairs_per_gpu": B, "global_batch": B * world, "seq_len": 255, "image_size": cfg.image_size,
-                       "parallelism": f"dp{world}", "full_length_sequences": bool(args.full_length),
+                       "parallelism": f"dp{world}", "full_length_sequences": bool(args.full_length), "unpadded_text_tower": bool(args.unpad),
                        "deviation": "Linear(768->1024) on the image CLS (the named pairing is dimensionally inconsistent in the reference, SURVEY N1)"},
-            "model_tflops_per_gpu": pairs / dt * TRAIN_FLOPS_PER_PAIR / 1e12 / world,
-            "mfma_fraction_whole_step": pairs / dt * TRAIN_FLOPS_PER_PAIR / 1e12 / world / 2500.0,
+            # dense FLOP count of the padded workload; with --unpad the padded rows are not computed, so it does not apply
+            "model_tflops_per_gpu": None if args.unpad else pairs / dt * TRAIN_FLOPS_PER_PAIR / 1e12 / world,
+            "mfma_fraction_whole_step": None if args.unpad else pairs / dt * TRAIN_FLOPS_PER_PAIR / 1e12 / world / 2500.0,
             "final_loss": final_loss,
             "roofline": {"bound": "mfma", "kernel": WGRAD_KERNEL, "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": achieved / 2500.0, "traffic": WGRAD_TRAFFIC_BYTES, "launches": nl.value,

@@ -235,9 +235,11 @@ int ia_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int64_t* 
                     ia_stream_t stream);
 size_t ia_embed_ln_bwd_workspace_bytes(int M, int H);
 int ia_embed_ln_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma, const int64_t* ids,
-                    const int64_t* type_ids, const int64_t* pos_ids, const int32_t* extra_idx, float* dword, float* dtype, float* dpos,
-                    float* dextra, float* dgamma, float* dbeta, int M, int H, int L, int word_pad, int pos_pad, float drop_p, uint32_t seed,
-                    uint32_t stream_id, void* workspace, size_t workspace_bytes, ia_stream_t stream);
+                    const int64_t* type_ids, const int64_t* pos_ids, const int32_t* extra_idx, const int32_t* row_order, float* dword,
+                    float* dtype, float* dpos, float* dextra, float* dgamma, float* dbeta, int M, int H, int L, int word_pad, int pos_pad,
+                    float drop_p, uint32_t seed, uint32_t stream_id, void* workspace, size_t workspace_bytes, ia_stream_t stream);
+/* row_order (int32 [M], may be NULL): the rows sorted by position id, for unpadded token rows that have no [M/L, L] grid — the
+ * position / token-type gradients are then run-length accumulated along that list instead of down the columns of the grid */
 
 /* ---- ViT input side (timm PatchEmbed + cls token + pos_embed; src/models/multimodal.py:811) */
 int ia_im2col_patch(const float* images, void* patches, int B, int C, int S, int P, ia_stream_t stream);
@@ -269,6 +271,15 @@ int ia_pair_head_ce_bwd(const float* probs, const int64_t* labels, const float* 
  * delimits the spans of each sample. */
 int ia_span_mean_fwd(const void* seq, int ld, const int* spans, float* out, int S, int H, ia_stream_t stream);
 int ia_span_mean_bwd(const float* dout, const int* spans, const int* span_ptr, void* dseq, int B, int L, int H, ia_stream_t stream);
+
+/* packed ("unpadded") self-attention: rows of all sequences back to back, sequence b = rows cu_seqlens[b] .. cu_seqlens[b+1]
+ * (int32 [B+1], device; total_tokens = cu_seqlens[B]); q / k / v share the row stride ld_qkv; no key mask; lse2 / delta stay
+ * [B, nh, Lmax] with Lmax the longest sequence.  Same arithmetic as ia_attn_fwd / ia_attn_bwd on the valid tokens. */
+int ia_attn_fwd_varlen(const void* q, const void* k, const void* v, int ld_qkv, const int* cu_seqlens, int total_tokens, void* out, int ld_o,
+                       float* lse2, int B, int nh, int Lmax, float scale, float drop_p, uint32_t seed, ia_stream_t stream);
+int ia_attn_bwd_varlen(const void* q, const void* k, const void* v, int ld_qkv, const int* cu_seqlens, int total_tokens, const void* out,
+                       const void* d_out, int ld_o, const float* lse2, float* delta, void* dq, void* dk, void* dv, int ld_dqkv, int B, int nh,
+                       int Lmax, float scale, float drop_p, uint32_t seed, ia_stream_t stream);
 
 /* ---- optimiser (torch.optim.AdamW, finetune_multimodal.py:296-308,460-468) */
 int ia_adamw_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, const void* chunk_table,
@@ -306,6 +317,11 @@ typedef struct {
   float hidden_drop, attn_drop;
   uint32_t seed;           /* per-step seed; the layer index is mixed in through layer_id */
   uint32_t layer_id;
+  /* unpadded ("packed") sequences: when cu_seqlens (int32 [B+1], device) is not NULL the layer runs on total_tokens =
+   * cu_seqlens[B] rows, sequence b owning rows cu_seqlens[b] .. cu_seqlens[b+1]; L is then the longest sequence and the
+   * key_mask argument is ignored (every token of a sequence is attendable).  NULL / 0: padded [B, L] rows. */
+  const int* cu_seqlens;
+  int total_tokens;
 } ia_layer_cfg;
 
 /* per-layer activation stash (saved by forward, read by backward) and shared backward scratch */

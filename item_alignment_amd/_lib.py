@@ -25,7 +25,7 @@ class LayerGrads(C.Structure):
 
 class LayerCfg(C.Structure):
     _fields_ = [("B", i32), ("L", i32), ("H", i32), ("I", i32), ("nh", i32), ("pre_ln", i32), ("eps", f32),
-                ("hidden_drop", f32), ("attn_drop", f32), ("seed", u32), ("layer_id", u32)]
+                ("hidden_drop", f32), ("attn_drop", f32), ("seed", u32), ("layer_id", u32), ("cu_seqlens", vp), ("total_tokens", i32)]
 
 
 # name -> (restype, argtypes); must list every symbol include/itemalign.h declares
@@ -93,7 +93,7 @@ SIGNATURES = {
     "ia_u8_to_nchw_normalized": (i32, [vp, vp, vp, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp]),
     "ia_embed_ln_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, u32, u32, vp]),
     "ia_embed_ln_bwd_workspace_bytes": (sz, [i32, i32]),
-    "ia_embed_ln_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, u32, u32,
+    "ia_embed_ln_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, u32, u32,
                                vp, sz, vp]),
     "ia_im2col_patch": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ia_vit_tokens_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
@@ -103,6 +103,8 @@ SIGNATURES = {
     "ia_linear_small_fwd": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "ia_linear_small_bwd": (i32, [vp, vp, vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
     "ia_pair_head_ce_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "ia_attn_fwd_varlen": (i32, [vp, vp, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, f32, f32, u32, vp]),
+    "ia_attn_bwd_varlen": (i32, [vp, vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, u32, vp]),
     "ia_span_mean_fwd": (i32, [vp, i32, vp, vp, i32, i32, vp]),
     "ia_span_mean_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "ia_pair_head_ce_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),

@@ -33,6 +33,8 @@ struct AttnArgs {
   float* lse2;                                    // [B, nh, L]  log2-domain log-sum-exp of scaled scores
   float* delta;                                   // [B, nh, L]  rowsum(dO * O)
   int B, nh, Lq, Lk;                              // queries / keys per sequence (self-attention: Lq == Lk)
+  const int* cu;                                  // packed (unpadded) self-attention: sequence b owns rows cu[b] .. cu[b+1] and
+                                                  // Lq == Lk is the longest sequence (grid size, stride of lse2 / delta); else null
   int ld_q, ld_kv, ld_o, ld_dq, ld_dkv;           // row strides in elements (q & o rows: b*Lq + i; k & v rows: b*Lk + j)
   uint32_t q_bytes, kv_bytes, o_bytes;
   float sc;                                       // softmax scale * log2(e)
@@ -250,9 +252,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int tile, h, b;
   attn_block_coords(p, p.Lq, tile, h, b);
-  const int Lq = p.Lq, L = p.Lk;                  // L: keys
+  int Lq = p.Lq, L = p.Lk;                        // L: keys
+  size_t qbase = (size_t)b * Lq, rowbase = (size_t)b * L;
+  if (p.cu) {                                     // packed rows: this sequence's own length and first row
+    const int s0 = p.cu[b];
+    Lq = L = p.cu[b + 1] - s0;
+    qbase = rowbase = (size_t)s0;
+    if (tile * 128 >= Lq) return;                 // block-uniform, before any barrier
+  }
   const int q0 = tile * 128 + wave * 32;
-  const size_t qbase = (size_t)b * Lq, rowbase = (size_t)b * L;
   const bool active = q0 < Lq;
   const int q = q0 + lq;
   const int qc = q < Lq ? q : Lq - 1;
@@ -304,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? p.inv_keep / l_tot : 0.f;
   if (q < Lq) {
-    if (hh == 0 && p.lse2) p.lse2[((size_t)b * p.nh + h) * Lq + q] = m_ref + __builtin_amdgcn_logf(l_tot);
+    if (hh == 0 && p.lse2) p.lse2[((size_t)b * p.nh + h) * p.Lq + q] = m_ref + __builtin_amdgcn_logf(l_tot);
     bf16* op = p.out + (qbase + q) * p.ld_o + h * 64;
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
@@ -398,9 +406,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int tile, h, b;
   attn_block_coords(p, p.Lq, tile, h, b);
-  const int Lq = p.Lq, L = p.Lk;                  // L: keys
+  int Lq = p.Lq, L = p.Lk;                        // L: keys
+  size_t qbase = (size_t)b * Lq, rowbase = (size_t)b * L;
+  if (p.cu) {                                     // packed rows: this sequence's own length and first row
+    const int s0 = p.cu[b];
+    Lq = L = p.cu[b + 1] - s0;
+    qbase = rowbase = (size_t)s0;
+    if (tile * 128 >= Lq) return;                 // block-uniform, before any barrier
+  }
   const int q0 = tile * 128 + wave * 32;
-  const size_t qbase = (size_t)b * Lq, rowbase = (size_t)b * L;
   const bool active = q0 < Lq;
   const int q = q0 + lq;
   const int qc = q < Lq ? q : Lq - 1;
@@ -415,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
       gf[kb] = *reinterpret_cast<const bf16x8*>(gp + kb * 16);
     }
   }
-  const size_t sidx = ((size_t)b * p.nh + h) * Lq + qc;
+  const size_t sidx = ((size_t)b * p.nh + h) * p.Lq + qc;
   const float lse = p.lse2[sidx];
   // delta = rowsum(dO * O) of this lane's query: each lane of the pair (lane, lane^32) holds half of the 64 columns.
   // Written out for the dK/dV kernel, which runs after this one on the same stream.
@@ -489,9 +503,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int tile, h, b;
   attn_block_coords(p, p.Lk, tile, h, b);
-  const int Lq = p.Lq, L = p.Lk;                  // L: keys
+  int Lq = p.Lq, L = p.Lk;                        // L: keys
+  size_t qbase = (size_t)b * Lq, rowbase = (size_t)b * L;
+  if (p.cu) {
+    const int s0 = p.cu[b];
+    Lq = L = p.cu[b + 1] - s0;
+    qbase = rowbase = (size_t)s0;
+    if (tile * 128 >= L) return;
+  }
   const int k0 = tile * 128 + wave * 32;
-  const size_t qbase = (size_t)b * Lq, rowbase = (size_t)b * L;
   const bool active = k0 < L;
   const int key = k0 + lk;
   const int kc = key < L ? key : L - 1;
@@ -509,8 +529,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   }
   const __amdgpu_buffer_rsrc_t rsQ = ia_rsrc(p.q, p.q_bytes);
   const __amdgpu_buffer_rsrc_t rsG = ia_rsrc(p.d_o, p.o_bytes);
-  const __amdgpu_buffer_rsrc_t rsL = ia_rsrc(p.lse2 + ((size_t)b * p.nh + h) * Lq, (uint32_t)Lq * 4u);
-  const __amdgpu_buffer_rsrc_t rsD = ia_rsrc(p.delta + ((size_t)b * p.nh + h) * Lq, (uint32_t)Lq * 4u);
+  const __amdgpu_buffer_rsrc_t rsL = ia_rsrc(p.lse2 + ((size_t)b * p.nh + h) * p.Lq, (uint32_t)Lq * 4u);
+  const __amdgpu_buffer_rsrc_t rsD = ia_rsrc(p.delta + ((size_t)b * p.nh + h) * p.Lq, (uint32_t)Lq * 4u);
   const uint32_t stream_id = (uint32_t)(b * p.nh + h);
 
   f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
@@ -619,11 +639,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   }
 }
 
-int fill_args(AttnArgs& a, int B, int nh, int Lq, int Lk, int ld_q, int ld_kv, int ld_o, float scale, float drop_p, uint32_t seed) {
+// packed_rows > 0: packed self-attention over that many token rows in total (AttnArgs::cu), Lq == Lk == longest sequence
+int fill_args(AttnArgs& a, int B, int nh, int Lq, int Lk, int ld_q, int ld_kv, int ld_o, float scale, float drop_p, uint32_t seed,
+              long packed_rows = 0) {
   if (B <= 0 || nh <= 0 || Lq <= 0 || Lk <= 0 || Lk > 64 * MAX_KT || Lq > (1 << 20) || (ld_q & 7) || (ld_kv & 7) || (ld_o & 7))
     return IA_ERR_ARG;
   if (ld_q < nh * 64 || ld_kv < nh * 64 || ld_o < nh * 64) return IA_ERR_ARG;
-  const uint64_t qb = (uint64_t)B * Lq * ld_q * 2, kb = (uint64_t)B * Lk * ld_kv * 2, ob = (uint64_t)B * Lq * ld_o * 2;
+  const uint64_t rq = packed_rows > 0 ? (uint64_t)packed_rows : (uint64_t)B * Lq, rk = packed_rows > 0 ? (uint64_t)packed_rows : (uint64_t)B * Lk;
+  const uint64_t qb = rq * ld_q * 2, kb = rk * ld_kv * 2, ob = rq * ld_o * 2;
   if (qb >= 0x7FFFFFFFull || kb >= 0x7FFFFFFFull || ob >= 0x7FFFFFFFull) return IA_ERR_ARG;
   a.B = B; a.nh = nh; a.Lq = Lq; a.Lk = Lk; a.ld_q = ld_q; a.ld_kv = ld_kv; a.ld_o = ld_o; a.ld_dq = ld_q; a.ld_dkv = ld_kv;
   // each rsrc is based at the operand pointer itself, which may start some columns into a packed row, so the
@@ -697,4 +720,45 @@ extern "C" int ia_attn_bwd(const void* q, const void* k, const void* v, int ld_q
                            int ld_dqkv, int B, int nh, int L, float scale, float drop_p, uint32_t seed, hipStream_t stream) {
   return ia_attn_bwd_x(q, ld_qkv, k, v, ld_qkv, key_mask, out, d_out, ld_o, lse2, delta, dq, ld_dqkv, dk, dv, ld_dqkv, B, nh, L, L, scale,
                        drop_p, seed, stream);
+}
+
+// Packed ("unpadded") self-attention: the token rows of all sequences lie back to back, sequence b owning rows
+// cu_seqlens[b] .. cu_seqlens[b+1] (int32 [B+1], device; total_tokens = cu_seqlens[B]); no key mask — every key of a sequence is
+// attendable.  Lmax = longest sequence (sets the grid and the row stride of lse2 / delta, which stay [B, nh, Lmax]).  Same
+// arithmetic as ia_attn_fwd / ia_attn_bwd on the valid tokens of a right-padded batch; padded positions are simply absent.
+extern "C" int ia_attn_fwd_varlen(const void* q, const void* k, const void* v, int ld_qkv, const int* cu_seqlens, int total_tokens, void* out,
+                                  int ld_o, float* lse2, int B, int nh, int Lmax, float scale, float drop_p, uint32_t seed, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!q || !k || !v || !out || !cu_seqlens || total_tokens <= 0) return IA_ERR_ARG;
+  AttnArgs a{};
+  int rc = fill_args(a, B, nh, Lmax, Lmax, ld_qkv, ld_qkv, ld_o, scale, drop_p, seed, total_tokens);
+  if (rc) return rc;
+  a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.out = (bf16*)out; a.mask = nullptr; a.lse2 = lse2; a.cu = cu_seqlens;
+  dim3 grid(((Lmax + 127) / 128) * nh * B), blk(256);
+  if (a.thr16) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, blk, 0, stream, a);
+  else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, blk, 0, stream, a);
+  return ia_check_launch();
+}
+
+extern "C" int ia_attn_bwd_varlen(const void* q, const void* k, const void* v, int ld_qkv, const int* cu_seqlens, int total_tokens,
+                                  const void* out, const void* d_out, int ld_o, const float* lse2, float* delta, void* dq, void* dk, void* dv,
+                                  int ld_dqkv, int B, int nh, int Lmax, float scale, float drop_p, uint32_t seed, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!q || !k || !v || !out || !d_out || !lse2 || !delta || !dq || !dk || !dv || !cu_seqlens || total_tokens <= 0) return IA_ERR_ARG;
+  AttnArgs a{};
+  int rc = fill_args(a, B, nh, Lmax, Lmax, ld_qkv, ld_qkv, ld_o, scale, drop_p, seed, total_tokens);
+  if (rc) return rc;
+  if ((ld_dqkv & 3) || ld_dqkv < nh * 64) return IA_ERR_ARG;
+  a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.o = (const bf16*)out; a.d_o = (const bf16*)d_out;
+  a.mask = nullptr; a.lse2 = const_cast<float*>(lse2); a.delta = delta; a.cu = cu_seqlens;
+  a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.ld_dq = ld_dqkv; a.ld_dkv = ld_dqkv;
+  dim3 grid(((Lmax + 127) / 128) * nh * B), blk(256);
+  if (a.thr16) {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, blk, 0, stream, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, blk, 0, stream, a);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, blk, 0, stream, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, blk, 0, stream, a);
+  }
+  return ia_check_launch();
 }

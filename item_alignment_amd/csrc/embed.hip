@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16* __restric
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const int64_t* __restrict__ ids,
                                                            const int64_t* __restrict__ tts, const int64_t* __restrict__ pids,
-                                                           const int32_t* __restrict__ xidx, float* __restrict__ dword,
+                                                           const int32_t* __restrict__ xidx, const int32_t* __restrict__ order,
+                                                           float* __restrict__ dword,
                                                            float* __restrict__ dtype, float* __restrict__ dpos,
                                                            float* __restrict__ dextra, float* __restrict__ part, int M, int H, int L,
                                                            int word_pad, int pos_pad, uint32_t thr16, float inv_keep, uint32_t seed,
@@ -110,7 +111,9 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16* __restric
   // visits share their position id and almost always their token type, so those two gradients are run-length
   // accumulated in registers and flushed with one atomicAdd per column per run (33M contended atomics on 2+512
   // table rows became ~L*G*H); word-row gradients go out per token (random rows, no contention).
-  const int S = M / L;
+  // `order` (rows sorted by position id; unpadded token rows have no [S, L] grid): the wave owns the l-th chunk of S
+  // consecutive entries of that list instead of a column of the grid
+  const int S = order ? (M + L - 1) / L : M / L;
   const int s_lo = (int)(((long)S * blockIdx.y) / gridDim.y), s_hi = (int)(((long)S * (blockIdx.y + 1)) / gridDim.y);
   float accp[NV][8], acct[NV][8];
   for (int l = blockIdx.x * 4 + wave; l < L; l += gridDim.x * 4) {
@@ -136,8 +139,8 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16* __restric
       for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
   };
   for (int sq = s_lo; sq <= s_hi; ++sq) {
-    if (sq == s_hi) { flush(accp, dpos, curp); flush(acct, dtype, curt); break; }
-    const int row = sq * L + l;
+    if (sq == s_hi || (order && (long)l * S + sq >= M)) { flush(accp, dpos, curp); flush(acct, dtype, curt); break; }
+    const int row = order ? order[(long)l * S + sq] : sq * L + l;
     const float mu = mean[row], rs = rstd[row];
     float g[NV][8], xh[NV][8];
     float s1 = 0.f, s2 = 0.f;
@@ -378,7 +381,8 @@ extern "C" size_t ia_embed_ln_bwd_workspace_bytes(int M, int H) { return (size_t
 // padding_idx, reference base.py:213,234-236); pass -1 for none.  All gradients accumulate (+=).
 extern "C" int ia_embed_ln_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
                                const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const int32_t* extra_idx,
-                               float* dword, float* dtype, float* dpos, float* dextra, float* dgamma, float* dbeta, int M, int H,
+                               const int32_t* row_order, float* dword, float* dtype, float* dpos, float* dextra, float* dgamma, float* dbeta,
+                               int M, int H,
                                int L, int word_pad, int pos_pad, float drop_p, uint32_t seed, uint32_t stream_id, void* workspace,
                                size_t workspace_bytes, hipStream_t stream) {
   (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
@@ -387,13 +391,15 @@ extern "C" int ia_embed_ln_bwd(const void* dy, const void* z, const float* mean,
   if (!workspace || workspace_bytes < ia_embed_ln_bwd_workspace_bytes(M, H)) return IA_ERR_WORKSPACE;
   uint32_t thr16; float inv_keep; drop_params(drop_p, thr16, inv_keep);
   if (L <= 0 || M % L) L = M;      // no sequence structure given: every row is its own position
+  if (row_order) L = M < 2048 ? M : 2048;   // chunks of the position-sorted row list, one per wave
   int gx, gy; embed_bwd_grid(M, L, gx, gy);
+  if (row_order) gy = 1;
   const int nb = gx * gy, nv = (H + 511) / 512;
   if ((size_t)nb * 2 * H * sizeof(float) > workspace_bytes) return IA_ERR_WORKSPACE;
   float* part = (float*)workspace;
   dim3 grid(gx, gy), blk(256);
 #define IA_E(NV) hipLaunchKernelGGL((embed_ln_bwd_kernel<NV>), grid, blk, 0, stream, (const bf16*)dy, (const bf16*)z, mean, rstd, gamma, ids, \
-    type_ids, pos_ids, extra_idx, dword, dtype, dpos, dextra, part, M, H, L, word_pad, pos_pad, thr16, inv_keep, seed, stream_id)
+    type_ids, pos_ids, extra_idx, row_order, dword, dtype, dpos, dextra, part, M, H, L, word_pad, pos_pad, thr16, inv_keep, seed, stream_id)
   switch (nv) { case 1: IA_E(1); break; case 2: IA_E(2); break; case 3: IA_E(3); break; case 4: IA_E(4); break; default: IA_E(8); }
 #undef IA_E
   hipLaunchKernelGGL(reduce2_kernel, dim3((2 * H + 31) / 32), dim3(1024), 0, stream, part, nb, H, dgamma, dbeta);

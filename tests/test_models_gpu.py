@@ -378,3 +378,26 @@ def test_resnet_two_tower_normalises_each_tower_separately(gpu):
     out.loss.backward()
     torch.cuda.synchronize()
     assert torch.isfinite(model.img_encoder.stem.conv.weight.grad).all()
+
+
+@pytest.mark.parametrize("name,cls", [("roberta_one_tower_cls_ce", "RobertaOneTower"), ("roberta_two_tower_ce", "RobertaTwoTower")])
+def test_unpadded_text_tower_matches_padded(gpu, name, cls, monkeypatch):
+    """IA_UNPAD=1 (models/text.py RobertaModel._forward_unpadded): dropping the padded rows before the embedding kernel and running
+    every layer on the packed tokens gives the reference golden outputs / gradients like the padded run does, and hidden states
+    come back in the padded shape."""
+    import item_alignment_amd.models.text as T
+    case = load_case(name)
+    monkeypatch.setattr(T, "UNPAD", True)
+    model = build(case, cls)
+    if cls == "RobertaOneTower":
+        out = model(input_ids=g(case, "input_ids"), attention_mask=g(case, "attention_mask"), token_type_ids=g(case, "token_type_ids"),
+                    position_ids=None, labels=g(case, "labels"), output_hidden_states=True)
+        m = g(case, "attention_mask").bool().cpu()
+        got, want = out.hidden_states[-1].float().cpu(), case.extra["hidden_last"]
+        assert rel(got[m], want[m]) < TOL
+        assert got[~m].abs().max().item() == 0.0
+    else:
+        out = model(input_ids_1=g(case, "input_ids_1"), attention_mask_1=g(case, "attention_mask_1"), token_type_ids_1=g(case, "token_type_ids_1"),
+                    input_ids_2=g(case, "input_ids_2"), attention_mask_2=g(case, "attention_mask_2"), token_type_ids_2=g(case, "token_type_ids_2"),
+                    labels=g(case, "labels"))
+    check(case, out, model)

@@ -53,6 +53,8 @@ def bench_attn():
         print(f"attn bwd B={B} L={L} nh={nh}: {t*1e6:8.1f} us {2.5*fl/t/1e12:7.1f} TF/s (algorithmic 10 L^2 d)")
         td = timeit(lambda: ops.attn_fwd(qkv, B, L, nh, key_mask=mask, drop_p=0.1, seed=1))
         print(f"attn fwd+dropout:              {td*1e6:8.1f} us")
+        td = timeit(lambda: ops.attn_bwd(qkv, ctx, d, lse, B, L, nh, key_mask=mask, drop_p=0.1, seed=1))
+        print(f"attn bwd+dropout:              {td*1e6:8.1f} us")
 
 
 def bench_ln():
