@@ -79,6 +79,9 @@ def run(args, model, datasets, collate_fn, call_model, checkpoint_name, path_fie
     """datasets: dict(train=..., valid=..., test=...) (entries may be None); call_model(model, batch) -> output where
     batch = collate output from index 2 on, already on `device`."""
     from .models import functional as Fn
+    if getattr(args, "unpad", False):
+        from .models import text as _text
+        _text.UNPAD = True
     rank, world, _ = iadist.init_from_env(device.type)
     is_hip = hasattr(model, "param_arena") and device.type == "cuda"
     out_dir = model_dir(args, path_fields)

@@ -105,6 +105,8 @@ def test_finetune_text_roberta_gpu(gpu, tmp_path, interaction, method, measure, 
            "--classification_method", method, "--similarity_measure", measure, "--loss_type", loss, "--do_train", "--do_eval", "--do_pred",
            "--train_batch_size", "8", "--eval_batch_size", "4", "--num_train_epochs", "1", "--learning_rate", "1e-4", "--log_steps", "1",
            "--pretrained_model_path", pre, "--max_seq_len", "8", "--max_seq_len_pv", "12", "--max_position_embeddings", "64", "--fp16"]
+    if interaction == "two_tower":
+        cmd.append("--unpad")                      # the unpadded tower path through the CLI
     r = _run(cmd)
     dirs = os.listdir(out)
     assert len(dirs) == 1, dirs
