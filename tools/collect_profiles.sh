@@ -21,3 +21,14 @@ mv $OUT/${TAG}_pmc_2.csv $OUT/${TAG}_pmc_write_size.csv
 cat $OUT/${TAG}_pmc_3.csv > $OUT/${TAG}_pmc_mfma.csv; tail -n +2 $OUT/${TAG}_pmc_4.csv >> $OUT/${TAG}_pmc_mfma.csv; rm -f $OUT/${TAG}_pmc_3.csv $OUT/${TAG}_pmc_4.csv
 rm -rf $OUT/kt $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4
 ls -la $OUT
+# secondary configurations: kernel-trace summaries only
+for cfg in c3 c3r; do
+  rocprofv3 --kernel-trace --stats -d $OUT/kt_$cfg -o b --output-format csv -- python3 $R/tools/config_bench.py $cfg > $OUT/${TAG}_${cfg}_log.txt 2>&1
+  python3 $R/tools/prof_summary.py $OUT/kt_$cfg/b_kernel_stats.csv 11 30 > $OUT/${TAG}_${cfg}_kernel_stats_summary.txt
+  tail -1 $OUT/${TAG}_${cfg}_log.txt | grep -v rocprofv3 >> $OUT/${TAG}_${cfg}_kernel_stats_summary.txt
+  rm -rf $OUT/kt_$cfg $OUT/${TAG}_${cfg}_log.txt
+done
+rocprofv3 --kernel-trace --stats -d $OUT/kt_u -o b --output-format csv -- python3 $R/bench.py --unpad --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_bench_unpad_under_rocprof.json 2> /dev/null
+python3 $R/tools/prof_summary.py $OUT/kt_u/b_kernel_stats.csv 7 30 > $OUT/${TAG}_bench_unpad_kernel_stats_summary.txt
+rm -rf $OUT/kt_u
+ls -la $OUT
