@@ -588,6 +588,32 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+// the same sum for deep cuts (conv weight gradients: hundreds of partials of a few KB each): 8 lanes share one output quad,
+// lane l adds partials l, l+8, ... in order and lane 0 folds the 8 lane sums in order (fixed order -> deterministic)
+__global__ __launch_bounds__(256) void splitk_reduce_deep_kernel(const float* __restrict__ ws, float* __restrict__ C, int M, int N, int ldc,
+                                                                 int splits, int accumulate, long gc) {
+  __shared__ f32x4 red[256];
+  ws += (size_t)blockIdx.y * splits * M * N;
+  C += (size_t)blockIdx.y * gc;
+  const size_t total4 = (size_t)M * N / 4;
+  const int lane = threadIdx.x & 7;
+  const size_t t = (size_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (t < total4)
+    for (int sp = lane; sp < splits; sp += 8) acc += *reinterpret_cast<const f32x4*>(ws + (size_t)sp * M * N + t * 4);
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (lane == 0 && t < total4) {
+    f32x4 sum = red[threadIdx.x];
+#pragma unroll
+    for (int l = 1; l < 8; ++l) sum += red[threadIdx.x + l];
+    const size_t e = t * 4;
+    float* c = C + (size_t)(e / N) * ldc + (e % N);
+    if (accumulate) sum += *reinterpret_cast<const f32x4*>(c);
+    *reinterpret_cast<f32x4*>(c) = sum;
+  }
+}
+
 struct Plan { bool big; int splits; };
 
 // Tile choice + split-K factor.  Weight-gradient GEMMs have outputs of only a few dozen tiles (1024x1024 ->
@@ -640,7 +666,11 @@ int launch(GemmArgs a, bool big, hipStream_t st) {
     a.tiles_m = (a.M + t128::BM - 1) / t128::BM; a.tiles_n = (a.N + t128::BN - 1) / t128::BN;
     hipLaunchKernelGGL((t128::gemm_kernel<AKS, BKS, EPI, OUTF32>), dim3(a.tiles_m * a.tiles_n, a.splits, a.groups), dim3(256), 0, st, a);
   }
-  if (OUTF32 && a.splits > 1) {
+  if (OUTF32 && a.splits > 16) {
+    const size_t g = ((size_t)a.M * a.N / 4 + 31) / 32;
+    hipLaunchKernelGGL(splitk_reduce_deep_kernel, dim3((unsigned)g, a.groups), dim3(256), 0, st, a.ws, (float*)a.C, a.M, a.N, a.ldc, a.splits,
+                       a.accumulate, a.gc);
+  } else if (OUTF32 && a.splits > 1) {
     size_t g = ((size_t)a.M * a.N / 4 + 255) / 256; if (g > 4096) g = 4096;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)g, a.groups), dim3(256), 0, st, a.ws, (float*)a.C, a.M, a.N, a.ldc, a.splits, a.accumulate,
                        a.gc);
