@@ -758,7 +758,7 @@ static int gemm_core(const void* A, int a_kstrided, int lda, const void* B, int 
   if (needs_bias && !bias) return IA_ERR_ARG;
   if (needs_aux && (!aux || (ldaux & 3))) return IA_ERR_ARG;
   if (epilogue == EPI_BIAS_GELU && !C2) return IA_ERR_ARG;
-  const bool big = pl.big && !view;     // the shifted views and the group batching live in the T128 kernel only
+  const bool big = pl.big && !view && !(g.dbg & 128);     // the shifted views and the group batching live in the T128 kernel only (dbg 128: force T128)
 
   if (!a_kstrided && !b_kstrided && !c_is_f32) {
     switch (epilogue) {

@@ -1,5 +1,5 @@
 """Micro-benchmarks of the hot kernels on one MI355X (random data, HIP-event timing).
-usage: python tools/kbench.py [gemm] [attn] [ln] [img]"""
+usage: python tools/kbench.py [gemm] [gemm_epi] [attn] [ln] [img]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -37,6 +37,24 @@ def bench_gemm():
             w = b
             t2 = timeit(lambda: torch.matmul(a, w.t()))
             print(f"     torch/hipBLASLt same shape:    {t2*1e6:8.1f} us  {2*M*N*K/t2/1e12:7.1f} TF/s")
+
+
+def bench_gemm_epi():
+    """the epilogue-heavy GEMMs of the RoBERTa-large layer at the bench size (128 sequences x 255 tokens)"""
+    M, H, I = 32640, 1024, 4096
+    x = torch.randn((M, H), device=dev).bfloat16(); w1 = (torch.randn((I, H), device=dev) * 0.03).bfloat16()
+    b1 = torch.zeros(I, device=dev)
+    pre = torch.empty((M, I), device=dev, dtype=torch.bfloat16); act = torch.empty_like(pre)
+    t = timeit(lambda: ops.gemm(x, w1, epilogue=ops.EPI_BIAS_GELU, bias=b1, out=act, pre_out=pre))
+    print(f"ffn1 bias+gelu  M={M} N={I} K={H}: {t*1e6:8.1f} us {2*M*I*H/t/1e12:7.1f} TF/s")
+    t = timeit(lambda: ops.gemm(x, w1, epilogue=ops.EPI_BIAS, bias=b1, out=act))
+    print(f"ffn1 bias       M={M} N={I} K={H}: {t*1e6:8.1f} us {2*M*I*H/t/1e12:7.1f} TF/s")
+    dy = torch.randn((M, H), device=dev).bfloat16(); w2 = (torch.randn((H, I), device=dev) * 0.03).bfloat16()     # fc2 weight [H, I]
+    dpre = torch.empty_like(pre)
+    t = timeit(lambda: ops.gemm(dy, w2, b_kstrided=True, epilogue=ops.EPI_DGELU, aux=pre, out=dpre))
+    print(f"dgrad x gelu'   M={M} N={I} K={H}: {t*1e6:8.1f} us {2*M*I*H/t/1e12:7.1f} TF/s")
+    t = timeit(lambda: ops.gemm(dy, w2, b_kstrided=True, out=dpre))
+    print(f"dgrad plain     M={M} N={I} K={H}: {t*1e6:8.1f} us {2*M*I*H/t/1e12:7.1f} TF/s")
 
 
 def bench_attn():
@@ -82,6 +100,7 @@ def bench_img():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "attn", "ln"]
     if "gemm" in which: bench_gemm()
+    if "gemm_epi" in which: bench_gemm_epi()
     if "attn" in which: bench_attn()
     if "ln" in which: bench_ln()
     if "img" in which: bench_img()
