@@ -91,6 +91,11 @@ class GradBucketReducer:
         main = getattr(self, "main_stream", None)
         return ([main] if main is not None else []) + (list(a.side_streams) if a is not None else [])
 
+    # gradient accumulation: the arena sums micro-batches locally; only the LAST micro-step's backward may start collectives
+    # (a bucket reduced early would be reduced with part of its sum and never again).  The train loop disarms the reducer for
+    # the other micro-steps; finish() then reduces every bucket that was not launched.
+    armed = True
+
     def reset(self):
         self.left = list(self.need)
         self.launched = [False] * len(self.buckets)
@@ -111,6 +116,8 @@ class GradBucketReducer:
 
     def grads_ready(self, params):
         """Hook target: these parameters' gradient kernels have been enqueued on the current stream."""
+        if not self.armed:
+            return
         for p in params:
             k = id(p)
             if k in self.seen or k not in self.param_buckets:

@@ -178,6 +178,8 @@ def run(args, model, datasets, collate_fn, call_model, checkpoint_name, path_fie
                     logger.info(f"[Epoch-{epoch} Step-{step}] loss: {loss}")
                 if args.gradient_accumulation_steps > 1:
                     loss = loss / args.gradient_accumulation_steps
+                if reducer is not None:       # collectives only start in the backward that completes the accumulated gradient
+                    reducer.armed = (step + 1) % args.gradient_accumulation_steps == 0
                 loss.backward()
                 if (step + 1) % args.gradient_accumulation_steps == 0:
                     scale = reducer.finish() if reducer is not None else 1.0

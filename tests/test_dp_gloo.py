@@ -33,6 +33,18 @@ def _worker(rank, world, port, out):
     red.grads_ready([params[3][0]])
     red.finish()
     ok = ok and bool(torch.allclose(flat, torch.full((n,), 3.0)))
+    # gradient accumulation: micro-step 1 (disarmed) only fills the arena, micro-step 2 (armed) adds to it and reduces once
+    flat.fill_(float(rank + 1))
+    red.armed = False
+    for p, _, _ in reversed(params):
+        red.grads_ready([p])
+    ok = ok and not any(red.launched)
+    flat.add_(float(rank + 1))
+    red.armed = True
+    for p, _, _ in reversed(params):
+        red.grads_ready([p])
+    red.finish()
+    ok = ok and bool(torch.allclose(flat, torch.full((n,), 6.0)))
     shard = iadist.shard_indices(101, rank, world, epoch_seed=5)
     gathered = [torch.zeros_like(shard) for _ in range(world)]
     dist.all_gather(gathered, shard)
