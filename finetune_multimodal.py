@@ -16,10 +16,12 @@ from item_alignment_amd.utils import VIT_WEIGHTS_NAME, logger
 from src.models import CoCaForItemAlignment, RobertaImageOneTower, RobertaImageTwoTower, RobertaModel
 
 
-def get_parser():
+def get_parser(extra_flags=None):
     p = argparse.ArgumentParser()
     add_common_flags(p)
     a = p.add_argument
+    if extra_flags is not None:
+        extra_flags(a)
     a("--interaction_type", required=True, type=str)
     a("--classification_method", required=True, type=str)
     a("--ensemble", required=True, type=str, help="begin | end (roberta_image) ; sum | cross_attn (coca)")
@@ -63,8 +65,9 @@ def load_raw_data(args):
     return with_images("finetune_train.tsv"), with_images("finetune_test.tsv"), with_images("finetune_test.tsv")
 
 
-def main():
-    args = get_parser()
+def main(args=None, before_run=None):
+    """before_run(args, model): hook between model construction and the train / eval / predict harness (model_soup_multimodal.py)"""
+    args = args or get_parser()
     train.seed_everything(args.seed)
     tokenizer = load_tokenizer(args)
     config = load_config(args.config_file, interaction_type=args.interaction_type, type_vocab_size=args.type_vocab_size,
@@ -95,6 +98,8 @@ def main():
     else:
         raise ValueError(f"Unsupported model name: {args.model_name}")
     freeze_and_resume(args, model)
+    if before_run is not None:
+        before_run(args, model)
     train_data, valid_data, test_data = load_raw_data(args)
     logger.info(f"# train samples: {len(train_data)}, # valid samples: {len(valid_data)}, # test samples: {len(test_data)}")
 

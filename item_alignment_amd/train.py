@@ -201,7 +201,7 @@ def run(args, model, datasets, collate_fn, call_model, checkpoint_name, path_fie
         json.dump({"w": head.weight.detach().cpu().numpy().tolist(), "b": head.bias.detach().cpu().numpy().tolist()},
                   open(os.path.join(out_dir, "weights.json"), "w", encoding="utf-8"), ensure_ascii=False)
         loader = DataLoader(datasets["test"], batch_size=args.eval_batch_size, shuffle=False, collate_fn=collate_fn, **dl_kw)
-        with open(os.path.join(out_dir, f"deepAI_result_threshold={args.threshold}.jsonl"), "w", encoding="utf-8") as w, torch.no_grad():
+        with open(os.path.join(out_dir, f"deepAI_result_{getattr(args, 'pred_tag', '')}threshold={args.threshold}.jsonl"), "w", encoding="utf-8") as w, torch.no_grad():
             for step, batch in enumerate(loader):
                 src_ids, tgt_ids = batch[:2]
                 out = call_model(model, to_dev(batch[2:]))

@@ -226,11 +226,29 @@ def test_finetune_multimodal_roberta_image_gpu(gpu, tmp_path, interaction, ensem
     cmd = [sys.executable, os.path.join(ROOT, "finetune_multimodal.py"), "--data_dir", root, "--output_dir", out, "--config_file",
            os.path.join(root, "ri.json"), "--model_name", "roberta_image_tiny", "--data_version", "v1", "--interaction_type", interaction,
            "--classification_method", "cls", "--ensemble", ensemble, "--loss_type", "ce", "--do_train", "--do_eval",
-           "--train_batch_size", "8", "--eval_batch_size", "4", "--num_train_epochs", "1", "--learning_rate", "1e-4", "--log_steps", "1",
+           "--train_batch_size", "8", "--eval_batch_size", "4", "--num_train_epochs", "2", "--learning_rate", "1e-4", "--log_steps", "1",
            "--pretrained_model_path", pre, "--max_seq_len", "8", "--max_seq_len_pv", "12", "--max_position_embeddings", "64",
            "--image_hidden_size", str(D), "--fp16"]
     r = _run(cmd)
     assert "f1=" in r.stderr and "loss:" in r.stderr
+    if (interaction, ensemble) != ("two_tower", "begin"):
+        return
+    # uniform model soup over the two epoch checkpoints + prediction with the averaged weights (reference model_soup_multimodal.py)
+    import torch
+    d = os.path.join(out, os.listdir(out)[0])
+    pattern = os.path.join(d, "multimodal_finetune_epoch-{}.bin")
+    soup = [sys.executable, os.path.join(ROOT, "model_soup_multimodal.py")] + cmd[2:]
+    for flag in ("--do_train", "--do_eval"):
+        soup.remove(flag)
+    soup += ["--file_state_dict", pattern, "--epochs", "0,1", "--threshold", "0.5"]
+    _run(soup)
+    files = os.listdir(d)
+    assert "multimodal_finetune-uniform_soup-epoch-0,1.bin" in files and "deepAI_result_uniform_soup_threshold=0.5.jsonl" in files, files
+    a, b = (torch.load(pattern.format(e), map_location="cpu") for e in (0, 1))
+    avg = torch.load(os.path.join(d, "multimodal_finetune-uniform_soup-epoch-0,1.bin"), map_location="cpu")
+    k = "classifier.out_proj.weight"
+    assert torch.allclose(avg[k], (a[k] + b[k]) / 2)
+    assert len(open(os.path.join(d, "deepAI_result_uniform_soup_threshold=0.5.jsonl")).readlines()) == 8
 
 
 def test_finetune_text_under_torchrun_rccl(gpu, tmp_path):
