@@ -29,9 +29,10 @@ TRAIN_FLOPS_PER_PAIR = 1.628e12      # 3 x (2 x text(255) + 2 
 WGRAD_VARIANT = 1101                 # gemm_kernel<A k-strided, B k-strided, EPI_NONE, fp32 out>  (dW = dY^T X)
 WGRAD_KERNEL = "t256::gemm_kernel<true, true, 0, true> (+ splitk_reduce_kernel)"
 # HBM bytes per launch of that kernel from rocprofv3 PMC passes of this same command (tools/collect_profiles.sh ->
-# profiles/r01_pmc_fetch_size.csv, r01_pmc_write_size.csv): mean FETCH_SIZE 507,187 KB x 2 (gfx950 reports half of wide
-# coalesced reads, MI355X_MICROARCH.md HBM section) + mean WRITE_SIZE 65,360 KB.  Re-measure when the kernel changes.
-WGRAD_TRAFFIC_BYTES = int((2 * 507187 + 65360) * 1024)
+# profiles/r01_pmc_fetch_size.csv, r01_pmc_write_size.csv): mean FETCH_SIZE 1,050,058 KB x 2 (gfx950 reports half of wide
+# coalesced reads, MI355X_MICROARCH.md HBM section) + mean WRITE_SIZE 65,350 KB, measured at the default 128 pairs per GPU (reported
+# as null for any other batch).  Re-measure when the kernel changes.
+WGRAD_TRAFFIC_BYTES = int((2 * 1050058 + 65350) * 1024)
 
 
 def roberta_large_config(**over):
@@ -103,7 +104,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs-per-gpu", type=int, default=64)
+    ap.add_argument("--pairs-per-gpu", type=int, default=128)
     ap.add_argument("--image-model", default="vit_base_patch16_384")
     ap.add_argument("--seed", type=int, default=2345)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -199,7 +200,7 @@ def main():
             "mfma_fraction_whole_step": None if args.unpad else pairs / dt * TRAIN_FLOPS_PER_PAIR / 1e12 / world / 2500.0,
             "final_loss": final_loss,
             "roofline": {"bound": "mfma", "kernel": WGRAD_KERNEL, "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s",
-                         "frac": achieved / 2500.0, "traffic": WGRAD_TRAFFIC_BYTES, "launches": nl.value,
+                         "frac": achieved / 2500.0, "traffic": WGRAD_TRAFFIC_BYTES if B == 128 else None, "launches": nl.value,
                          "avg_launch_us": ms.value * 1e3 / max(1, nl.value)},
         }
         if world == 1 and not args.no_cpu_baseline:
