@@ -562,3 +562,60 @@ def test_attention_packed_sequences_match_padded(gpu, nh, lens, drop):
     check(lib.ia_attn_bwd_varlen(base, base + 2 * H, base + 4 * H, 3 * H, cu.data_ptr(), T, out.data_ptr(), pd.data_ptr(), H, lse2.data_ptr(),
                                  delta.data_ptr(), db, db + 2 * H, db + 4 * H, 3 * H, B, nh, L, 0.125, drop, 7, stream_ptr()), "bwd_varlen")
     assert rel_err(dp, dqkv.index_select(0, idx)) < 1e-2
+
+
+def test_conv3x3_padded_full_size_against_miopen(gpu):
+    """The eca_nfnet_l0 stage-1 shape at full resolution (200x200, 64 channels, 4 images) and a stage-3 one (50x50, 6 groups of 64):
+    forward and both gradients against torch.conv2d in fp32 on the GPU."""
+    from item_alignment_amd import _lib
+    from item_alignment_amd.ops import check, stream_ptr
+    lib = _lib.load()
+    for B, H, W, groups in ((4, 200, 200, 1), (8, 50, 50, 6)):
+        C = 64 * groups
+        x, dy = rnd((B, H, W, C), gpu, 1.0, 51), rnd((B, H, W, C), gpu, 1.0, 52)
+        w = rnd((C, 64, 3, 3), gpu, 0.05, 53)
+        what = w.permute(0, 2, 3, 1).reshape(C, 576).contiguous()
+        xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+        wr = w.float().requires_grad_(True)
+        ref = torch.nn.functional.conv2d(xr, wr, None, padding=1, groups=groups)
+        ref.backward(dy.float().permute(0, 3, 1, 2))
+        xp, dyp = _pad_nhwc(x), _pad_nhwc(dy)
+        yp, dxp = torch.empty_like(xp), torch.empty_like(xp)
+        check(lib.ia_conv3x3_padded_fwd(xp.data_ptr(), what.data_ptr(), None, yp.data_ptr(), B, H, W, C, C, groups, stream_ptr()), "fwd")
+        check(lib.ia_conv3x3_padded_bwd_data(dyp.data_ptr(), what.data_ptr(), dxp.data_ptr(), B, H, W, C, C, groups, stream_ptr()), "dgrad")
+        wsb = lib.ia_conv3x3_padded_workspace_bytes(B, H, W, C, C, groups)
+        ws = torch.empty(max(wsb, 16), device=gpu, dtype=torch.uint8)
+        dwhat = torch.empty((C, 576), device=gpu, dtype=torch.float32)
+        check(lib.ia_conv3x3_padded_bwd_weight(xp.data_ptr(), dyp.data_ptr(), dwhat.data_ptr(), None, B, H, W, C, C, groups, ws.data_ptr(), wsb,
+                                               stream_ptr()), "wgrad")
+        assert rel_err(yp[:, 1:-1, 1:-1], ref.permute(0, 2, 3, 1)) < 2e-2
+        assert rel_err(dxp[:, 1:-1, 1:-1], xr.grad.permute(0, 2, 3, 1)) < 2e-2
+        assert rel_err(dwhat.view(C, 3, 3, 64).permute(0, 3, 1, 2), wr.grad) < 2e-3      # sums over up to 160 000 pixels, fp32 split-K
+
+
+def test_batchnorm_full_size_statistics(gpu):
+    """resnetv2_50 stage-1 activation size (2 x 320 000 rows x 256 channels): without the ReLU every (segment, channel) of the
+    output has mean beta and variance gamma^2, whatever the input scale and offset; the backward output sums to zero per
+    (segment, channel) (the defining properties of BatchNorm in training mode)."""
+    from item_alignment_amd import _lib
+    from item_alignment_amd.ops import check, stream_ptr
+    lib = _lib.load()
+    rows, C, seg = 640000, 256, 2
+    g = torch.Generator(device="cpu").manual_seed(61)
+    x = ((torch.randn((rows, C), generator=g) * 3.0 + 1.5).to(gpu) * torch.linspace(0.1, 4.0, C, device=gpu)).to(torch.bfloat16)
+    gamma, beta = torch.linspace(0.5, 1.5, C, device=gpu), torch.linspace(-1, 1, C, device=gpu)
+    y = torch.empty_like(x)
+    mean, rstd = torch.empty((seg, C), device=gpu), torch.empty((seg, C), device=gpu)
+    wsb = lib.ia_bn_act_workspace_bytes(rows, C, seg)
+    ws = torch.empty(wsb, device=gpu, dtype=torch.uint8)
+    check(lib.ia_bn_act_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None, None, y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, C,
+                            seg, 1e-5, 0.1, 1, 0, ws.data_ptr(), wsb, stream_ptr()), "bn_fwd")
+    yv = y.float().view(seg, rows // seg, C)
+    assert (yv.mean(1) - beta).abs().max().item() < 5e-3
+    assert (yv.var(1, unbiased=False) / gamma ** 2 - 1).abs().max().item() < 1e-2
+    dy = torch.randn((rows, C), generator=g).to(gpu).to(torch.bfloat16)
+    dx = torch.empty_like(x)
+    check(lib.ia_bn_act_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(), None, dx.data_ptr(),
+                            None, None, rows, C, seg, 1, 0, ws.data_ptr(), wsb, stream_ptr()), "bn_bwd")
+    s = dx.float().view(seg, rows // seg, C).sum(1)
+    assert (s.abs() / (dx.float().abs().view(seg, rows // seg, C).sum(1) + 1e-6)).max().item() < 2e-3
