@@ -57,7 +57,7 @@ def c2(pairs=64):
         pairs, 1.001e12)
 
 
-def c3(pairs=8, S=800):
+def c3(pairs=16, S=800):
     from types import SimpleNamespace
     cfg = SimpleNamespace(num_labels=2, hidden_dropout_prob=0.1, loss_type="ce", loss_margin=0.0, classification_method="cls", hidden_size=2304)
     g = torch.Generator().manual_seed(0)
@@ -67,7 +67,7 @@ def c3(pairs=8, S=800):
     run(f"C3 eca_nfnet_l0 two_tower {S}x{S}", M.NFNetTwoTower(cfg, M.create_model("eca_nfnet_l0")), lambda m: m(im1, im2, labels), pairs, 6.49e11)
 
 
-def c3r(pairs=8, S=800):
+def c3r(pairs=16, S=800):
     """resnetv2_50 two_tower (reference README.md:187-197): 4.1 GMAC @224 (timm model table) -> 52.3 GMAC / image @800"""
     from types import SimpleNamespace
     cfg = SimpleNamespace(num_labels=2, hidden_dropout_prob=0.1, loss_type="ce", loss_margin=0.0, classification_method="cls", hidden_size=2048)
