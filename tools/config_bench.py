@@ -46,7 +46,7 @@ def run(name, model, batch_fn, pairs, flops_per_pair, steps=8, warm=3):
     torch.cuda.empty_cache()
 
 
-def c2(pairs=64):
+def c2(pairs=128):
     cfg = roberta_large_config(interaction_type="one_tower")
     rs = np.random.RandomState(2345)
     t = {k: torch.from_numpy(v).to(dev) for k, v in one_tower_text(rs, pairs).items()}
@@ -78,7 +78,7 @@ def c3r(pairs=16, S=800):
     run(f"C3r resnetv2_50 two_tower {S}x{S}", M.ResNetTwoTower(cfg, M.create_model("resnetv2_50")), lambda m: m(im1, im2, labels), pairs, 6.28e11)
 
 
-def c4(pairs=128):
+def c4(pairs=256):
     S, P = 50, 30
     cfg = roberta_large_config(interaction_type="one_tower", max_seq_len=S, max_seq_len_pv=None, max_pvs=P, num_entities=258211,
                                num_relations=1379, kg_embedding_dim=1024, entity_projection_bias=False)
