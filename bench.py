@@ -29,10 +29,10 @@ TRAIN_FLOPS_PER_PAIR = 1.628e12      # 3 x (2 x text(255) + 2 
 WGRAD_VARIANT = 1101                 # gemm_kernel<A k-strided, B k-strided, EPI_NONE, fp32 out>  (dW = dY^T X)
 WGRAD_KERNEL = "t256::gemm_kernel<true, true, 0, true> (+ splitk_reduce_kernel)"
 # HBM bytes per launch of that kernel from rocprofv3 PMC passes of this same command (tools/collect_profiles.sh ->
-# profiles/r01_pmc_fetch_size.csv, r01_pmc_write_size.csv): mean FETCH_SIZE 1,050,058 KB x 2 (gfx950 reports half of wide
-# coalesced reads, MI355X_MICROARCH.md HBM section) + mean WRITE_SIZE 65,350 KB, measured at the default 128 pairs per GPU (reported
+# profiles/r01_pmc_fetch_size.csv, r01_pmc_write_size.csv): mean FETCH_SIZE 1,052,992 KB x 2 (gfx950 reports half of wide
+# coalesced reads, MI355X_MICROARCH.md HBM section) + mean WRITE_SIZE 65,352 KB, measured at the default 128 pairs per GPU (reported
 # as null for any other batch).  Re-measure when the kernel changes.
-WGRAD_TRAFFIC_BYTES = int((2 * 1050058 + 65350) * 1024)
+WGRAD_TRAFFIC_BYTES = int((2 * 1052992 + 65352) * 1024)
 
 
 def roberta_large_config(**over):
