@@ -174,8 +174,18 @@ class VitTwoTower(_ImageTwoTower):
 
 
 class NFNetTwoTower(_ImageTwoTower):
+    # The conv kernels address an operand with 32-bit byte offsets (2 GiB windows); at 800x800 the strided patch-gather
+    # convolutions reach that at 33 images.  The tower is image-independent (no BatchNorm), so bigger batches run in chunks.
+    max_images = 32
+
     def _embed(self, images):
-        return self.img_encoder.head.global_pool(self.img_encoder.forward_features(images))
+        enc = self.img_encoder
+        n = images.shape[0]
+        per = self.max_images * 800 * 800 // max(1, images.shape[-1] * images.shape[-2])
+        per = max(1, per)
+        if n <= per:
+            return enc.head.global_pool(enc.forward_features(images))
+        return torch.cat([enc.head.global_pool(enc.forward_features(images[i:i + per])) for i in range(0, n, per)], dim=0)
 
 
 class ResNetTwoTower(NFNetTwoTower):

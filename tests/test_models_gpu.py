@@ -401,3 +401,28 @@ def test_unpadded_text_tower_matches_padded(gpu, name, cls, monkeypatch):
                     input_ids_2=g(case, "input_ids_2"), attention_mask_2=g(case, "attention_mask_2"), token_type_ids_2=g(case, "token_type_ids_2"),
                     labels=g(case, "labels"))
     check(case, out, model)
+
+
+def test_nfnet_two_tower_chunked_batch_equals_whole(gpu):
+    """NFNetTwoTower runs batches beyond the kernels' 2 GiB operand window in image chunks (the tower has no batch statistics):
+    chunks of one image must give the loss and the gradients of the whole batch."""
+    import item_alignment_amd.models as M
+    from item_alignment_amd.models.nfnet import NormFreeNet
+    cfg = SimpleNamespace(num_labels=2, hidden_dropout_prob=0.0, loss_type="ce", loss_margin=0.0, classification_method="cls", hidden_size=512)
+    torch.manual_seed(3)
+    model = M.NFNetTwoTower(cfg, NormFreeNet((1, 1, 1, 1), (256, 512, 512, 512), 1.0)).cuda().train()
+    g = torch.Generator().manual_seed(9)
+    im1, im2 = torch.randn((3, 3, 64, 64), generator=g).cuda(), torch.randn((3, 3, 64, 64), generator=g).cuda()
+    labels = torch.tensor([1, 0, 1]).cuda()
+    grads = []
+    losses = []
+    for max_images in (32, 0):                      # 0 -> one image per chunk
+        model.max_images = max_images
+        out = model(im1, im2, labels)
+        model.param_arena.zero_grad()
+        out.loss.backward()
+        torch.cuda.synchronize()
+        losses.append(out.loss.item())
+        grads.append(model.img_encoder.stem.conv2.weight.grad.float().clone())
+    assert abs(losses[0] - losses[1]) < 2e-3, losses
+    assert rel(grads[1], grads[0]) < 2e-2
