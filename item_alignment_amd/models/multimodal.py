@@ -81,8 +81,12 @@ class CoCaModel(nn.Module):
         self.img_encoder = image_encoder
         self.text_encoder = text_encoder
 
-    def embed_text(self, input_ids, attention_mask, token_type_ids, position_ids):
-        out = self.text_encoder(input_ids, attention_mask=attention_mask, token_type_ids=token_type_ids, position_ids=position_ids)
+    def embed_text(self, input_ids, attention_mask, token_type_ids, position_ids, padded_rows_matter=False):
+        # padded_rows_matter: the caller reads the hidden states of PADDED positions (the cross_attn multimodal layers attend
+        # over all L text tokens without a padding mask, reference multimodal.py:529-616), so the unpadded tower run (IA_UNPAD),
+        # which leaves zeros there, must not be used
+        out = self.text_encoder(input_ids, attention_mask=attention_mask, token_type_ids=token_type_ids, position_ids=position_ids,
+                                allow_unpad=not padded_rows_matter)
         return out.last_hidden_state
 
     def embed_image(self, images):
@@ -293,7 +297,7 @@ class CoCaForItemAlignment(HipModule):
         and multimodal layers are therefore not run at all (same outputs, same gradients, half the work)."""
         B, L = input_ids.shape
         img_tok = self.coca.embed_image(images)                                                     # [B, N, Hi] bf16
-        txt = self.coca.embed_text(input_ids, attention_mask, token_type_ids, position_ids)         # [B, L, H] bf16
+        txt = self.coca.embed_text(input_ids, attention_mask, token_type_ids, position_ids, padded_rows_matter=True)   # [B, L, H] bf16
         H, N = txt.shape[-1], img_tok.shape[1]
         x = txt.reshape(B * L, H)
         ctx = img_tok.reshape(B * N, img_tok.shape[-1])

@@ -108,13 +108,13 @@ class RobertaModel(HipModule, PretrainedMixin):
         return self.embeddings.word_embeddings
 
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, cate_ids=None, head_mask=None,
-                inputs_embeds=None, output_attentions=None, output_hidden_states=None, return_dict=None, **unused):
+                inputs_embeds=None, output_attentions=None, output_hidden_states=None, return_dict=None, allow_unpad=True, **unused):
         (self._root if "_root" in self.__dict__ else self).ensure_arena()
         if input_ids is None:
             raise ValueError("You have to specify input_ids")
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
-        if UNPAD and cate_ids is None:
+        if UNPAD and allow_unpad and cate_ids is None:
             hs = self._forward_unpadded(input_ids, attention_mask, token_type_ids, position_ids)
             if hs is not None:
                 return BaseModelOutput(last_hidden_state=hs[-1], hidden_states=hs)

@@ -426,3 +426,13 @@ def test_nfnet_two_tower_chunked_batch_equals_whole(gpu):
         grads.append(model.img_encoder.stem.conv2.weight.grad.float().clone())
     assert abs(losses[0] - losses[1]) < 2e-3, losses
     assert rel(grads[1], grads[0]) < 2e-2
+
+
+def test_coca_with_unpadding_enabled(gpu, monkeypatch):
+    """IA_UNPAD=1 on the CoCa wrapper: `ensemble=sum` reads only the text CLS, so its text tower runs unpadded; `cross_attn` feeds ALL
+    text positions (padding included, there is no padding mask in the reference's multimodal blocks) to the multimodal layers,
+    so it must keep the padded tower run — both still reproduce the reference golden cases."""
+    import item_alignment_amd.models.text as T
+    monkeypatch.setattr(T, "UNPAD", True)
+    test_coca_sum(gpu)
+    test_coca_cross_attn(gpu)
