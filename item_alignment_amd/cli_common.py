@@ -83,7 +83,8 @@ def freeze_and_resume(args, model):
 
 
 def pick_device(model):
-    """HIP models need the GPU; the TextCNN plumbing config is plain torch and runs wherever torch does."""
+    """HIP models need the GPU.  TextCNN (BASELINE config C1, the reference's CPU plumbing case) is plain torch and stays on the host
+    cores: there is no torch-eager GPU path in this package."""
     from .models.base import HipModule
     if isinstance(model, HipModule):
         if not torch.cuda.is_available():
@@ -91,4 +92,4 @@ def pick_device(model):
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
         return torch.device("cuda", local)
-    return torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    return torch.device("cpu")
