@@ -8,14 +8,17 @@ the global-batch gradient.
 
 Design (MI355X-first): gradients already live in one flat fp32 arena (arena.py), so a bucket is a slice of
 it — no packing copies.  Backward fills the arena from its end; as soon as every parameter overlapping a
-bucket has been reported ready (models.functional.register_grad_ready_hook, called right after the layer's
-kernels were enqueued) the bucket's all-reduce is issued asynchronously: RCCL's stream waits for exactly
+bucket has been reported FINAL (models.functional.register_grad_ready_hook, called right after the layer's
+kernels were enqueued; final = no other node of this backward adds to those gradients, which the encoder stacks
+establish by counting their uses) the bucket's all-reduce is issued asynchronously: RCCL's stream waits for exactly
 the kernels enqueued so far and the remaining backward keeps the compute stream busy.  The 1/world
 averaging is folded into the optimiser's grad_scale, so no extra pass touches the gradients.
 xGMI is point-to-point (7 links/GPU); large buckets (default 128 MiB) keep per-link rings bandwidth-bound.
 """
+import datetime
 import os
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -35,7 +38,8 @@ def init_from_env(device_type="cuda"):
         backend = "nccl" if device_type == "cuda" else "gloo"
         if device_type == "cuda":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # generous collective timeout: a rank may legitimately wait for the others' data loading or checkpoint write
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(hours=2))
     return rank, world, local
 
 
@@ -114,9 +118,13 @@ class GradBucketReducer:
                     cur.wait_stream(st)
             self.works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def grads_ready(self, params):
-        """Hook target: these parameters' gradient kernels have been enqueued on the current stream."""
-        if not self.armed:
+    def grads_ready(self, params, final=False):
+        """Hook target: these parameters' gradient kernels have been enqueued on the current stream.  Only a FINAL report
+        (no other autograd node of this backward adds to the gradient: models.functional._notify) counts towards launching a
+        bucket early; everything else is reduced by finish().  A module applied twice, the two sides of the KG embedding or a
+        chunked conv tower report the same parameter from several nodes: treating the first report as final would all-reduce a
+        partial sum and silently drop the rest."""
+        if not self.armed or not final:
             return
         for p in params:
             k = id(p)
@@ -137,6 +145,11 @@ class GradBucketReducer:
         for w in self.works:
             w.wait()
         self.reset()
+        try:
+            from .models import functional as Fn
+            Fn.reset_use_counts()
+        except Exception:        # the reducer is also used stand-alone (tests) without the model package
+            pass
         return 1.0 / self.world
 
 
@@ -151,3 +164,23 @@ def all_reduce_scalar(x, op=None):
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(x, op=op or dist.ReduceOp.SUM)
     return x
+
+
+def gather_interleaved(local, world):
+    """Rank r holds the items r, r + world, r + 2 world, ... of a sequence (numpy array): every rank gets the whole sequence back
+    in its original order."""
+    parts = [None] * world
+    dist.all_gather_object(parts, np.asarray(local))
+    n = sum(len(p) for p in parts)
+    out = np.empty((n,) + parts[0].shape[1:], dtype=parts[0].dtype)
+    for r, p in enumerate(parts):
+        out[r::world] = p
+    return out
+
+
+def all_reduce_grads(model, world):
+    """Gradient averaging for plain torch models without a parameter arena (TextCNN, config C1)."""
+    for p in model.parameters():
+        if p.grad is not None:
+            dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
+            p.grad.div_(world)

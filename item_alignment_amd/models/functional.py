@@ -44,9 +44,23 @@ def clear_grad_ready_hooks():
     del _notify_hooks[:]
 
 
-def _notify(params):
+def _notify(params, final=False):
+    """final=True: no other autograd node of this backward will add to these gradients (only then may a data-parallel bucket
+    be reduced before backward ends).  Most nodes cannot know that - a module applied twice, a two-sided embedding, a chunked
+    tower all += into the same gradient from several nodes - so the default is False and such parameters are reduced after
+    backward; the encoder stacks, which hold >90 % of the parameters, count their uses (below)."""
     for fn in _notify_hooks:
-        fn(params)
+        fn(params, final)
+
+
+# uses of an encoder stack whose backward has not run yet in this step (forward +1, backward -1): the layer gradients are
+# final when the count returns to zero.  Cleared by the train loop / reducer every step (a forward whose output never
+# reaches the loss would otherwise leave a count behind).
+_pending_uses = {}
+
+
+def reset_use_counts():
+    _pending_uses.clear()
 
 
 # ------------------------------------------------------------------------------------------ embeddings
@@ -135,6 +149,8 @@ class EncoderStackFn(torch.autograd.Function):
             inputs.append(cur)
         ctx.stack, ctx.cfgs, ctx.stash, ctx.stash_bytes = stack, cfgs, stash, stash_bytes
         ctx.inputs, ctx.key_mask = inputs, key_mask
+        if keep:
+            _pending_uses[id(stack)] = _pending_uses.get(id(stack), 0) + 1
         return tuple(outs)
 
     @staticmethod
@@ -145,6 +161,8 @@ class EncoderStackFn(torch.autograd.Function):
         scratch = torch.empty(scratch_bytes, device=ctx.stash.device, dtype=torch.uint8)
         mp = ptr(ctx.key_mask)
         dy = None
+        left = _pending_uses.get(id(stack), 1) - 1
+        _pending_uses[id(stack)] = left
         for i in reversed(range(n)):
             g = grads[i]
             if g is not None:
@@ -156,7 +174,7 @@ class EncoderStackFn(torch.autograd.Function):
             check(lib.ia_layer_bwd(C.byref(cfgs[i]), C.byref(stack.weights(i)), C.byref(stack.grads(i)), x.data_ptr(), mp,
                                    ctx.inputs[i + 1].data_ptr(), ctx.stash.data_ptr() + i * ctx.stash_bytes, dy.data_ptr(), dy.data_ptr(),
                                    scratch.data_ptr(), scratch_bytes, stream_ptr()), f"ia_layer_bwd[{i}]")
-            _notify(stack.layer_params(i))
+            _notify(stack.layer_params(i), final=left <= 0)
         ctx.stash = None
         ctx.inputs = None
         return dy, None, None, None, None, None, None, None

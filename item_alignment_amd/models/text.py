@@ -41,11 +41,15 @@ class PretrainedMixin:
                     logger.warning(f"{f} not found: those weights keep their random initialisation")
         if merged:
             own = model.state_dict()
-            loaded, skipped = {}, []
+            loaded, skipped, unmatched = {}, [], []
             for k, v in merged.items():
-                cands = [k, "roberta." + k, k.replace("bert.", "roberta.", 1), "roberta.embeddings." + k]
+                # checkpoint keys may carry a base-model prefix the target lacks (a bare RobertaModel as CoCa's text tower loading
+                # a "roberta." / "bert." checkpoint: HF strips base_model_prefix) or lack one the target has
+                bare = k.split(".", 1)[1] if k.startswith(("roberta.", "bert.")) else k
+                cands = [k, "roberta." + k, k.replace("bert.", "roberta.", 1), "roberta.embeddings." + k, bare]
                 tgt = next((c for c in cands if c in own), None)
                 if tgt is None:
+                    unmatched.append(k)
                     continue
                 if own[tgt].shape != v.shape:
                     if not ignore_mismatched_sizes:
@@ -53,9 +57,17 @@ class PretrainedMixin:
                     skipped.append(tgt)
                     continue
                 loaded[tgt] = v
+            if not loaded:
+                raise RuntimeError(f"no checkpoint key matches {cls.__name__} (first checkpoint keys: {list(merged)[:5]}, first model keys: "
+                                   f"{list(own)[:5]}): the model would silently keep its random initialisation")
             model.load_state_dict(loaded, strict=False)
             if skipped:
                 logger.warning(f"ignored mismatched sizes: {skipped}")
+            if unmatched:
+                logger.warning(f"{len(unmatched)} checkpoint keys have no counterpart in {cls.__name__} (first: {unmatched[:8]})")
+            missing = [k for k in own if k not in loaded]
+            if missing:
+                logger.warning(f"{len(missing)} model tensors keep their random initialisation (first: {missing[:8]})")
         model.eval()
         return model
 

@@ -119,8 +119,14 @@ def run(args, model, datasets, collate_fn, call_model, checkpoint_name, path_fie
         # never fork() a process that owns HIP streams: workers come from a clean fork server and only see the pickled dataset
         dl_kw["multiprocessing_context"] = "forkserver"
 
-    def evaluate(loader, tag):
+    def evaluate(dataset, tag):
+        """Scores the whole set.  Under data parallelism every rank scores positions rank::world and the pieces are gathered
+        (in the original order) on all ranks: no rank sits in a collective while another one evaluates alone."""
         model.eval()
+        n = len(dataset)
+        mine = list(range(rank, n, world)) if world > 1 else None
+        loader = DataLoader(dataset if mine is None else Subset(dataset, mine), batch_size=args.eval_batch_size, shuffle=False,
+                            collate_fn=collate_fn, **dl_kw)
         probs_all, labels_all = None, None
         with torch.no_grad():
             for batch in loader:
@@ -133,6 +139,10 @@ def run(args, model, datasets, collate_fn, call_model, checkpoint_name, path_fie
                     probs = probs[:, 1]
                 probs_all = probs if probs_all is None else np.append(probs_all, probs)
                 labels_all = labels if labels_all is None else np.append(labels_all, labels)
+        if world > 1:
+            probs_all, labels_all = iadist.gather_interleaved(probs_all, world), iadist.gather_interleaved(labels_all, world)
+        if rank != 0:
+            return
         from sklearn.metrics import f1_score, precision_score, recall_score
         for threshold in np.arange(0.1, 1.0, 0.1):
             pred = probs_all >= threshold
@@ -171,7 +181,8 @@ def run(args, model, datasets, collate_fn, call_model, checkpoint_name, path_fie
             opt.zero_grad()
             for step, batch in enumerate(loader):
                 b = to_dev(batch[2:])
-                Fn.set_step_seed(args.seed * 1000003 + global_step * 131 + step)
+                # dropout streams differ per rank (every rank holds other samples of the global batch: identical masks would correlate them)
+                Fn.set_step_seed((args.seed * 1000003 + global_step * 131 + step + rank * 0x9E3779B1) & 0xFFFFFFFF)
                 out = call_model(model, b)
                 loss = out.loss
                 if step % args.log_steps == 0:
@@ -182,18 +193,20 @@ def run(args, model, datasets, collate_fn, call_model, checkpoint_name, path_fie
                     reducer.armed = (step + 1) % args.gradient_accumulation_steps == 0
                 loss.backward()
                 if (step + 1) % args.gradient_accumulation_steps == 0:
+                    if reducer is None and world > 1:     # plain torch models (TextCNN): average the gradients over the ranks
+                        iadist.all_reduce_grads(model, world)
                     scale = reducer.finish() if reducer is not None else 1.0
                     opt.step(linear_schedule_with_warmup(global_step, warm, total), grad_scale=scale)
                     opt.zero_grad()
                     global_step += 1
-            if args.do_eval and datasets.get("valid") is not None and rank == 0:
+            if args.do_eval and datasets.get("valid") is not None:
                 logger.info(f"[Epoch-{epoch}] Starting evaluation ...")
-                evaluate(DataLoader(datasets["valid"], batch_size=args.eval_batch_size, shuffle=False, collate_fn=collate_fn, **dl_kw), f"Epoch-{epoch}")
+                evaluate(datasets["valid"], f"Epoch-{epoch}")
             if rank == 0:
                 logger.info(f"[Epoch-{epoch}] saving model")
                 torch.save(model.state_dict(), os.path.join(out_dir, f"{checkpoint_name}_epoch-{epoch}.bin"))
     elif args.do_eval and datasets.get("valid") is not None:
-        evaluate(DataLoader(datasets["valid"], batch_size=args.eval_batch_size, shuffle=False, collate_fn=collate_fn, **dl_kw), "Eval")
+        evaluate(datasets["valid"], "Eval")
 
     if args.do_pred and datasets.get("test") is not None and rank == 0:
         model.eval()

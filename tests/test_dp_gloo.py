@@ -25,24 +25,37 @@ def _worker(rank, world, port, out):
         p = torch.nn.Parameter(torch.zeros(m)); params.append((p, off, m)); off += m
     red = iadist.GradBucketReducer(flat, params, bucket_bytes=3000 * 4)
     for p, _, _ in reversed(params):                     # backward order: last parameter first
-        red.grads_ready([p])
+        red.grads_ready([p], final=True)
+    ok0 = all(red.launched)                              # every bucket went out during "backward"
     scale = red.finish()
-    ok = bool(torch.allclose(flat, torch.full((n,), 3.0))) and scale == 0.5
+    ok = ok0 and bool(torch.allclose(flat, torch.full((n,), 3.0))) and scale == 0.5
+    # a parameter whose gradient is produced by two autograd nodes (module applied twice, chunked tower): its reports are not
+    # final, so its bucket must NOT be reduced before the second contribution has been added
+    flat.fill_(float(rank + 1))
+    red.grads_ready([params[3][0]], final=False)         # first node
+    launched_early = red.launched[0]
+    flat[7500:].add_(10.0 * (rank + 1))                  # second node adds to the same gradient
+    red.grads_ready([params[3][0]], final=False)
+    for p, _, _ in reversed(params[:3]):
+        red.grads_ready([p], final=True)
+    red.finish()
+    want = torch.full((n,), 3.0); want[7500:] += 30.0
+    ok = ok and not launched_early and bool(torch.allclose(flat, want))
     # second round re-uses the reducer (state reset), with one parameter never reported (frozen)
     flat.fill_(float(rank + 1))
-    red.grads_ready([params[3][0]])
+    red.grads_ready([params[3][0]], final=True)
     red.finish()
     ok = ok and bool(torch.allclose(flat, torch.full((n,), 3.0)))
     # gradient accumulation: micro-step 1 (disarmed) only fills the arena, micro-step 2 (armed) adds to it and reduces once
     flat.fill_(float(rank + 1))
     red.armed = False
     for p, _, _ in reversed(params):
-        red.grads_ready([p])
+        red.grads_ready([p], final=True)
     ok = ok and not any(red.launched)
     flat.add_(float(rank + 1))
     red.armed = True
     for p, _, _ in reversed(params):
-        red.grads_ready([p])
+        red.grads_ready([p], final=True)
     red.finish()
     ok = ok and bool(torch.allclose(flat, torch.full((n,), 6.0)))
     shard = iadist.shard_indices(101, rank, world, epoch_seed=5)
@@ -50,6 +63,17 @@ def _worker(rank, world, port, out):
     dist.all_gather(gathered, shard)
     allidx = torch.cat(gathered)
     ok = ok and len(set(allidx.tolist())) == len(allidx) == 100
+    # sharded evaluation: rank r scores items r::world, every rank gets the whole sequence back in order
+    import numpy as np
+    whole = np.arange(11, dtype=np.float32) * 0.5
+    back = iadist.gather_interleaved(whole[rank::world], world)
+    ok = ok and back.shape == whole.shape and bool((back == whole).all())
+    # plain torch models (TextCNN): gradient averaging without an arena
+    lin = torch.nn.Linear(3, 2)
+    for p in lin.parameters():
+        p.grad = torch.full_like(p, float(rank + 1))
+    iadist.all_reduce_grads(lin, world)
+    ok = ok and all(bool(torch.allclose(p.grad, torch.full_like(p, 1.5))) for p in lin.parameters())
     out[rank] = ok
     dist.destroy_process_group()
 

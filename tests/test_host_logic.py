@@ -40,11 +40,13 @@ def test_bucket_reducer_bookkeeping_single_process():
     assert r.buckets[0] == (744, 1000) and r.buckets[-1][0] == 0       # buckets run from the end of the arena
     launched = []
     r._launch = lambda i: (launched.append(i), r.launched.__setitem__(i, True))
-    r.grads_ready([params[3][0]])                                       # last parameter covers buckets 0,1 fully, 2 partly
+    r.grads_ready([params[3][0]])                                       # not final (another node may add to it): nothing goes out
+    assert launched == []
+    r.grads_ready([params[3][0]], final=True)                           # last parameter covers buckets 0,1 fully, 2 partly
     assert launched == [0, 1]
-    r.grads_ready([params[2][0], params[1][0]])
+    r.grads_ready([params[2][0], params[1][0]], final=True)
     assert 2 in launched
-    r.grads_ready([params[0][0]])
+    r.grads_ready([params[0][0]], final=True)
     assert sorted(launched) == list(range(len(r.buckets)))
     assert r.finish() == 1.0
 
