@@ -257,7 +257,8 @@ def main():
 
     # ---- CoCa (sum / cross_attn).  timm is absent: the image encoder handed to the reference class is the
     # oracle's ViT restatement wrapped as a module with timm's key names, so the wrapper code is pinned
-    # while the ViT arithmetic itself stays "unpinned by the reference" (cross-checked against HF ViT elsewhere).
+    # while the ViT arithmetic itself stays "unpinned by the reference" (cross-checked against transformers.ViTModel by
+    # oracle/gen_golden_r2.py vit_hf -> tests/golden/vit_hf_crosscheck.npz).
     class VitModule(torch.nn.Module):
         def __init__(self, vcfg, spec):
             super().__init__()

@@ -9,9 +9,10 @@ load into the reference classes (oracle/gen_golden.py), this oracle, and the HIP
 
 Pinning: tests/test_oracle_golden.py checks these functions against tests/golden/*.npz captured from
 the reference's own classes in the build container (text towers, PKGM, image-embedding towers,
-TextCNN, CoCa sum / cross_attn, heads and losses).  The ViT and NFNet encoders are third-party code
-(timm==0.6.5, absent offline): ViT is restated from the published timm definition and cross-checked
-against transformers.ViTModel; both are marked "parity unpinned by the reference".
+TextCNN, CoCa sum / cross_attn, heads and losses, and - oracle/gen_golden_r2.py - the image two-tower wrapper classes and a
+24-layer roberta_large stack).  The ViT, NFNet and ResNetV2 encoders are third-party code (timm==0.6.5, absent offline): they
+are restated from the published timm definitions and stay "parity unpinned by the reference"; the ViT restatement is additionally
+cross-checked against transformers.ViTModel (tests/golden/vit_hf_crosscheck.npz, test_vit_restatement_against_transformers_vit).
 """
 import math
 from types import SimpleNamespace

@@ -26,9 +26,18 @@ def case_names():
     return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz"))
 
 
+# narrow instances of the timm towers used by the image two-tower fixtures (oracle/gen_golden_r2.py)
+NARROW_NFNET = SimpleNamespace(depths=(1, 2, 1, 1), channels=(256, 512, 512, 512), stem_chs=128, group_size=64, bottle_ratio=0.25,
+                               num_features=512, alpha=0.2, attn_gain=2.0, eps=1e-5, ch_div=8)
+NARROW_RESNET = SimpleNamespace(layers=(1, 2, 1, 1), channels=(64, 128, 256, 256), stem_chs=32, bottle_ratio=0.25, eps=1e-5, momentum=0.1,
+                                num_features=256)
+TINY_VIT = SimpleNamespace(embed_dim=128, depth=2, num_heads=2, patch_size=16, eps=1e-6, image_size=64)
+
+
 def weights(case, requires_grad=False):
     from oracle.weights import seeded_state_dict
-    sd = seeded_state_dict(case.spec, case.seed)
+    scale = float(case.extra["seed_scale"]) if "seed_scale" in case.extra else -1.0
+    sd = seeded_state_dict(case.spec, case.seed, scale=scale) if scale > 0 else seeded_state_dict(case.spec, case.seed)
     if requires_grad:
         for v in sd.values():
             v.requires_grad_(True)
@@ -73,6 +82,15 @@ def run_oracle(case, sd, training=False):
                                          i["input_ids_2"], i["attention_mask_2"], i["token_type_ids_2"], None, i["img2"], i["labels"], training)
     if n.startswith("textcnn"):
         return O.textcnn_two_tower(sd, cfg, i["input_ids_1"], i["input_ids_2"], i["labels"], training)
+    if n.startswith("nfnet_two_tower"):
+        return O.nfnet_two_tower(sd, cfg, NARROW_NFNET, i["images_1"], i["images_2"], i["labels"], training)
+    if n.startswith("resnet_two_tower"):
+        stats = O.resnetv2_running_stats(NARROW_RESNET, "img_encoder")
+        return O.resnetv2_two_tower(sd, cfg, NARROW_RESNET, i["images_1"], i["images_2"], i["labels"], training, stats)
+    if n.startswith("vit_two_tower"):
+        f1 = O.vit_forward_head(O.vit_forward_features(sd, "img_encoder", TINY_VIT, i["images_1"]))
+        f2 = O.vit_forward_head(O.vit_forward_features(sd, "img_encoder", TINY_VIT, i["images_2"]))
+        return O.image_two_tower(sd, cfg, f1, f2, i["labels"], training)
     if n.startswith("coca"):
         return O.coca_item_alignment(sd, cfg, vit_cfg(case), i["input_ids_1"], i["attention_mask_1"], i["token_type_ids_1"], None, i["img1"],
                                      i["input_ids_2"], i["attention_mask_2"], i["token_type_ids_2"], None, i["img2"], i["labels"], training)

@@ -11,6 +11,10 @@ from golden_util import load_case, weights, vit_cfg
 
 pytestmark = pytest.mark.gpu
 TOL = 5e-2
+COS_MIN = 0.99           # gradient direction; see check().  Measured (tools/parity_report.py, profiles/r02_parity_report.txt): median 1.0000
+# tensors measured below 0.99: a bias gradient that is a sum over the few tokens of a 3-sample batch (cancellation), bf16 ReLU gates
+COS_EXCEPTIONS = {("roberta_two_tower_ce", "roberta.embeddings.LayerNorm.bias"): 0.97}
+MEASURED = []            # (case, kind, key, value) of everything check() compared: printed by tools/parity_report.py
 
 
 def rel(a, b):
@@ -35,11 +39,13 @@ def build(case, cls, *args):
     return model.cuda().eval()
 
 
-def check(case, out, model, tol=TOL):
+def check(case, out, model, tol=TOL, cos_min=None):
+    cos_min = COS_MIN if cos_min is None else cos_min
     for k, want in case.outs.items():
         got = getattr(out, k)
         assert got is not None, k
         assert tuple(got.shape) == tuple(want.shape), (k, got.shape, want.shape)
+        MEASURED.append((case.name, "out rel", k, rel(got.detach(), want)))
         assert rel(got.detach(), want) < tol, (case.name, k, rel(got.detach(), want))
     if case.grads:
         model.param_arena.zero_grad()
@@ -47,14 +53,16 @@ def check(case, out, model, tol=TOL):
         torch.cuda.synchronize()
         params = dict(model.named_parameters())
         # gradients pass through bf16 activations (B = 3 samples, so little averaging): direction must agree
-        # (cosine >= 0.97) and magnitude within 0.25 of the reference's max; kernel-level backward parity is
+        # (cosine >= 0.99) and magnitude within 0.25 of the reference's max; kernel-level backward parity is
         # checked much tighter in test_kernels_gpu.py / test_engine_gpu.py against same-precision inputs.
         for k, want in case.grads.items():
             got = params[k].grad
             assert torch.isfinite(got).all(), k
             a, b = got.float().cpu().flatten(), want.float().flatten()
             c = (torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)).item()
-            assert c > 0.97, (case.name, "grad cosine", k, c)
+            MEASURED.append((case.name, "grad cos", k, c))
+            MEASURED.append((case.name, "grad rel", k, rel(got, want)))
+            assert c > min(cos_min, COS_EXCEPTIONS.get((case.name, k), 1.0)), (case.name, "grad cosine", k, c)
             assert rel(got, want) < 0.25, (case.name, "grad", k, rel(got, want))
 
 
@@ -193,6 +201,72 @@ def test_coca_cross_attn(gpu):
     check(case, out, model)
 
 
+@pytest.mark.parametrize("name", ["nfnet_two_tower", "resnet_two_tower", "vit_two_tower"])
+def test_image_two_tower_wrappers_vs_reference(gpu, name):
+    """NFNetTwoTower / ResNetTwoTower / VitTwoTower against golden vectors captured from the REFERENCE's own wrapper classes
+    (src/models/image.py:212-294, :298-378, :418-499; oracle/gen_golden_r2.py wrappers).  The encoder handed to the reference class
+    evaluates the oracle's restatement of the timm tower, so the wrapper logic (pooling calls, pair head, probs[:, 0] / probs[:, 1] as
+    embeds, loss) is pinned by the reference while the tower arithmetic stays parity-unpinned (timm is absent offline)."""
+    import item_alignment_amd.models as M
+    from golden_util import NARROW_NFNET, NARROW_RESNET, TINY_VIT
+    case = load_case(name)
+    cfg = cfg_of(case)
+    if name.startswith("nfnet"):
+        from item_alignment_amd.models.nfnet import NormFreeNet
+        model = M.NFNetTwoTower(cfg, NormFreeNet(NARROW_NFNET.depths, NARROW_NFNET.channels, 1.0))
+    elif name.startswith("resnet"):
+        from item_alignment_amd.models.resnetv2 import ResNetV2
+        model = M.ResNetTwoTower(cfg, ResNetV2(NARROW_RESNET.layers, NARROW_RESNET.channels, stem_chs=NARROW_RESNET.stem_chs))
+    else:
+        v = TINY_VIT
+        model = M.VitTwoTower(cfg, M.VisionTransformer(img_size=v.image_size, patch_size=v.patch_size, embed_dim=v.embed_dim, depth=v.depth,
+                                                       num_heads=v.num_heads))
+    missing, unexpected = model.load_state_dict(weights(case), strict=False)
+    assert not unexpected, unexpected
+    assert all((".head." in k or "running_" in k or "num_batches" in k) for k in missing), missing
+    model = model.cuda().eval()
+    out = model(g(case, "images_1"), g(case, "images_2"), g(case, "labels"))
+    # ReLU towers in bf16 flip gates near zero (DESIGN.md section 5): direction of deep-layer gradients is looser there
+    check(case, out, model, cos_min=0.97 if name.startswith("resnet") else None)
+
+
+def test_vit_tokens_vs_transformers_vit(gpu):
+    """The HIP ViT tower against transformers.ViTModel's output on the same seeded weights (tests/golden/vit_hf_crosscheck.npz,
+    oracle/gen_golden_r2.py vit_hf): a third-party cross-check of the tower arithmetic, not a pin by the reference."""
+    import item_alignment_amd.models as M
+    case = load_case("vit_hf_crosscheck")
+    c = case.cfg
+    vit = M.VisionTransformer(img_size=c.image_size, patch_size=c.patch_size, embed_dim=c.embed_dim, depth=c.depth, num_heads=c.num_heads)
+    missing, unexpected = vit.load_state_dict({k[2:]: v for k, v in weights(case).items()}, strict=False)
+    assert not unexpected and all(k.startswith("head.") for k in missing), (missing, unexpected)
+    vit = vit.cuda().eval()
+    with torch.no_grad():
+        tok = vit.forward_features(g(case, "images"))
+    r = rel(tok, case.outs["tokens"])
+    MEASURED.append((case.name, "out rel", "tokens", r))
+    assert r < TOL, r
+
+
+def test_24_layer_stack_bf16_drift(gpu):
+    """All 24 layers of roberta_large.json (config C2 shapes: B = 2, L = 510) in the bf16 engine against the fp32 reference's
+    hidden states (tests/golden/roberta_large_24_layers.npz): the error after 1, 6, 12, 18 and 24 layers stays inside the bf16
+    tolerance north_star states (5e-2 of the tensor's max magnitude) - i.e. bf16 rounding does not compound over depth."""
+    import item_alignment_amd.models as M
+    case = load_case("roberta_large_24_layers")
+    model = M.RobertaModel(cfg_of(case), add_pooling_layer=False)
+    model.load_state_dict(weights(case), strict=False)
+    model = model.cuda().eval()
+    with torch.no_grad():
+        out = model(g(case, "input_ids"), attention_mask=g(case, "attention_mask"), token_type_ids=g(case, "token_type_ids"))
+    hs = out.hidden_states
+    m = g(case, "attention_mask").bool().cpu()[:, ::15]
+    for layer in (0, 1, 6, 12, 18, 24):
+        got, want = hs[layer][:, ::15, ::16].float().cpu(), case.extra[f"h{layer}_sub"]
+        r = rel(got[m], want[m])
+        MEASURED.append((case.name, "out rel", f"hidden[{layer}]", r))
+        assert r < TOL, (layer, r)
+
+
 def test_full_width_layer(gpu):
     """roberta_large geometry, one layer, L = 510 (the C2 shapes): hidden states vs the reference subsample."""
     import item_alignment_amd.models as M
@@ -236,6 +310,51 @@ def test_train_step_decreases_loss_and_matches_adamw(gpu):
         arena.adamw_step(1e-3)
         losses.append(l.item())
     assert losses[-1] < losses[0], losses
+
+
+def test_fused_adamw_parameter_groups_match_torch(gpu):
+    """The fused arena AdamW against torch.optim.AdamW with the reference's two parameter groups (finetune_multimodal.py:296-308:
+    names containing "bias" or "LayerNorm.weight" get weight_decay 0).  Covers a decayed weight, a bias, a LayerNorm.weight and a
+    CoCa-style `norm.gamma`, which the reference's name rule does NOT exempt (quirk A17: it is decayed); weight_decay is set large
+    so a wrong group shows; two steps exercise the moment buffers and the bias correction; grad_scale = the 1/world factor."""
+    from item_alignment_amd.arena import ParamArena
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.dense = torch.nn.Linear(96, 80)
+            self.LayerNorm = torch.nn.LayerNorm(80)
+            self.norm = torch.nn.Module()
+            self.norm.gamma = torch.nn.Parameter(torch.ones(80))
+
+    torch.manual_seed(3)
+    net = Net()
+    for q in net.parameters():
+        q.data.normal_(0, 0.5)
+    ref = {n: q.detach().clone().requires_grad_(True) for n, q in net.named_parameters()}
+    arena = ParamArena(net, "cuda")
+    no_decay = ("bias", "LayerNorm.weight")
+    wd, lr, scale = 0.1, 1e-2, 0.5
+    opt = torch.optim.AdamW([{"params": [q for n, q in ref.items() if not any(nd in n for nd in no_decay)], "weight_decay": wd},
+                             {"params": [q for n, q in ref.items() if any(nd in n for nd in no_decay)], "weight_decay": 0.0}],
+                            lr=lr, betas=(0.9, 0.98), eps=1e-8)
+    params = dict(net.named_parameters())
+    for step in range(2):
+        for n, q in params.items():
+            gr = torch.randn(q.shape, generator=torch.Generator().manual_seed(10 * step + len(n)))
+            q.grad.copy_(gr.cuda())
+            ref[n].grad = gr * scale
+        opt.step()
+        arena.adamw_step(lr, weight_decay=wd, grad_scale=scale)
+    torch.cuda.synchronize()
+    assert set(params) == {"dense.weight", "dense.bias", "LayerNorm.weight", "LayerNorm.bias", "norm.gamma"}
+    for n, q in params.items():
+        assert torch.allclose(q.detach().cpu(), ref[n].detach(), atol=2e-6, rtol=1e-5), n
+        # the bf16 shadow the GEMMs read follows the master weights
+        assert torch.equal(arena.shadow_of(q).float().cpu(), q.detach().cpu().to(torch.bfloat16).float()), n
+    # the decay really distinguishes the groups at this setting
+    g0 = ref["norm.gamma"].detach()
+    assert not torch.allclose(g0, (g0 + lr * wd * g0), atol=1e-7)
 
 
 def test_nfnet_tower_vs_oracle(gpu):

@@ -6,7 +6,8 @@ import torch
 
 from golden_util import case_names, load_case, run_oracle, weights
 
-CASES = [c for c in case_names() if c != "roberta_large_one_layer"]
+SPECIAL = ("roberta_large_one_layer", "roberta_large_24_layers", "vit_hf_crosscheck")
+CASES = [c for c in case_names() if c not in SPECIAL]
 
 
 def close(a, b, what):
@@ -44,6 +45,36 @@ def test_full_width_layer():
     close(hs[0][0, ::16, ::16], case.extra["h0_sub"], "h0_sub")
     close(hs[1][0, ::16, ::16], case.extra["h1_sub"], "h1_sub")
     close(hs[1][0, :4, :], case.extra["h1_rows"], "h1_rows")
+
+
+def test_24_layer_stack():
+    """roberta_large.json with all 24 layers, B = 2, L = 510 (config C2 shapes) against the reference's RobertaModel: strided
+    subsamples of the hidden states after layers 0, 1, 6, 12, 18, 24 (oracle/gen_golden_r2.py deep)."""
+    from oracle import ref_models as O
+    case = load_case("roberta_large_24_layers")
+    sd = {"roberta." + k: v for k, v in weights(case).items()}
+    i = case.inputs
+    with torch.no_grad():
+        hs = O.roberta_model(sd, "roberta", case.cfg, i["input_ids"], i["attention_mask"], i["token_type_ids"], None)
+    for layer in (0, 1, 6, 12, 18, 24):
+        got, want = hs[layer][:, ::15, ::16], case.extra[f"h{layer}_sub"]
+        assert got.shape == want.shape
+        assert torch.allclose(got, want, atol=2e-4, rtol=1e-3), (layer, (got - want).abs().max().item())   # fp32 over 24 layers
+    assert torch.allclose(hs[24][:, :3, :], case.extra["h24_rows"], atol=2e-4, rtol=1e-3)
+
+
+def test_vit_restatement_against_transformers_vit():
+    """Cross-check (NOT a pin by the reference: timm 0.6.5 is absent offline): the oracle's restatement of timm's VisionTransformer
+    reproduces transformers.ViTModel (eager attention, layer_norm_eps 1e-6) on the same seeded weights, captured by
+    oracle/gen_golden_r2.py vit_hf.  Two independent statements of the same public architecture agree to fp32 round-off."""
+    from types import SimpleNamespace
+    from oracle import ref_models as O
+    case = load_case("vit_hf_crosscheck")
+    c = case.cfg
+    vcfg = SimpleNamespace(embed_dim=c.embed_dim, depth=c.depth, num_heads=c.num_heads, patch_size=c.patch_size, eps=1e-6)
+    with torch.no_grad():
+        got = O.vit_forward_features(weights(case), "v", vcfg, case.inputs["images"])
+    close(got, case.outs["tokens"], "vit tokens")
 
 
 def test_known_answer_quirks():

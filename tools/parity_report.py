@@ -1,32 +1,23 @@
-"""Prints the relative error (vs the reference golden vectors) of every output / gradient of every fixture."""
-import sys, os
+"""Runs the model-level parity tests on the GPU and prints what they measured against the reference golden vectors: relative
+error of every output and cosine / relative error of every parameter gradient of every fixture (tests/test_models_gpu.py check()).
+usage: python tools/parity_report.py > gpurun_out/parity.txt"""
+import os
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import torch
-from golden_util import load_case, weights
-import test_models_gpu as T
-import item_alignment_amd.models as M
+sys.path.insert(0, ROOT)
+import pytest  # noqa: E402
 
-def g(case, k):
-    v = case.inputs.get(k); return None if v is None else v.cuda()
-
-for name in ["roberta_one_tower_cls_ce", "roberta_two_tower_ce"]:
-    case = load_case(name)
-    if "one_tower" in name:
-        model = T.build(case, "RobertaOneTower")
-        out = model(input_ids=g(case, "input_ids"), attention_mask=g(case, "attention_mask"), token_type_ids=g(case, "token_type_ids"),
-                    labels=g(case, "labels"), output_hidden_states=True)
-        m = g(case, "attention_mask").bool().cpu()
-        for k, idx in (("hidden0", 0), ("hidden1", 1), ("hidden_last", -1)):
-            print(name, k, T.rel(out.hidden_states[idx].float().cpu()[m], case.extra[k][m]))
-    else:
-        model = T.build(case, "RobertaTwoTower")
-        out = model(input_ids_1=g(case, "input_ids_1"), attention_mask_1=g(case, "attention_mask_1"), token_type_ids_1=g(case, "token_type_ids_1"),
-                    input_ids_2=g(case, "input_ids_2"), attention_mask_2=g(case, "attention_mask_2"), token_type_ids_2=g(case, "token_type_ids_2"),
-                    labels=g(case, "labels"))
-    for k, want in case.outs.items():
-        print(name, k, T.rel(getattr(out, k).detach(), want), getattr(out, k).detach().flatten()[:4].tolist(), want.flatten()[:4].tolist())
-    model.param_arena.zero_grad(); out.loss.backward(); torch.cuda.synchronize()
-    P = dict(model.named_parameters())
-    for k, want in case.grads.items():
-        print(name, "grad", k, T.rel(P[k].grad, want))
+rc = pytest.main([os.path.join(ROOT, "tests", "test_models_gpu.py"), "-q", "-m", "gpu", "-p", "no:cacheprovider"])
+T = sys.modules.get("test_models_gpu")
+rows = sorted(set(T.MEASURED)) if T is not None else []
+print(f"\npytest exit code {rc}; {len(rows)} measurements")
+print(f"{'fixture':36s} {'kind':9s} {'tensor':62s} value")
+for case, kind, key, val in rows:
+    print(f"{case:36s} {kind:9s} {key:62s} {val:.4f}")
+cos = [v for _, k, _, v in rows if k == "grad cos"]
+if cos:
+    print(f"\ngradient cosine: min {min(cos):.4f}, median {sorted(cos)[len(cos) // 2]:.4f} over {len(cos)} tensors")
+rels = [v for _, k, _, v in rows if k == "out rel"]
+if rels:
+    print(f"output relative error: max {max(rels):.4f}, median {sorted(rels)[len(rels) // 2]:.4f} over {len(rels)} tensors")
