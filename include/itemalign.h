@@ -223,6 +223,18 @@ int ia_conv_weight_unpack_grad(const float* dwhat, float* dw, int Cout, int Cg, 
  * by the host (item_alignment_amd/data/gpu_preproc.py): results are bit-identical to Image.resize(size, BICUBIC). */
 int ia_resize_pass_u8(const uint8_t* src, uint8_t* dst, const int* bounds, const int* coeffs, int ksize, int B, int in_len, int out_len,
                       int other_len, int horizontal, ia_stream_t stream);
+/* The same pass with an explicit source layout for the horizontal pass (rows src_pitch_bytes apart, frames src_frame_bytes apart): a
+ * RandomResizedCrop window of a decoded frame is the frame's own pitch with src at the window's first pixel and in_len = the window
+ * width; out_len may be the CenterCrop sub-range of a resize when bounds / coeffs are the matching slice of the tables (timm
+ * create_transform as the reference calls it, src/data/data.py:838-841; torchvision on PIL images -> Pillow Resample.c). */
+int ia_resize_pass_u8_ex(const uint8_t* src, size_t src_pitch_bytes, size_t src_frame_bytes, uint8_t* dst, const int* bounds,
+                         const int* coeffs, int ksize, int B, int in_len, int out_len, int other_len, int horizontal, ia_stream_t stream);
+/* One step of torchvision ColorJitter (= Pillow ImageEnhance.{Brightness,Contrast,Color}: Image.blend(degenerate, image, factor),
+ * Blend.c float arithmetic) on uint8 frames [B,H,W,3] in place.  op [B] int32: 0 none, 1 brightness, 2 contrast, 3 saturation;
+ * factor [B] fp32; scratch: B x 8 bytes of device memory (contrast means); any_contrast != 0 when some op[b] == 2.  One call per
+ * position of the images' random op order (reference --color_jitter, data.py:841). */
+int ia_color_jitter_step_u8(uint8_t* frames, const int* op, const float* factor, void* scratch, int B, int H, int W, int any_contrast,
+                            ia_stream_t stream);
 /* uint8 [B,S0,S1,3] -> fp32 [B,3,S0,S1] = (x/255 - mean)/std with IEEE fp32 division (ToTensor + Normalize), optional
  * per-image horizontal flip (flip: [B] device bytes or NULL); mean3 / std3: HOST arrays of 3 floats */
 int ia_u8_to_nchw_normalized(const uint8_t* src, const uint8_t* flip, float* out, int B, int S0, int S1, const float* mean3,

@@ -90,6 +90,8 @@ SIGNATURES = {
     "ia_conv_weight_pack": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "ia_conv_weight_unpack_grad": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "ia_resize_pass_u8": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "ia_resize_pass_u8_ex": (i32, [vp, sz, sz, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "ia_color_jitter_step_u8": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "ia_u8_to_nchw_normalized": (i32, [vp, vp, vp, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp]),
     "ia_embed_ln_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, u32, u32, vp]),
     "ia_embed_ln_bwd_workspace_bytes": (sz, [i32, i32]),

@@ -39,7 +39,7 @@ def add_common_flags(parser, config_required=True):
     # not in the reference (its DataLoader has 0 workers and transforms run inside __getitem__): host-side decode workers and
     # the GPU resize / normalise kernels of SURVEY §8(f) rank 1.  Defaults keep the reference behaviour.
     a("--num_workers", default=0, type=int, help="DataLoader worker processes for decode / tokenisation")
-    a("--gpu_preproc", action="store_true", help="decode images to uint8 on the host, resize + normalise on the GPU (bit-identical to PIL bicubic)")
+    a("--gpu_preproc", action="store_true", help="decode images to uint8 on the host, the transform (resize / crop / flip / colour jitter / normalise) on the GPU, bit-identical to the Pillow path")
     a("--unpad", action="store_true", help="run the RoBERTa towers on the valid tokens only (no compute on the padding; same outputs and "
       "gradients, models/text.py RobertaModel._forward_unpadded).  Same as IA_UNPAD=1")
 

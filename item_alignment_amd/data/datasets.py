@@ -4,13 +4,15 @@ Scope: the *formats* feeding the train step are
 every collate_* below returns the reference's tuple order (two id lists first, then tensors / None), so the
 train scripts can slice batch[2:] exactly as the reference does.  Tokenisation itself is host-side plumbing:
 the tokenizer is whatever object the script passes in (transformers.BertTokenizer when a vocab.txt exists);
-jieba word segmentation is used when importable and skipped otherwise; image decoding uses PIL + numpy with a
-plain resize / normalise (timm's create_transform is third-party and absent offline; a GPU-side decode/resize
-pipeline is the listed next step).
+jieba word segmentation is used when importable and skipped otherwise; images are decoded with PIL and go through
+data/transforms.py ImageTransform (the reference's timm create_transform: evaluation = bilinear Resize + CenterCrop, training =
+RandomResizedCrop + flip + colour jitter), on the host or - with raw=True / --gpu_preproc - on the GPU (data/gpu_preproc.py).
 """
 import numpy as np
 import torch
 from torch.utils.data import Dataset
+
+from .transforms import ImageTransform
 
 IMG_TOKEN = "[unused99]"
 IMG_TOKEN_ID = 99
@@ -308,16 +310,16 @@ class RobertaImageTwoTowerDataset(Dataset):
                 "tgt_item_id": tgt_id}
 
 
-IMAGENET_MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32)
-IMAGENET_STD = np.array([0.229, 0.224, 0.225], dtype=np.float32)
-
-
 class RawImage:
-    """Decoded but unprocessed frame for the GPU pipeline (data/gpu_preproc.py): uint8 [H, W, 3] + the flip decision."""
-    __slots__ = ("u8", "flip")
+    """Decoded but unprocessed frame for the GPU pipeline (data/gpu_preproc.py): uint8 [H, W, 3] + the transform's random draw."""
+    __slots__ = ("u8", "params")
 
-    def __init__(self, u8, flip):
-        self.u8, self.flip = u8, bool(flip)
+    def __init__(self, u8, params):
+        self.u8, self.params = u8, params
+
+    @property
+    def flip(self):
+        return bool(self.params.flip)
 
 
 class RawImageBatch:
@@ -337,28 +339,24 @@ def stack_images(items):
     return torch.stack(items)
 
 
-def load_image(path, size, is_training=False, hflip=0.5, rng=None, raw=False):
-    """PIL open -> RGB -> bicubic resize to size x size -> (train: random horizontal flip) -> ImageNet mean/std,
-    CHW fp32: the tensor layout timm's create_transform yields (reference data.py:838-866).  raw=True stops after the
-    decode and returns a RawImage: the resize / flip / normalisation then run on the GPU (same arithmetic, gpu_preproc.py)."""
+def load_image(path, transform, raw=False):
+    """PIL open -> RGB -> `transform` (data/transforms.py ImageTransform = the reference's timm create_transform, data.py:838-866):
+    CHW fp32.  raw=True stops after the decode and returns a RawImage carrying the transform's random parameters: crop / resize /
+    flip / jitter / normalisation then run on the GPU (same arithmetic, gpu_preproc.py)."""
     from PIL import Image
     img = Image.open(path).convert("RGB")
-    flip = bool(is_training and hflip and (rng or np.random).random() < hflip)
+    params = transform.draw(img.width, img.height)
     if raw:
-        return RawImage(torch.from_numpy(np.ascontiguousarray(np.asarray(img, dtype=np.uint8))), flip)
-    img = img.resize((size, size), Image.BICUBIC)
-    a = np.asarray(img, dtype=np.float32) / 255.0
-    if flip:
-        a = a[:, ::-1]
-    a = (a - IMAGENET_MEAN) / IMAGENET_STD
-    return torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))
+        return RawImage(torch.from_numpy(np.array(img, dtype=np.uint8)), params)
+    return transform.apply(img, params)
 
 
 class PairedImageDataset(Dataset):
     """reference data.py:835-869."""
 
-    def __init__(self, data, input_size, is_training, hflip=0.5, color_jitter=None, raw=False):
-        self.data, self.size, self.train, self.hflip, self.raw = data, input_size, is_training, hflip, raw
+    def __init__(self, data, input_size, is_training, hflip=0.5, color_jitter=None, raw=False, seed=None):
+        self.data, self.size, self.raw = data, input_size, raw
+        self.transform = ImageTransform(input_size, is_training, hflip, color_jitter, seed)
 
     def __len__(self):
         return len(self.data)
@@ -367,8 +365,8 @@ class PairedImageDataset(Dataset):
         label, src_id, src_path, tgt_id, tgt_path = self.data[item]
         rec = {"labels": int(label), "src_item_id": src_id, "tgt_item_id": tgt_id}
         try:
-            rec["src_input"] = load_image(src_path, self.size, self.train, self.hflip, raw=self.raw)
-            rec["tgt_input"] = load_image(tgt_path, self.size, self.train, self.hflip, raw=self.raw)
+            rec["src_input"] = load_image(src_path, self.transform, raw=self.raw)
+            rec["tgt_input"] = load_image(tgt_path, self.transform, raw=self.raw)
         except Exception:
             pass                        # the collate drops samples without images (reference data.py:848-860, :84)
         return rec
@@ -378,8 +376,9 @@ class PairedMultimodalDataset(Dataset):
     """reference data.py:918-989 (CoCa pairs: text ids with explicit position ids 0..L-1 + two images)."""
 
     def __init__(self, data, ensemble, image_size, is_training, text_tokenizer, max_seq_len, max_seq_len_pv=None, hflip=0.5,
-                 color_jitter=None, raw=False):
-        self.data, self.ensemble, self.size, self.train, self.hflip, self.raw = data, ensemble, image_size, is_training, hflip, raw
+                 color_jitter=None, raw=False, seed=None):
+        self.data, self.ensemble, self.size, self.raw = data, ensemble, image_size, raw
+        self.transform = ImageTransform(image_size, is_training, hflip, color_jitter, seed)
         self.tk, self.max_seq_len, self.max_seq_len_pv = text_tokenizer, max_seq_len, max_seq_len_pv
 
     def __len__(self):
@@ -399,8 +398,8 @@ class PairedMultimodalDataset(Dataset):
                "tgt_input_ids": t["input_ids"], "tgt_token_type_ids": t["token_type_ids"], "tgt_attention_mask": t["attention_mask"],
                "tgt_position_ids": list(range(len(t["input_ids"])))}
         try:
-            rec["src_image"] = load_image(src_path, self.size, self.train, self.hflip, raw=self.raw)
-            rec["tgt_image"] = load_image(tgt_path, self.size, self.train, self.hflip, raw=self.raw)
+            rec["src_image"] = load_image(src_path, self.transform, raw=self.raw)
+            rec["tgt_image"] = load_image(tgt_path, self.transform, raw=self.raw)
         except Exception:
             pass
         return rec

@@ -91,22 +91,14 @@ def run(args, model, datasets, collate_fn, call_model, checkpoint_name, path_fie
     pipelines = {}
 
     def gpu_images(raw_batch):
-        """RawImageBatch -> normalised [B, 3, S, S] on the device (data/gpu_preproc.py); frames are grouped by size so each
-        group is one batched launch."""
+        """RawImageBatch -> normalised [B, 3, S, S] on the device (data/gpu_preproc.py): the reference's transform, parameters drawn on
+        the host, arithmetic on the GPU."""
         from .data.gpu_preproc import GpuImagePipeline
         size = int(getattr(args, "image_size", 0) or 0)
         pipe = pipelines.get(size)
         if pipe is None:
             pipe = pipelines[size] = GpuImagePipeline(size, device)
-        items = raw_batch.items
-        out = torch.empty((len(items), 3, size, size), device=device, dtype=torch.float32)
-        groups = {}
-        for i, it in enumerate(items):
-            groups.setdefault(tuple(it.u8.shape), []).append(i)
-        for idxs in groups.values():
-            frames = torch.stack([items[i].u8 for i in idxs])
-            out[torch.as_tensor(idxs, device=device)] = pipe(frames, flip=[int(items[i].flip) for i in idxs])
-        return out
+        return pipe.process(raw_batch.items)
 
     def to_dev(batch):
         from .data.datasets import RawImageBatch

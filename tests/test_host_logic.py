@@ -177,14 +177,14 @@ def test_resnetv2_structure_and_timm_names():
 
 def test_resize_tables_reproduce_pillow_bit_exact():
     """The host-built resampling tables (data/gpu_preproc.py: Pillow Resample.c precompute_coeffs + normalize_coeffs_8bpc) and
-    the 8.22 fixed-point two-pass arithmetic the GPU kernels implement reproduce PIL Image.resize(..., BICUBIC) bit for bit
-    (numpy emulation of csrc/image.hip here; the kernels themselves are checked in test_kernels_gpu.py)."""
+    the 8.22 fixed-point two-pass arithmetic the GPU kernels implement reproduce PIL Image.resize(..., BICUBIC / BILINEAR) bit for
+    bit (numpy emulation of csrc/image.hip here; the kernels themselves are checked in test_kernels_gpu.py)."""
     import numpy as np
     from PIL import Image
     from item_alignment_amd.data.gpu_preproc import PRECISION_BITS, precompute_coeffs
 
-    def one_pass(x, n_out, axis):
-        b, k, _ = precompute_coeffs(x.shape[axis], n_out)
+    def one_pass(x, n_out, axis, filt):
+        b, k, _ = precompute_coeffs(x.shape[axis], n_out, filt)
         x = np.moveaxis(x.astype(np.int64), axis, 0)
         out = np.zeros((n_out,) + x.shape[1:], dtype=np.int64)
         for i in range(n_out):
@@ -195,9 +195,44 @@ def test_resize_tables_reproduce_pillow_bit_exact():
     rs = np.random.RandomState(0)
     for H, W, S in [(800, 800, 384), (333, 517, 384), (90, 70, 224), (801, 640, 800)]:
         img = rs.randint(0, 256, size=(H, W, 3)).astype(np.uint8)
-        ref = np.asarray(Image.fromarray(img).resize((S, S), Image.BICUBIC))
-        got = one_pass(one_pass(img, S, 1), S, 0)          # Pillow: horizontal pass first
-        assert np.array_equal(ref, got.astype(np.uint8)), (H, W, S)
+        for filt, pil in (("bicubic", Image.BICUBIC), ("bilinear", Image.BILINEAR)):
+            ref = np.asarray(Image.fromarray(img).resize((S, S), pil))
+            got = one_pass(one_pass(img, S, 1, filt), S, 0, filt)          # Pillow: horizontal pass first
+            assert np.array_equal(ref, got.astype(np.uint8)), (H, W, S, filt)
+
+
+def test_image_transform_matches_the_timm_restatement():
+    """data/transforms.py ImageTransform (host execution) against oracle/timm_transform.py, the restatement of the reference's
+    timm create_transform(input_size, is_training, hflip, color_jitter) [third party, parity unpinned] (data.py:838-841):
+    evaluation = Resize(floor(S / 0.875), bilinear) + CenterCrop, training = RandomResizedCrop + flip + ColorJitter.  The random
+    draw of the product follows timm's / torchvision's procedures (same random.Random stream -> same crop box), and given the same
+    draw both produce the same tensor bit for bit."""
+    import random
+    import numpy as np
+    from PIL import Image
+    from item_alignment_amd.data.transforms import ImageTransform, center_crop_geometry
+    from oracle import timm_transform as TT
+    rs = np.random.RandomState(3)
+    for (h, w), S in [((800, 800), 384), ((333, 517), 224), ((97, 64), 64), ((500, 1400), 384)]:
+        img = Image.fromarray(rs.randint(0, 256, size=(h, w, 3)).astype(np.uint8))
+        assert center_crop_geometry(w, h, S) == TT.eval_geometry(w, h, S)
+        ev = ImageTransform(S, False)
+        assert torch.equal(ev(img), TT.eval_transform(img, S))
+        tr = ImageTransform(S, True, hflip=0.5, color_jitter=0.4, seed=11)
+        ref_rng = random.Random(11)
+        for _ in range(4):
+            p = tr.draw(w, h)
+            assert p.box == TT.random_resized_crop_params(ref_rng, w, h)          # timm get_params on the same stream
+            # the product's remaining draws (flip, jitter order and factors) advance the same stream
+            flip = ref_rng.random() < 0.5
+            order = [0, 1, 2, 3]; ref_rng.shuffle(order)
+            factors = [ref_rng.uniform(0.6, 1.4) for _ in range(3)]
+            assert (p.flip, p.jitter) == (flip, (tuple(order), *factors))
+            want = TT.train_transform(img, S, TT.TrainParams(p.box, p.flip, p.jitter))
+            assert torch.equal(tr.apply(img, p), want)
+    # no colour jitter unless asked for (the reference's CLI default is None), no flip with hflip = 0
+    p = ImageTransform(64, True, hflip=0.0, color_jitter=None, seed=1).draw(100, 80)
+    assert p.jitter is None and p.flip is False and p.train
 
 
 def test_raw_image_mode_collates_without_resizing(tmp_path):
@@ -214,12 +249,14 @@ def test_raw_image_mode_collates_without_resizing(tmp_path):
         Image.fromarray(rs.randint(0, 256, size=(h, w, 3)).astype(np.uint8)).save(p)
         paths.append(str(p))
     data = [(1, "a", paths[0], "b", paths[1]), (0, "c", paths[2], "d", paths[3]), (1, "e", paths[0], "f", str(tmp_path / "missing.png"))]
-    raw = PairedImageDataset(data, 32, True, hflip=0.5, raw=True)
+    raw = PairedImageDataset(data, 32, True, hflip=0.5, raw=True, seed=4)
     src_ids, tgt_ids, a, b, labels = collate_image([raw[i] for i in range(3)])
     assert src_ids == ["a", "c"] and labels.tolist() == [1, 0]                 # the sample with a missing image is dropped
     assert isinstance(a, RawImageBatch) and isinstance(b, RawImageBatch) and len(a) == 2
     assert isinstance(a.items[0], RawImage) and a.items[0].u8.dtype == torch.uint8 and tuple(a.items[0].u8.shape) == (40, 50, 3)
     assert tuple(b.items[1].u8.shape) == (20, 90, 3)
+    pr = a.items[0].params
+    assert pr.train and len(pr.box) == 4 and pr.box[2] <= 40 and pr.box[3] <= 50 and pr.jitter is None
     std = PairedImageDataset(data, 32, False)
     _, _, a2, b2, _ = collate_image([std[i] for i in range(2)])
     assert tuple(a2.shape) == (2, 3, 32, 32) and a2.dtype == torch.float32

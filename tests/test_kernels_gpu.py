@@ -316,26 +316,45 @@ def test_layernorm_full_size_statistics(gpu):
 
 @pytest.mark.parametrize("H,W,S", [(800, 800, 384), (600, 811, 384), (96, 130, 224), (801, 640, 800)])
 def test_gpu_image_pipeline_bit_exact(gpu, tmp_path, H, W, S):
-    """ia_resize_pass_u8 + ia_u8_to_nchw_normalized against the host path the reference uses (PIL
-    bicubic resize -> /255 -> mean/std, data.py:838-866): integer pixels bit-exact, normalised fp32 tensor bit-exact."""
+    """ia_resize_pass_u8(_ex) + ia_color_jitter_step_u8 + ia_u8_to_nchw_normalized against the restatement
+    of the transform the reference applies on the host (oracle/timm_transform.py: timm create_transform, data.py:838-866) on the
+    same decoded frames and the same random draw: plain resizes bit-exact for both filters, the evaluation transform
+    (bilinear Resize(floor(S / 0.875)) + CenterCrop) bit-exact, the training transform (RandomResizedCrop window, flip, colour
+    jitter in its random order) bit-exact - uint8 pixels and the normalised fp32 tensor."""
     import numpy as np
     from PIL import Image
-    from item_alignment_amd.data.datasets import load_image
+    from item_alignment_amd.data.datasets import RawImage
     from item_alignment_amd.data.gpu_preproc import GpuImagePipeline
+    from item_alignment_amd.data.transforms import ImageTransform
+    from oracle import timm_transform as TT
     rs = np.random.RandomState(H + W)
     frames = rs.randint(0, 256, size=(3, H, W, 3)).astype(np.uint8)
+    for filt, pil in (("bicubic", Image.BICUBIC), ("bilinear", Image.BILINEAR)):
+        pipe = GpuImagePipeline(S, gpu, filt=filt)
+        got_u8 = pipe.resize(torch.from_numpy(frames)).cpu().numpy()
+        for i in range(3):
+            assert np.array_equal(got_u8[i], np.asarray(Image.fromarray(frames[i]).resize((S, S), pil))), (filt, i)
     pipe = GpuImagePipeline(S, gpu)
-    got_u8 = pipe.resize(torch.from_numpy(frames)).cpu().numpy()
+    imgs = [Image.fromarray(f) for f in frames]
+    # evaluation transform, batched
+    ev = ImageTransform(S, False)
+    out = pipe.process([RawImage(torch.from_numpy(f), ev.draw(W, H)) for f in frames]).cpu()
     for i in range(3):
-        assert np.array_equal(got_u8[i], np.asarray(Image.fromarray(frames[i]).resize((S, S), Image.BICUBIC))), i
-    out = pipe(torch.from_numpy(frames), flip=[0, 1, 0]).cpu()
-    for i in range(3):
-        path = tmp_path / f"f{i}.png"
-        Image.fromarray(frames[i]).save(path)
-        want = load_image(str(path), S)
-        if i == 1:
-            want = want.flip(-1)
-        assert torch.equal(out[i], want), i
+        assert torch.equal(out[i], TT.eval_transform(imgs[i], S)), ("eval", i)
+    # training transform with every random ingredient, several draws; evaluation and training items mixed in one batch
+    tr = ImageTransform(S, True, hflip=0.5, color_jitter=0.4, seed=H * 7 + W)
+    items, want = [], []
+    for rep in range(3):
+        for i in range(3):
+            p = tr.draw(W, H)
+            items.append(RawImage(torch.from_numpy(frames[i]), p))
+            want.append(TT.train_transform(imgs[i], S, TT.TrainParams(p.box, p.flip, p.jitter)))
+    items.append(RawImage(torch.from_numpy(frames[0]), ev.draw(W, H)))
+    want.append(TT.eval_transform(imgs[0], S))
+    out = pipe.process(items).cpu()
+    for i in range(len(items)):
+        assert torch.equal(out[i], want[i]), ("train", i, items[i].params)
+    assert any(it.params.flip for it in items) and any(it.params.jitter[0][0] == 1 for it in items[:-1] if it.params.jitter)
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(8200, 2056, 256, "none"), (8200, 2056, 320, "bias_gelu"), (16500, 1032, 192, "add")])
