@@ -7,17 +7,27 @@ fp32 master weights, on synthetic pairs (BASELINE.json metric)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One JSON line on rank 0.  `value` = pairs processed by ALL ranks / max-over-ranks wall time of the K timed
-steps (inputs resident in HBM, weak scaling: per-GPU batch fixed).  Extra objects:
+steps (inputs resident in HBM, weak scaling: per-GPU batch fixed).  The batches are drawn without replacement from the
+50 000-pair synthetic set of SURVEY §8(d) (32 resident global batches, never repeated inside a default run).  Extra objects:
   roofline     the dominant kernel (by summed time: the wgrad GEMM instantiation), timed per launch with HIP
-               events on its launch stream inside the timed region: achieved = algorithmic FLOPs / time.
+               events on its launch stream inside the timed region: achieved = algorithmic FLOPs / time; `traffic` = HBM
+               bytes per launch from two rocprofv3 --pmc child passes of this same command (FETCH_SIZE x 2 on gfx950 +
+               WRITE_SIZE, MI355X_MICROARCH.md HBM section), N = 1 only, null when rocprofv3 is unavailable.
+  variants     the same step with every sequence at the full 255 tokens, and with the unpadded text towers (--unpad,
+               DESIGN.md 4.8), a few steps each after the headline measurement (not part of `value`).
   cpu_baseline the CPU oracle (oracle/ref_models.py, a pure-torch port pinned to the reference by golden
                vectors) running the same train step on the host cores, bounded sample, rank 0 at N=1 only.
 """
 import argparse
+import csv
 import ctypes as C
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import torch
@@ -28,11 +38,39 @@ sys.path.insert(0, ROOT)
 TRAIN_FLOPS_PER_PAIR = 1.628e12      # 3 x (2 x text(255) + 2 x ViT-B/16@384) forward FLOPs
 WGRAD_VARIANT = 1101                 # gemm_kernel<A k-strided, B k-strided, EPI_NONE, fp32 out>  (dW = dY^T X)
 WGRAD_KERNEL = "t256::gemm_kernel<true, true, 0, true> (+ splitk_reduce_kernel)"
-# HBM bytes per launch of that kernel from rocprofv3 PMC passes of this same command (tools/collect_profiles.sh ->
-# profiles/r01_pmc_fetch_size.csv, r01_pmc_write_size.csv): mean FETCH_SIZE 1,052,992 KB x 2 (gfx950 reports half of wide
-# coalesced reads, MI355X_MICROARCH.md HBM section) + mean WRITE_SIZE 65,352 KB, measured at the default 128 pairs per GPU (reported
-# as null for any other batch).  Re-measure when the kernel changes.
-WGRAD_TRAFFIC_BYTES = int((2 * 1052992 + 65352) * 1024)
+DATASET_PAIRS = 50_000               # size of the synthetic pair set the batches are drawn from
+RESIDENT_BATCHES = 32
+
+
+def pmc_traffic(args):
+    """HBM bytes per launch of the wgrad kernel, measured by running this same command (2 steps) under rocprofv3 --pmc, one pass
+    per counter (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950).  FETCH_SIZE counts 64 B per 128 B request of a wide
+    coalesced read on this part, so it is doubled (MI355X_MICROARCH.md, HBM).  Returns (bytes, note)."""
+    rocprof = shutil.which("rocprofv3")
+    if rocprof is None:
+        return None, "rocprofv3 not found"
+    kb = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="ia_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+        cmd = [rocprof, "--pmc", counter, "-d", out, "-o", "p", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
+               "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-pmc", "--no-variants", "--pairs-per-gpu", str(args.pairs_per_gpu),
+               "--image-model", args.image_model, "--seed", str(args.seed)]
+        try:
+            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=420, check=True, cwd=out)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            tot, n = 0.0, 0
+            for r in csv.DictReader(open(files[0])):
+                if "gemm_kernel<true, true, 0, true>" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                    tot += float(r["Counter_Value"]); n += 1
+            if n == 0:
+                return None, f"{counter}: kernel not in the trace"
+            kb[counter] = tot / n
+        except Exception as e:
+            return None, f"{counter} pass failed: {e!r}"
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    return int((2 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024), (f"rocprofv3 --pmc, mean per launch: FETCH_SIZE {kb['FETCH_SIZE']:.0f} KB x 2 "
+                                                                    f"+ WRITE_SIZE {kb['WRITE_SIZE']:.0f} KB")
 
 
 def roberta_large_config(**over):
@@ -113,6 +151,9 @@ def main():
     ap.add_argument("--full-length", action="store_true", help="all sequences at the full 255 tokens (mask all ones)")
     ap.add_argument("--unpad", action="store_true", help="text towers on the valid tokens only (IA_UNPAD=1, DESIGN.md 4.8); off by "
                     "default: the reference computes densely on the padding and the headline number keeps that workload")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes behind roofline.traffic")
+    ap.add_argument("--no-variants", action="store_true", help="skip the full-length / unpadded side measurements")
+    ap.add_argument("--variant-steps", type=int, default=4)
     args = ap.parse_args()
     if args.unpad:
         os.environ["IA_UNPAD"] = "1"
@@ -141,17 +182,26 @@ def main():
 
     B = args.pairs_per_gpu
     n_steps = args.warmup + args.steps
-    data = SyntheticCocaPairs(B * world * 4, image_size=cfg.image_size, seed=args.seed, full_length=args.full_length)
-    # four distinct global batches, resident in HBM before timing starts; rank r owns pairs r::world of each
-    batches = [data.batch([g * B * world + rank + world * i for i in range(B)], dev) for g in range(4)]
+    # a 50 000-pair synthetic set; the run walks a seeded permutation of it in global batches of B * world pairs,
+    # RESIDENT_BATCHES of them generated device-side and resident in HBM before timing starts (14.5 GB at 128 pairs per GPU);
+    # rank r owns pairs r::world of each global batch.  A default run (25 steps) never sees a batch twice.
+    data = SyntheticCocaPairs(DATASET_PAIRS, image_size=cfg.image_size, seed=args.seed, full_length=args.full_length)
+    perm = torch.randperm(DATASET_PAIRS, generator=torch.Generator().manual_seed(args.seed)).tolist()
+    n_batches = min(RESIDENT_BATCHES, DATASET_PAIRS // (B * world))
+
+    def make_batches(ds, count):
+        return [ds.batch([perm[g * B * world + rank + world * i] for i in range(B)], dev, device_images=True) for g in range(count)]
+    batches = make_batches(data, n_batches)
     total_opt_steps = max(n_steps, 100)
     warm = int(0.3 * total_opt_steps)
     base_lr = 1e-5
 
-    def step(i):
-        Fn.set_step_seed(args.seed * 1000003 + i)
+    def step(i, pool=None):
+        pool = batches if pool is None else pool
+        Fn.set_step_seed((args.seed * 1000003 + i + rank * 0x9E3779B1) & 0xFFFFFFFF)    # dropout streams differ per rank
         arena.zero_grad()
-        out = model(*batches[i % 4][:10], labels=batches[i % 4][10])
+        b = pool[i % len(pool)]
+        out = model(*b[:10], labels=b[10])
         out.loss.backward()
         scale = reducer.finish()
         arena.adamw_step(base_lr * linear_schedule(i, total_opt_steps, warm), betas=(0.9, 0.98), eps=1e-8, weight_decay=1e-5,
@@ -183,6 +233,34 @@ def main():
     dt = tmax.item()
     final_loss = float(loss.detach())
 
+    def timed(pool, k, first):
+        """k more steps on `pool` (2 untimed first), max over ranks, like the headline region"""
+        for i in range(2):
+            step(first + i, pool)
+        torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+        t = time.perf_counter()
+        for i in range(k):
+            step(first + 2 + i, pool)
+        torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+        tm = torch.tensor([time.perf_counter() - t], device=dev, dtype=torch.float64)
+        if world > 1 or iadist.FORCE:
+            torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
+        return {"value": B * world * k / tm.item(), "unit": "item-pairs/sec", "ms_per_step": tm.item() / k * 1e3, "steps": k}
+
+    variants = None
+    if not args.no_variants and not args.unpad and not args.full_length:
+        from item_alignment_amd.models import text as _text
+        variants = {}
+        full = SyntheticCocaPairs(B * world * 2, image_size=cfg.image_size, seed=args.seed + 1, full_length=True)
+        pool = [full.batch([g * B * world + rank + world * i for i in range(B)], dev, device_images=True) for g in range(2)]
+        variants["full_length_sequences"] = timed(pool, args.variant_steps, n_steps)
+        del pool
+        _text.UNPAD = True
+        try:
+            variants["unpadded_text_tower"] = timed(batches, args.variant_steps, n_steps + 2 + args.variant_steps)
+        finally:
+            _text.UNPAD = False
+
     if rank == 0:
         pairs = B * world * args.steps
         achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
@@ -200,9 +278,21 @@ def main():
             "mfma_fraction_whole_step": None if args.unpad else pairs / dt * TRAIN_FLOPS_PER_PAIR / 1e12 / world / 2500.0,
             "final_loss": final_loss,
             "roofline": {"bound": "mfma", "kernel": WGRAD_KERNEL, "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s",
-                         "frac": achieved / 2500.0, "traffic": WGRAD_TRAFFIC_BYTES if B == 128 else None, "launches": nl.value,
+                         "frac": achieved / 2500.0, "traffic": None, "launches": nl.value,
                          "avg_launch_us": ms.value * 1e3 / max(1, nl.value)},
+            "variants": variants,
         }
+        res["config"]["dataset_pairs"] = DATASET_PAIRS
+        res["config"]["resident_batches"] = n_batches
+        if world == 1 and not args.no_pmc:
+            # free this process's HBM first: the child runs build their own model and batches
+            del batches
+            torch.cuda.empty_cache()
+            traffic, note = pmc_traffic(args)
+            res["roofline"]["traffic"] = traffic
+            res["roofline"]["traffic_source"] = note
+            if traffic:
+                res["roofline"]["traffic_GBps"] = traffic / (ms.value * 1e-3 / max(1, nl.value)) / 1e9
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(cfg, args.image_model, args.cpu_pairs, args.cpu_steps, args.seed)

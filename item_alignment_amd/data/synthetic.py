@@ -62,13 +62,20 @@ class SyntheticCocaPairs:
         self.labels = rs.randint(0, 2, size=n_pairs).astype(np.int64)
         self.n, self.image_size, self.seed = n_pairs, image_size, seed
 
-    def batch(self, indices, device):
+    def batch(self, indices, device, device_images=False):
+        """device_images: draw the N(0,1) images with the device's generator (fast for many large resident batches; a different
+        stream than the host generator, still a function of (seed, first index) only)."""
         idx = np.asarray(indices)
         t = {k: torch.from_numpy(v[idx]).to(device) for k, v in self.text.items()}
-        g = torch.Generator(device="cpu").manual_seed(self.seed * 7919 + int(idx[0]))
         S = self.image_size
-        im1 = torch.randn((len(idx), 3, S, S), generator=g).to(device)
-        im2 = torch.randn((len(idx), 3, S, S), generator=g).to(device)
+        if device_images and torch.device(device).type == "cuda":
+            g = torch.Generator(device=device).manual_seed(self.seed * 7919 + int(idx[0]))
+            im1 = torch.randn((len(idx), 3, S, S), generator=g, device=device)
+            im2 = torch.randn((len(idx), 3, S, S), generator=g, device=device)
+        else:
+            g = torch.Generator(device="cpu").manual_seed(self.seed * 7919 + int(idx[0]))
+            im1 = torch.randn((len(idx), 3, S, S), generator=g).to(device)
+            im2 = torch.randn((len(idx), 3, S, S), generator=g).to(device)
         labels = torch.from_numpy(self.labels[idx]).to(device)
         # PairedMultimodalDataset emits explicit position ids 0..L-1 (reference data.py:979,984)
         pos = torch.arange(t["input_ids_1"].shape[1], device=device).unsqueeze(0).expand(len(idx), -1).contiguous()
