@@ -42,9 +42,9 @@ int ia_abi_version(void);
  * a Linear weight) or k-strided ([K,N], ldb).  epilogue: */
 #define IA_EPI_NONE 0
 #define IA_EPI_BIAS 1      /* + bias[N] (fp32) */
-#define IA_EPI_BIAS_GELU 2 /* C2 = bf16(acc + bias) (pre-activation), C = gelu_erf(C2) */
+#define IA_EPI_BIAS_GELU 2 /* x = bf16(acc + bias): C = gelu_erf(x), C2 = gelu_erf'(x) (saved for IA_EPI_DGELU) */
 #define IA_EPI_ADD 3       /* + aux[M,N] (bf16, ldaux) */
-#define IA_EPI_DGELU 4     /* * gelu'(aux[M,N]) */
+#define IA_EPI_DGELU 4     /* * aux[M,N], the derivative IA_EPI_BIAS_GELU saved in C2 */
 #define IA_EPI_BIAS_ADD 5  /* + bias + aux */
 int ia_gemm_bf16(const void* A, int a_kstrided, int lda, const void* B, int b_kstrided, int ldb, void* C, int c_is_f32, int ldc,
                  int M, int N, int K, int epilogue, const float* bias, const void* aux, int ldaux, void* C2, int accumulate,

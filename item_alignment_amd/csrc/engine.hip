@@ -15,7 +15,7 @@ inline size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
 inline size_t rows_of(const ia_layer_cfg* c) { return c->cu_seqlens ? (size_t)c->total_tokens : (size_t)c->B * c->L; }
 
 struct Stash {
-  char* qkv; char* ctx; char* t0; char* t1; char* t2; char* hpre; char* hact;
+  char* qkv; char* ctx; char* t0; char* t1; char* t2; char* hpre; char* hact;   // hpre holds gelu'(pre-activation) (IA_EPI_BIAS_GELU C2), hact the activation
   float* lse; float* mean1; float* rstd1; float* mean2; float* rstd2;
   size_t bytes;
 };

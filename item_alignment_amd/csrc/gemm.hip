@@ -38,7 +38,8 @@ struct GemmArgs {
   uint32_t a_bytes, b_bytes;
   int accumulate;
   int tiles_m, tiles_n;
-  int splits, nk_per_split;   // split-K (fp32 output only): blockIdx.y owns k-tiles [y*nk_per_split, ...)
+  int splits, nk_per_split;   // split-K (fp32 output only): split s owns k-tiles [s*nk_per_split, ...)
+  int split_id;               // set inside the kernels (T128: blockIdx.y; T256: derived from the XCD-aware work order)
   float* ws;                  // [splits][M][N] fp32 partials when splits > 1
   int dbg;                    // ablation switches for tuning runs (IA_GEMM_DBG env): results are WRONG when non-zero
   // Shifted operand views (T128 only) that turn the GEMM into a 3x3 convolution over a zero-bordered NHWC tensor
@@ -64,26 +65,32 @@ IA_DEV void epi_store4(const GemmArgs& p, int m, int n, f32x4 v) {
     v += b;
   }
   if (EPI == EPI_BIAS_GELU) {
-    bf16x4 pre = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-    *reinterpret_cast<bf16x4*>(p.C2 + (size_t)m * p.ldc + n) = pre;
-    // activation is taken on the bf16-rounded pre-activation so the backward (which only has the
-    // stored bf16 value) differentiates exactly the function the forward evaluated
+    // C = gelu(pre), C2 = gelu'(pre), both of the bf16-rounded pre-activation: the derivative shares the exp / rcp of the
+    // activation (two more multiply-adds here) and turns the data-gradient epilogue (EPI_DGELU) into one multiply per element
+    bf16x4 der;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(bf2f(pre[r]));
+    for (int r = 0; r < 4; ++r) {
+      const float x = bf2f(f2bf(v[r]));
+      float c, d;
+      gelu_parts(x, c, d);
+      v[r] = x * c;
+      der[r] = f2bf(__builtin_fmaf(x, d, c));
+    }
+    *reinterpret_cast<bf16x4*>(p.C2 + (size_t)m * p.ldc + n) = der;
   }
   if (EPI == EPI_ADD || EPI == EPI_BIAS_ADD) {
     const bf16x4 a = *reinterpret_cast<const bf16x4*>(p.aux + (size_t)m * p.ldaux + n);
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] += bf2f(a[r]);
   }
-  if (EPI == EPI_DGELU) {
+  if (EPI == EPI_DGELU) {   // aux = the saved gelu'(pre-activation)
     const bf16x4 a = *reinterpret_cast<const bf16x4*>(p.aux + (size_t)m * p.ldaux + n);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad(bf2f(a[r]));
+    for (int r = 0; r < 4; ++r) v[r] *= bf2f(a[r]);
   }
   if (OUTF32) {
     if (p.splits > 1) {   // partial sums; the second-stage kernel adds them into C in a fixed order
-      *reinterpret_cast<f32x4*>(p.ws + ((size_t)blockIdx.y * p.M + m) * p.N + n) = v;
+      *reinterpret_cast<f32x4*>(p.ws + ((size_t)p.split_id * p.M + m) * p.N + n) = v;
       return;
     }
     float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
@@ -117,24 +124,28 @@ IA_DEV void epi_store8(const GemmArgs& p, int m, int n, f32x4 lo, f32x4 hi) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) { v[r] += b0[r]; v[4 + r] += b1[r]; }
   }
-  if (EPI == EPI_BIAS_GELU) {
-    bf16x8 pre;
+  if (EPI == EPI_BIAS_GELU) {   // see epi_store4
+    bf16x8 der;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) pre[r] = f2bf(v[r]);
-    gstore16(p.C2 + (size_t)m * p.ldc + n, pre);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = gelu_erf(bf2f(pre[r]));
+    for (int r = 0; r < 8; ++r) {
+      const float x = bf2f(f2bf(v[r]));
+      float c, d;
+      gelu_parts(x, c, d);
+      v[r] = x * c;
+      der[r] = f2bf(__builtin_fmaf(x, d, c));
+    }
+    gstore16(p.C2 + (size_t)m * p.ldc + n, der);
   }
   if (EPI == EPI_ADD || EPI == EPI_BIAS_ADD || EPI == EPI_DGELU) {
     const bf16x8 a = *reinterpret_cast<const bf16x8*>(p.aux + (size_t)m * p.ldaux + n);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      if (EPI == EPI_DGELU) v[r] *= gelu_erf_grad(bf2f(a[r]));
+      if (EPI == EPI_DGELU) v[r] *= bf2f(a[r]);
       else v[r] += bf2f(a[r]);
     }
   }
   if (OUTF32) {
-    float* c = p.splits > 1 ? p.ws + ((size_t)blockIdx.y * p.M + m) * p.N + n : reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+    float* c = p.splits > 1 ? p.ws + ((size_t)p.split_id * p.M + m) * p.N + n : reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
     f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
     if (p.splits <= 1 && p.accumulate) { o0 += *reinterpret_cast<const f32x4*>(c); o1 += *reinterpret_cast<const f32x4*>(c + 4); }
     gstore16(c, o0);
@@ -147,18 +158,23 @@ IA_DEV void epi_store8(const GemmArgs& p, int m, int n, f32x4 lo, f32x4 hi) {
   }
 }
 
-// XCD-aware tile order: the 8 XCDs each take a contiguous run of tiles (bijective for any grid size), and
-// inside the run 8 m-tiles are swept per n so one XCD re-uses the same B panel from its private L2.
-IA_DEV void tile_of_index(const GemmArgs& p, int bid, int nwg, int& bm, int& bn) {
+// XCD-aware work order.  Workgroups are dealt round-robin to the 8 XCDs (each with a private L2): xcd_chunk renumbers them so that
+// every XCD takes a contiguous run of the work list (bijective for any grid size) ...
+IA_DEV int xcd_chunk(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-  bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+// ... and the work list sweeps 8 m-tiles per n, so a run of 32 tiles is an 8 x 4 block: 8 A panels and 4 B panels feed 32 tiles
+// out of one XCD's L2.
+IA_DEV void tile_of_order(const GemmArgs& p, int t, int& bm, int& bn) {
   const int GM = 8;
-  const int group = bid / (GM * p.tiles_n);
+  const int group = t / (GM * p.tiles_n);
   const int first_m = group * GM;
   const int gsz = min(p.tiles_m - first_m, GM);
-  bm = first_m + (bid % (GM * p.tiles_n)) % gsz;
-  bn = (bid % (GM * p.tiles_n)) / gsz;
+  bm = first_m + (t % (GM * p.tiles_n)) % gsz;
+  bn = (t % (GM * p.tiles_n)) / gsz;
 }
+IA_DEV void tile_of_index(const GemmArgs& p, int bid, int nwg, int& bm, int& bn) { tile_of_order(p, xcd_chunk(bid, nwg), bm, bn); }
 
 // ============================================================================== T128 (4 waves, 16x16x32)
 namespace t128 {
@@ -216,6 +232,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   int bm, bn;
   tile_of_index(p, blockIdx.x, gridDim.x, bm, bn);
   const int m0 = bm * BM, n0 = bn * BN;
+  p.split_id = blockIdx.y;
   if (p.groups > 1) {                  // uniform: the kernel argument copy is ours to edit
     const long z = blockIdx.z;
     p.A += z * p.ga; p.B += z * p.gb;
@@ -462,9 +479,21 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;          // 2 x 4 waves, 128 x 64 each; waves w and w+4 share a SIMD
   const int nk_all = (p.K + BK - 1) / BK;
-  const int kt0 = blockIdx.y * p.nk_per_split;
-  const int n_tiles = min(nk_all, kt0 + p.nk_per_split) - kt0;
   const int total_tiles = p.tiles_m * p.tiles_n;
+  // Split-K launches are a 1-D grid of tiles x splits workgroups whose XCD-aware order has the split OUTERMOST: one XCD's run of
+  // 32 work items is then an 8 x 4 block of tiles of ONE k-slab, i.e. 12 operand panel streams per XCD instead of 36 when the
+  // splits of a tile shared an XCD (HBM bytes of the fc1 weight gradient: 2.2 GB -> 0.9 GB per launch, algorithmic 0.67 GB).
+  int first_tile = blockIdx.x;          // index into the tile work order
+  bool ordered = false;                 // first_tile already is a position of that order (no XCD renumbering inside run())
+  p.split_id = 0;
+  if (p.splits > 1) {
+    const int w = xcd_chunk(blockIdx.x, gridDim.x);
+    p.split_id = w / total_tiles;
+    first_tile = w % total_tiles;
+    ordered = true;
+  }
+  const int kt0 = p.split_id * p.nk_per_split;
+  const int n_tiles = min(nk_all, kt0 + p.nk_per_split) - kt0;
 
   // Ping-pong schedule.  The 8 waves form two groups (grp = wm: rows 0..127 / 128..255 of the block tile); every
   // SIMD hosts one wave of each group.  A wave alternates a LOAD phase (all 24 fragment reads of one k-tile into
@@ -481,9 +510,12 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs p) {
   // ~2 us HBM round trip of a tile prologue hides behind the epilogue instead of idling the CU.
   constexpr int PEND = 16 * epi_stores_per_call<EPI, OUTF32>();   // store instructions of one full-tile epilogue, per wave
   static_assert(PEND < 60, "vmcnt is a 6-bit counter");
+  auto coords = [&](int tile, int& bm, int& bn) {
+    if (ordered) tile_of_order(p, tile, bm, bn); else tile_of_index(p, tile, total_tiles, bm, bn);
+  };
   auto run = [&](int tile, bool prologue_only, f32x16 (&acc)[4][2], bool stores_in_flight) {
     int bm, bn;
-    tile_of_index(p, tile, total_tiles, bm, bn);
+    coords(tile, bm, bn);
     // keep per-lane address arithmetic from being hoisted out of the tile loop (it would stay live across the
     // epilogue and push the 256-register kernel into scratch): every call derives it afresh from an opaque lane id
     int lane = lane0;
@@ -493,7 +525,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs p) {
   };
 
   f32x16 acc[4][2];
-  int tile = blockIdx.x;
+  int tile = first_tile;
   run(tile, true, acc, false);
   bool stores_in_flight = false;
   while (true) {
@@ -504,7 +536,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     run(tile, false, acc, stores_in_flight);
-    const int next = tile + gridDim.x;
+    const int next = ordered ? total_tiles : tile + gridDim.x;      // a split-K workgroup owns exactly one (tile, k-slab)
 
     // The k-tile buffers are free once the main loop's last barrier has passed: start the NEXT tile's first two k-tiles
     // now, so their HBM round trip (~2 us) runs under this tile's epilogue.
@@ -517,7 +549,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs p) {
     // as full 128-byte row segments, 8 rows per instruction.  C^T fragment: lane (m = li, half hh) register r <-> fragment
     // row i = (r&3) + 8*(r>>2) + 4*hh; k-contiguous B: n = hh*16 + r; k-strided B: n = i.
     int bm, bn;
-    tile_of_index(p, tile, total_tiles, bm, bn);
+    coords(tile, bm, bn);
     const int m0 = bm * BM + wm * 128, n0 = bn * BN + wn * 64;
     int lane_e = lane0;
     asm volatile("" : "+v"(lane_e));
@@ -660,8 +692,10 @@ int launch(GemmArgs a, bool big, hipStream_t st) {
       attr_set = true;
     }
     const int ntile = a.tiles_m * a.tiles_n;
-    const int gx = a.splits > 1 ? ntile : (ntile < 256 ? ntile : 256);   // persistent over tiles, one workgroup per CU
-    hipLaunchKernelGGL(kern, dim3(gx, a.splits), dim3(512), t256::LDS_BYTES, st, a);
+    // split-K: one workgroup per (tile, k-slab), 1-D so the kernel can order them XCD-aware with the slab outermost;
+    // otherwise persistent over tiles, one workgroup per CU
+    const int gx = a.splits > 1 ? ntile * a.splits : (ntile < 256 ? ntile : 256);
+    hipLaunchKernelGGL(kern, dim3(gx), dim3(512), t256::LDS_BYTES, st, a);
   } else {
     a.tiles_m = (a.M + t128::BM - 1) / t128::BM; a.tiles_n = (a.N + t128::BN - 1) / t128::BN;
     hipLaunchKernelGGL((t128::gemm_kernel<AKS, BKS, EPI, OUTF32>), dim3(a.tiles_m * a.tiles_n, a.splits, a.groups), dim3(256), 0, st, a);

@@ -28,9 +28,11 @@ def test_gemm_nt_epilogues(gpu, M, N, K):
     ref = a.float() @ w.float().t()
     assert rel_err(ops.gemm(a, w), ref) < 2e-2
     assert rel_err(ops.gemm(a, w, epilogue=ops.EPI_BIAS, bias=bias), ref + bias) < 2e-2
-    act, pre = ops.gemm(a, w, epilogue=ops.EPI_BIAS_GELU, bias=bias)
-    assert rel_err(pre, ref + bias) < 2e-2
-    assert rel_err(act, torch.nn.functional.gelu(pre.float())) < 2e-2
+    act, der = ops.gemm(a, w, epilogue=ops.EPI_BIAS_GELU, bias=bias)      # activation and its saved derivative
+    x = (ref + bias).requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    assert rel_err(act, torch.nn.functional.gelu(x.detach())) < 2e-2
+    assert rel_err(der, x.grad) < 2e-2
     assert rel_err(ops.gemm(a, w, epilogue=ops.EPI_BIAS_ADD, bias=bias, aux=aux), ref + bias + aux.float()) < 2e-2
     assert rel_err(ops.gemm(a, w, out_f32=True), ref) < 2e-3
 
@@ -44,9 +46,8 @@ def test_gemm_nn_dgrad(gpu, M, N, K):
     ref = dy.float() @ w.float()
     assert rel_err(ops.gemm(dy, w, b_kstrided=True), ref) < 2e-2
     assert rel_err(ops.gemm(dy, w, b_kstrided=True, epilogue=ops.EPI_ADD, aux=aux), ref + aux.float()) < 2e-2
-    x = aux.float().requires_grad_(True)
-    torch.nn.functional.gelu(x).sum().backward()
-    assert rel_err(ops.gemm(dy, w, b_kstrided=True, epilogue=ops.EPI_DGELU, aux=aux), ref * x.grad) < 2e-2
+    # EPI_DGELU multiplies by the derivative the forward's EPI_BIAS_GELU epilogue saved
+    assert rel_err(ops.gemm(dy, w, b_kstrided=True, epilogue=ops.EPI_DGELU, aux=aux), ref * aux.float()) < 2e-2
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (192, 64, 300), (1024, 3072, 1000), (3072, 1024, 2040), (64, 64, 40)])
@@ -368,9 +369,11 @@ def test_gemm_persistent_rounds_with_clipped_tiles(gpu, M, N, K, epi):
         assert rel_err(ops.gemm(a, w), ref) < 2e-2
     elif epi == "bias_gelu":
         bias = torch.randn(N, device=gpu)
-        act, pre = ops.gemm(a, w, epilogue=ops.EPI_BIAS_GELU, bias=bias)
-        assert rel_err(pre, ref + bias) < 2e-2
-        assert rel_err(act, torch.nn.functional.gelu(pre.float())) < 2e-2
+        act, der = ops.gemm(a, w, epilogue=ops.EPI_BIAS_GELU, bias=bias)
+        x = (ref + bias).requires_grad_(True)
+        torch.nn.functional.gelu(x).sum().backward()
+        assert rel_err(act, torch.nn.functional.gelu(x.detach())) < 2e-2
+        assert rel_err(der, x.grad) < 2e-2
     else:
         aux = rnd((M, N), gpu, 1.0, 53)
         assert rel_err(ops.gemm(a, w, epilogue=ops.EPI_ADD, aux=aux), ref + aux.float()) < 2e-2
