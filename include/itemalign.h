@@ -68,6 +68,11 @@ size_t ia_ln_bwd_workspace_bytes(int M, int H);
 int ia_ln_bwd(const void* dy, const void* dres, const void* z, const float* mean, const float* rstd, const float* gamma, void* dz,
               void* dx, float* dgamma, float* dbeta, float* dbias, int M, int H, float drop_p, uint32_t seed, uint32_t stream_id,
               void* workspace, size_t workspace_bytes, int accumulate, ia_stream_t stream);
+/* the same with a second upstream gradient: LayerNorm output gradient = dy + dy2 (dy2 may be NULL; dz may alias dy2).  Replaces the
+ * "+ residual gradient" epilogue of the GEMM producing dy in a post-LN layer (transformers RobertaOutput / RobertaSelfOutput backward). */
+int ia_ln_bwd2(const void* dy, const void* dy2, const void* dres, const void* z, const float* mean, const float* rstd, const float* gamma,
+               void* dz, void* dx, float* dgamma, float* dbeta, float* dbias, int M, int H, float drop_p, uint32_t seed, uint32_t stream_id,
+               void* workspace, size_t workspace_bytes, int accumulate, ia_stream_t stream);
 size_t ia_colsum_workspace_bytes(int M, int N);
 int ia_colsum(const void* x, int ld, int M, int N, float* out, int accumulate, void* workspace, size_t workspace_bytes,
               ia_stream_t stream);
@@ -346,6 +351,14 @@ int ia_layer_fwd(const ia_layer_cfg* cfg, const ia_layer_weights* w, const void*
 /* dy [M,H] bf16 -> dx [M,H] bf16 (dx may alias dy); parameter gradients accumulate into g. */
 int ia_layer_bwd(const ia_layer_cfg* cfg, const ia_layer_weights* w, const ia_layer_grads* g, const void* x, const uint8_t* key_mask,
                  const void* y, const void* stash, const void* dy, void* dx, void* scratch, size_t scratch_bytes, ia_stream_t stream);
+/* Split-residual form for stacks of post-LN layers: the gradient of the layer OUTPUT arrives as dy + dy2 (dy2 may be NULL) and the
+ * gradient of the layer INPUT leaves as dx + dx2, dx2 being the residual-path part (the attention sub-block's LayerNorm input
+ * gradient) - the next layer down takes (dx, dx2) as its (dy, dy2) and sums them inside its first LayerNorm backward, so no GEMM
+ * carries a "+ aux" epilogue.  dx may alias dy, dx2 may alias dy2.  dx2 == NULL: dx holds the whole input gradient (bottom layer).
+ * Pre-LN (ViT) layers: dy2 / dx2 must be NULL. */
+int ia_layer_bwd2(const ia_layer_cfg* cfg, const ia_layer_weights* w, const ia_layer_grads* g, const void* x, const uint8_t* key_mask,
+                  const void* y, const void* stash, const void* dy, const void* dy2, void* dx, void* dx2, void* scratch,
+                  size_t scratch_bytes, ia_stream_t stream);
 
 #ifdef __cplusplus
 }

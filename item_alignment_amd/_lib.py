@@ -39,6 +39,7 @@ SIGNATURES = {
     "ia_ln_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, u32, u32, vp]),
     "ia_ln_bwd_workspace_bytes": (sz, [i32, i32]),
     "ia_ln_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, u32, u32, vp, sz, i32, vp]),
+    "ia_ln_bwd2": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, u32, u32, vp, sz, i32, vp]),
     "ia_colsum_workspace_bytes": (sz, [i32, i32]),
     "ia_colsum": (i32, [vp, i32, i32, i32, vp, i32, vp, sz, vp]),
     "ia_attn_fwd": (i32, [vp, vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, f32, f32, u32, vp]),
@@ -117,6 +118,7 @@ SIGNATURES = {
     "ia_layer_bwd_scratch_bytes": (sz, [C.POINTER(LayerCfg)]),
     "ia_layer_fwd": (i32, [C.POINTER(LayerCfg), C.POINTER(LayerWeights), vp, vp, vp, vp, vp]),
     "ia_layer_bwd": (i32, [C.POINTER(LayerCfg), C.POINTER(LayerWeights), C.POINTER(LayerGrads), vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "ia_layer_bwd2": (i32, [C.POINTER(LayerCfg), C.POINTER(LayerWeights), C.POINTER(LayerGrads), vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
 }
 
 _lib = None

@@ -128,20 +128,33 @@ extern "C" int ia_layer_fwd(const ia_layer_cfg* c, const ia_layer_weights* w, co
     IA_TRY(ia_ln_fwd(x, nullptr, nullptr, nullptr, s.t0, s.mean1, s.rstd1, w->ln1_g, w->ln1_b, M, H, c->eps, 0.f, 0, 0, st));
     IA_TRY(ia_gemm_bf16(s.t0, 0, H, w->w_qkv, 0, H, s.qkv, 0, 3 * H, M, 3 * H, H, IA_EPI_BIAS, w->b_qkv, nullptr, 0, nullptr, 0, nullptr, 0, st));
     IA_TRY(attn_fwd(c, s.qkv, key_mask, s.ctx, s.lse, scale, 0.f, 0, st));
-    IA_TRY(ia_gemm_bf16(s.ctx, 0, H, w->w_o, 0, H, s.t1, 0, H, M, H, H, IA_EPI_BIAS_ADD, w->b_o, x, H, nullptr, 0, nullptr, 0, st));
-    IA_TRY(ia_ln_fwd(s.t1, nullptr, nullptr, nullptr, s.t2, s.mean2, s.rstd2, w->ln2_g, w->ln2_b, M, H, c->eps, 0.f, 0, 0, st));
+    // x1 = x + ctx Wo^T + b_o and LN2(x1): the bias and the residual are added by the LayerNorm kernel (it streams the rows anyway),
+    // so the projection keeps the plain epilogue; t1 receives x1 in place of the raw projection
+    IA_TRY(ia_gemm_bf16(s.ctx, 0, H, w->w_o, 0, H, s.t1, 0, H, M, H, H, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
+    IA_TRY(ia_ln_fwd(s.t1, w->b_o, x, s.t1, s.t2, s.mean2, s.rstd2, w->ln2_g, w->ln2_b, M, H, c->eps, 0.f, 0, 0, st));
     IA_TRY(ia_gemm_bf16(s.t2, 0, H, w->w_fc1, 0, H, s.hact, 0, I, M, I, H, IA_EPI_BIAS_GELU, w->b_fc1, nullptr, 0, s.hpre, 0, nullptr, 0, st));
     IA_TRY(ia_gemm_bf16(s.hact, 0, I, w->w_fc2, 0, I, y, 0, H, M, H, I, IA_EPI_BIAS_ADD, w->b_fc2, s.t1, H, nullptr, 0, nullptr, 0, st));
   }
   return IA_OK;
 }
 
+extern "C" int ia_layer_bwd2(const ia_layer_cfg* c, const ia_layer_weights* w, const ia_layer_grads* g, const void* x,
+                             const uint8_t* key_mask, const void* y, const void* stash, const void* dy, const void* dy2, void* dx, void* dx2,
+                             void* scratch, size_t scratch_bytes, ia_stream_t st);
+
 extern "C" int ia_layer_bwd(const ia_layer_cfg* c, const ia_layer_weights* w, const ia_layer_grads* g, const void* x,
                             const uint8_t* key_mask, const void* y, const void* stash, const void* dy, void* dx, void* scratch,
                             size_t scratch_bytes, ia_stream_t st) {
+  return ia_layer_bwd2(c, w, g, x, key_mask, y, stash, dy, nullptr, dx, nullptr, scratch, scratch_bytes, st);
+}
+
+extern "C" int ia_layer_bwd2(const ia_layer_cfg* c, const ia_layer_weights* w, const ia_layer_grads* g, const void* x,
+                             const uint8_t* key_mask, const void* y, const void* stash, const void* dy, const void* dy2, void* dx, void* dx2,
+                             void* scratch, size_t scratch_bytes, ia_stream_t st) {
   (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   (void)y;
   if (!cfg_ok(c) || !w || !g || !x || !stash || !dy || !dx || !scratch) return IA_ERR_ARG;
+  if (c->pre_ln && (dy2 || dx2)) return IA_ERR_UNSUPPORTED;
   if (scratch_bytes < ia_layer_bwd_scratch_bytes(c)) return IA_ERR_WORKSPACE;
   const int M = (int)rows_of(c), H = c->H, I = c->I;
   const Stash s = carve_stash(c, const_cast<void*>(stash));
@@ -150,25 +163,32 @@ extern "C" int ia_layer_bwd(const ia_layer_cfg* c, const ia_layer_weights* w, co
   const uint32_t attn_seed = c->seed * 2654435761u + c->layer_id * 97u + 17u;
   const bool drop = c->hidden_drop > 0.f;
   if (!c->pre_ln) {
-    // LN2 backward: dz2 -> g0, masked branch gradient -> g1 (or g0 when p == 0)
-    IA_TRY(ia_ln_bwd(dy, nullptr, s.t2, s.mean2, s.rstd2, w->ln2_g, k.g0, drop ? k.g1 : nullptr, g->ln2_g, g->ln2_b, g->b_fc2, M, H,
-                     c->hidden_drop, c->seed, c->layer_id * 4u + 1u, k.ws, k.ws_bytes, 1, st));
+    // The two residual additions of a post-LN layer make each LayerNorm output's gradient a sum of two terms; both LayerNorm
+    // backward kernels take the two terms (ia_ln_bwd2), so the GEMMs in front of them keep the plain epilogue.
+    // LN2 backward: d(output) = dy (+ dy2) -> dz2 in g0, masked branch gradient -> g1 (or g0 when p == 0)
+    IA_TRY(ia_ln_bwd2(dy, dy2, nullptr, s.t2, s.mean2, s.rstd2, w->ln2_g, k.g0, drop ? k.g1 : nullptr, g->ln2_g, g->ln2_b, g->b_fc2, M, H,
+                      c->hidden_drop, c->seed, c->layer_id * 4u + 1u, k.ws, k.ws_bytes, 1, st));
     const char* d_ffn = drop ? k.g1 : k.g0;
     IA_TRY(ia_gemm_bf16(d_ffn, 1, H, s.hact, 1, I, g->w_fc2, 1, I, H, I, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
     IA_TRY(ia_gemm_bf16(d_ffn, 0, H, w->w_fc2, 1, I, k.gI, 0, I, M, I, H, IA_EPI_DGELU, nullptr, s.hpre, I, nullptr, 0, nullptr, 0, st));
     IA_TRY(ia_colsum(k.gI, I, M, I, g->b_fc1, 1, k.ws, k.ws_bytes, st));
     IA_TRY(ia_gemm_bf16(k.gI, 1, I, s.t1, 1, H, g->w_fc1, 1, H, I, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
-    IA_TRY(ia_gemm_bf16(k.gI, 0, I, w->w_fc1, 1, H, k.g2, 0, H, M, H, I, IA_EPI_ADD, nullptr, k.g0, H, nullptr, 0, nullptr, 0, st));
-    // LN1 backward
-    IA_TRY(ia_ln_bwd(k.g2, nullptr, s.t0, s.mean1, s.rstd1, w->ln1_g, k.g0, drop ? k.g1 : nullptr, g->ln1_g, g->ln1_b, g->b_o, M, H,
-                     c->hidden_drop, c->seed, c->layer_id * 4u + 0u, k.ws, k.ws_bytes, 1, st));
-    const char* d_att = drop ? k.g1 : k.g0;
+    IA_TRY(ia_gemm_bf16(k.gI, 0, I, w->w_fc1, 1, H, k.g2, 0, H, M, H, I, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
+    // LN1 backward: d(y1) = g2 (through fc1) + g0 (residual into LN2) -> dz1 (the layer input's residual-path gradient) in
+    // dz1buf: the caller's dx2 when the split form is wanted, else g0 (in place over the term just consumed)
+    char* dz1buf = dx2 ? (char*)dx2 : k.g0;
+    IA_TRY(ia_ln_bwd2(k.g2, k.g0, nullptr, s.t0, s.mean1, s.rstd1, w->ln1_g, dz1buf, drop ? k.g1 : nullptr, g->ln1_g, g->ln1_b, g->b_o, M, H,
+                      c->hidden_drop, c->seed, c->layer_id * 4u + 0u, k.ws, k.ws_bytes, 1, st));
+    const char* d_att = drop ? k.g1 : dz1buf;
     IA_TRY(ia_gemm_bf16(d_att, 1, H, s.ctx, 1, H, g->w_o, 1, H, H, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
     IA_TRY(ia_gemm_bf16(d_att, 0, H, w->w_o, 1, H, k.g2, 0, H, M, H, H, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
     IA_TRY(attn_bwd(c, s.qkv, key_mask, s.ctx, k.g2, s.lse, k.delta, k.gqkv, scale, c->attn_drop, attn_seed, st));
     IA_TRY(ia_colsum(k.gqkv, 3 * H, M, 3 * H, g->b_qkv, 1, k.ws, k.ws_bytes, st));
     IA_TRY(ia_gemm_bf16(k.gqkv, 1, 3 * H, x, 1, H, g->w_qkv, 1, H, 3 * H, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
-    IA_TRY(ia_gemm_bf16(k.gqkv, 0, 3 * H, w->w_qkv, 1, H, dx, 0, H, M, H, 3 * H, IA_EPI_ADD, nullptr, k.g0, H, nullptr, 0, nullptr, 0, st));
+    if (dx2)   // split form: dx = the attention sub-block's data gradient, dx2 = dz1 (already written)
+      IA_TRY(ia_gemm_bf16(k.gqkv, 0, 3 * H, w->w_qkv, 1, H, dx, 0, H, M, H, 3 * H, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
+    else
+      IA_TRY(ia_gemm_bf16(k.gqkv, 0, 3 * H, w->w_qkv, 1, H, dx, 0, H, M, H, 3 * H, IA_EPI_ADD, nullptr, dz1buf, H, nullptr, 0, nullptr, 0, st));
   } else {
     IA_TRY(ia_colsum(dy, H, M, H, g->b_fc2, 1, k.ws, k.ws_bytes, st));
     IA_TRY(ia_gemm_bf16(dy, 1, H, s.hact, 1, I, g->w_fc2, 1, I, H, I, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));

@@ -23,6 +23,7 @@
 // swapped operands (C^T fragments) so each lane ends up with runs of consecutive output columns.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -102,25 +103,28 @@ IA_DEV void epi_store4(const GemmArgs& p, int m, int n, f32x4 v) {
   }
 }
 
-// One 16-byte global store as exactly one VMEM instruction.  The persistent T256 kernel leaves a tile's output stores in
-// flight while the next tile's main loop starts and waits with a COUNTED s_waitcnt vmcnt(N) for the k-tile DMA issued
-// before them (vmcnt retires in issue order), so the number of store instructions per epilogue must be known exactly.
+// One 16-byte global store = one VMEM instruction (hipcc emits a single global_store_dwordx4 for an aligned 16-byte vector store;
+// tools/check_gemm_isa.sh counts them).  The persistent T256 kernel leaves a tile's output stores in flight while the next tile's
+// main loop starts and waits with a COUNTED s_waitcnt vmcnt(N) for the k-tile DMA issued before them (vmcnt retires in order), so
+// the number of store instructions per epilogue must be known exactly.  The store is a plain (compiler-visible) one on purpose: the
+// epilogue's aux / bias loads are software-pipelined two slices ahead of the stores, and only when hipcc counts the stores too does
+// it wait for such a load with vmcnt(k > 0) and leave the younger stores in flight (an asm store is invisible to its counters: every
+// load wait became vmcnt(0), i.e. a full store + load round trip per 8-row slice, 16 times per tile).
 template <typename V>
 IA_DEV void gstore16(void* ptr, V v) {
   static_assert(sizeof(V) == 16, "16-byte store");
-  // s_nop 1: a store of more than 8 bytes reads its data registers over several cycles; a VALU write to them in the next
-  // two wait states corrupts the stored value (the compiler pads its own stores, it cannot see inside an asm statement)
-  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(ptr), "v"(v) : "memory");
+  *reinterpret_cast<V*>(ptr) = v;
 }
 template <int EPI, bool OUTF32>
 constexpr int epi_stores_per_call() { return OUTF32 ? 2 : (EPI == EPI_BIAS_GELU ? 2 : 1); }
 
-// v = 8 consecutive output columns n..n+7 of row m (row-coalesced epilogue of the T256 kernel)
-template <int EPI, bool OUTF32>
-IA_DEV void epi_store8(const GemmArgs& p, int m, int n, f32x4 lo, f32x4 hi) {
+// v = 8 consecutive output columns n..n+7 of row m (row-coalesced epilogue of the T256 kernel).  PRE: bias (pb0 | pb1) and aux (ax)
+// were fetched ahead by the caller; else they are loaded here.
+template <int EPI, bool OUTF32, bool PRE>
+IA_DEV void epi_store8(const GemmArgs& p, int m, int n, f32x4 lo, f32x4 hi, f32x4 pb0, f32x4 pb1, bf16x8 ax) {
   float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_ADD) {
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+    const f32x4 b0 = PRE ? pb0 : *reinterpret_cast<const f32x4*>(p.bias + n), b1 = PRE ? pb1 : *reinterpret_cast<const f32x4*>(p.bias + n + 4);
 #pragma unroll
     for (int r = 0; r < 4; ++r) { v[r] += b0[r]; v[4 + r] += b1[r]; }
   }
@@ -137,7 +141,7 @@ IA_DEV void epi_store8(const GemmArgs& p, int m, int n, f32x4 lo, f32x4 hi) {
     gstore16(p.C2 + (size_t)m * p.ldc + n, der);
   }
   if (EPI == EPI_ADD || EPI == EPI_BIAS_ADD || EPI == EPI_DGELU) {
-    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p.aux + (size_t)m * p.ldaux + n);
+    const bf16x8 a = PRE ? ax : *reinterpret_cast<const bf16x8*>(p.aux + (size_t)m * p.ldaux + n);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       if (EPI == EPI_DGELU) v[r] *= bf2f(a[r]);
@@ -556,37 +560,71 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs p) {
     const int hh = lane_e >> 5, li = lane_e & 31;
     char* stg = smem + 2 * 2 * TILE_BYTES + wave * STAGE_BYTES;
     const int wrow = li & 15, rrow = lane_e >> 3, c8 = lane_e & 7;
-    if (!(p.dbg & 32))
+    // this wave's 128 x 64 part lies entirely inside C: no row / column guards, the store count of the tile is exact
+    const bool full = m0 + 128 <= p.M && n0 + 64 <= p.N;
+    constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_ADD;
+    constexpr bool HAS_AUX = EPI == EPI_ADD || EPI == EPI_BIAS_ADD || EPI == EPI_DGELU;
+    // Slice c (c = 0..15) = rows (c>>2)*32 + ((c>>1)&1)*16 + (c&1)*8 + rrow of this wave's part, the lane's 8 columns n0 + c8*8.
+    // PRE (full parts): the bias - the same 8 columns for all slices - is read once per tile, and the aux operand runs AHEAD slices
+    // ahead of the stores: VMEM retires in order, so a load issued behind a store can only be waited for by draining that store;
+    // issued ahead, hipcc's own counters leave the younger stores in flight (vmcnt(2 * AHEAD) in the steady state).
+    constexpr int AHEAD = 4;
+    auto drain_tile = [&](auto PREFETCHED) {
+      constexpr bool PRE = decltype(PREFETCHED)::value;
+      f32x4 pb0 = {0.f, 0.f, 0.f, 0.f}, pb1 = pb0;
+      bf16x8 ax[AHEAD + 1];
+      auto aux_of = [&](int c) {
+        const int row = m0 + (c >> 2) * 32 + ((c >> 1) & 1) * 16 + (c & 1) * 8 + rrow;
+        return *reinterpret_cast<const bf16x8*>(p.aux + (size_t)row * p.ldaux + n0 + c8 * 8);
+      };
+      if (PRE && HAS_BIAS) { pb0 = *reinterpret_cast<const f32x4*>(p.bias + n0 + c8 * 8); pb1 = *reinterpret_cast<const f32x4*>(p.bias + n0 + c8 * 8 + 4); }
+      if (PRE && HAS_AUX) {
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-#pragma unroll
-      for (int h16 = 0; h16 < 2; ++h16) {
-        if ((li >> 4) == h16) {
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-              const int chunk = (ni * 32 + (BKS ? rg * 8 + hh * 4 : hh * 16 + rg * 4)) >> 2;
-              const f32x4 v = {acc[mi][ni][rg * 4], acc[mi][ni][rg * 4 + 1], acc[mi][ni][rg * 4 + 2], acc[mi][ni][rg * 4 + 3]};
-              *reinterpret_cast<f32x4*>(stg + wrow * 256 + ((chunk ^ wrow) << 4)) = v;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const int row = it * 8 + rrow;
-          const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + row * 256 + (((2 * c8) ^ row) << 4));
-          const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * 256 + (((2 * c8 + 1) ^ row) << 4));
-          const int m = m0 + mi * 32 + h16 * 16 + row, n = n0 + c8 * 8;
-          if (m < p.M && n < p.N && !(p.dbg & 64)) epi_store8<EPI, OUTF32>(p, m, n, lo, hi);
-          if (p.dbg & 64) asm volatile("" : : "v"(lo), "v"(hi));
-        }
-        __builtin_amdgcn_wave_barrier();
+        for (int c = 0; c < AHEAD; ++c) ax[c] = aux_of(c);
       }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+        for (int h16 = 0; h16 < 2; ++h16) {
+          if ((li >> 4) == h16) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+              for (int rg = 0; rg < 4; ++rg) {
+                const int chunk = (ni * 32 + (BKS ? rg * 8 + hh * 4 : hh * 16 + rg * 4)) >> 2;
+                const f32x4 v = {acc[mi][ni][rg * 4], acc[mi][ni][rg * 4 + 1], acc[mi][ni][rg * 4 + 2], acc[mi][ni][rg * 4 + 3]};
+                *reinterpret_cast<f32x4*>(stg + wrow * 256 + ((chunk ^ wrow) << 4)) = v;
+              }
+          }
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const int row = it * 8 + rrow;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + row * 256 + (((2 * c8) ^ row) << 4));
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * 256 + (((2 * c8 + 1) ^ row) << 4));
+            const int m = m0 + mi * 32 + h16 * 16 + row, n = n0 + c8 * 8;
+            const int c = mi * 4 + h16 * 2 + it;
+            if (PRE) {
+              if (HAS_AUX && c + AHEAD < 16) {
+                ax[(c + AHEAD) % (AHEAD + 1)] = aux_of(c + AHEAD);
+                asm volatile("" ::: "memory");      // the load stays in front of this slice's store (hipcc would sink it behind)
+              }
+              if (!(p.dbg & 64)) epi_store8<EPI, OUTF32, true>(p, m, n, lo, hi, pb0, pb1, ax[c % (AHEAD + 1)]);
+            } else {
+              if (m < p.M && n < p.N && !(p.dbg & 64)) epi_store8<EPI, OUTF32, false>(p, m, n, lo, hi, pb0, pb1, ax[0]);
+            }
+            if (p.dbg & 64) asm volatile("" : : "v"(lo), "v"(hi));
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    };
+    if (!(p.dbg & 32)) {
+      if (full && (HAS_BIAS || HAS_AUX) && !(p.dbg & 256)) drain_tile(std::true_type{}); else drain_tile(std::false_type{});
     }
     if (next >= total_tiles) break;
     // a wave whose 128 x 64 part of the tile was clipped by M or N issued fewer stores than PEND: drain instead of counting
-    stores_in_flight = !(p.dbg & 96) && m0 + 128 <= p.M && n0 + 64 <= p.N;
+    stores_in_flight = !(p.dbg & 96) && full;
     if (!stores_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     tile = next;
   }

@@ -103,10 +103,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
 
 // partial layout: part[blk][3][H] : 0 = dgamma, 1 = dbeta, 2 = dbias (gradient of the GEMM branch)
 template <int NV>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ dres,
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* dy2, const bf16* __restrict__ dres,
                                                      const bf16* __restrict__ z, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                     bf16* __restrict__ dz, bf16* __restrict__ dx, float* __restrict__ part,
+                                                     bf16* dz, bf16* __restrict__ dx, float* __restrict__ part,
                                                      int M, int H, uint32_t thr16, float inv_keep, uint32_t seed,
                                                      uint32_t stream) {
   __shared__ float red[3][4][512];
@@ -135,6 +135,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
       const int col = i * 512 + lane * 8;
       if (col < H) {
         d[i] = *reinterpret_cast<const bf16x8*>(dy + (size_t)row * H + col);
+        if (dy2) {   // second upstream gradient (the residual path of a post-LN layer): summed in fp32, dz may alias dy2
+          const bf16x8 e = *reinterpret_cast<const bf16x8*>(dy2 + (size_t)row * H + col);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) d[i][j] = f2bf(bf2f(d[i][j]) + bf2f(e[j]));
+        }
         z_[i] = *reinterpret_cast<const bf16x8*>(z + (size_t)row * H + col);
         if (dres) r[i] = *reinterpret_cast<const bf16x8*>(dres + (size_t)row * H + col);
       }
@@ -300,11 +305,28 @@ extern "C" int ia_ln_fwd(const void* x, const float* bias, const void* residual,
 
 extern "C" size_t ia_ln_bwd_workspace_bytes(int M, int H) { return (size_t)ln_blocks(M) * 3 * H * sizeof(float); }
 
+extern "C" int ia_ln_bwd2(const void* dy, const void* dy2, const void* dres, const void* z, const float* mean, const float* rstd,
+                          const float* gamma, void* dz, void* dx, float* dgamma, float* dbeta, float* dbias, int M, int H,
+                          float drop_p, uint32_t seed, uint32_t stream_id, void* workspace, size_t workspace_bytes,
+                          int accumulate, hipStream_t stream);
+
 // dgamma/dbeta/dbias may be null (skipped); all three accumulate (+=) into fp32 when `accumulate`.
 extern "C" int ia_ln_bwd(const void* dy, const void* dres, const void* z, const float* mean, const float* rstd,
                          const float* gamma, void* dz, void* dx, float* dgamma, float* dbeta, float* dbias, int M, int H,
                          float drop_p, uint32_t seed, uint32_t stream_id, void* workspace, size_t workspace_bytes,
                          int accumulate, hipStream_t stream) {
+  return ia_ln_bwd2(dy, nullptr, dres, z, mean, rstd, gamma, dz, dx, dgamma, dbeta, dbias, M, H, drop_p, seed, stream_id, workspace,
+                    workspace_bytes, accumulate, stream);
+}
+
+// The same with a second upstream gradient dy2 (may be null): the LayerNorm output's gradient is dy + dy2.  A post-LN layer's
+// output feeds the next sub-block AND its residual connection; taking both gradients here replaces the "+ residual gradient"
+// epilogue of the GEMM that produces dy (one more row stream for an HBM-bound kernel instead of an aux operand in a GEMM epilogue).
+// dz may alias dy2.
+extern "C" int ia_ln_bwd2(const void* dy, const void* dy2, const void* dres, const void* z, const float* mean, const float* rstd,
+                          const float* gamma, void* dz, void* dx, float* dgamma, float* dbeta, float* dbias, int M, int H,
+                          float drop_p, uint32_t seed, uint32_t stream_id, void* workspace, size_t workspace_bytes,
+                          int accumulate, hipStream_t stream) {
   (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!dy || !z || !mean || !rstd || !gamma || !dz || M <= 0 || (H & 7) || H > 512 * MAXV) return IA_ERR_ARG;
   if (workspace_bytes < ia_ln_bwd_workspace_bytes(M, H) || !workspace) return IA_ERR_WORKSPACE;
@@ -314,7 +336,7 @@ extern "C" int ia_ln_bwd(const void* dy, const void* dres, const void* z, const 
   const int nv = (H + 511) / 512, nb = ln_blocks(M);
   float* part = (float*)workspace;
   dim3 grid(nb), blk(256);
-#define IA_LN_BWD(NV) hipLaunchKernelGGL((ln_bwd_kernel<NV>), grid, blk, 0, stream, (const bf16*)dy, (const bf16*)dres, (const bf16*)z, \
+#define IA_LN_BWD(NV) hipLaunchKernelGGL((ln_bwd_kernel<NV>), grid, blk, 0, stream, (const bf16*)dy, (const bf16*)dy2, (const bf16*)dres, (const bf16*)z, \
     mean, rstd, gamma, (bf16*)dz, (bf16*)dx, part, M, H, thr16, inv_keep, seed, stream_id)
   switch (nv) {
     case 1: IA_LN_BWD(1); break;

@@ -160,7 +160,7 @@ class EncoderStackFn(torch.autograd.Function):
         scratch_bytes = lib.ia_layer_bwd_scratch_bytes(C.byref(cfgs[0]))
         scratch = torch.empty(scratch_bytes, device=ctx.stash.device, dtype=torch.uint8)
         mp = ptr(ctx.key_mask)
-        dy = None
+        dy, dy2buf, have_dy2 = None, None, False
         left = _pending_uses.get(id(stack), 1) - 1
         _pending_uses[id(stack)] = left
         for i in reversed(range(n)):
@@ -171,9 +171,16 @@ class EncoderStackFn(torch.autograd.Function):
             if dy is None:
                 continue                                          # layers above the last tapped one get no gradient
             x = ctx.inputs[i]
-            check(lib.ia_layer_bwd(C.byref(cfgs[i]), C.byref(stack.weights(i)), C.byref(stack.grads(i)), x.data_ptr(), mp,
-                                   ctx.inputs[i + 1].data_ptr(), ctx.stash.data_ptr() + i * ctx.stash_bytes, dy.data_ptr(), dy.data_ptr(),
-                                   scratch.data_ptr(), scratch_bytes, stream_ptr()), f"ia_layer_bwd[{i}]")
+            # post-LN stacks hand the input gradient down in two parts (ia_layer_bwd2): the data path (dy, in place) and the residual
+            # path (dy2); the layer below sums them inside its first LayerNorm backward.  The bottom layer returns the sum.
+            split = not cfgs[i].pre_ln and i > 0
+            if split and dy2buf is None:
+                dy2buf = torch.empty_like(dy)
+            check(lib.ia_layer_bwd2(C.byref(cfgs[i]), C.byref(stack.weights(i)), C.byref(stack.grads(i)), x.data_ptr(), mp,
+                                    ctx.inputs[i + 1].data_ptr(), ctx.stash.data_ptr() + i * ctx.stash_bytes, dy.data_ptr(),
+                                    dy2buf.data_ptr() if have_dy2 else None, dy.data_ptr(), dy2buf.data_ptr() if split else None,
+                                    scratch.data_ptr(), scratch_bytes, stream_ptr()), f"ia_layer_bwd2[{i}]")
+            have_dy2 = split
             _notify(stack.layer_params(i), final=left <= 0)
         ctx.stash = None
         ctx.inputs = None

@@ -89,6 +89,24 @@ def test_layer_fwd_bwd(gpu, B, L, nh, pre_ln, masked):
     torch.cuda.synchronize()
     assert torch.isfinite(dx.float()).all()
     assert cos(dx, xr.grad.view(M, H)) > 0.995 and rel(dx, xr.grad.view(M, H)) < 5e-2
+    if not pre_ln:
+        # split-residual form (ia_layer_bwd2): the output gradient arrives in two parts, the input gradient leaves in two parts whose
+        # sum is the input gradient of the single-tensor form; parameter gradients accumulate a second, equal contribution
+        G2 = {k: torch.zeros_like(v) for k, v in P32.items()}
+        g2 = LayerGrads()
+        for k in P32:
+            setattr(g2, k, G2[k].data_ptr())
+        part = bf(torch.randn(M, H, generator=torch.Generator().manual_seed(7)).to(gpu) * 0.5)
+        da, db = (dy.view(M, H).float() - part.float()).to(torch.bfloat16), part.clone()
+        dxa, dxb = da.clone(), db.clone()                      # in place: dx over dy, dx2 over dy2
+        _lib.check(lib.ia_layer_bwd2(C.byref(cfg), C.byref(w), C.byref(g2), x.data_ptr(), _lib.ptr(mask), y.data_ptr(), stash.data_ptr(),
+                                     dxa.data_ptr(), dxb.data_ptr(), dxa.data_ptr(), dxb.data_ptr(), scratch.data_ptr(), scratch.numel(), st), "bwd2")
+        torch.cuda.synchronize()
+        both = dxa.float() + dxb.float()
+        assert cos(both, xr.grad.view(M, H)) > 0.995 and rel(both, xr.grad.view(M, H)) < 5e-2
+        assert rel(both, dx) < 3e-2                            # bf16 rounding of the split (da + db) and of the two-term sums
+        for k in P32:
+            assert cos(G2[k], Pref[k].grad) > 0.995, (k, cos(G2[k], Pref[k].grad))
     for k in P32:
         want = Pref[k].grad
         assert torch.isfinite(G[k]).all(), k
