@@ -46,12 +46,15 @@ int ia_abi_version(void);
 #define IA_EPI_ADD 3       /* + aux[M,N] (bf16, ldaux) */
 #define IA_EPI_DGELU 4     /* * aux[M,N], the derivative IA_EPI_BIAS_GELU saved in C2 */
 #define IA_EPI_BIAS_ADD 5  /* + bias + aux */
+#define IA_EPI_DGELU_COLSUM 6 /* IA_EPI_DGELU, and C2 (fp32 [N]) += column sums of C: the bias gradient of the Linear in front of the GELU
+                               * (row-major C with ldc == N; workspace >= ia_gemm_colsum_workspace_bytes(M, N)) */
 int ia_gemm_bf16(const void* A, int a_kstrided, int lda, const void* B, int b_kstrided, int ldb, void* C, int c_is_f32, int ldc,
                  int M, int N, int K, int epilogue, const float* bias, const void* aux, int ldaux, void* C2, int accumulate,
                  void* workspace, size_t workspace_bytes, ia_stream_t stream);
 /* fp32-output (weight-gradient) GEMMs cut K across workgroups when given this much scratch; partial sums are
  * combined in a fixed order (deterministic).  workspace may be NULL (no split). */
 size_t ia_gemm_workspace_bytes(int M, int N, int K, int c_is_f32);
+size_t ia_gemm_colsum_workspace_bytes(int M, int N);
 
 /* per-launch HIP-event timing of one GEMM instantiation (variant = a_kstrided*1000 + b_kstrided*100 + epilogue*10 + c_is_f32),
  * recorded on the launch stream; used by bench.py for the roofline of the dominant kernel. */

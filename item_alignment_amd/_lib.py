@@ -34,6 +34,7 @@ SIGNATURES = {
     "ia_abi_version": (i32, []),
     "ia_gemm_bf16": (i32, [vp, i32, i32, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, sz, vp]),
     "ia_gemm_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "ia_gemm_colsum_workspace_bytes": (sz, [i32, i32]),
     "ia_prof_begin": (i32, [i32, i32]),
     "ia_prof_end": (i32, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i32)]),
     "ia_ln_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, u32, u32, vp]),

@@ -127,5 +127,10 @@ struct IaViewGemm {
   int groups; long ga, gb, gc, gbias;   // per-group element strides of A, B, C, bias
 };
 __attribute__((visibility("hidden"))) int ia_gemm_view(const IaViewGemm& v, hipStream_t stream);
+// out[c] (+)= sum_b part[b][c], b < nblk, fixed order (layernorm.hip); the second stage of fused column sums
+__attribute__((visibility("hidden"))) int ia_sum_rows_f32(const float* part, int nblk, int N, float* out, int accumulate, hipStream_t stream);
+extern "C" size_t ia_colsum_workspace_bytes(int M, int N);
+extern "C" int ia_colsum(const void* x, int ld, int M, int N, float* out, int accumulate, void* workspace, size_t workspace_bytes,
+                         hipStream_t stream);
 __attribute__((visibility("hidden"))) size_t ia_gemm_view_workspace_bytes(int M, int N, int K, int groups);
 

@@ -49,7 +49,7 @@ Scratch carve_scratch(const ia_layer_cfg* c, void* base) {
   s.g0 = take(M * H * 2); s.g1 = take(M * H * 2); s.g2 = take(M * H * 2);
   s.gI = take(M * I * 2); s.gqkv = take(M * 3 * H * 2);
   s.delta = (float*)take((size_t)c->B * c->nh * c->L * 4);
-  s.ws_bytes = max3(ia_ln_bwd_workspace_bytes((int)M, (int)H), ia_colsum_workspace_bytes((int)M, (int)I),
+  s.ws_bytes = max3(ia_ln_bwd_workspace_bytes((int)M, (int)H), ia_gemm_colsum_workspace_bytes((int)M, (int)I),
                     ia_colsum_workspace_bytes((int)M, (int)(3 * H)));
   s.ws = take(s.ws_bytes);
   // split-K partial sums of the four weight-gradient GEMMs (largest of them)
@@ -170,8 +170,8 @@ extern "C" int ia_layer_bwd2(const ia_layer_cfg* c, const ia_layer_weights* w, c
                       c->hidden_drop, c->seed, c->layer_id * 4u + 1u, k.ws, k.ws_bytes, 1, st));
     const char* d_ffn = drop ? k.g1 : k.g0;
     IA_TRY(ia_gemm_bf16(d_ffn, 1, H, s.hact, 1, I, g->w_fc2, 1, I, H, I, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
-    IA_TRY(ia_gemm_bf16(d_ffn, 0, H, w->w_fc2, 1, I, k.gI, 0, I, M, I, H, IA_EPI_DGELU, nullptr, s.hpre, I, nullptr, 0, nullptr, 0, st));
-    IA_TRY(ia_colsum(k.gI, I, M, I, g->b_fc1, 1, k.ws, k.ws_bytes, st));
+    // d(pre-activation) = (d_ffn W2) * gelu'(pre), and its column sums (the fc1 bias gradient) out of the same epilogue
+    IA_TRY(ia_gemm_bf16(d_ffn, 0, H, w->w_fc2, 1, I, k.gI, 0, I, M, I, H, IA_EPI_DGELU_COLSUM, nullptr, s.hpre, I, g->b_fc1, 0, k.ws, k.ws_bytes, st));
     IA_TRY(ia_gemm_bf16(k.gI, 1, I, s.t1, 1, H, g->w_fc1, 1, H, I, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
     IA_TRY(ia_gemm_bf16(k.gI, 0, I, w->w_fc1, 1, H, k.g2, 0, H, M, H, I, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
     // LN1 backward: d(y1) = g2 (through fc1) + g0 (residual into LN2) -> dz1 (the layer input's residual-path gradient) in
@@ -192,8 +192,7 @@ extern "C" int ia_layer_bwd2(const ia_layer_cfg* c, const ia_layer_weights* w, c
   } else {
     IA_TRY(ia_colsum(dy, H, M, H, g->b_fc2, 1, k.ws, k.ws_bytes, st));
     IA_TRY(ia_gemm_bf16(dy, 1, H, s.hact, 1, I, g->w_fc2, 1, I, H, I, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
-    IA_TRY(ia_gemm_bf16(dy, 0, H, w->w_fc2, 1, I, k.gI, 0, I, M, I, H, IA_EPI_DGELU, nullptr, s.hpre, I, nullptr, 0, nullptr, 0, st));
-    IA_TRY(ia_colsum(k.gI, I, M, I, g->b_fc1, 1, k.ws, k.ws_bytes, st));
+    IA_TRY(ia_gemm_bf16(dy, 0, H, w->w_fc2, 1, I, k.gI, 0, I, M, I, H, IA_EPI_DGELU_COLSUM, nullptr, s.hpre, I, g->b_fc1, 0, k.ws, k.ws_bytes, st));
     IA_TRY(ia_gemm_bf16(k.gI, 1, I, s.t2, 1, H, g->w_fc1, 1, H, I, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
     IA_TRY(ia_gemm_bf16(k.gI, 0, I, w->w_fc1, 1, H, k.g0, 0, H, M, H, I, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
     // LN2 backward (+ residual path dy) -> g1 = d x2 ; its column sum is the proj-bias gradient

@@ -30,7 +30,7 @@ namespace {
 constexpr int BK = 64;
 constexpr uint32_t OOB = 0xFFFFFFF0u;
 
-enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_ADD = 3, EPI_DGELU = 4, EPI_BIAS_ADD = 5 };
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_ADD = 3, EPI_DGELU = 4, EPI_BIAS_ADD = 5, EPI_DGELU_CS = 6 };
 
 struct GemmArgs {
   const bf16* A; const bf16* B; void* C; bf16* C2; const float* bias; const bf16* aux;
@@ -40,6 +40,7 @@ struct GemmArgs {
   int accumulate;
   int tiles_m, tiles_n;
   int splits, nk_per_split;   // split-K (fp32 output only): split s owns k-tiles [s*nk_per_split, ...)
+  float* csum_part;           // EPI_DGELU_CS: [ceil(M/128)][N] fp32 column sums of each 128-row block of the output (T256 only)
   int split_id;               // set inside the kernels (T128: blockIdx.y; T256: derived from the XCD-aware work order)
   float* ws;                  // [splits][M][N] fp32 partials when splits > 1
   int dbg;                    // ablation switches for tuning runs (IA_GEMM_DBG env): results are WRONG when non-zero
@@ -84,7 +85,7 @@ IA_DEV void epi_store4(const GemmArgs& p, int m, int n, f32x4 v) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] += bf2f(a[r]);
   }
-  if (EPI == EPI_DGELU) {   // aux = the saved gelu'(pre-activation)
+  if (EPI == EPI_DGELU || EPI == EPI_DGELU_CS) {   // aux = the saved gelu'(pre-activation); T128 leaves the column sums to ia_colsum
     const bf16x4 a = *reinterpret_cast<const bf16x4*>(p.aux + (size_t)m * p.ldaux + n);
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] *= bf2f(a[r]);
@@ -117,11 +118,13 @@ IA_DEV void gstore16(void* ptr, V v) {
 }
 template <int EPI, bool OUTF32>
 constexpr int epi_stores_per_call() { return OUTF32 ? 2 : (EPI == EPI_BIAS_GELU ? 2 : 1); }
+template <int EPI>
+constexpr int epi_extra_stores() { return EPI == EPI_DGELU_CS ? 2 : 0; }     // the wave's column-sum partial: two 16-byte stores
 
 // v = 8 consecutive output columns n..n+7 of row m (row-coalesced epilogue of the T256 kernel).  PRE: bias (pb0 | pb1) and aux (ax)
 // were fetched ahead by the caller; else they are loaded here.
 template <int EPI, bool OUTF32, bool PRE>
-IA_DEV void epi_store8(const GemmArgs& p, int m, int n, f32x4 lo, f32x4 hi, f32x4 pb0, f32x4 pb1, bf16x8 ax) {
+IA_DEV void epi_store8(const GemmArgs& p, int m, int n, f32x4 lo, f32x4 hi, f32x4 pb0, f32x4 pb1, bf16x8 ax, float (&cs)[8]) {
   float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_ADD) {
     const f32x4 b0 = PRE ? pb0 : *reinterpret_cast<const f32x4*>(p.bias + n), b1 = PRE ? pb1 : *reinterpret_cast<const f32x4*>(p.bias + n + 4);
@@ -140,12 +143,13 @@ IA_DEV void epi_store8(const GemmArgs& p, int m, int n, f32x4 lo, f32x4 hi, f32x
     }
     gstore16(p.C2 + (size_t)m * p.ldc + n, der);
   }
-  if (EPI == EPI_ADD || EPI == EPI_BIAS_ADD || EPI == EPI_DGELU) {
+  if (EPI == EPI_ADD || EPI == EPI_BIAS_ADD || EPI == EPI_DGELU || EPI == EPI_DGELU_CS) {
     const bf16x8 a = PRE ? ax : *reinterpret_cast<const bf16x8*>(p.aux + (size_t)m * p.ldaux + n);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      if (EPI == EPI_DGELU) v[r] *= bf2f(a[r]);
+      if (EPI == EPI_DGELU || EPI == EPI_DGELU_CS) v[r] *= bf2f(a[r]);
       else v[r] += bf2f(a[r]);
+      if (EPI == EPI_DGELU_CS) cs[r] += v[r];       // this lane's 8 columns, summed over the rows it stores
     }
   }
   if (OUTF32) {
@@ -512,7 +516,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs p) {
   // The workgroup is persistent over output tiles (one workgroup per CU): the DMA of the NEXT tile's first two
   // k-tiles is issued before the current tile's epilogue (which stages through LDS outside the k-tile buffers), so the
   // ~2 us HBM round trip of a tile prologue hides behind the epilogue instead of idling the CU.
-  constexpr int PEND = 16 * epi_stores_per_call<EPI, OUTF32>();   // store instructions of one full-tile epilogue, per wave
+  constexpr int PEND = 16 * epi_stores_per_call<EPI, OUTF32>() + epi_extra_stores<EPI>();   // store instructions of one full-tile epilogue, per wave
   static_assert(PEND < 60, "vmcnt is a 6-bit counter");
   auto coords = [&](int tile, int& bm, int& bn) {
     if (ordered) tile_of_order(p, tile, bm, bn); else tile_of_index(p, tile, total_tiles, bm, bn);
@@ -563,7 +567,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs p) {
     // this wave's 128 x 64 part lies entirely inside C: no row / column guards, the store count of the tile is exact
     const bool full = m0 + 128 <= p.M && n0 + 64 <= p.N;
     constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_ADD;
-    constexpr bool HAS_AUX = EPI == EPI_ADD || EPI == EPI_BIAS_ADD || EPI == EPI_DGELU;
+    constexpr bool HAS_AUX = EPI == EPI_ADD || EPI == EPI_BIAS_ADD || EPI == EPI_DGELU || EPI == EPI_DGELU_CS;
     // Slice c (c = 0..15) = rows (c>>2)*32 + ((c>>1)&1)*16 + (c&1)*8 + rrow of this wave's part, the lane's 8 columns n0 + c8*8.
     // PRE (full parts): the bias - the same 8 columns for all slices - is read once per tile, and the aux operand runs AHEAD slices
     // ahead of the stores: VMEM retires in order, so a load issued behind a store can only be waited for by draining that store;
@@ -571,7 +575,12 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs p) {
     constexpr int AHEAD = 4;
     auto drain_tile = [&](auto PREFETCHED) {
       constexpr bool PRE = decltype(PREFETCHED)::value;
-      f32x4 pb0 = {0.f, 0.f, 0.f, 0.f}, pb1 = pb0;
+      f32x4 pb0, pb1;          // only read when the epilogue has a bias (left undefined otherwise: no registers, no spill)
+      float cs[8];
+      if (EPI == EPI_DGELU_CS) {      // zeroed here, opaquely: a hoisted zero vector would live (and spill) across the whole main loop
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("v_mov_b32 %0, 0" : "=v"(cs[j]));
+      }
       bf16x8 ax[AHEAD + 1];
       auto aux_of = [&](int c) {
         const int row = m0 + (c >> 2) * 32 + ((c >> 1) & 1) * 16 + (c & 1) * 8 + rrow;
@@ -609,13 +618,36 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs p) {
                 ax[(c + AHEAD) % (AHEAD + 1)] = aux_of(c + AHEAD);
                 asm volatile("" ::: "memory");      // the load stays in front of this slice's store (hipcc would sink it behind)
               }
-              if (!(p.dbg & 64)) epi_store8<EPI, OUTF32, true>(p, m, n, lo, hi, pb0, pb1, ax[c % (AHEAD + 1)]);
+              if (!(p.dbg & 64)) epi_store8<EPI, OUTF32, true>(p, m, n, lo, hi, pb0, pb1, ax[c % (AHEAD + 1)], cs);
             } else {
-              if (m < p.M && n < p.N && !(p.dbg & 64)) epi_store8<EPI, OUTF32, false>(p, m, n, lo, hi, pb0, pb1, ax[0]);
+              if (m < p.M && n < p.N && !(p.dbg & 64)) epi_store8<EPI, OUTF32, false>(p, m, n, lo, hi, pb0, pb1, ax[0], cs);
             }
             if (p.dbg & 64) asm volatile("" : : "v"(lo), "v"(hi));
           }
           __builtin_amdgcn_wave_barrier();
+        }
+      }
+      if (EPI == EPI_DGELU_CS) {
+        // column sums of this wave's 128 rows: the 8 lanes that share a column group (lane & 7) differ in lane bits 3..5
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          float v = cs[r];
+          v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x128, 0xF, 0xF,
+                                                                     false));                    // row_ror:8   -> lane ^ 8
+          {                                                                                       // lane ^ 16 (rows 1,3 <-> rows 0,2)
+            const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+            v = __builtin_bit_cast(float, sw[0]) + __builtin_bit_cast(float, sw[1]);
+          }
+          {                                                                                       // lane ^ 32 (upper half <-> lower half)
+            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+            v = __builtin_bit_cast(float, sw[0]) + __builtin_bit_cast(float, sw[1]);
+          }
+          cs[r] = v;
+        }
+        if (rrow == 0 && n0 + c8 * 8 < p.N) {      // lanes 0..7: 8 consecutive columns each (two 16-byte stores, counted in PEND)
+          float* dst = p.csum_part + (size_t)(m0 >> 7) * p.N + n0 + c8 * 8;
+          gstore16(dst, f32x4{cs[0], cs[1], cs[2], cs[3]});
+          gstore16(dst + 4, f32x4{cs[4], cs[5], cs[6], cs[7]});
         }
       }
     };
@@ -768,6 +800,14 @@ static int gemm_core(const void* A, int a_kstrided, int lda, const void* B, int 
                      int N, int K, int epilogue, const float* bias, const void* aux, int ldaux, void* C2, int accumulate, void* workspace,
                      size_t workspace_bytes, const IaViewGemm* view, hipStream_t stream);
 
+// workspace of an IA_EPI_DGELU_COLSUM GEMM: one fp32 row of N partial sums per 128-row block of the output (and never less than
+// the stand-alone column-sum kernel needs, which small shapes fall back to)
+extern "C" size_t ia_gemm_colsum_workspace_bytes(int M, int N) {
+  if (M <= 0 || N <= 0) return 0;
+  const size_t fused = (size_t)((M + 255) / 256) * 2 * N * sizeof(float), plain = ia_colsum_workspace_bytes(M, N);
+  return fused > plain ? fused : plain;
+}
+
 extern "C" int ia_gemm_bf16(const void* A, int a_kstrided, int lda, const void* B, int b_kstrided, int ldb,
                             void* C, int c_is_f32, int ldc, int M, int N, int K, int epilogue,
                             const float* bias, const void* aux, int ldaux, void* C2, int accumulate, void* workspace,
@@ -806,6 +846,7 @@ static int gemm_core(const void* A, int a_kstrided, int lda, const void* B, int 
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux; g.accumulate = accumulate;
   const uint64_t ab = a_window ? a_window : (a_kstrided ? ((uint64_t)(K - 1) * lda + M) * 2 : ((uint64_t)(M - 1) * lda + K) * 2);
   const uint64_t bb = b_window ? b_window : (b_kstrided ? ((uint64_t)(K - 1) * ldb + N) * 2 : ((uint64_t)(N - 1) * ldb + K) * 2);
+  g.csum_part = nullptr; g.split_id = 0;
   g.a_view = g.b_view = g.pw = 0; g.lca = g.lcbk = g.lcbn = 6;
   g.groups = 1; g.ga = g.gb = g.gc = g.gbias = 0;
   if (view) {
@@ -826,7 +867,7 @@ static int gemm_core(const void* A, int a_kstrided, int lda, const void* B, int 
     g.ws = (float*)workspace;
   }
   const bool needs_bias = epilogue == EPI_BIAS || epilogue == EPI_BIAS_GELU || epilogue == EPI_BIAS_ADD;
-  const bool needs_aux = epilogue == EPI_ADD || epilogue == EPI_DGELU || epilogue == EPI_BIAS_ADD;
+  const bool needs_aux = epilogue == EPI_ADD || epilogue == EPI_DGELU || epilogue == EPI_BIAS_ADD || epilogue == EPI_DGELU_CS;
   if (needs_bias && !bias) return IA_ERR_ARG;
   if (needs_aux && (!aux || (ldaux & 3))) return IA_ERR_ARG;
   if (epilogue == EPI_BIAS_GELU && !C2) return IA_ERR_ARG;
@@ -845,6 +886,17 @@ static int gemm_core(const void* A, int a_kstrided, int lda, const void* B, int 
       case EPI_NONE: return launch<false, true, EPI_NONE, false>(g, big, stream);
       case EPI_ADD: return launch<false, true, EPI_ADD, false>(g, big, stream);
       case EPI_DGELU: return launch<false, true, EPI_DGELU, false>(g, big, stream);
+      case EPI_DGELU_CS: {
+        // C2 (fp32 [N]) += column sums of the output: the bias gradient of the Linear in front of the GELU
+        if (!C2 || !workspace || workspace_bytes < ia_gemm_colsum_workspace_bytes(M, N) || ldc != N) return IA_ERR_WORKSPACE;
+        if (!big) {                                  // small shapes: plain epilogue, then the stand-alone column-sum kernel
+          int rc = launch<false, true, EPI_DGELU, false>(g, false, stream);
+          return rc ? rc : ia_colsum(C, ldc, M, N, (float*)C2, 1, workspace, workspace_bytes, stream);
+        }
+        g.csum_part = (float*)workspace;
+        int rc = launch<false, true, EPI_DGELU_CS, false>(g, true, stream);
+        return rc ? rc : ia_sum_rows_f32((const float*)workspace, ((M + 255) / 256) * 2, N, (float*)C2, 1, stream);
+      }
     }
   } else if (a_kstrided && b_kstrided && c_is_f32) {
     if (epilogue == EPI_NONE) return launch<true, true, EPI_NONE, true>(g, big, stream);

@@ -353,6 +353,12 @@ extern "C" int ia_ln_bwd2(const void* dy, const void* dy2, const void* dres, con
   return ia_check_launch();
 }
 
+int ia_sum_rows_f32(const float* part, int nblk, int N, float* out, int accumulate, hipStream_t stream) {
+  ReduceOuts outs{{out, nullptr, nullptr}};
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 31) / 32), dim3(1024), 0, stream, part, nblk, 1, N, outs, accumulate);
+  return ia_check_launch();
+}
+
 // Narrow matrices (N < 512 dividing 512, rows contiguous: conv-tower bias gradients with 16..256 channels) are summed as
 // [M*N/512, 512]: every lane of the column-sum kernel stays busy, and the 512/N column groups fold for free because the
 // partial buffer [rows][512] read as [rows * 512/N][N] is exactly what the second stage sums over.

@@ -7,7 +7,7 @@ import torch
 from . import _lib
 from ._lib import check, ptr, stream_ptr
 
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_ADD, EPI_DGELU, EPI_BIAS_ADD = 0, 1, 2, 3, 4, 5
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_ADD, EPI_DGELU, EPI_BIAS_ADD, EPI_DGELU_COLSUM = 0, 1, 2, 3, 4, 5, 6
 ACT_NONE, ACT_TANH = 0, 1
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -24,8 +24,9 @@ def _need(t, dtype, name):
 
 
 def gemm(a, b, *, a_kstrided=False, b_kstrided=False, epilogue=EPI_NONE, bias=None, aux=None, out=None, out_f32=False,
-         accumulate=False, pre_out=None):
-    """C = A*B (+epilogue).  a: [M,K] (or [K,M] if a_kstrided); b: [N,K] (or [K,N] if b_kstrided)."""
+         accumulate=False, pre_out=None, colsum_out=None):
+    """C = A*B (+epilogue).  a: [M,K] (or [K,M] if a_kstrided); b: [N,K] (or [K,N] if b_kstrided).
+    EPI_DGELU_COLSUM also adds the column sums of C into colsum_out (fp32 [N])."""
     lib = _lib.load()
     _need(a, BF16, "a"); _need(b, BF16, "b"); _need(bias, F32, "bias"); _need(aux, BF16, "aux")
     if a_kstrided:
@@ -44,6 +45,12 @@ def gemm(a, b, *, a_kstrided=False, b_kstrided=False, epilogue=EPI_NONE, bias=No
     if epilogue == EPI_BIAS_GELU and pre_out is None:
         pre_out = torch.empty((M, N), device=a.device, dtype=BF16)
     ws_bytes = lib.ia_gemm_workspace_bytes(M, N, K, int(out_f32))
+    if epilogue == EPI_DGELU_COLSUM:
+        _need(colsum_out, F32, "colsum_out")
+        if colsum_out is None:
+            raise ValueError("gemm: EPI_DGELU_COLSUM needs colsum_out")
+        pre_out = colsum_out
+        ws_bytes = max(ws_bytes, lib.ia_gemm_colsum_workspace_bytes(M, N))
     ws = torch.empty(ws_bytes, device=a.device, dtype=torch.uint8) if ws_bytes else None
     check(lib.ia_gemm_bf16(a.data_ptr(), int(a_kstrided), a.shape[1], b.data_ptr(), int(b_kstrided), b.shape[1], out.data_ptr(),
                            int(out_f32), N, M, N, K, epilogue, ptr(bias), ptr(aux), N if aux is not None else 0, ptr(pre_out),

@@ -90,6 +90,25 @@ def test_layernorm_fwd_bwd(gpu, M, H):
     assert rel_err(y2, torch.nn.functional.layer_norm(x.float(), (H,), gamma, beta, 1e-6)) < 1e-2
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 512, 256), (1000, 776, 192), (4096 + 130, 1024, 256)])
+def test_gemm_dgelu_with_fused_column_sums(gpu, M, N, K):
+    """IA_EPI_DGELU_COLSUM: same C as IA_EPI_DGELU, and the fp32 column sums of C (before its rounding to bf16) added into C2."""
+    from item_alignment_amd import ops
+    torch.manual_seed(M + N)
+    a = (torch.randn(M, K, device="cuda") * 0.5).bfloat16()
+    b = (torch.randn(K, N, device="cuda") * 0.5).bfloat16()
+    aux = torch.rand(M, N, device="cuda").bfloat16()
+    want = ops.gemm(a, b, b_kstrided=True, epilogue=ops.EPI_DGELU, aux=aux)
+    prior = torch.randn(N, device="cuda")
+    cs = prior.clone()
+    got = ops.gemm(a, b, b_kstrided=True, epilogue=ops.EPI_DGELU_COLSUM, aux=aux, colsum_out=cs)
+    assert torch.equal(got, want)
+    ref = (a.float() @ b.float()) * aux.float()
+    tol = 2e-3 * ref.abs().sum(0).max().item()
+    assert (cs - prior - ref.sum(0)).abs().max().item() < tol
+    assert (cs - prior - want.float().sum(0)).abs().max().item() < tol
+
+
 def test_colsum(gpu):
     from item_alignment_amd import ops
     x = rnd((1000, 3072), gpu, 1.0, 13)

@@ -53,6 +53,11 @@ def bench_gemm_epi():
     dpre = torch.empty_like(pre)
     t = timeit(lambda: ops.gemm(dy, w2, b_kstrided=True, epilogue=ops.EPI_DGELU, aux=pre, out=dpre))
     print(f"dgrad x gelu'   M={M} N={I} K={H}: {t*1e6:8.1f} us {2*M*I*H/t/1e12:7.1f} TF/s")
+    cs = torch.zeros(I, device=dev)
+    t = timeit(lambda: ops.gemm(dy, w2, b_kstrided=True, epilogue=ops.EPI_DGELU_COLSUM, aux=pre, out=dpre, colsum_out=cs))
+    print(f"dgrad x gelu' + column sums      : {t*1e6:8.1f} us {2*M*I*H/t/1e12:7.1f} TF/s")
+    t = timeit(lambda: ops.colsum(dpre, cs, accumulate=True))
+    print(f"separate column sums of [M,{I}]  : {t*1e6:8.1f} us {M*I*2/t/1e9:7.0f} GB/s")
     t = timeit(lambda: ops.gemm(dy, w2, b_kstrided=True, out=dpre))
     print(f"dgrad plain     M={M} N={I} K={H}: {t*1e6:8.1f} us {2*M*I*H/t/1e12:7.1f} TF/s")
 
