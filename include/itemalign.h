@@ -52,7 +52,9 @@ int ia_gemm_bf16(const void* A, int a_kstrided, int lda, const void* B, int b_ks
                  int M, int N, int K, int epilogue, const float* bias, const void* aux, int ldaux, void* C2, int accumulate,
                  void* workspace, size_t workspace_bytes, ia_stream_t stream);
 /* fp32-output (weight-gradient) GEMMs cut K across workgroups when given this much scratch; partial sums are
- * combined in a fixed order (deterministic).  workspace may be NULL (no split). */
+ * combined in a fixed order (deterministic).  workspace may be NULL (no split).
+ * Weight-gradient form (A and B k-strided, fp32 C, IA_EPI_NONE): a non-NULL C2 (fp32 [M]) += sum_k A[k][m], i.e. the bias
+ * gradient of the layer whose dW this GEMM computes, out of the same pass over dy (ScaledStdConv2d bias, timm std_conv.py). */
 size_t ia_gemm_workspace_bytes(int M, int N, int K, int c_is_f32);
 size_t ia_gemm_colsum_workspace_bytes(int M, int N);
 

@@ -121,6 +121,7 @@ struct IaViewGemm {
   void* C; int c_is_f32, ldc;
   int M, N, K;
   const float* bias;                 // NULL = no bias
+  float* rsum_out;                   // weight-gradient form only: [groups * M] fp32 += sum_k A[k][m] (the bias gradient); NULL = off
   void* workspace; size_t workspace_bytes;
   int a_view, b_view, pw, lca, lcbk, lcbn;
   size_t a_window, b_window;         // bytes addressable from A / B of group 0 (to the end of the tensor)

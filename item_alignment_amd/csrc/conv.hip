@@ -416,8 +416,8 @@ int geom(ConvGeom& g, int B, int H, int W, int C, int Cout, int k, int stride, i
   g.Wo = k == 1 ? W : (W + 2 - 3) / stride + 1;
   g.K = k * k * g.Cg;
   g.M = (size_t)B * g.Ho * g.Wo;
-  // one GEMM operand window must stay below 2 GiB (32-bit buffer offsets)
-  if (g.M * (size_t)(k * k * C) * 2 >= 0x7FFFFFFFull || g.M * (size_t)Cout * 2 >= 0x7FFFFFFFull) return IA_ERR_ARG;
+  // operands may exceed 2 GiB (the GEMM re-bases a 32-bit buffer window per workgroup); row counts are ints
+  if (g.M >= 0x7FFFFFFFull || (size_t)B * H * W >= 0x7FFFFFFFull) return IA_ERR_ARG;
   return IA_OK;
 }
 
@@ -508,14 +508,12 @@ extern "C" int ia_conv_nhwc_bwd_weight(const void* x, const void* dy, float* dwh
     a = cols; lda = 9 * C;
   }
   void* gws = need > cols_bytes ? (char*)workspace + cols_bytes : nullptr;
+  // C2 = the bias gradient of the group's output channels: row sums of dy^T out of the same GEMM (a separate column-sum pass
+  // only where the 256x256 kernel serves the shape)
   for (int gi = 0; gi < groups && !rc; ++gi)
     rc = ia_gemm_bf16((const bf16*)dy + gi * g.Ng, 1, Cout, a + (size_t)gi * g.K, 1, lda, dwhat + (size_t)gi * g.Ng * g.K, 1, g.K, g.Ng, g.K,
-                      (int)g.M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, gws, need - cols_bytes, stream);
-  if (rc || !dbias) return rc;
-  // bias gradient: column sums of dy, through the same scratch (the GEMMs above are stream-ordered before it)
-  const size_t cs = ia_colsum_workspace_bytes((int)g.M, Cout);
-  if (need - cols_bytes < cs) return IA_ERR_WORKSPACE;
-  return ia_colsum(dy, Cout, (int)g.M, Cout, dbias, 1, gws, need - cols_bytes, stream);
+                      (int)g.M, IA_EPI_NONE, nullptr, nullptr, 0, dbias ? dbias + gi * g.Ng : nullptr, 0, gws, need - cols_bytes, stream);
+  return rc;
 }
 
 // what [Cout][kk*Cgp] bf16 from w [Cout][Cg][kk] fp32 (PyTorch conv weight), gain [Cout]; saves mean / rstd [Cout]
@@ -637,7 +635,7 @@ static int padded_ok(int B, int H, int W, int Cin, int Cout, int groups) {
   if (B <= 0 || H <= 0 || W <= 0 || groups <= 0 || Cin <= 0 || Cout <= 0 || Cin % groups || Cout % groups) return IA_ERR_ARG;
   const int ci = Cin / groups, co = Cout / groups;
   if (ci < 8 || co < 8 || (ci & (ci - 1)) || (co & (co - 1))) return IA_ERR_UNSUPPORTED;
-  if ((size_t)B * (H + 2) * (W + 2) * (Cin > Cout ? Cin : Cout) * 2 >= 0x7FFFFFFFull) return IA_ERR_ARG;
+  if ((size_t)B * (H + 2) * (W + 2) >= 0x7FFFFFFFull) return IA_ERR_ARG;       // rows are ints; the byte size is not limited
   return IA_OK;
 }
 
@@ -698,9 +696,8 @@ extern "C" int ia_conv3x3_padded_bwd_weight(const void* xp, const void* dyp, flo
   v.b_view = 2; v.pw = W + 2; v.lca = v.lcbk = 6; v.lcbn = ilog2(ci);
   v.a_window = Mp * Cout * 2; v.b_window = Mp * Cin * 2;
   v.groups = groups; v.ga = co; v.gb = ci; v.gc = (long)co * 9 * ci;
-  rc = ia_gemm_view(v, stream);
-  if (rc || !dbias) return rc;
-  return ia_colsum(dyp, Cout, (int)Mp, Cout, dbias, 1, workspace, workspace_bytes, stream);
+  v.rsum_out = dbias;       // bias gradient = row sums of dy^T, taken inside the same GEMM (dyp's border rows are zero)
+  return ia_gemm_view(v, stream);
 }
 
 // y = silu(x) * scale moving between the compact [B,H,W,C] and the zero-bordered [B,H+2,W+2,C] layouts (flags per side)

@@ -36,13 +36,17 @@ struct GemmArgs {
   const bf16* A; const bf16* B; void* C; bf16* C2; const float* bias; const bf16* aux;
   int M, N, K;
   int lda, ldb, ldc, ldaux;
-  uint32_t a_bytes, b_bytes;
+  uint64_t a_bytes, b_bytes;  // bytes addressable from A / B (to the end of the tensor); each workgroup re-bases a < 2 GiB buffer window inside them
   int accumulate;
   int tiles_m, tiles_n;
   int splits, nk_per_split;   // split-K (fp32 output only): split s owns k-tiles [s*nk_per_split, ...)
   float* csum_part;           // EPI_DGELU_CS: [ceil(M/128)][N] fp32 column sums of each 128-row block of the output (T256 only)
-  int split_id;               // set inside the kernels (T128: blockIdx.y; T256: derived from the XCD-aware work order)
+  int split_id;               // set inside the kernels (derived from the XCD-aware work order)
   float* ws;                  // [splits][M][N] fp32 partials when splits > 1
+  // weight-gradient form (A, B k-strided, fp32 C), T128: rsum_out[group * M + m] += sum_k A[k][m] -- the bias gradient of the layer,
+  // taken from the A tiles already in LDS by one more MFMA against a fragment of ones (no second pass over dy).
+  float* rsum_out;            // NULL = off
+  float* rsum_ws;             // [groups][splits][M] partials when splits > 1 (folded by the split-K reduce kernels)
   int dbg;                    // ablation switches for tuning runs (IA_GEMM_DBG env): results are WRONG when non-zero
   // Shifted operand views (T128 only) that turn the GEMM into a 3x3 convolution over a zero-bordered NHWC tensor
   // [B, H+2, W+2, C] without a patch matrix: the k axis is (tap, channel) with a power-of-two channel count per tap, and tap t
@@ -51,12 +55,20 @@ struct GemmArgs {
   //   b_view 1 (k-strided B = W[o][(tap << lcbn) + c]): k = (tap << lcbk) + o, column n reads W[o][(tap << lcbn) + n]   (data grad)
   //   b_view 2 (k-strided B = the activations): column n = (tap << lcbn) + ch reads row k + tap_delta(tap), column ch  (weight grad)
   int a_view, b_view, pw, lca, lcbk, lcbn;
-  // blockIdx.z = channel group: operands advance by ga / gb / gc / gbias elements per group (all groups in one launch)
+  // channel groups: operands advance by ga / gb / gc / gbias elements per group (all groups in one launch)
   int groups;
   long ga, gb, gc, gbias;
 };
 
 IA_DEV int tap_delta(int t, int pw) { return (t / 3 - 1) * pw + (t % 3 - 1); }
+
+// Buffer window that starts `origin` elements into an operand of `total_bytes` bytes.  Buffer offsets are 32-bit, operands (an
+// 800x800 feature map of 64 images, a 9x patch matrix) are not: every workgroup addresses its tile / k-slab relative to its own
+// origin, and the range check still ends at the end of the tensor (lanes past it read zeros).
+IA_DEV __amdgpu_buffer_rsrc_t rsrc_at(const bf16* base, uint64_t total_bytes, uint64_t origin) {
+  const uint64_t ob = origin * 2, rem = total_bytes > ob ? total_bytes - ob : 0;
+  return ia_rsrc(base + origin, (uint32_t)(rem < 0x7FFFFFF0ull ? rem : 0x7FFFFFF0ull));
+}
 
 // ---------------------------------------------------------------------------------- shared epilogue
 // v = 4 consecutive output columns n..n+3 of row m
@@ -114,7 +126,7 @@ IA_DEV void epi_store4(const GemmArgs& p, int m, int n, f32x4 v) {
 template <typename V>
 IA_DEV void gstore16(void* ptr, V v) {
   static_assert(sizeof(V) == 16, "16-byte store");
-  *reinterpret_cast<V*>(ptr) = v;
+  *reinterpret_cast<V*>(ptr) = v;      // (a non-temporal store measured the same: tools/README.md, GEMM ablations)
 }
 template <int EPI, bool OUTF32>
 constexpr int epi_stores_per_call() { return OUTF32 ? 2 : (EPI == EPI_BIAS_GELU ? 2 : 1); }
@@ -137,11 +149,12 @@ IA_DEV void epi_store8(const GemmArgs& p, int m, int n, f32x4 lo, f32x4 hi, f32x
     for (int r = 0; r < 8; ++r) {
       const float x = bf2f(f2bf(v[r]));
       float c, d;
+      if (p.dbg & 512) { c = x; d = x; } else
       gelu_parts(x, c, d);
       v[r] = x * c;
       der[r] = f2bf(__builtin_fmaf(x, d, c));
     }
-    gstore16(p.C2 + (size_t)m * p.ldc + n, der);
+    gstore16(((p.dbg & 1024) ? reinterpret_cast<bf16*>(p.C) : p.C2) + (size_t)m * p.ldc + n, der);
   }
   if (EPI == EPI_ADD || EPI == EPI_BIAS_ADD || EPI == EPI_DGELU || EPI == EPI_DGELU_CS) {
     const bf16x8 a = PRE ? ax : *reinterpret_cast<const bf16x8*>(p.aux + (size_t)m * p.ldaux + n);
@@ -191,8 +204,9 @@ constexpr int BM = 128, BN = 128, TILE_BYTES = 16384;
 // 32-byte-slot swizzle of a k-strided tile row (row = k index within the 64-row tile, 256 B rows)
 IA_DEV int ks_swz(int k) { return ((k & 3) | (((k >> 3) & 1) << 2)) << 1; }
 
+// x0 (k-contiguous) / korg (k-strided, views 0 and 2) are relative to the origin row of the buffer window `rs`
 template <bool KS>
-IA_DEV void stage_tile(__amdgpu_buffer_rsrc_t rs, char* s, int kt, int x0, int ld, int K, int tid, int wave, int view = 0, int pw = 0,
+IA_DEV void stage_tile(__amdgpu_buffer_rsrc_t rs, char* s, int kt, int x0, int ld, int K, int tid, int wave, int korg, int view = 0, int pw = 0,
                        int lck = 6, int lcn = 6) {
 #pragma unroll
   for (int issue = 0; issue < 4; ++issue) {
@@ -208,9 +222,9 @@ IA_DEV void stage_tile(__amdgpu_buffer_rsrc_t rs, char* s, int kt, int x0, int l
       const int row = issue * 16 + (tid >> 4);
       const int c = (tid & 15) ^ ks_swz(row);
       const int k = kt * BK + row;
-      if (view == 0) off = (uint32_t)((k * ld + x0 + c * 8) * 2);
+      if (view == 0) off = (uint32_t)(((k - korg) * ld + x0 + c * 8) * 2);
       else if (view == 1) off = (uint32_t)(((k & ((1 << lck) - 1)) * ld + ((k >> lck) << lcn) + x0 + c * 8) * 2);
-      else { const int col = x0 + c * 8; off = (uint32_t)(((k + tap_delta(col >> lcn, pw)) * ld + (col & ((1 << lcn) - 1))) * 2); }
+      else { const int col = x0 + c * 8; off = (uint32_t)(((k - korg + tap_delta(col >> lcn, pw)) * ld + (col & ((1 << lcn) - 1))) * 2); }
       if (k >= K) off = OOB;
     }
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, IA_LDS(s + issue * 4096 + wave * 1024), 16, off, 0, 0, 0);
@@ -237,20 +251,30 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  int bm, bn;
-  tile_of_index(p, blockIdx.x, gridDim.x, bm, bn);
+  // 1-D grid over (k-slab, m-tile, channel group, n-tile), n-tile fastest, renumbered so that every XCD takes a contiguous run of it:
+  // the work items that read the same rows of A -- the n-tiles of one slab (for a 3x3 weight gradient: its nine taps, i.e. nine
+  // shifted views of the same rows) and the channel groups (128-byte column slices of the same rows) -- then run side by side on ONE
+  // XCD and share its L2.  (As a 3-D grid they were dealt round-robin over the 8 XCDs and each XCD fetched the slab for itself.)
+  int bm, bn, grp = 0;
+  p.split_id = 0;
+  if (p.groups > 1 || p.splits > 1) {
+    int w = xcd_chunk(blockIdx.x, gridDim.x);
+    bn = w % p.tiles_n; w /= p.tiles_n;
+    grp = w % p.groups; w /= p.groups;
+    bm = w % p.tiles_m;
+    p.split_id = w / p.tiles_m;
+  } else {
+    tile_of_index(p, blockIdx.x, gridDim.x, bm, bn);
+  }
   const int m0 = bm * BM, n0 = bn * BN;
-  p.split_id = blockIdx.y;
   if (p.groups > 1) {                  // uniform: the kernel argument copy is ours to edit
-    const long z = blockIdx.z;
+    const long z = grp;
     p.A += z * p.ga; p.B += z * p.gb;
-    p.a_bytes -= (uint32_t)(z * p.ga * 2); p.b_bytes -= (uint32_t)(z * p.gb * 2);     // the windows end where the tensors end
+    p.a_bytes -= (uint64_t)(z * p.ga * 2); p.b_bytes -= (uint64_t)(z * p.gb * 2);     // the windows end where the tensors end
     p.C = reinterpret_cast<char*>(p.C) + z * p.gc * (OUTF32 ? 4 : 2);
     if (p.bias) p.bias += z * p.gbias;
     if (p.ws) p.ws += z * (long)p.splits * p.M * p.N;
   }
-  const __amdgpu_buffer_rsrc_t rsA = ia_rsrc(p.A, p.a_bytes);
-  const __amdgpu_buffer_rsrc_t rsB = ia_rsrc(p.B, p.b_bytes);
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -259,22 +283,37 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk_all = (p.K + BK - 1) / BK;
-  const int kt0 = blockIdx.y * p.nk_per_split;
+  const int kt0 = p.split_id * p.nk_per_split;
   const int nk = min(nk_all, kt0 + p.nk_per_split);
-  stage_tile<AKS>(rsA, smem, kt0, m0, p.lda, p.K, tid, wave, p.a_view, p.pw, p.lca, 0);
-  stage_tile<BKS>(rsB, smem + TILE_BYTES, kt0, n0, p.ldb, p.K, tid, wave, p.b_view, p.pw, p.lcbk, p.lcbn);
+  // buffer windows of this workgroup (rsrc_at): a k-contiguous operand starts at its tile's first row, a k-strided one at its
+  // k-slab's first row, both moved back by the largest tap shift (pw + 1 rows) when the operand is read through shifted views
+  const int a_org = !AKS ? max(0, m0 - (p.a_view ? p.pw + 1 : 0)) : kt0 * BK;
+  const int b_org = !BKS ? n0 : (p.b_view == 1 ? 0 : max(0, kt0 * BK - (p.b_view == 2 ? p.pw + 1 : 0)));
+  const __amdgpu_buffer_rsrc_t rsA = rsrc_at(p.A, p.a_bytes, (uint64_t)a_org * p.lda);
+  const __amdgpu_buffer_rsrc_t rsB = rsrc_at(p.B, p.b_bytes, (uint64_t)b_org * p.ldb);
+  const int xa = AKS ? m0 : m0 - a_org, xb = BKS ? n0 : 0;
+  stage_tile<AKS>(rsA, smem, kt0, xa, p.lda, p.K, tid, wave, a_org, p.a_view, p.pw, p.lca, 0);
+  stage_tile<BKS>(rsB, smem + TILE_BYTES, kt0, xb, p.ldb, p.K, tid, wave, b_org, p.b_view, p.pw, p.lcbk, p.lcbn);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   const int g = lane >> 4, li = lane & 15;
   // a wave whose 64 x 64 quadrant lies entirely outside C (M or N <= 64: conv groups, heads) only helps with the staging
   const bool quadrant_live = m0 + wm * 64 < p.M && n0 + wn * 64 < p.N;
+  constexpr bool WGRAD = AKS && BKS && OUTF32 && EPI == EPI_NONE;
+  const bool row_sums = WGRAD && p.rsum_out != nullptr && bn == 0 && wn == 0;      // uniform per wave
+  f32x4 racc[4];
+  bf16x8 ones;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) racc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = f2bf(1.0f);
   for (int kt = kt0; kt < nk; ++kt) {
     const int buf = (kt - kt0) & 1;
     if (kt + 1 < nk) {
       char* nb = smem + (buf ^ 1) * 2 * TILE_BYTES;
-      stage_tile<AKS>(rsA, nb, kt + 1, m0, p.lda, p.K, tid, wave, p.a_view, p.pw, p.lca, 0);
-      stage_tile<BKS>(rsB, nb + TILE_BYTES, kt + 1, n0, p.ldb, p.K, tid, wave, p.b_view, p.pw, p.lcbk, p.lcbn);
+      stage_tile<AKS>(rsA, nb, kt + 1, xa, p.lda, p.K, tid, wave, a_org, p.a_view, p.pw, p.lca, 0);
+      stage_tile<BKS>(rsB, nb + TILE_BYTES, kt + 1, xb, p.ldb, p.K, tid, wave, b_org, p.b_view, p.pw, p.lcbk, p.lcbn);
     }
     const char* sA = smem + buf * 2 * TILE_BYTES;
     const char* sB = sA + TILE_BYTES;
@@ -303,6 +342,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
+      if (WGRAD && row_sums)          // D[n][m] = sum_k 1 * A[m][k] for every n: each lane's column li holds the sum of its m
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) racc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[mi], racc[mi], 0, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -317,6 +359,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       const int n = n0 + wn * 64 + (BKS ? ni * 16 + g * 4 : g * 16 + ni * 4);
       if (n >= p.N) continue;
       epi_store4<EPI, OUTF32>(p, m, n, acc[mi][ni]);
+    }
+  }
+  if (WGRAD && row_sums && g == 0) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int m = m0 + wm * 64 + mi * 16 + li;
+      if (m >= p.M) continue;
+      if (p.splits > 1) p.rsum_ws[((size_t)grp * p.splits + p.split_id) * p.M + m] = racc[mi][0];
+      else p.rsum_out[(size_t)grp * p.M + m] += racc[mi][0];
     }
   }
 }
@@ -375,8 +426,10 @@ IA_DEV bf16x8 frag_ks(const char* s, int k0, int col0, int lane) {
 // Ping-pong main loop of one wave group (GRP 0: rows 0..127 of the block tile and the A-operand DMA;
 // GRP 1: rows 128..255 and the B-operand DMA).  See the schedule comment in gemm_kernel.
 template <int GRP, bool AKS, bool BKS, int PEND>
-IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][2], __amdgpu_buffer_rsrc_t rs, int x0, int ld, int kt0,
+IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][2], __amdgpu_buffer_rsrc_t rs, int x0, int ld, int kt0, int kta0,
                       int n_tiles, int nk_all, int wn, int lane, bool prologue_only, bool stores_in_flight) {
+  // rs is this workgroup's buffer window (rsrc_at): x0 and the k-tile index used for ADDRESSES (kta0 + u) are relative to its
+  // origin -- tile row 0 of a k-contiguous operand (kta0 = kt0: the k offset is a column), slab row 0 of a k-strided one (kta0 = 0)
   constexpr bool MYKS = GRP ? BKS : AKS;            // layout of the operand this group streams
   const int hh = lane >> 5, li = lane & 31;
   const int gt = wn * 64 + lane;                    // thread index inside the group (0..255)
@@ -399,12 +452,12 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][2], __amdg
 
   auto dma_piece = [&](int u, int i) {             // piece i of this group's half of k-tile u -> buffer u&1
     char* dst = my_half + (u & 1) * 2 * TILE_BYTES + i * 4096;
-    const int kt = kt0 + u;
+    const int kt = kt0 + u, kta = kta0 + u;
     if (!ragged_k || kt != nk_all - 1) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, IA_LDS(dst), 16, voff0, (int)(kt * kstep + i * piece_step), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, IA_LDS(dst), 16, voff0, (int)(kta * kstep + i * piece_step), 0, 0);
     } else {                                        // last, partial k-tile: lanes past K fetch zeros
       const int k = MYKS ? kt * BK + i * 8 + (gt >> 5) : kt * BK + ((gt & 7) ^ (((gt >> 3) >> 1) & 7)) * 8;
-      const uint32_t off = k < p.K ? voff0 + kt * kstep + i * piece_step : OOB;
+      const uint32_t off = k < p.K ? voff0 + kta * kstep + i * piece_step : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, IA_LDS(dst), 16, off, 0, 0, 0);
     }
   };
@@ -528,10 +581,16 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs p) {
     // epilogue and push the 256-register kernel into scratch): every call derives it afresh from an opaque lane id
     int lane = lane0;
     asm volatile("" : "+v"(lane));
-    if (wm == 0) main_loop<0, AKS, BKS, PEND>(p, smem, acc, ia_rsrc(p.A, p.a_bytes), bm * BM, p.lda, kt0, n_tiles, nk_all, wn, lane, prologue_only, stores_in_flight);
-    else         main_loop<1, AKS, BKS, PEND>(p, smem, acc, ia_rsrc(p.B, p.b_bytes), bn * BN, p.ldb, kt0, n_tiles, nk_all, wn, lane, prologue_only, stores_in_flight);
+    if (wm == 0) main_loop<0, AKS, BKS, PEND>(p, smem, acc, rsrc_at(p.A, p.a_bytes, (uint64_t)(AKS ? kt0 * BK : bm * BM) * p.lda), AKS ? bm * BM : 0, p.lda,
+                                               kt0, AKS ? 0 : kt0, n_tiles, nk_all, wn, lane, prologue_only, stores_in_flight);
+    else         main_loop<1, AKS, BKS, PEND>(p, smem, acc, rsrc_at(p.B, p.b_bytes, (uint64_t)(BKS ? kt0 * BK : bn * BN) * p.ldb), BKS ? bn * BN : 0, p.ldb,
+                                               kt0, BKS ? 0 : kt0, n_tiles, nk_all, wn, lane, prologue_only, stores_in_flight);
   };
 
+  if ((p.dbg & 2048) && ((blockIdx.x >> 3) & 1)) {     // ablation: every other CU of an XCD starts (dbg >> 16) us late
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < (unsigned long long)(p.dbg >> 16) * 100ull) __builtin_amdgcn_s_sleep(8);
+  }
   f32x16 acc[4][2];
   int tile = first_tile;
   run(tile, true, acc, false);
@@ -674,8 +733,32 @@ struct GemmProf {
 GemmProf g_prof;
 
 // C[m][n] (+)= sum_s ws[s][m][n]
+// out[group * M + m] += sum_s rsum_ws[group][s][m] (workgroup x = 0 of each group does it): 8 lanes per m, lane l adds partials
+// l, l+8, ... in order and lane 0 folds the 8 lane sums in order (fixed order -> deterministic)
+IA_DEV void fold_row_sums(const float* rsum_ws, float* rsum_out, int M, int splits) {
+  __shared__ float rs[256];
+  if (!rsum_ws || blockIdx.x != 0) return;          // uniform per workgroup
+  const int lane = threadIdx.x & 7;
+  for (int mb = 0; mb < M; mb += 32) {
+    const int m = mb + (threadIdx.x >> 3);
+    float a = 0.f;
+    if (m < M)
+      for (int sp = lane; sp < splits; sp += 8) a += rsum_ws[((size_t)blockIdx.y * splits + sp) * M + m];
+    rs[threadIdx.x] = a;
+    __syncthreads();
+    if (lane == 0 && m < M) {
+      float sum = rs[threadIdx.x];
+#pragma unroll
+      for (int l = 1; l < 8; ++l) sum += rs[threadIdx.x + l];
+      rsum_out[(size_t)blockIdx.y * M + m] += sum;
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int M, int N, int ldc,
-                                                            int splits, int accumulate, long gc) {
+                                                            int splits, int accumulate, long gc, const float* rsum_ws, float* rsum_out) {
+  fold_row_sums(rsum_ws, rsum_out, M, splits);
   ws += (size_t)blockIdx.y * splits * M * N;       // blockIdx.y = channel group of a batched convolution GEMM
   C += (size_t)blockIdx.y * gc;
   const size_t total4 = (size_t)M * N / 4;
@@ -693,8 +776,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // the same sum for deep cuts (conv weight gradients: hundreds of partials of a few KB each): 8 lanes share one output quad,
 // lane l adds partials l, l+8, ... in order and lane 0 folds the 8 lane sums in order (fixed order -> deterministic)
 __global__ __launch_bounds__(256) void splitk_reduce_deep_kernel(const float* __restrict__ ws, float* __restrict__ C, int M, int N, int ldc,
-                                                                 int splits, int accumulate, long gc) {
+                                                                 int splits, int accumulate, long gc, const float* rsum_ws, float* rsum_out) {
   __shared__ f32x4 red[256];
+  fold_row_sums(rsum_ws, rsum_out, M, splits);
   ws += (size_t)blockIdx.y * splits * M * N;
   C += (size_t)blockIdx.y * gc;
   const size_t total4 = (size_t)M * N / 4;
@@ -768,16 +852,16 @@ int launch(GemmArgs a, bool big, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(gx), dim3(512), t256::LDS_BYTES, st, a);
   } else {
     a.tiles_m = (a.M + t128::BM - 1) / t128::BM; a.tiles_n = (a.N + t128::BN - 1) / t128::BN;
-    hipLaunchKernelGGL((t128::gemm_kernel<AKS, BKS, EPI, OUTF32>), dim3(a.tiles_m * a.tiles_n, a.splits, a.groups), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((t128::gemm_kernel<AKS, BKS, EPI, OUTF32>), dim3(a.tiles_m * a.tiles_n * a.splits * a.groups), dim3(256), 0, st, a);
   }
   if (OUTF32 && a.splits > 16) {
     const size_t g = ((size_t)a.M * a.N / 4 + 31) / 32;
     hipLaunchKernelGGL(splitk_reduce_deep_kernel, dim3((unsigned)g, a.groups), dim3(256), 0, st, a.ws, (float*)a.C, a.M, a.N, a.ldc, a.splits,
-                       a.accumulate, a.gc);
+                       a.accumulate, a.gc, a.rsum_out ? a.rsum_ws : nullptr, a.rsum_out);
   } else if (OUTF32 && a.splits > 1) {
     size_t g = ((size_t)a.M * a.N / 4 + 255) / 256; if (g > 4096) g = 4096;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)g, a.groups), dim3(256), 0, st, a.ws, (float*)a.C, a.M, a.N, a.ldc, a.splits, a.accumulate,
-                       a.gc);
+                       a.gc, a.rsum_out ? a.rsum_ws : nullptr, a.rsum_out);
   }
   if (rec) {
     (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st);
@@ -793,7 +877,7 @@ int launch(GemmArgs a, bool big, hipStream_t st) {
 extern "C" size_t ia_gemm_workspace_bytes(int M, int N, int K, int c_is_f32) {
   if (!c_is_f32 || M <= 0 || N <= 0 || K <= 0) return 0;
   const Plan pl = make_plan(M, N, K, true);
-  return pl.splits > 1 ? (size_t)pl.splits * M * N * sizeof(float) : 0;
+  return pl.splits > 1 ? (size_t)pl.splits * M * (N + 1) * sizeof(float) : 0;      // + the row-sum partials of the weight-gradient form
 }
 
 static int gemm_core(const void* A, int a_kstrided, int lda, const void* B, int b_kstrided, int ldb, void* C, int c_is_f32, int ldc, int M,
@@ -823,13 +907,13 @@ int ia_gemm_view(const IaViewGemm& v, hipStream_t stream) {
       v.pw <= 2 || (!v.a_view && !v.b_view) || v.groups < 1 || v.lca < 3 || v.lcbk < 3 || v.lcbn < 3)
     return IA_ERR_ARG;
   return gemm_core(v.A, v.a_kstrided, v.lda, v.B, v.b_kstrided, v.ldb, v.C, v.c_is_f32, v.ldc, v.M, v.N, v.K, v.bias ? EPI_BIAS : EPI_NONE,
-                   v.bias, nullptr, 0, nullptr, 0, v.workspace, v.workspace_bytes, &v, stream);
+                   v.bias, nullptr, 0, v.rsum_out, 0, v.workspace, v.workspace_bytes, &v, stream);
 }
 
 size_t ia_gemm_view_workspace_bytes(int M, int N, int K, int groups) {
   if (M <= 0 || N <= 0 || K <= 0 || groups <= 0) return 0;
   const Plan pl = make_plan(M, N, K, true, groups);
-  return pl.splits > 1 ? (size_t)groups * pl.splits * M * N * sizeof(float) : 0;
+  return pl.splits > 1 ? (size_t)groups * pl.splits * M * (N + 1) * sizeof(float) : 0;      // + the row-sum partials (bias gradient)
 }
 
 static int gemm_core(const void* A, int a_kstrided, int lda, const void* B, int b_kstrided, int ldb, void* C, int c_is_f32, int ldc, int M,
@@ -853,25 +937,36 @@ static int gemm_core(const void* A, int a_kstrided, int lda, const void* B, int 
     g.a_view = view->a_view; g.b_view = view->b_view; g.pw = view->pw; g.lca = view->lca; g.lcbk = view->lcbk; g.lcbn = view->lcbn;
     g.groups = groups; g.ga = view->ga; g.gb = view->gb; g.gc = view->gc; g.gbias = view->gbias;
   }
-  if (ab >= 0x7FFFFFFFull || bb >= 0x7FFFFFFFull) return IA_ERR_ARG;
   if (!a_kstrided && (K & 7)) return IA_ERR_ARG;
-  g.a_bytes = (uint32_t)ab; g.b_bytes = (uint32_t)bb;
+  g.a_bytes = ab; g.b_bytes = bb;
   g.tiles_m = g.tiles_n = 0;
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("IA_GEMM_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
   const int nk = (K + BK - 1) / BK;
   Plan pl = make_plan(M, N, K, c_is_f32 != 0, groups);
   g.splits = 1; g.nk_per_split = nk; g.ws = nullptr;
-  if (c_is_f32 && pl.splits > 1 && workspace && workspace_bytes >= (size_t)groups * pl.splits * M * N * sizeof(float)) {
+  const bool big = pl.big && !view && !(g.dbg & 128);     // the shifted views and the group batching live in the T128 kernel only (dbg 128: force T128)
+  // weight-gradient form with C2: the fp32 row sums of A^T (bias gradient) come out of the same launch (T128 kernel)
+  const bool wgrad_form = a_kstrided && b_kstrided && c_is_f32 && epilogue == EPI_NONE;
+  g.rsum_out = (wgrad_form && !big) ? (float*)C2 : nullptr;
+  g.rsum_ws = nullptr;
+  if (c_is_f32 && pl.splits > 1 && workspace && workspace_bytes >= (size_t)groups * pl.splits * M * (N + (g.rsum_out ? 1 : 0)) * sizeof(float)) {
     g.nk_per_split = (nk + pl.splits - 1) / pl.splits;
     g.splits = (nk + g.nk_per_split - 1) / g.nk_per_split;
     g.ws = (float*)workspace;
+    g.rsum_ws = g.ws + (size_t)groups * g.splits * M * N;
+  }
+  {  // every workgroup addresses its operands through a 32-bit buffer window that starts at its tile / k-slab (rsrc_at): that
+     // window -- not the tensor -- has to stay below 2 GiB
+    const uint64_t margin = view ? 2 * (uint64_t)(view->pw + 1) : 0, slab = (uint64_t)g.nk_per_split * BK + margin, tile = 256 + margin;
+    const uint64_t wa = (a_kstrided ? slab : tile) * (uint64_t)lda * 2 + (a_kstrided ? 0 : (uint64_t)K * 2);
+    const uint64_t wb = (b_kstrided ? slab : tile) * (uint64_t)ldb * 2 + (b_kstrided ? 0 : (uint64_t)K * 2);
+    if (wa >= 0x7FFFFFF0ull || wb >= 0x7FFFFFF0ull) return IA_ERR_ARG;
   }
   const bool needs_bias = epilogue == EPI_BIAS || epilogue == EPI_BIAS_GELU || epilogue == EPI_BIAS_ADD;
   const bool needs_aux = epilogue == EPI_ADD || epilogue == EPI_DGELU || epilogue == EPI_BIAS_ADD || epilogue == EPI_DGELU_CS;
   if (needs_bias && !bias) return IA_ERR_ARG;
   if (needs_aux && (!aux || (ldaux & 3))) return IA_ERR_ARG;
   if (epilogue == EPI_BIAS_GELU && !C2) return IA_ERR_ARG;
-  const bool big = pl.big && !view && !(g.dbg & 128);     // the shifted views and the group batching live in the T128 kernel only (dbg 128: force T128)
 
   if (!a_kstrided && !b_kstrided && !c_is_f32) {
     switch (epilogue) {
@@ -899,7 +994,13 @@ static int gemm_core(const void* A, int a_kstrided, int lda, const void* B, int 
       }
     }
   } else if (a_kstrided && b_kstrided && c_is_f32) {
-    if (epilogue == EPI_NONE) return launch<true, true, EPI_NONE, true>(g, big, stream);
+    if (epilogue == EPI_NONE) {
+      int rc = launch<true, true, EPI_NONE, true>(g, big, stream);
+      // 256x256 kernel: no spare accumulators for the row sums -> the stand-alone column-sum pass over A (stream-ordered after the
+      // split-K reduce, so it may reuse the workspace)
+      if (!rc && C2 && big) rc = ia_colsum(A, lda, K, M, (float*)C2, 1, workspace, workspace_bytes, stream);
+      return rc;
+    }
   } else if (!a_kstrided && !b_kstrided && c_is_f32) {
     if (epilogue == EPI_NONE) return launch<false, false, EPI_NONE, true>(g, big, stream);
     if (epilogue == EPI_BIAS) return launch<false, false, EPI_BIAS, true>(g, big, stream);

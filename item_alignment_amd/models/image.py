@@ -174,13 +174,17 @@ class VitTwoTower(_ImageTwoTower):
 
 
 class NFNetTwoTower(_ImageTwoTower):
-    # The conv kernels address an operand with 32-bit byte offsets (2 GiB windows); at 800x800 the strided patch-gather
-    # convolutions reach that at 33 images.  The tower is image-independent (no BatchNorm), so bigger batches run in chunks.
-    max_images = 32
+    # Operand size is not a limit (the GEMM re-bases its 32-bit buffer windows per workgroup), activation memory is: one 800x800
+    # image keeps ~0.8 GiB of activations for backward, so a 288 GB MI355X holds ~300 of them in one pass.  The tower is
+    # image-independent (no BatchNorm), so a caller short of memory can run it in chunks of `max_images` 800x800-equivalents
+    # (None = one pass; 0 = one image per chunk).
+    max_images = None
 
     def _embed(self, images):
         enc = self.img_encoder
         n = images.shape[0]
+        if self.max_images is None:
+            return enc.head.global_pool(enc.forward_features(images))
         per = self.max_images * 800 * 800 // max(1, images.shape[-1] * images.shape[-2])
         per = max(1, per)
         if n <= per:

@@ -328,8 +328,8 @@ class ScaledStdConv2d(nn.Module):
         return (PADDED_CONV and self.kernel_size == 3 and self.stride == 1 and ci >= 8 and co >= 8 and not (ci & (ci - 1)) and not (co & (co - 1)))
 
     def fits_padded(self, B, H, W):
-        """the shifted-view GEMMs address the padded tensor with 32-bit byte offsets"""
-        return B * (H + 2) * (W + 2) * max(self.in_channels, self.out_channels) * 2 < 0x7FFFFFFF
+        """row indices of the padded tensor are 32-bit ints (its byte size is not limited)"""
+        return B * (H + 2) * (W + 2) < 0x7FFFFFFF
 
     def forward(self, f):
         y = StdConvFn.apply(f.t, self.weight, self, f.B, f.H, f.W)

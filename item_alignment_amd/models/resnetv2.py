@@ -159,7 +159,7 @@ class Conv3x3Fn(torch.autograd.Function):
         dev = x.device
         what = _packed_weight(conv, C, 9 * C)
         padded = (PADDED_CONV and s == 1 and not (C & (C - 1)) and not (Cout & (Cout - 1)) and C >= 8 and Cout >= 8
-                  and B * (H + 2) * (W + 2) * max(C, Cout) * 2 < 0x7FFFFFFF)
+                  and B * (H + 2) * (W + 2) < 0x7FFFFFFF)
         ctx.padded = padded
         if padded:
             Mp = B * (H + 2) * (W + 2)
@@ -238,8 +238,6 @@ class StemConvFn(torch.autograd.Function):
         pad = ((s - 1) + (k - 1)) // 2                       # timm padding.py get_padding (dilation 1)
         Kp = (k * k * C + 7) // 8 * 8
         Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
-        if B * Ho * Wo * Kp * 2 >= 0x7FFFFFFF:
-            raise _lib.ItemAlignError(f"stem patch matrix of {B} images exceeds the 2 GiB operand window; lower the per-GPU batch")
         cols = torch.empty((B * Ho * Wo, Kp), device=images.device, dtype=BF16)
         check(lib.ia_patches_nchw(images.data_ptr(), cols.data_ptr(), B, C, H, W, k, s, pad, Kp, stream_ptr()), "ia_patches_nchw")
         what = _packed_weight(conv, C, Kp)

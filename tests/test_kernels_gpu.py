@@ -634,6 +634,83 @@ def test_conv3x3_padded_full_size_against_miopen(gpu):
         assert rel_err(dwhat.view(C, 3, 3, 64).permute(0, 3, 1, 2), wr.grad) < 2e-3      # sums over up to 160 000 pixels, fp32 split-K
 
 
+def test_conv_operands_beyond_2gib(gpu):
+    """Operands larger than 2 GiB (more than 32 images of 800x800 in one tower pass): the GEMM addresses them through per-workgroup
+    32-bit buffer windows.  Images are independent, so the whole batch must equal the same kernels run on sub-batches (whose
+    operands are small and are checked against torch by the tests above); weight / bias gradients must equal the sum over them."""
+    from item_alignment_amd import _lib
+    from item_alignment_amd.ops import check, stream_ptr
+    lib = _lib.load()
+    torch.manual_seed(77)
+    # --- shifted-view 3x3 on the zero-bordered domain: 56 x 400 x 400 x 128 bf16 = 2.29 GB per operand
+    B, H, W, C, groups = 56, 398, 398, 128, 2
+    rows = (H + 2) * (W + 2)
+    xp = torch.zeros((B, H + 2, W + 2, C), device=gpu, dtype=torch.bfloat16)
+    dyp = torch.zeros_like(xp)
+    xp[:, 1:-1, 1:-1] = torch.randn((B, H, W, C), device=gpu).bfloat16()
+    dyp[:, 1:-1, 1:-1] = torch.randn((B, H, W, C), device=gpu).bfloat16()
+    assert xp.numel() * 2 > 2 ** 31
+    what = (torch.randn((C, 9 * C // groups), device=gpu) * 0.05).bfloat16()
+    bias = torch.randn(C, device=gpu)
+
+    def run(b0, b1):
+        n = b1 - b0
+        x_, dy_ = xp[b0:b1], dyp[b0:b1]
+        yp, dxp = torch.empty_like(x_), torch.empty_like(x_)
+        check(lib.ia_conv3x3_padded_fwd(x_.data_ptr(), what.data_ptr(), bias.data_ptr(), yp.data_ptr(), n, H, W, C, C, groups, stream_ptr()), "fwd")
+        check(lib.ia_conv3x3_padded_bwd_data(dy_.data_ptr(), what.data_ptr(), dxp.data_ptr(), n, H, W, C, C, groups, stream_ptr()), "dgrad")
+        wsb = lib.ia_conv3x3_padded_workspace_bytes(n, H, W, C, C, groups)
+        ws = torch.empty(max(wsb, 16), device=gpu, dtype=torch.uint8)
+        dwhat = torch.empty((C, 9 * C // groups), device=gpu, dtype=torch.float32)
+        dbias = torch.zeros(C, device=gpu)
+        check(lib.ia_conv3x3_padded_bwd_weight(x_.data_ptr(), dy_.data_ptr(), dwhat.data_ptr(), dbias.data_ptr(), n, H, W, C, C, groups,
+                                               ws.data_ptr(), wsb, stream_ptr()), "wgrad")
+        return yp, dxp, dwhat, dbias
+
+    yp, dxp, dwhat, dbias = run(0, B)
+    dw_sum, db_sum = torch.zeros_like(dwhat), torch.zeros_like(dbias)
+    for b0 in range(0, B, 14):
+        y_, dx_, dw_, db_ = run(b0, b0 + 14)
+        assert torch.equal(yp[b0:b0 + 14, 1:-1, 1:-1], y_[:, 1:-1, 1:-1]) and torch.equal(dxp[b0:b0 + 14, 1:-1, 1:-1], dx_[:, 1:-1, 1:-1]), b0
+        dw_sum += dw_
+        db_sum += db_
+    assert rel_err(dwhat, dw_sum) < 1e-4 and rel_err(dbias, db_sum) < 1e-4
+    del xp, dyp, yp, dxp
+    # --- strided 3x3 through the patch matrix: 48 x 200 x 200 rows x 576 columns bf16 = 2.2 GB
+    B, H, W, C, Cout, s = 48, 400, 400, 64, 64, 2
+    x = torch.randn((B * H * W, C), device=gpu).bfloat16()
+    Ho = Wo = (H - 1) // s + 1
+    dy = torch.randn((B * Ho * Wo, Cout), device=gpu).bfloat16()
+    what = (torch.randn((Cout, 9 * C), device=gpu) * 0.05).bfloat16()
+    assert B * Ho * Wo * 9 * C * 2 > 2 ** 31
+
+    def run2(b0, b1):
+        n = b1 - b0
+        x_, dy_ = x[b0 * H * W:b1 * H * W], dy[b0 * Ho * Wo:b1 * Ho * Wo]
+        wsb = lib.ia_conv_nhwc_workspace_bytes(n, H, W, C, Cout, 3, s, 1)
+        ws = torch.empty(max(wsb, 16), device=gpu, dtype=torch.uint8)
+        y = torch.empty((n * Ho * Wo, Cout), device=gpu, dtype=torch.bfloat16)
+        check(lib.ia_conv_nhwc_fwd(x_.data_ptr(), what.data_ptr(), bias[:Cout].data_ptr(), y.data_ptr(), n, H, W, C, Cout, 3, s, 1, ws.data_ptr(), wsb,
+                                   stream_ptr()), "fwd")
+        dwhat = torch.empty((Cout, 9 * C), device=gpu, dtype=torch.float32)
+        dbias = torch.zeros(Cout, device=gpu)
+        check(lib.ia_conv_nhwc_bwd_weight(x_.data_ptr(), dy_.data_ptr(), dwhat.data_ptr(), dbias.data_ptr(), n, H, W, C, Cout, 3, s, 1, 1, ws.data_ptr(),
+                                          wsb, stream_ptr()), "wgrad")
+        dx = torch.empty_like(x_)
+        check(lib.ia_conv_nhwc_bwd_data(dy_.data_ptr(), what.data_ptr(), dx.data_ptr(), n, H, W, C, Cout, 3, s, 1, ws.data_ptr(), wsb, stream_ptr()),
+              "dgrad")
+        return y, dx, dwhat, dbias
+
+    y, dx, dwhat, dbias = run2(0, B)
+    dw_sum, db_sum = torch.zeros_like(dwhat), torch.zeros_like(dbias)
+    for b0 in range(0, B, 16):
+        y_, dx_, dw_, db_ = run2(b0, b0 + 16)
+        assert torch.equal(y[b0 * Ho * Wo:(b0 + 16) * Ho * Wo], y_) and torch.equal(dx[b0 * H * W:(b0 + 16) * H * W], dx_), b0
+        dw_sum += dw_
+        db_sum += db_
+    assert rel_err(dwhat, dw_sum) < 1e-4 and rel_err(dbias, db_sum) < 1e-4
+
+
 def test_batchnorm_full_size_statistics(gpu):
     """resnetv2_50 stage-1 activation size (2 x 320 000 rows x 256 channels): without the ReLU every (segment, channel) of the
     output has mean beta and variance gamma^2, whatever the input scale and offset; the backward output sums to zero per

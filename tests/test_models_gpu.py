@@ -535,7 +535,7 @@ def test_nfnet_two_tower_chunked_batch_equals_whole(gpu):
     labels = torch.tensor([1, 0, 1]).cuda()
     grads = []
     losses = []
-    for max_images in (32, 0):                      # 0 -> one image per chunk
+    for max_images in (None, 0):                    # one pass; 0 -> one image per chunk
         model.max_images = max_images
         out = model(im1, im2, labels)
         model.param_arena.zero_grad()

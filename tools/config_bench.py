@@ -1,12 +1,19 @@
 """Train-step throughput of the other BASELINE.json configurations on one MI355X (synthetic inputs, dropout on, fused
 AdamW; SURVEY.md §8(d) shapes and FLOP counts).  bench.py stays the headline C5 measurement; this fills DESIGN.md §7.
 
-usage: python tools/config_bench.py [c2] [c3] [c4] [c5x]
+usage: python tools/config_bench.py [--pmc] [c2] [c3] [c3r] [c4] [c5x]
+  --pmc  also re-run each configuration (1 warm-up + 2 steps) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes)
+         and print the HBM bytes per step, the achieved HBM GB/s at the measured step time and its fraction of the 8 TB/s peak
   c2  roberta_large one_tower cls/ce, L = 510          c3  eca_nfnet_l0 two_tower, 800x800
   c4  pkgm_large one_tower, max_pvs 30 (L = 220)        c5x CoCa roberta_large + vit_large_patch16_384, --ensemble cross_attn
 """
+import csv
+import glob
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,7 +27,38 @@ from item_alignment_amd.data.synthetic import SyntheticCocaPairs, one_tower_text
 dev = torch.device("cuda:0")
 
 
-def run(name, model, batch_fn, pairs, flops_per_pair, steps=8, warm=3):
+HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+PMC = False
+CHILD_STEPS = os.environ.get("IA_CB_CHILD_STEPS")     # set in the profiled child: "warm,steps"
+
+
+def hbm_bytes_per_step(which):
+    """Sum of FETCH_SIZE x 2 + WRITE_SIZE (KB; the x2 is the gfx950 correction for wide reads, MI355X_MICROARCH.md) over every
+    kernel of a 1 + 2 step child run of configuration `which`, divided by its 3 steps."""
+    rocprof = shutil.which("rocprofv3")
+    if rocprof is None:
+        return None
+    kb = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="ia_cb_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+        env = dict(os.environ, IA_CB_CHILD_STEPS="1,2")
+        try:
+            subprocess.run([rocprof, "--pmc", counter, "-d", out, "-o", "p", "--output-format", "csv", "--", sys.executable,
+                            os.path.abspath(__file__), which], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900, check=True,
+                           cwd=out, env=env)
+            f = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)[0]
+            kb[counter] = sum(float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter) / 3.0
+        except Exception as e:
+            print(f"  ({counter} pass failed: {e!r})")
+            return None
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    return (2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0
+
+
+def run(name, model, batch_fn, pairs, flops_per_pair, steps=8, warm=3, which=None):
+    if CHILD_STEPS:
+        warm, steps = (int(v) for v in CHILD_STEPS.split(","))
     model = model.cuda().train()
     arena = model.param_arena
 
@@ -44,6 +82,11 @@ def run(name, model, batch_fn, pairs, flops_per_pair, steps=8, warm=3):
           f"peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
     del model
     torch.cuda.empty_cache()
+    if PMC and which and not CHILD_STEPS:
+        b = hbm_bytes_per_step(which)
+        if b is not None:
+            print(f"  HBM traffic {b/1e9:.2f} GB/step (rocprofv3 --pmc, all kernels) -> {b/dt/1e9:.0f} GB/s achieved = "
+                  f"{b/dt/HBM_PEAK*100:.1f} % of the 8 TB/s HBM peak; {flops_per_pair*pairs/b:.0f} FLOP per HBM byte", flush=True)
 
 
 def c2(pairs=128):
@@ -54,7 +97,7 @@ def c2(pairs=128):
     torch.manual_seed(2345)
     run("C2 roberta_large one_tower L=510", M.RobertaOneTower(cfg),
         lambda m: m(input_ids=t["input_ids"], attention_mask=t["attention_mask"], token_type_ids=t["token_type_ids"], labels=labels),
-        pairs, 1.001e12)
+        pairs, 1.001e12, which="c2")
 
 
 def c3(pairs=16, S=800):
@@ -64,7 +107,7 @@ def c3(pairs=16, S=800):
     im1, im2 = torch.randn((pairs, 3, S, S), generator=g).to(dev), torch.randn((pairs, 3, S, S), generator=g).to(dev)
     labels = torch.randint(0, 2, (pairs,), generator=g).to(dev)
     torch.manual_seed(2345)
-    run(f"C3 eca_nfnet_l0 two_tower {S}x{S}", M.NFNetTwoTower(cfg, M.create_model("eca_nfnet_l0")), lambda m: m(im1, im2, labels), pairs, 6.49e11)
+    run(f"C3 eca_nfnet_l0 two_tower {S}x{S}", M.NFNetTwoTower(cfg, M.create_model("eca_nfnet_l0")), lambda m: m(im1, im2, labels), pairs, 6.49e11, which="c3")
 
 
 def c3r(pairs=16, S=800):
@@ -75,7 +118,7 @@ def c3r(pairs=16, S=800):
     im1, im2 = torch.randn((pairs, 3, S, S), generator=g).to(dev), torch.randn((pairs, 3, S, S), generator=g).to(dev)
     labels = torch.randint(0, 2, (pairs,), generator=g).to(dev)
     torch.manual_seed(2345)
-    run(f"C3r resnetv2_50 two_tower {S}x{S}", M.ResNetTwoTower(cfg, M.create_model("resnetv2_50")), lambda m: m(im1, im2, labels), pairs, 6.28e11)
+    run(f"C3r resnetv2_50 two_tower {S}x{S}", M.ResNetTwoTower(cfg, M.create_model("resnetv2_50")), lambda m: m(im1, im2, labels), pairs, 6.28e11, which="c3r")
 
 
 def c4(pairs=256):
@@ -105,7 +148,7 @@ def c4(pairs=256):
     labels = torch.from_numpy(rs.randint(0, 2, size=pairs)).to(dev)
     torch.manual_seed(2345)
     run("C4 pkgm_large one_tower L=220", M.PKGMOneTower(cfg),
-        lambda m: m(input_ids=t[0], attention_mask=t[1], token_type_ids=t[2], position_ids=t[3], labels=labels), pairs, 4.129e11)
+        lambda m: m(input_ids=t[0], attention_mask=t[1], token_type_ids=t[2], position_ids=t[3], labels=labels), pairs, 4.129e11, which="c4")
 
 
 def c5x(pairs=16):
@@ -121,10 +164,14 @@ def c5x(pairs=16):
     mm = 24 * (2 * L * H * (H + 128 + 2 * F) + 2 * L * H * H + 2 * L * F * H + 4 * L * L * 16 * 64       # parallel block
                + 2 * L * H * H + 2 * N * H * 128 + 4 * L * N * 16 * 64 + 2 * L * H * H + 2 * L * H * 2 * F + 2 * L * F * H)   # cross attention
     fwd = 1.604e11 + 3.9e11 + mm
-    run("C5x CoCa roberta_large + ViT-L/16 cross_attn (coca_large.json)", model, lambda m: m(*batch[:10], labels=batch[10]), pairs, 3 * fwd)
+    run("C5x CoCa roberta_large + ViT-L/16 cross_attn (coca_large.json)", model, lambda m: m(*batch[:10], labels=batch[10]), pairs, 3 * fwd, which="c5x")
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["c2", "c3", "c4", "c5x"]
+    argv = sys.argv[1:]
+    if "--pmc" in argv:
+        PMC = True
+        argv.remove("--pmc")
+    which = argv or ["c2", "c3", "c4", "c5x"]
     for w in which:
         globals()[w]()
