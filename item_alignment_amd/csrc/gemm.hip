@@ -722,6 +722,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs p) {
 }
 }  // namespace t256
 
+
 // Optional per-launch timing of ONE kernel instantiation with HIP events on the launch stream
 // (bench.py's roofline leg): variant id = AKS*1000 + BKS*100 + EPI*10 + OUTF32.
 struct GemmProf {
@@ -733,27 +734,24 @@ struct GemmProf {
 GemmProf g_prof;
 
 // C[m][n] (+)= sum_s ws[s][m][n]
-// out[group * M + m] += sum_s rsum_ws[group][s][m] (workgroup x = 0 of each group does it): 8 lanes per m, lane l adds partials
-// l, l+8, ... in order and lane 0 folds the 8 lane sums in order (fixed order -> deterministic)
+// out[group * M + m] += sum_s rsum_ws[group][s][m]: workgroup x of a group folds m = 32x .. 32x+31 (workgroups beyond M/32 skip it);
+// 8 lanes per m, lane l adds partials l, l+8, ... in order and lane 0 folds the 8 lane sums in order (fixed order -> deterministic)
 IA_DEV void fold_row_sums(const float* rsum_ws, float* rsum_out, int M, int splits) {
   __shared__ float rs[256];
-  if (!rsum_ws || blockIdx.x != 0) return;          // uniform per workgroup
-  const int lane = threadIdx.x & 7;
-  for (int mb = 0; mb < M; mb += 32) {
-    const int m = mb + (threadIdx.x >> 3);
-    float a = 0.f;
-    if (m < M)
-      for (int sp = lane; sp < splits; sp += 8) a += rsum_ws[((size_t)blockIdx.y * splits + sp) * M + m];
-    rs[threadIdx.x] = a;
-    __syncthreads();
-    if (lane == 0 && m < M) {
-      float sum = rs[threadIdx.x];
+  if (!rsum_ws || (int)blockIdx.x * 32 >= M) return;          // uniform per workgroup
+  const int lane = threadIdx.x & 7, m = blockIdx.x * 32 + (threadIdx.x >> 3);
+  float a = 0.f;
+  if (m < M)
+    for (int sp = lane; sp < splits; sp += 8) a += rsum_ws[((size_t)blockIdx.y * splits + sp) * M + m];
+  rs[threadIdx.x] = a;
+  __syncthreads();
+  if (lane == 0 && m < M) {
+    float sum = rs[threadIdx.x];
 #pragma unroll
-      for (int l = 1; l < 8; ++l) sum += rs[threadIdx.x + l];
-      rsum_out[(size_t)blockIdx.y * M + m] += sum;
-    }
-    __syncthreads();
+    for (int l = 1; l < 8; ++l) sum += rs[threadIdx.x + l];
+    rsum_out[(size_t)blockIdx.y * M + m] += sum;
   }
+  __syncthreads();
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int M, int N, int ldc,
@@ -855,11 +853,13 @@ int launch(GemmArgs a, bool big, hipStream_t st) {
     hipLaunchKernelGGL((t128::gemm_kernel<AKS, BKS, EPI, OUTF32>), dim3(a.tiles_m * a.tiles_n * a.splits * a.groups), dim3(256), 0, st, a);
   }
   if (OUTF32 && a.splits > 16) {
-    const size_t g = ((size_t)a.M * a.N / 4 + 31) / 32;
+    size_t g = ((size_t)a.M * a.N / 4 + 31) / 32;
+    if (a.rsum_out && g < (size_t)(a.M + 31) / 32) g = (size_t)(a.M + 31) / 32;
     hipLaunchKernelGGL(splitk_reduce_deep_kernel, dim3((unsigned)g, a.groups), dim3(256), 0, st, a.ws, (float*)a.C, a.M, a.N, a.ldc, a.splits,
                        a.accumulate, a.gc, a.rsum_out ? a.rsum_ws : nullptr, a.rsum_out);
   } else if (OUTF32 && a.splits > 1) {
     size_t g = ((size_t)a.M * a.N / 4 + 255) / 256; if (g > 4096) g = 4096;
+    if (a.rsum_out && g < (size_t)(a.M + 31) / 32) g = (size_t)(a.M + 31) / 32;      // fold_row_sums: one workgroup per 32 rows
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)g, a.groups), dim3(256), 0, st, a.ws, (float*)a.C, a.M, a.N, a.ldc, a.splits, a.accumulate,
                        a.gc, a.rsum_out ? a.rsum_ws : nullptr, a.rsum_out);
   }

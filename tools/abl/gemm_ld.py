@@ -1,4 +1,5 @@
-"""Ablation: does the row stride (leading dimension) of A / B / C change the T256 GEMM rate?  (power-of-two strides vs padded ones)"""
+"""Ablation: does the row stride (leading dimension) of A / B / C change the 256x256 GEMM rate?  (power-of-two strides vs padded)
+usage: python tools/abl/gemm_ld.py  (IA_GEMM_WIDE=0/1 picks the kernel)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -20,16 +21,15 @@ def run(M, N, K, lda, ldb, ldc, bks=0):
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    for _ in range(20): f()
+    for _ in range(10): f()
     e.record(); torch.cuda.synchronize()
-    t = s.elapsed_time(e) / 20 * 1e-3
-    print(f"M={M} N={N} K={K} lda={lda} ldb={ldb} ldc={ldc} bks={bks}: {t*1e6:7.1f} us {2*M*N*K/t/1e12:7.1f} TF/s", flush=True)
+    t = s.elapsed_time(e) / 10 * 1e-3
+    print(f"WIDE={os.environ.get('IA_GEMM_WIDE','0')} M={M} N={N} K={K} lda={lda} ldb={ldb} ldc={ldc} bks={bks}: {t*1e6:7.1f} us {2*M*N*K/t/1e12:7.1f} TF/s", flush=True)
 
 
-for M, N, K in [(16384, 4096, 1024), (16384, 3072, 1024), (32768, 4096, 1024)]:
+for M, N, K in [(8192, 8192, 8192), (65280, 4096, 1024), (65280, 1024, 4096)]:
     run(M, N, K, K, K, N)
-    run(M, N, K, K, K, N + 64)
     run(M, N, K, K + 64, K + 64, N)
     run(M, N, K, K + 64, K + 64, N + 64)
     run(M, N, K, K, N, N, bks=1)
-    run(M, N, K, K, N + 64, N + 64, bks=1)
+    run(M, N, K, K + 64, N + 64, N + 64, bks=1)
