@@ -109,6 +109,28 @@ def test_gemm_dgelu_with_fused_column_sums(gpu, M, N, K):
     assert (cs - prior - want.float().sum(0)).abs().max().item() < tol
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 576, 5000), (128, 128, 70000), (1024, 1024, 4096 + 40)])
+def test_gemm_wgrad_form_emits_row_sums(gpu, M, N, K):
+    """Weight-gradient form (A, B k-strided, fp32 C) with C2: C2[m] += sum_k A[k][m] -- the bias gradient out of the same launch
+    (T128: one more MFMA against ones, split-K partials folded by the reduce kernel; 256x256 shapes: the column-sum pass)."""
+    from item_alignment_amd import _lib
+    from item_alignment_amd.ops import check, stream_ptr
+    lib = _lib.load()
+    torch.manual_seed(K)
+    dy = torch.randn((K, M), device=gpu).bfloat16()
+    x = torch.randn((K, N), device=gpu).bfloat16()
+    dw = torch.empty((M, N), device=gpu, dtype=torch.float32)
+    prior = torch.randn(M, device=gpu)
+    db = prior.clone()
+    wsb = max(lib.ia_gemm_workspace_bytes(M, N, K, 1), lib.ia_colsum_workspace_bytes(K, M), 16)
+    ws = torch.empty(wsb, device=gpu, dtype=torch.uint8)
+    check(lib.ia_gemm_bf16(dy.data_ptr(), 1, M, x.data_ptr(), 1, N, dw.data_ptr(), 1, N, M, N, K, 0, None, None, 0, db.data_ptr(), 0, ws.data_ptr(), wsb,
+                           stream_ptr()), "ia_gemm_bf16")
+    assert rel_err(dw, dy.float().t() @ x.float()) < 2e-3
+    ref = dy.float().sum(0)
+    assert ((db - prior - ref).abs().max() / ref.abs().max()).item() < 2e-3
+
+
 def test_colsum(gpu):
     from item_alignment_amd import ops
     x = rnd((1000, 3072), gpu, 1.0, 13)
