@@ -56,7 +56,10 @@ def pmc_traffic(args):
                "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-pmc", "--no-variants", "--pairs-per-gpu", str(args.pairs_per_gpu),
                "--image-model", args.image_model, "--seed", str(args.seed)]
         try:
-            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=420, check=True, cwd=out)
+            # a plain single-process child even when this run was started by a launcher (no inherited rendezvous)
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                                     "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=420, check=True, cwd=out, env=env)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             tot, n = 0.0, 0
             for r in csv.DictReader(open(files[0])):

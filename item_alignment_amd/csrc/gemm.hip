@@ -723,6 +723,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs p) {
 }  // namespace t256
 
 
+
 // Optional per-launch timing of ONE kernel instantiation with HIP events on the launch stream
 // (bench.py's roofline leg): variant id = AKS*1000 + BKS*100 + EPI*10 + OUTF32.
 struct GemmProf {

@@ -1,19 +1,37 @@
 // PARKED EXPERIMENT (round 2) -- not compiled into the library.  This is the `t256w` namespace that sat in csrc/gemm.hip behind
-// IA_GEMM_WIDE=1: the 256 x 256 x 64 GEMM with ONE wave per SIMD owning a 128 x 128 part (256 accumulators in AGPRs), fragments of
-// k-step s+1 requested before the MFMAs of step s, one barrier per k-tile, and (second version, below) k-tiles travelling
-// global -> VGPR -> LDS with two register sets so that two more k-tiles are in flight than the LDS double buffer holds.
-// Results (tools/abl/gemm_wide.py, gemm_wide_abl.py; all epilogues and operand forms bit-compatible with T256, parity green):
-//   * with the fetches sent out of range (IA_GEMM_DBG=2) it runs at 1466-1549 TFLOP/s where T256 reaches 1337: the 128 x 128 wave
-//     tile does remove T256's LDS-port ceiling (192 + 64 KiB of LDS traffic per k-tile -> 128 + 64 KiB);
-//   * with real fetches it is NOT faster than T256 (8192^3: 1072 vs 1086 on the same box; K = 1024 shapes 2-8 % slower), and the
-//     deeper register-staged pipeline is slower still (924-1041): the limiter is not latency.  With the MFMAs compiled out
-//     (-DIA_GEMM_NOMATH) the fetch stream alone needs 1.27 us per 64 KiB k-tile per CU (~13 TB/s over the chip at idle-pipe clocks),
-//     0.79 us when every k-tile re-reads k-tile 0 (IA_GEMM_DBG=4) -- against 1.3-1.46 us of MFMA time per k-tile.  A 256 x 256
-//     tile needs 64 KiB per 8.4 MFLOP = 128 FLOP per L2 byte: both kernels sit on the L2 -> LDS bandwidth of the chip under MFMA
-//     clocks (~8.5-10 TB/s measured), which is the 1.1-1.3 PFLOP/s they deliver.  Going further needs more FLOP per fetched byte
-//     (a 256 x 384 tile = 154 FLOP/B), i.e. 384 accumulators per lane.
+// IA_GEMM_WIDE=1 (it also needs `raw_rsrc_at` / `i32x4` from below): the 256 x 256 x 64 GEMM with ONE wave per SIMD owning a
+// 128 x 128 part (256 accumulators in AGPRs), fragments of k-step s+1 requested before the MFMAs of step s, one barrier per
+// k-tile.  k-tiles 0 and 1 of an output tile arrive by LDS-DMA (issued before the previous tile's epilogue); inside the loop
+// k-tiles travel global -> VGPR -> LDS through two register sets of 16 x 16 bytes per lane (asm buffer loads, explicit counted
+// vmcnt waits: 31 younger loads in the steady state), i.e. two more k-tiles in flight than the LDS double buffer holds -- the
+// "prefetch global read 2" scheme of Tensile's 256x256x64 kernels.  Steady state and the last four k-tiles are straight-line
+// code: any branch around the accumulator updates makes hipcc copy all 256 of them.
+// Results (tools/abl/gemm_wide.py, gemm_wide_abl.py; all epilogues and operand forms, parity green in all three versions):
+//   v1  DMA inside the loop (pieces of k-tile u+2 between the MFMAs of the last k-step of tile u): 8192^3 1072 TFLOP/s where T256 gets
+//       1086 on the same box; with the fetches sent out of range (IA_GEMM_DBG=2) 1466-1549 against T256's 1337 -- the 128 x 128
+//       wave tile does remove T256's LDS-port ceiling (192 + 64 KiB of LDS traffic per k-tile -> 128 + 64 KiB);
+//   v2  register staging with builtin loads: hipcc waits vmcnt(0) in front of many LDS writes -> 924-1041;
+//   v3  (this file) asm loads + counted waits: 1043 (T256 1098 same box; K = 4096 shapes 1037 vs 1161), out-of-range fetches 1381.
+//   So a k-tile's worth of extra lead (v3 has ~2.8 us) does not buy anything: it is not fetch latency.  With the MFMAs compiled out
+//   (-DIA_GEMM_NOMATH, v1) the fetch stream alone takes 1.27 us per 64 KiB k-tile per CU (0.79 us when every k-tile re-reads
+//   k-tile 0), the no-fetch MFMA loop 1.4 us, both together 2.0 us: real data arriving (VGPR / LDS write-back, L2 and fabric
+//   activity under the power cap) slows the MFMA stream itself.  hipBLASLt's hand-written 256x256x64 kernel (16x16x32 MFMAs) gets
+//   1343-1541 on the same shapes and boxes, so the ceiling is not physical; what it does differently was not found.
 // To revive: paste the namespace back after `}  // namespace t256` in csrc/gemm.hip and dispatch to t256w::gemm_kernel (256 threads,
-// t256::LDS_BYTES of dynamic LDS) in launch().
+// t256::LDS_BYTES of dynamic LDS, k loops of at least 5 k-tiles) in launch().
+
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+// a buffer window (see rsrc_at in gemm.hip) as four raw descriptor words in SGPRs, for asm buffer loads
+IA_DEV i32x4 raw_rsrc_at(const bf16* base, uint64_t total_bytes, uint64_t origin) {
+  const uint64_t ob = origin * 2, rem = total_bytes > ob ? total_bytes - ob : 0;
+  const uint64_t addr = (uint64_t)(uintptr_t)(base + origin);
+  i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)addr);
+  r[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)((addr >> 32) & 0xFFFFu));
+  r[2] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(rem < 0x7FFFFFF0ull ? rem : 0x7FFFFFF0ull));
+  r[3] = 0x00020000;
+  return r;
+}
 
 // ============================================================================== T256W (4 waves, 128 x 128 per wave, 32x32x16)
 // Same 256 x 256 x 64 block tile, LDS layout, DMA pattern, tile order and epilogue as T256, but ONE wave per SIMD owning a
@@ -108,7 +126,7 @@ template <int N> IA_DEV void tie(Op<true>& o) {
 }
 
 template <bool AKS, bool BKS, int PEND>
-IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB, int xa, int xb,
+IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB, i32x4 rawA, i32x4 rawB, int xa, int xb,
                       int kt0, int ktaA0, int ktaB0, int n_tiles, int nk_all, int wm, int wn, int wave, int lane, bool prologue_only,
                       bool stores_in_flight) {
   const int li = lane & 31;
@@ -121,6 +139,7 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
   else { const int row = gt >> 5; voffB = (uint32_t)((row * p.ldb + xb + (((gt & 31) ^ ((row & 3) << 2)) * 8)) * 2); stepB = (uint32_t)(8 * p.ldb * 2); }
   const uint32_t kstepA = AKS ? (uint32_t)(BK * p.lda * 2) : (uint32_t)(BK * 2), kstepB = BKS ? (uint32_t)(BK * p.ldb * 2) : (uint32_t)(BK * 2);
   char* const my_part = smem + wave * 1024;
+  const bool dma_on = !(p.dbg & 2);
 
   // piece i (0..7: A, 8..15: B) of k-tile u -> buffer u & 1.  Branch-free: lanes past K (the ragged last k-tile) and, with
   // valid == false, the whole piece are sent out of range -- they write zeros into a buffer nobody reads any more -- so the MFMA
@@ -145,15 +164,18 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
   // its data is needed -- less than the L2 / fabric round trip under load, and the fetch path (~13 TB/s over the chip, measured
   // with the MFMAs compiled out) is nearly as busy as the matrix pipe, so every such stall is lost for good.  Two register sets
   // of 16 x 16 bytes per lane keep two MORE k-tiles in flight (the wave has 256 VGPRs beside its 256 accumulators).
-  auto load_piece = [&](int u, int i, bool valid) -> u32x4 {
+  // asm on purpose: hipcc cannot count loads that stay in flight across loop iterations and falls back to vmcnt(0) in front of the
+  // LDS writes (measured: the builtin form of this loop was slower than the plain DMA loop); here every wait is an explicit counted one
+  auto load_piece = [&](u32x4& dst, int u, int i) {           // u >= n_tiles (the zero pad tile of an odd count): out of range -> zeros
     const bool isB = i >= 8;
     const int j = i & 7;
     const int kt = kt0 + u, kta = (p.dbg & 4) ? 0 : (isB ? ktaB0 : ktaA0) + u;
     const uint32_t voff = isB ? voffB : voffA, kstep = isB ? kstepB : kstepA, pstep = isB ? stepB : stepA;
     const bool ks = isB ? BKS : AKS;
     const int k = ks ? kt * BK + j * 8 + (gt >> 5) : kt * BK + ((gt & 7) ^ (((gt >> 3) >> 1) & 7)) * 8;
-    const uint32_t off = (valid && k < p.K) ? voff + (uint32_t)(kta * kstep + j * pstep) : OOB;
-    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(isB ? rsB : rsA, off, 0, 0));
+    const uint32_t off = (u < n_tiles && dma_on && k < p.K) ? voff + (uint32_t)(kta * kstep + j * pstep) : OOB;
+    if (isB) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "+v"(dst) : "v"(off), "s"(rawB));
+    else     asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "+v"(dst) : "v"(off), "s"(rawA));
   };
   const uint32_t my_lds = ia_lds_addr(smem) + wave * 1024 + lane * 16;
   auto store_piece = [&](uint32_t bufoff, int i, u32x4 v) {        // where DMA piece i of the k-tile would have landed
@@ -179,16 +201,30 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
   frag_bases<AKS>(baseA, smem_addr, wm * 128, lane, li);
   frag_bases<BKS>(baseB, smem_addr + TILE_BYTES, wn * 128, lane, nperm);
   constexpr int NR = ((AKS ? 8 : 4) + (BKS ? 8 : 4)) > 15 ? 15 : ((AKS ? 8 : 4) + (BKS ? 8 : 4));    // LDS ops of one fragment set
-  const bool dma_on = !(p.dbg & 2);
 
   Op<AKS> a0, a1;
   Op<BKS> b0, b1;
   read_operand<0>(a0, baseA, 0u);
   read_operand<0>(b0, baseB, 0u);
 
-  // the 16 MFMAs of one k-step; with STAGE == true, slot i between them hands piece i of the register set R (k-tile u2) over to
-  // the LDS buffer that just became free and re-arms the registers with the same piece of k-tile u2 + 2
-  auto mfmas = [&](const Op<AKS>& fa, const Op<BKS>& fb, auto STAGE, u32x4 (&R)[16], uint32_t bufoff, int u2) {
+  // k-tiles 0 and 1 arrive by DMA (issued before the previous tile's epilogue), k-tiles 2 .. n_even-1 through the register sets
+  // (n_even = n_tiles rounded up to even: the loop has no control flow around the accumulators, a pad tile is all zeros).
+  const int n_even = (n_tiles + 1) & ~1;
+  u32x4 R0[16], R1[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { R0[i] = u32x4{0u, 0u, 0u, 0u}; R1[i] = u32x4{0u, 0u, 0u, 0u}; }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) load_piece(R0[i], 2, i);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) load_piece(R1[i], 3, i);
+
+  // the 16 MFMAs of one k-step.  MODE > 0: slot i between them waits for piece i of the register set R (k-tile u2 = u + 2, requested
+  // two k-tiles ago) and hands it to the LDS buffer that just became free; MODE 1 also re-arms the registers with the same piece of
+  // k-tile u2 + 2.  VMEM retires in order, so "piece i has landed" = at most (15 - i) + 16 + i = 31 younger loads outstanding in the
+  // steady state (the rest of this set, the whole other set, the i re-armed so far); MODE 2 / 3 = the last two register tiles of
+  // the k loop (no re-arming: 31 - i, then 15 - i).  No control flow anywhere near the accumulators.
+  auto mfmas = [&](const Op<AKS>& fa, const Op<BKS>& fb, auto MODE, u32x4 (&R)[16], uint32_t bufoff, int u2) {
+    constexpr int mode = decltype(MODE)::value;
     bf16x8 va[4], vb[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { va[j] = frag_of(fa, j); vb[j] = frag_of(fb, j); }
@@ -196,38 +232,34 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
-        if (decltype(STAGE)::value) {
-          const int i = mi * 4 + ni;
-          store_piece(bufoff, i, R[i]);
-          R[i] = load_piece(u2 + 2, i, u2 + 2 < n_tiles && dma_on);
-        }
+        const int i = mi * 4 + ni;
+        if (mode == 1) asm volatile("s_waitcnt vmcnt(31)" : "+v"(R[i]));
+        if (mode == 2) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(R[i]) : "n"(31 - i));
+        if (mode == 3) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(R[i]) : "n"(15 - i));
+        if (mode >= 1) store_piece(bufoff, i, R[i]);
+        if (mode == 1) load_piece(R[i], u2 + 2, i);
         if (NOMATH) continue;       // ablation build (-DIA_GEMM_NOMATH): transfers + waits + barriers only
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb[ni], va[mi], acc[mi][ni], 0, 0, 0);
       }
     __builtin_amdgcn_sched_barrier(0);      // the MFMAs stay in their step (the waits of the next step are volatile asm, MFMAs are not)
   };
-
-  u32x4 R0[16], R1[16], Rnone[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { R0[i] = load_piece(2, i, 2 < n_tiles && dma_on); }
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { R1[i] = load_piece(3, i, 3 < n_tiles && dma_on); }
+  using M0 = std::integral_constant<int, 0>;
 
   // one k-tile: buffer u & 1.  R = the register set that holds k-tile u + 2.
-  auto ktile = [&](int u, u32x4 (&R)[16]) {
+  auto ktile = [&](int u, u32x4 (&R)[16], auto MODE) {
     const uint32_t bo = (uint32_t)(u & 1) * 2 * TILE_BYTES, bn = bo ^ (2 * TILE_BYTES);
     // step 0: request step 1, compute step 0
     read_operand<1>(a1, baseA, bo); read_operand<1>(b1, baseB, bo);
     tie<NR>(a0); tie<NR>(b0);
-    mfmas(a0, b0, std::false_type{}, Rnone, 0u, 0);
+    mfmas(a0, b0, M0{}, R, 0u, 0);
     // step 1
     read_operand<2>(a0, baseA, bo); read_operand<2>(b0, baseB, bo);
     tie<NR>(a1); tie<NR>(b1);
-    mfmas(a1, b1, std::false_type{}, Rnone, 0u, 0);
+    mfmas(a1, b1, M0{}, R, 0u, 0);
     // step 2
     read_operand<3>(a1, baseA, bo); read_operand<3>(b1, baseB, bo);
     tie<NR>(a0); tie<NR>(b0);
-    mfmas(a0, b0, std::false_type{}, Rnone, 0u, 0);
+    mfmas(a0, b0, M0{}, R, 0u, 0);
     // step 3: every fragment of this k-tile is in registers (and this wave's LDS writes of k-tile u+1 have landed): once all waves
     // are here the buffer is free for k-tile u+2 and k-tile u+1 is complete
     tie<0>(a1); tie<0>(b1);
@@ -235,14 +267,19 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
     if (!(p.dbg & 16)) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     read_operand<0>(a0, baseA, bn); read_operand<0>(b0, baseB, bn);       // (past the last k-tile: unused)
-    mfmas(a1, b1, std::true_type{}, R, bo, u + 2);
+    mfmas(a1, b1, MODE, R, bo, u + 2);
   };
-  // an even number of k-tiles: the one past an odd K / slab is all zeros (its buffer was zero-filled by the prologue or by an
-  // out-of-range register set), so the loop body has no control flow around the accumulators
-  for (int u = 0; u < n_tiles; u += 2) {
-    ktile(u, R0);
-    ktile(u + 1, R1);
-  }
+  // n_even >= 6 (the launcher sends shorter k loops to the other kernel): steady state, then the last four k-tiles in straight-line code
+  int u = 0;
+  do {                        // n_even >= 6: at least one trip (no merge of "loop ran" / "loop skipped" accumulators)
+    ktile(u, R0, std::integral_constant<int, 1>{});
+    ktile(u + 1, R1, std::integral_constant<int, 1>{});
+    u += 2;
+  } while (u + 4 < n_even);
+  ktile(u, R0, std::integral_constant<int, 2>{});
+  ktile(u + 1, R1, std::integral_constant<int, 3>{});
+  ktile(u + 2, R0, M0{});
+  ktile(u + 3, R1, M0{});
 }
 
 // the T256 epilogue (see t256::gemm_kernel) for one 128 x 64 half (NH = 0 / 1) of the wave's 128 x 128 part
@@ -361,8 +398,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     coords(tile, bm, bn);
     int lane = lane0;
     asm volatile("" : "+v"(lane));      // keep per-lane address arithmetic from being hoisted across the tile loop
-    main_loop<AKS, BKS, PEND>(p, smem, acc, rsrc_at(p.A, p.a_bytes, (uint64_t)(AKS ? kt0 * BK : bm * BM) * p.lda),
-                              rsrc_at(p.B, p.b_bytes, (uint64_t)(BKS ? kt0 * BK : bn * BN) * p.ldb), AKS ? bm * BM : 0, BKS ? bn * BN : 0, kt0,
+    const uint64_t oa = (uint64_t)(AKS ? kt0 * BK : bm * BM) * p.lda, ob = (uint64_t)(BKS ? kt0 * BK : bn * BN) * p.ldb;
+    main_loop<AKS, BKS, PEND>(p, smem, acc, rsrc_at(p.A, p.a_bytes, oa), rsrc_at(p.B, p.b_bytes, ob), raw_rsrc_at(p.A, p.a_bytes, oa),
+                              raw_rsrc_at(p.B, p.b_bytes, ob), AKS ? bm * BM : 0, BKS ? bn * BN : 0, kt0,
                               AKS ? 0 : kt0, BKS ? 0 : kt0, n_tiles, nk_all, wm, wn, wave, lane, prologue_only, stores_in_flight);
   };
 
