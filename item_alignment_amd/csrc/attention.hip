@@ -70,8 +70,8 @@ IA_DEV void build_valid_table(const AttnArgs& p, uint32_t (*s_valid)[2], size_t 
   }
 }
 
-// K tile / Q tile read with ds_read_b128 (row = key or query, 128 B rows, 16 B chunk XOR row&7)
-IA_DEV int swz_b128(int row) { return row & 7; }
+// K tile / Q tile read with ds_read_b128 (row = key or query, 128 B rows, 16 B chunk XOR (row>>1)&7)
+IA_DEV int swz_b128(int row) { return (row >> 1) & 7; }   // two 128-byte rows span the 64 banks: conflict-free for any 16 consecutive rows
 // tile read with the transpose read (row-major [row][64 d]); 32 B slot XOR
 IA_DEV int swz_tr(int row) { return ((row >> 1) & 1) << 2; }
 
@@ -85,6 +85,21 @@ IA_DEV void stage64(__amdgpu_buffer_rsrc_t rs, char* s, size_t row0, int nvalid,
     uint32_t off = (uint32_t)(((row0 + row) * ld + col0 + c * 8) * 2);
     if (row >= nvalid) off = OOB;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, IA_LDS(s + issue * 4096 + wave * 1024), 16, off, 0, 0, 0);
+  }
+}
+
+// A wave's own 32 rows x 64 columns (this head's slice of q / k / v / o / dO rows row0 .. row0+31) into a wave-private 4 KiB LDS
+// slot in the ds_read_b128 layout of frag_b128: four 16-byte LDS-DMA issues, each moving 8 whole 128-byte rows.  (Loaded straight into
+// the fragment registers, every lane pair fetches 32 bytes of 32 different rows per instruction; that cost the forward kernel 15 %.)
+// Rows >= nvalid arrive as zeros.  The reader waits vmcnt(0) itself; no workgroup barrier is involved.
+IA_DEV void stage_rows32(__amdgpu_buffer_rsrc_t rs, char* slot, size_t row0, int nvalid, int ld, int col0, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = i * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ swz_b128(row);
+    uint32_t off = (uint32_t)(((row0 + row) * ld + col0 + c * 8) * 2);
+    if (row >= nvalid) off = OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, IA_LDS(slot + i * 1024), 16, off, 0, 0, 0);
   }
 }
 
@@ -140,6 +155,36 @@ IA_DEV bool drop_keep(uint32_t seed, uint32_t stream, int q, int key, uint32_t t
   const uint32_t r = ia_rng(seed, stream, (uint32_t)q * 1024u + ((uint32_t)key >> 1));
   const uint32_t u = (key & 1) ? (r >> 16) : (r & 0xFFFFu);
   return u >= thr16;
+}
+
+// Epilogue store of a wave's 32 x 64 bf16 block that sits in two transposed accumulator blocks (a0: columns d = 0..31, a1: d = 32..63
+// of the output row this lane's column lane&31 stands for).  Written straight from the accumulators a lane owns 8-byte pieces of 32
+// different rows (a row stride apart): 16 partial-line requests per lane pair and store instruction, which made the store tail a
+// third of the forward kernel at L = 255.  Staged through a wave-private LDS slot (32 rows x 144 B: the 16-byte pad keeps the
+// 8-byte writes at two lanes per bank) the block leaves as whole 128-byte rows, 16 B per lane, 8 rows per instruction.
+constexpr int EPI_ROW = 144, EPI_SLOT = 32 * EPI_ROW;
+IA_DEV void store_block_rows(char* slot, const f32x16& a0, const f32x16& a1, float mul, bool zero, bf16* out, size_t ld, int nrows, int lane) {
+  const int hh = lane >> 5, lq = lane & 31;
+  char* w = slot + lq * EPI_ROW + hh * 8;
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) {
+    bf16x4 a, c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // a masked column may hold inf / nan: select, do not multiply
+      a[j] = f2bf(zero ? 0.f : a0[rg * 4 + j] * mul);
+      c[j] = f2bf(zero ? 0.f : a1[rg * 4 + j] * mul);
+    }
+    *reinterpret_cast<bf16x4*>(w + rg * 16) = a;
+    *reinterpret_cast<bf16x4*>(w + 64 + rg * 16) = c;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private slot: the wave's own LDS writes are in order, no barrier
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = i * 8 + (lane >> 3), c = lane & 7;
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(slot + row * EPI_ROW + c * 16);
+    if (row < nrows) *reinterpret_cast<bf16x8*>(out + (size_t)row * ld + c * 8) = v;
+  }
 }
 
 // One 64-key tile of the forward pass for this wave's 32 queries (S^T orientation, see the header comment).
@@ -263,17 +308,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   const int q0 = tile * 128 + wave * 32;
   const bool active = q0 < Lq;
   const int q = q0 + lq;
-  const int qc = q < Lq ? q : Lq - 1;
 
-  bf16x8 qf[4];
-  {
-    const bf16* qp = p.q + (qbase + qc) * p.ld_q + h * 64 + hh * 8;
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) qf[kb] = *reinterpret_cast<const bf16x8*>(qp + kb * 16);
-  }
   const __amdgpu_buffer_rsrc_t rsK = ia_rsrc(p.k, p.kv_bytes);
   const __amdgpu_buffer_rsrc_t rsV = ia_rsrc(p.v, p.kv_bytes);
 
+  bf16x8 qf[4];
   float m_ref = 0.f, l_run = 0.f;
   f32x16 o0 = zero16(), o1 = zero16();
   const int nkt = (L + 63) >> 6;
@@ -296,9 +335,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   };
+  // this wave's 32 query rows travel through its 4 KiB of the second ring slot (free until tile 1 is prefetched after the barrier)
+  char* qslot = smem + 16384 + wave * 4096;
+  stage_rows32(ia_rsrc(p.q, p.q_bytes), qslot, qbase + q0, Lq - q0, p.ld_q, h * 64, lane);
   prefetch(0, 0);
   build_valid_table(p, s_valid, rowbase, L, lane, wave);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) qf[kb] = frag_b128(qslot, lq, kb * 2 + hh);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
   for (int kt = 0; kt < nkt; kt += 2) {
     prefetch(1, kt + 1);
@@ -311,18 +356,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   if (!active) return;
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? p.inv_keep / l_tot : 0.f;
-  if (q < Lq) {
-    if (hh == 0 && p.lse2) p.lse2[((size_t)b * p.nh + h) * p.Lq + q] = m_ref + __builtin_amdgcn_logf(l_tot);
-    bf16* op = p.out + (qbase + q) * p.ld_o + h * 64;
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const int d = 8 * rg + 4 * hh;
-      bf16x4 a = {f2bf(o0[rg * 4] * inv), f2bf(o0[rg * 4 + 1] * inv), f2bf(o0[rg * 4 + 2] * inv), f2bf(o0[rg * 4 + 3] * inv)};
-      bf16x4 c = {f2bf(o1[rg * 4] * inv), f2bf(o1[rg * 4 + 1] * inv), f2bf(o1[rg * 4 + 2] * inv), f2bf(o1[rg * 4 + 3] * inv)};
-      *reinterpret_cast<bf16x4*>(op + d) = a;
-      *reinterpret_cast<bf16x4*>(op + 32 + d) = c;
-    }
-  }
+  if (q < Lq && hh == 0 && p.lse2) p.lse2[((size_t)b * p.nh + h) * p.Lq + q] = m_ref + __builtin_amdgcn_logf(l_tot);
+  // the K/V ring is free after the loop's last barrier: wave-private staging slots at its start
+  store_block_rows(smem + wave * EPI_SLOT, o0, o1, inv, false, p.out + (qbase + q0) * p.ld_o + h * 64, p.ld_o, Lq - q0, lane);
 }
 
 // ------------------------------------------------------------------------------------- backward: dQ
@@ -400,8 +436,9 @@ IA_DEV void dq_tile(const AttnArgs& p, const char* sK, const bf16x8 (&qf)[4], co
 template <bool DROPOUT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
   // per buffer: K (b128 layout) | K (transpose-read layout) | V (b128 layout) = 24 KiB; then the valid-key table
-  __shared__ __attribute__((aligned(16))) char smem[2 * 24576 + MAX_KT * 8];
-  uint32_t (*s_valid)[2] = reinterpret_cast<uint32_t (*)[2]>(smem + 2 * 24576);
+  // + 24 KiB: the prologue stages 12 KiB of q / dO / o rows per wave in the 48 KiB behind ring slot 0
+  __shared__ __attribute__((aligned(16))) char smem[3 * 24576 + MAX_KT * 8];
+  uint32_t (*s_valid)[2] = reinterpret_cast<uint32_t (*)[2]>(smem + 3 * 24576);
   const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, lq = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int tile, h, b;
@@ -418,44 +455,40 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
   const bool active = q0 < Lq;
   const int q = q0 + lq;
   const int qc = q < Lq ? q : Lq - 1;
-
-  bf16x8 qf[4], gf[4];
-  {
-    const bf16* qp = p.q + (qbase + qc) * p.ld_q + h * 64 + hh * 8;
-    const bf16* gp = p.d_o + (qbase + qc) * p.ld_o + h * 64 + hh * 8;
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      qf[kb] = *reinterpret_cast<const bf16x8*>(qp + kb * 16);
-      gf[kb] = *reinterpret_cast<const bf16x8*>(gp + kb * 16);
-    }
-  }
-  const size_t sidx = ((size_t)b * p.nh + h) * p.Lq + qc;
-  const float lse = p.lse2[sidx];
-  // delta = rowsum(dO * O) of this lane's query: each lane of the pair (lane, lane^32) holds half of the 64 columns.
-  // Written out for the dK/dV kernel, which runs after this one on the same stream.
-  float dlt = 0.f;
-  {
-    const bf16* op = p.o + (qbase + qc) * p.ld_o + h * 64 + hh * 8;
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      const bf16x8 ov = *reinterpret_cast<const bf16x8*>(op + kb * 16);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) dlt += bf2f(ov[j]) * bf2f(gf[kb][j]);
-    }
-    dlt += __shfl_xor(dlt, 32, 64);
-    if (active && hh == 0 && q < Lq) p.delta[sidx] = dlt;
-  }
   const __amdgpu_buffer_rsrc_t rsK = ia_rsrc(p.k, p.kv_bytes);
   const __amdgpu_buffer_rsrc_t rsV = ia_rsrc(p.v, p.kv_bytes);
   const uint32_t stream_id = (uint32_t)(b * p.nh + h);
-
-  f32x16 dq0 = zero16(), dq1 = zero16();
   const int nkt = (L + 63) >> 6;
+
+  // One memory round trip for the whole prologue: this wave's q / dO / o rows (wave-private 4 KiB slots behind ring slot 0), the
+  // first key tile, the saved log-sum-exp and the mask bytes are all requested before the single wait.
+  char* rslot = smem + 24576 + wave * 12288;
+  stage_rows32(ia_rsrc(p.q, p.q_bytes), rslot, qbase + q0, Lq - q0, p.ld_q, h * 64, lane);
+  stage_rows32(ia_rsrc(p.d_o, p.o_bytes), rslot + 4096, qbase + q0, Lq - q0, p.ld_o, h * 64, lane);
+  stage_rows32(ia_rsrc(p.o, p.o_bytes), rslot + 8192, qbase + q0, Lq - q0, p.ld_o, h * 64, lane);
   stage64<false>(rsK, smem, rowbase, L, p.ld_kv, h * 64, tid, wave);
   stage64<true>(rsK, smem + 8192, rowbase, L, p.ld_kv, h * 64, tid, wave);
   stage64<false>(rsV, smem + 16384, rowbase, L, p.ld_kv, h * 64, tid, wave);
+  const size_t sidx = ((size_t)b * p.nh + h) * p.Lq + qc;
+  const float lse = p.lse2[sidx];
   build_valid_table(p, s_valid, rowbase, L, lane, wave);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  bf16x8 qf[4], gf[4];
+  // delta = rowsum(dO * O) of this lane's query: each lane of the pair (lane, lane^32) holds half of the 64 columns.
+  // Written out for the dK/dV kernel, which runs after this one on the same stream.
+  float dlt = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    qf[kb] = frag_b128(rslot, lq, kb * 2 + hh);
+    gf[kb] = frag_b128(rslot + 4096, lq, kb * 2 + hh);
+    const bf16x8 ov = frag_b128(rslot + 8192, lq, kb * 2 + hh);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dlt += bf2f(ov[j]) * bf2f(gf[kb][j]);
+  }
+  dlt += __shfl_xor(dlt, 32, 64);
+  if (active && hh == 0 && q < Lq) p.delta[sidx] = dlt;
+  f32x16 dq0 = zero16(), dq1 = zero16();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
 
   for (int kt = 0; kt < nkt; ++kt) {
@@ -476,17 +509,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  if (!active || q >= Lq) return;
-  bf16* op = p.dq + (qbase + q) * p.ld_dq + h * 64;
-  const float sc = p.scale;
-#pragma unroll
-  for (int rg = 0; rg < 4; ++rg) {
-    const int d = 8 * rg + 4 * hh;
-    bf16x4 a = {f2bf(dq0[rg * 4] * sc), f2bf(dq0[rg * 4 + 1] * sc), f2bf(dq0[rg * 4 + 2] * sc), f2bf(dq0[rg * 4 + 3] * sc)};
-    bf16x4 c = {f2bf(dq1[rg * 4] * sc), f2bf(dq1[rg * 4 + 1] * sc), f2bf(dq1[rg * 4 + 2] * sc), f2bf(dq1[rg * 4 + 3] * sc)};
-    *reinterpret_cast<bf16x4*>(op + d) = a;
-    *reinterpret_cast<bf16x4*>(op + 32 + d) = c;
-  }
+  if (!active) return;
+  store_block_rows(smem + wave * EPI_SLOT, dq0, dq1, p.scale, false, p.dq + (qbase + q0) * p.ld_dq + h * 64, p.ld_dq, Lq - q0, lane);
 }
 
 // ---------------------------------------------------------------------------------- backward: dK, dV
@@ -517,16 +541,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   const int kc = key < L ? key : L - 1;
   const bool key_ok = key < L && (p.mask == nullptr || p.mask[rowbase + kc] != 0);
 
-  bf16x8 kf[4], vf[4];
-  {
-    const bf16* kp = p.k + (rowbase + kc) * p.ld_kv + h * 64 + hh * 8;
-    const bf16* vp = p.v + (rowbase + kc) * p.ld_kv + h * 64 + hh * 8;
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      kf[kb] = *reinterpret_cast<const bf16x8*>(kp + kb * 16);
-      vf[kb] = *reinterpret_cast<const bf16x8*>(vp + kb * 16);
-    }
-  }
   const __amdgpu_buffer_rsrc_t rsQ = ia_rsrc(p.q, p.q_bytes);
   const __amdgpu_buffer_rsrc_t rsG = ia_rsrc(p.d_o, p.o_bytes);
   const __amdgpu_buffer_rsrc_t rsL = ia_rsrc(p.lse2 + ((size_t)b * p.nh + h) * p.Lq, (uint32_t)Lq * 4u);
@@ -545,8 +559,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     if (wave == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsL, IA_LDS(s + 32768), 4, (uint32_t)(qt * 64 + lane) * 4u, 0, 0, 0);
     if (wave == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, IA_LDS(s + 32768 + 256), 4, (uint32_t)(qt * 64 + lane) * 4u, 0, 0, 0);
   };
+  // this wave's 32 key rows of K and V travel through wave-private 4 KiB slots of the second ring slot (free until the loop
+  // prefetches query tile 1 behind the barrier), requested together with query tile 0
+  char* kslot = smem + BUF + wave * 8192;
+  stage_rows32(ia_rsrc(p.k, p.kv_bytes), kslot, rowbase + k0, L - k0, p.ld_kv, h * 64, lane);
+  stage_rows32(ia_rsrc(p.v, p.kv_bytes), kslot + 4096, rowbase + k0, L - k0, p.ld_kv, h * 64, lane);
   stage_all(smem, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    kf[kb] = frag_b128(kslot, lk, kb * 2 + hh);
+    vf[kb] = frag_b128(kslot + 4096, lk, kb * 2 + hh);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
 
   for (int qt = 0; qt < nqt; ++qt) {
@@ -618,25 +644,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  if (!active || key >= L) return;
-  bf16* kp = p.dk + (rowbase + key) * p.ld_dkv + h * 64;
-  bf16* vp = p.dv + (rowbase + key) * p.ld_dkv + h * 64;
-  const float sk = key_ok ? p.scale : 0.f, sv = key_ok ? 1.f : 0.f;
-#pragma unroll
-  for (int rg = 0; rg < 4; ++rg) {
-    const int d = 8 * rg + 4 * hh;
-    bf16x4 a, c, e, f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      // a masked key may hold inf / nan (its P is not bounded by the saved log-sum-exp): select, do not multiply
-      a[j] = f2bf(key_ok ? dk0[rg * 4 + j] * sk : 0.f); c[j] = f2bf(key_ok ? dk1[rg * 4 + j] * sk : 0.f);
-      e[j] = f2bf(key_ok ? dv0[rg * 4 + j] * sv : 0.f); f[j] = f2bf(key_ok ? dv1[rg * 4 + j] * sv : 0.f);
-    }
-    *reinterpret_cast<bf16x4*>(kp + d) = a;
-    *reinterpret_cast<bf16x4*>(kp + 32 + d) = c;
-    *reinterpret_cast<bf16x4*>(vp + d) = e;
-    *reinterpret_cast<bf16x4*>(vp + 32 + d) = f;
-  }
+  if (!active) return;
+  // a masked key's outputs are zero (its P is not bounded by the saved log-sum-exp, so the accumulators may hold inf / nan)
+  store_block_rows(smem + wave * 2 * EPI_SLOT, dk0, dk1, p.scale, !key_ok, p.dk + (rowbase + k0) * p.ld_dkv + h * 64, p.ld_dkv, L - k0, lane);
+  store_block_rows(smem + (wave * 2 + 1) * EPI_SLOT, dv0, dv1, 1.f, !key_ok, p.dv + (rowbase + k0) * p.ld_dkv + h * 64, p.ld_dkv, L - k0, lane);
 }
 
 // packed_rows > 0: packed self-attention over that many token rows in total (AttnArgs::cu), Lq == Lk == longest sequence
@@ -692,7 +703,7 @@ extern "C" int ia_attn_bwd_x(const void* q, int ld_q, const void* k, const void*
   AttnArgs a{};
   int rc = fill_args(a, B, nh, Lq, Lk, ld_q, ld_kv, ld_o, scale, drop_p, seed);
   if (rc) return rc;
-  if ((ld_dq & 3) || (ld_dkv & 3) || ld_dq < nh * 64 || ld_dkv < nh * 64) return IA_ERR_ARG;
+  if ((ld_dq & 7) || (ld_dkv & 7) || ld_dq < nh * 64 || ld_dkv < nh * 64) return IA_ERR_ARG;
   a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.o = (const bf16*)out; a.d_o = (const bf16*)d_out;
   a.mask = key_mask; a.lse2 = const_cast<float*>(lse2); a.delta = delta;
   a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.ld_dq = ld_dq; a.ld_dkv = ld_dkv;
@@ -748,7 +759,7 @@ extern "C" int ia_attn_bwd_varlen(const void* q, const void* k, const void* v, i
   AttnArgs a{};
   int rc = fill_args(a, B, nh, Lmax, Lmax, ld_qkv, ld_qkv, ld_o, scale, drop_p, seed, total_tokens);
   if (rc) return rc;
-  if ((ld_dqkv & 3) || ld_dqkv < nh * 64) return IA_ERR_ARG;
+  if ((ld_dqkv & 7) || ld_dqkv < nh * 64) return IA_ERR_ARG;
   a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.o = (const bf16*)out; a.d_o = (const bf16*)d_out;
   a.mask = nullptr; a.lse2 = const_cast<float*>(lse2); a.delta = delta; a.cu = cu_seqlens;
   a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.ld_dq = ld_dqkv; a.ld_dkv = ld_dqkv;

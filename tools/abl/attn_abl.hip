@@ -1,6 +1,9 @@
 // Ablation / timing harness for the attention kernels (no torch): includes attention.hip compiled with -DIA_ABL=n.
 // usage: attn_abl B L nh [mode: 0 fwd, 1 bwd] ; prints average time of 20 launches.
-#include "../../item_alignment_amd/csrc/attention.hip"
+#ifndef IA_ATTN_SRC
+#define IA_ATTN_SRC "../../item_alignment_amd/csrc/attention.hip"
+#endif
+#include IA_ATTN_SRC
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
