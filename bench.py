@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 
 TRAIN_FLOPS_PER_PAIR = 1.628e12      # 3 x (2 x text(255) + 2 x ViT-B/16@384) forward FLOPs
 WGRAD_VARIANT = 1101                 # gemm_kernel<A k-strided, B k-strided, EPI_NONE, fp32 out>  (dW = dY^T X)
-WGRAD_KERNEL = "t256::gemm_kernel<true, true, 0, true> (+ splitk_reduce_kernel)"
+WGRAD_KERNEL = "t256w::gemm_kernel<true, true, 0, true> (+ splitk_reduce_kernel)"
 DATASET_PAIRS = 50_000               # size of the synthetic pair set the batches are drawn from
 RESIDENT_BATCHES = 32
 

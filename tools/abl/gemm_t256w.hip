@@ -1,4 +1,7 @@
-// PARKED EXPERIMENT (round 2) -- not compiled into the library.  This is the `t256w` namespace that sat in csrc/gemm.hip behind
+// PARKED EXPERIMENT (round 2, versions 1-3) -- not compiled into the library.  SUPERSEDED: the t256w namespace is back in csrc/gemm.hip
+// with a fourth main loop (whole k-tile of fragments in registers, buffer free after half an iteration, DMA pieces spread behind the
+// MFMAs of the second half, counted vmcnt(8)) that beats T256 by 5-10 % and serves every GEMM without a VALU-heavy epilogue.
+//  This is the `t256w` namespace that sat in csrc/gemm.hip behind
 // IA_GEMM_WIDE=1 (it also needs `raw_rsrc_at` / `i32x4` from below): the 256 x 256 x 64 GEMM with ONE wave per SIMD owning a
 // 128 x 128 part (256 accumulators in AGPRs), fragments of k-step s+1 requested before the MFMAs of step s, one barrier per
 // k-tile.  k-tiles 0 and 1 of an output tile arrive by LDS-DMA (issued before the previous tile's epilogue); inside the loop
