@@ -935,11 +935,80 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
   } while (u < n_tiles);
 }
 
-// the T256 epilogue (see t256::gemm_kernel) for one 128 x 64 half (NH = 0 / 1) of the wave's 128 x 128 part
+// Plain bf16 output (no bias / aux operand): the accumulators are rounded to bf16 BEFORE the trip through LDS, so one pass stages
+// 32 rows x 64 columns in 4 KiB (LDS writes run at 64-85 B/clk: they, not the reads or the global stores, are the price of the
+// row-major staging) and a lane reads back exactly the 16 bytes it stores.  Same pipelining and accumulator clearing as drain_half.
+// WITH_BIAS (k-contiguous B only): bct[ni][q] = the bias of the lane's columns ni*32 + hh*16 + 4q .. +3 (accumulator layout, fetched
+// before the main loop), added in fp32 before the rounding.
+template <bool BKS, int NH, bool WITH_BIAS>
+IA_DEV void drain_half_plain(const GemmArgs& p, f32x16 (&acc)[4][4], int m0, int n0, char* stg, int lane_e, const f32x4 (&bct)[4][4]) {
+  static_assert(!(WITH_BIAS && BKS), "bias rows are laid out for the k-contiguous B fragment permutation");
+  const int hh = lane_e >> 5, li = lane_e & 31, rrow = lane_e >> 3, c8 = lane_e & 7;
+  auto stage = [&](int mi) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      f32x16& a = acc[mi][NH * 2 + ni];
+      if (!BKS) {          // 16 consecutive columns per lane: two 16-byte chunks
+#pragma unroll
+        for (int h8 = 0; h8 < 2; ++h8) {
+          // accumulators live in AGPRs, the conversions are VALU work: copy eight at a time into VGPRs HERE (opaque to the register
+          // allocator, which otherwise moves the whole accumulator array into arch VGPRs for the epilogue and spills the main loop): explicit
+          // v_accvgpr_read with the source constrained to an AGPR
+          f32x4 t0, t1;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t0[j]) : "a"(a[h8 * 8 + j]));
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t1[j]) : "a"(a[h8 * 8 + 4 + j]));
+          }
+          if (WITH_BIAS) { t0 += bct[NH * 2 + ni][h8 * 2]; t1 += bct[NH * 2 + ni][h8 * 2 + 1]; }
+          const bf16x8 v = {f2bf(t0[0]), f2bf(t0[1]), f2bf(t0[2]), f2bf(t0[3]), f2bf(t1[0]), f2bf(t1[1]), f2bf(t1[2]), f2bf(t1[3])};
+          const int chunk = (ni * 32 + hh * 16 + h8 * 8) >> 3;
+          *reinterpret_cast<bf16x8*>(stg + li * 128 + ((chunk ^ (li & 7)) << 4)) = v;
+        }
+      } else {             // four runs of 4 columns, 8 apart: 8-byte pieces
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          f32x4 t0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t0[j]) : "a"(a[rg * 4 + j]));
+          const bf16x4 v = {f2bf(t0[0]), f2bf(t0[1]), f2bf(t0[2]), f2bf(t0[3])};
+          const int col = ni * 32 + rg * 8 + hh * 4;
+          *reinterpret_cast<bf16x4*>(stg + li * 128 + (((col >> 3) ^ (li & 7)) << 4) + (col & 7) * 2) = v;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a[r] = 0.f;      // dead now: cleared for the next tile in the shadow of the LDS round trip
+      __builtin_amdgcn_sched_barrier(0);             // one block at a time: hoisting every accumulator read ran the kernel into scratch
+    }
+  };
+  stage(0);
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    __builtin_amdgcn_wave_barrier();
+    bf16x8 v[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + rrow;
+      v[it] = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((c8 ^ (row & 7)) << 4));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+    __builtin_amdgcn_wave_barrier();
+    if (mi < 3) stage(mi + 1);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int m = m0 + mi * 32 + it * 8 + rrow, n = n0 + c8 * 8;
+      if (m < p.M && n < p.N && !(p.dbg & 64)) gstore16(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n, v[it]);
+      if (p.dbg & 64) asm volatile("" : : "v"(v[it]));
+    }
+  }
+}
+
+// the T256 epilogue arithmetic (see t256::gemm_kernel) for one 128 x 64 half (NH = 0 / 1) of the wave's 128 x 128 part
 template <int EPI, bool OUTF32, bool BKS, int NH>
-IA_DEV void drain_half(const GemmArgs& p, f32x16 (&acc)[4][4], int m0, int n0, char* stg, int lane_e, bool full) {
+IA_DEV void drain_half(const GemmArgs& p, f32x16 (&acc)[4][4], int m0, int n0, char* stg, int lane_e, bool full, bool bias_ready, f32x4 bias_lo,
+                       f32x4 bias_hi) {
   const int hh = lane_e >> 5, li = lane_e & 31;
-  const int wrow = li & 15, rrow = lane_e >> 3, c8 = lane_e & 7;
+  const int rrow = lane_e >> 3, c8 = lane_e & 7;
   constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_ADD;
   constexpr bool HAS_AUX = EPI == EPI_ADD || EPI == EPI_BIAS_ADD || EPI == EPI_DGELU || EPI == EPI_DGELU_CS;
   constexpr int AHEAD = 4;
@@ -956,46 +1025,61 @@ IA_DEV void drain_half(const GemmArgs& p, f32x16 (&acc)[4][4], int m0, int n0, c
       const int row = m0 + (c >> 2) * 32 + ((c >> 1) & 1) * 16 + (c & 1) * 8 + rrow;
       return *reinterpret_cast<const bf16x8*>(p.aux + (size_t)row * p.ldaux + n0 + c8 * 8);
     };
-    if (PRE && HAS_BIAS) { pb0 = *reinterpret_cast<const f32x4*>(p.bias + n0 + c8 * 8); pb1 = *reinterpret_cast<const f32x4*>(p.bias + n0 + c8 * 8 + 4); }
+    if (PRE && HAS_BIAS) {      // normally fetched before the main loop (a load issued here queues behind the previous stores)
+      if (bias_ready) { pb0 = bias_lo; pb1 = bias_hi; }
+      else { pb0 = *reinterpret_cast<const f32x4*>(p.bias + n0 + c8 * 8); pb1 = *reinterpret_cast<const f32x4*>(p.bias + n0 + c8 * 8 + 4); }
+    }
     if (PRE && HAS_AUX) {
 #pragma unroll
       for (int c = 0; c < AHEAD; ++c) ax[c] = aux_of(c);
     }
+    // One pass = one 32-row block (mi): all 64 lanes stage their 8 quads (32 rows x 64 columns fp32 = 8 KiB, the wave's two 4-KiB
+    // slots: with four waves the eight slots of the block are two per wave), then the wave reads them back as rows.  The wave is
+    // alone on its SIMD, so the passes are pipelined by hand: the quads of block mi+1 are written as soon as the rows of block mi
+    // have been read, and the math / stores of block mi run while that write is in flight.
+    auto stage = [&](int mi) {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int chunk = (ni * 32 + (BKS ? rg * 8 + hh * 4 : hh * 16 + rg * 4)) >> 2;
+          f32x16& a = acc[mi][NH * 2 + ni];
+          const f32x4 v = {a[rg * 4], a[rg * 4 + 1], a[rg * 4 + 2], a[rg * 4 + 3]};
+          *reinterpret_cast<f32x4*>(stg + li * 256 + ((chunk ^ (li & 15)) << 4)) = v;
+          // the block is dead now: clear it for the next tile here, in the shadow of the LDS round trip (256 accumulator writes in
+          // front of the next main loop were ~0.5 us per tile)
+          a[rg * 4] = 0.f; a[rg * 4 + 1] = 0.f; a[rg * 4 + 2] = 0.f; a[rg * 4 + 3] = 0.f;
+        }
+    };
+    stage(0);
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
+      __builtin_amdgcn_wave_barrier();
+      f32x4 lo[4], hi[4];
 #pragma unroll
-      for (int h16 = 0; h16 < 2; ++h16) {
-        if ((li >> 4) == h16) {
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + rrow;
+        lo[it] = *reinterpret_cast<const f32x4*>(stg + row * 256 + (((2 * c8) ^ (row & 15)) << 4));
+        hi[it] = *reinterpret_cast<const f32x4*>(stg + row * 256 + (((2 * c8 + 1) ^ (row & 15)) << 4));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
+      __builtin_amdgcn_wave_barrier();
+      if (mi < 3) stage(mi + 1);
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-              const int chunk = (ni * 32 + (BKS ? rg * 8 + hh * 4 : hh * 16 + rg * 4)) >> 2;
-              const f32x16& a = acc[mi][NH * 2 + ni];
-              const f32x4 v = {a[rg * 4], a[rg * 4 + 1], a[rg * 4 + 2], a[rg * 4 + 3]};
-              *reinterpret_cast<f32x4*>(stg + wrow * 256 + ((chunk ^ wrow) << 4)) = v;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const int row = it * 8 + rrow;
-          const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + row * 256 + (((2 * c8) ^ row) << 4));
-          const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * 256 + (((2 * c8 + 1) ^ row) << 4));
-          const int m = m0 + mi * 32 + h16 * 16 + row, n = n0 + c8 * 8;
-          const int c = mi * 4 + h16 * 2 + it;
-          if (PRE) {
-            if (HAS_AUX && c + AHEAD < 16) {
-              ax[(c + AHEAD) % (AHEAD + 1)] = aux_of(c + AHEAD);
-              asm volatile("" ::: "memory");
-            }
-            if (!(p.dbg & 64)) epi_store8<EPI, OUTF32, true>(p, m, n, lo, hi, pb0, pb1, ax[c % (AHEAD + 1)], cs);
-          } else {
-            if (m < p.M && n < p.N && !(p.dbg & 64)) epi_store8<EPI, OUTF32, false>(p, m, n, lo, hi, pb0, pb1, ax[0], cs);
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + rrow;
+        const int m = m0 + mi * 32 + row, n = n0 + c8 * 8;
+        const int c = mi * 4 + it;
+        if (PRE) {
+          if (HAS_AUX && c + AHEAD < 16) {
+            ax[(c + AHEAD) % (AHEAD + 1)] = aux_of(c + AHEAD);
+            asm volatile("" ::: "memory");
           }
-          if (p.dbg & 64) asm volatile("" : : "v"(lo), "v"(hi));
+          if (!(p.dbg & 64)) epi_store8<EPI, OUTF32, true>(p, m, n, lo[it], hi[it], pb0, pb1, ax[c % (AHEAD + 1)], cs);
+        } else {
+          if (m < p.M && n < p.N && !(p.dbg & 64)) epi_store8<EPI, OUTF32, false>(p, m, n, lo[it], hi[it], pb0, pb1, ax[0], cs);
         }
-        __builtin_amdgcn_wave_barrier();
+        if (p.dbg & 64) asm volatile("" : : "v"(lo[it]), "v"(hi[it]));
       }
     }
     if (EPI == EPI_DGELU_CS) {
@@ -1057,30 +1141,70 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   };
 
   f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;      // later tiles: the epilogue clears every block it has staged
   int tile = first_tile;
   run(tile, true, acc, false);
   bool stores_in_flight = false;
+  constexpr bool HAS_BIAS_K = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_ADD;
   while (true) {
+    int bm, bn;
+    coords(tile, bm, bn);
+    const int m0_pre = bm * BM + wm * 128, n0_pre = bn * BN + wn * 128;
+    const bool full = m0_pre + 128 <= p.M && n0_pre + 128 <= p.N;      // both halves inside C: the store count of the tile is exact
+    // the bias of this tile's columns is fetched BEFORE the main loop: VMEM retires in order, so a load issued in the epilogue
+    // could only be awaited by draining the stores in front of it (the bias epilogue cost 27 us more than the plain one at
+    // 32640 x 4096 x 1024).  Waited for right behind the main loop, where nothing slow is in flight yet.
+    // Plain bias + bf16 output: in ACCUMULATOR layout (16 consecutive columns per lane and 32-column block: 64 floats, the wave has
+    // 140 spare VGPRs), so the sum is rounded before the LDS trip (drain_half_plain); the other bias epilogues: row layout.
+    constexpr bool BIAS_CT = EPI == EPI_BIAS && !OUTF32 && !BKS;
+    f32x4 pbv[4] = {};
+    f32x4 bct[4][4] = {};
+    int lane_b = lane0;
+    asm volatile("" : "+v"(lane_b));
+    const bool bias_pre = HAS_BIAS_K && full;
+    if (bias_pre && BIAS_CT) {
+      const float* bp = p.bias + n0_pre + (lane_b >> 5) * 16;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int q = 0; q < 4; ++q) bct[ni][q] = *reinterpret_cast<const f32x4*>(bp + ni * 32 + q * 4);
+    } else if (bias_pre) {
+      const float* bp = p.bias + n0_pre + (lane_b & 7) * 8;
+      pbv[0] = *reinterpret_cast<const f32x4*>(bp); pbv[1] = *reinterpret_cast<const f32x4*>(bp + 4);
+      pbv[2] = *reinterpret_cast<const f32x4*>(bp + 64); pbv[3] = *reinterpret_cast<const f32x4*>(bp + 68);
+    }
     run(tile, false, acc, stores_in_flight);
+    if (bias_pre && BIAS_CT) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(bct[ni][0]), "+v"(bct[ni][1]), "+v"(bct[ni][2]), "+v"(bct[ni][3]));
+    } else if (bias_pre) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pbv[0]), "+v"(pbv[1]), "+v"(pbv[2]), "+v"(pbv[3]));
     const int next = ordered ? total_tiles : tile + gridDim.x;
     if (next < total_tiles) run(next, true, acc, false);      // the next tile's first two k-tiles travel under this epilogue
 
-    int bm, bn;
-    coords(tile, bm, bn);
-    const int m0 = bm * BM + wm * 128, n0 = bn * BN + wn * 128;
     int lane_e = lane0;
     asm volatile("" : "+v"(lane_e));
-    char* stg = smem + 2 * 2 * TILE_BYTES + wave * STAGE_BYTES;
-    const bool full = m0 + 128 <= p.M && n0 + 128 <= p.N;      // both halves inside C: the store count of the tile is exact
+    // (the tile origin is known before the main loop now: keep the epilogue's address arithmetic from being scheduled in front of
+    // the loop, where it would stay live across it and spill)
+    int m0 = m0_pre, n0 = n0_pre;
+    asm volatile("" : "+s"(m0), "+s"(n0));
+    char* stg = smem + 2 * 2 * TILE_BYTES + wave * 2 * STAGE_BYTES;      // 8 KiB per wave (t256's eight 4-KiB slots, two per wave)
     if (!(p.dbg & 32)) {
-      drain_half<EPI, OUTF32, BKS, 0>(p, acc, m0, n0, stg, lane_e, full || (m0 + 128 <= p.M && n0 + 64 <= p.N));
-      drain_half<EPI, OUTF32, BKS, 1>(p, acc, m0, n0 + 64, stg, lane_e, full);
+      if constexpr (EPI == EPI_NONE && !OUTF32) {
+        drain_half_plain<BKS, 0, false>(p, acc, m0, n0, stg, lane_e, bct);
+        drain_half_plain<BKS, 1, false>(p, acc, m0, n0 + 64, stg, lane_e, bct);
+      } else if (BIAS_CT && bias_pre) {
+        drain_half_plain<false, 0, BIAS_CT>(p, acc, m0, n0, stg, lane_e, bct);
+        drain_half_plain<false, 1, BIAS_CT>(p, acc, m0, n0 + 64, stg, lane_e, bct);
+      } else {
+        drain_half<EPI, OUTF32, BKS, 0>(p, acc, m0, n0, stg, lane_e, full || (m0 + 128 <= p.M && n0 + 64 <= p.N), bias_pre, pbv[0], pbv[1]);
+        drain_half<EPI, OUTF32, BKS, 1>(p, acc, m0, n0 + 64, stg, lane_e, full, bias_pre, pbv[2], pbv[3]);
+      }
     }
     if (next >= total_tiles) break;
     stores_in_flight = !(p.dbg & 96) && full;
