@@ -91,6 +91,13 @@ int ia_attn_fwd(const void* q, const void* k, const void* v, int ld_qkv, const u
 int ia_attn_bwd(const void* q, const void* k, const void* v, int ld_qkv, const uint8_t* key_mask, const void* out, const void* d_out,
                 int ld_o, const float* lse2, float* delta, void* dq, void* dk, void* dv, int ld_dqkv, int B, int nh, int L,
                 float scale, float drop_p, uint32_t seed, ia_stream_t stream);
+/* ia_attn_bwd that also returns the bias gradient of the fused QKV projection (reference: the autograd of nn.Linear's bias behind
+ * RobertaSelfAttention.query/key/value, src/models/text.py:1241): dbias[3*nh*64] fp32 (q | k | v) += column sums of dq, dk, dv over
+ * all tokens, taken in the kernels' epilogues (deterministic two-stage sum); workspace: ia_attn_bwd_bias_workspace_bytes(B, nh, L). */
+size_t ia_attn_bwd_bias_workspace_bytes(int B, int nh, int L);
+int ia_attn_bwd_bias(const void* q, const void* k, const void* v, int ld_qkv, const uint8_t* key_mask, const void* out, const void* d_out,
+                     int ld_o, const float* lse2, float* delta, void* dq, void* dk, void* dv, int ld_dqkv, float* dbias, void* workspace,
+                     size_t workspace_bytes, int B, int nh, int L, float scale, float drop_p, uint32_t seed, ia_stream_t stream);
 
 /* General form (cross-attention and multi-query attention of the CoCa multimodal layers, src/models/multimodal.py:590-616
  * ParallelTransformerBlock and :665-706 CrossAttention): Lq queries attend to Lk keys per (sequence, head).  q / out /

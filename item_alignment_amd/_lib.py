@@ -45,6 +45,8 @@ SIGNATURES = {
     "ia_colsum": (i32, [vp, i32, i32, i32, vp, i32, vp, sz, vp]),
     "ia_attn_fwd": (i32, [vp, vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, f32, f32, u32, vp]),
     "ia_attn_bwd": (i32, [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, u32, vp]),
+    "ia_attn_bwd_bias_workspace_bytes": (sz, [i32, i32, i32]),
+    "ia_attn_bwd_bias": (i32, [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, sz, i32, i32, i32, f32, f32, u32, vp]),
     "ia_attn_fwd_x": (i32, [vp, i32, vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, f32, f32, u32, vp]),
     "ia_attn_bwd_x": (i32, [vp, i32, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, f32, f32, u32, vp]),
     "ia_rotary_split_fwd": (i32, [vp, i32, vp, vp, i32, i32, i32, vp]),

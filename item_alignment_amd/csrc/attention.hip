@@ -40,6 +40,8 @@ struct AttnArgs {
   float sc;                                       // softmax scale * log2(e)
   float scale;                                    // softmax scale
   uint32_t thr16; float inv_keep; uint32_t seed;
+  float* cs_part;                                 // backward, optional: [(b*ntile + tile)*4 + wave][3*nh*64] fp32 column sums of this wave's
+                                                  // dq | dk | dv block (the QKV bias gradient, summed over rows by ia_sum_rows_f32); null = off
 };
 
 // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): renumber them so that consecutive
@@ -163,7 +165,10 @@ IA_DEV bool drop_keep(uint32_t seed, uint32_t stream, int q, int key, uint32_t t
 // third of the forward kernel at L = 255.  Staged through a wave-private LDS slot (32 rows x 144 B: the 16-byte pad keeps the
 // 8-byte writes at two lanes per bank) the block leaves as whole 128-byte rows, 16 B per lane, 8 rows per instruction.
 constexpr int EPI_ROW = 144, EPI_SLOT = 32 * EPI_ROW;
-IA_DEV void store_block_rows(char* slot, const f32x16& a0, const f32x16& a1, float mul, bool zero, bf16* out, size_t ld, int nrows, int lane) {
+// cs_out != null: the 64 column sums of the block's stored rows (of the bf16 values as stored) go to cs_out[0..63] -- each lane adds up
+// its 8 columns over its 4 rows, lanes with equal lane&7 are folded with row_ror / permlane swaps (the GEMM column-sum epilogue's pattern).
+IA_DEV void store_block_rows(char* slot, const f32x16& a0, const f32x16& a1, float mul, bool zero, bf16* out, size_t ld, int nrows, int lane,
+                             float* cs_out = nullptr) {
   const int hh = lane >> 5, lq = lane & 31;
   char* w = slot + lq * EPI_ROW + hh * 8;
 #pragma unroll
@@ -179,12 +184,37 @@ IA_DEV void store_block_rows(char* slot, const f32x16& a0, const f32x16& a1, flo
     *reinterpret_cast<bf16x4*>(w + 64 + rg * 16) = c;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private slot: the wave's own LDS writes are in order, no barrier
+  float cs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cs[j] = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = i * 8 + (lane >> 3), c = lane & 7;
     const bf16x8 v = *reinterpret_cast<const bf16x8*>(slot + row * EPI_ROW + c * 16);
-    if (row < nrows) *reinterpret_cast<bf16x8*>(out + (size_t)row * ld + c * 8) = v;
+    if (row < nrows) {
+      *reinterpret_cast<bf16x8*>(out + (size_t)row * ld + c * 8) = v;
+      if (cs_out) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cs[j] += bf2f(v[j]);
+      }
+    }
   }
+  if (cs_out) {                                     // wave-uniform
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float x = cs[j];
+      x += ia_dpp<0x128>(x);                        // row_ror 8: lane ^ 8
+      cs[j] = ia_add_xor32(ia_add_xor16(x));
+    }
+    if (lane < 8) {
+      *reinterpret_cast<f32x4*>(cs_out + lane * 8) = f32x4{cs[0], cs[1], cs[2], cs[3]};
+      *reinterpret_cast<f32x4*>(cs_out + lane * 8 + 4) = f32x4{cs[4], cs[5], cs[6], cs[7]};
+    }
+  }
+}
+// a wave without rows (past the end of the sequence) still owns a row of the partial-sum matrix: zeros
+IA_DEV void zero_cs_row(float* cs_out, int lane) {
+  if (lane < 16) *reinterpret_cast<f32x4*>(cs_out + lane * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
 // One 64-key tile of the forward pass for this wave's 32 queries (S^T orientation, see the header comment).
@@ -509,8 +539,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  if (!active) return;
-  store_block_rows(smem + wave * EPI_SLOT, dq0, dq1, p.scale, false, p.dq + (qbase + q0) * p.ld_dq + h * 64, p.ld_dq, Lq - q0, lane);
+  float* cs_row = p.cs_part ? p.cs_part + ((size_t)(b * ((p.Lq + 127) >> 7) + tile) * 4 + wave) * (3 * p.nh * 64) + h * 64 : nullptr;
+  if (!active) { if (cs_row) zero_cs_row(cs_row, lane); return; }
+  store_block_rows(smem + wave * EPI_SLOT, dq0, dq1, p.scale, false, p.dq + (qbase + q0) * p.ld_dq + h * 64, p.ld_dq, Lq - q0, lane, cs_row);
 }
 
 // ---------------------------------------------------------------------------------- backward: dK, dV
@@ -644,10 +675,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  if (!active) return;
+  float* cs_row = p.cs_part ? p.cs_part + ((size_t)(b * ((p.Lk + 127) >> 7) + tile) * 4 + wave) * (3 * p.nh * 64) + p.nh * 64 + h * 64 : nullptr;
+  if (!active) { if (cs_row) { zero_cs_row(cs_row, lane); zero_cs_row(cs_row + p.nh * 64, lane); } return; }
   // a masked key's outputs are zero (its P is not bounded by the saved log-sum-exp, so the accumulators may hold inf / nan)
-  store_block_rows(smem + wave * 2 * EPI_SLOT, dk0, dk1, p.scale, !key_ok, p.dk + (rowbase + k0) * p.ld_dkv + h * 64, p.ld_dkv, L - k0, lane);
-  store_block_rows(smem + (wave * 2 + 1) * EPI_SLOT, dv0, dv1, 1.f, !key_ok, p.dv + (rowbase + k0) * p.ld_dkv + h * 64, p.ld_dkv, L - k0, lane);
+  store_block_rows(smem + wave * 2 * EPI_SLOT, dk0, dk1, p.scale, !key_ok, p.dk + (rowbase + k0) * p.ld_dkv + h * 64, p.ld_dkv, L - k0, lane, cs_row);
+  store_block_rows(smem + (wave * 2 + 1) * EPI_SLOT, dv0, dv1, 1.f, !key_ok, p.dv + (rowbase + k0) * p.ld_dkv + h * 64, p.ld_dkv, L - k0, lane,
+                   cs_row ? cs_row + p.nh * 64 : nullptr);
 }
 
 // packed_rows > 0: packed self-attention over that many token rows in total (AttnArgs::cu), Lq == Lk == longest sequence
@@ -731,6 +764,42 @@ extern "C" int ia_attn_bwd(const void* q, const void* k, const void* v, int ld_q
                            int ld_dqkv, int B, int nh, int L, float scale, float drop_p, uint32_t seed, hipStream_t stream) {
   return ia_attn_bwd_x(q, ld_qkv, k, v, ld_qkv, key_mask, out, d_out, ld_o, lse2, delta, dq, ld_dqkv, dk, dv, ld_dqkv, B, nh, L, L, scale,
                        drop_p, seed, stream);
+}
+
+// ia_attn_bwd that also returns the bias gradient of the fused QKV projection: dbias[3*nh*64] (q | k | v order) += column sums of
+// dq, dk, dv over all tokens, taken from the rows as they are stored (each wave's 64 sums go to a row of the workspace matrix, one
+// fixed-order fold afterwards: deterministic) -- the separate column-sum pass over [tokens, 3H] disappears from the layer backward.
+extern "C" size_t ia_attn_bwd_bias_workspace_bytes(int B, int nh, int L) {
+  if (B <= 0 || nh <= 0 || L <= 0) return 0;
+  return (size_t)B * ((L + 127) / 128) * 4 * 3 * nh * 64 * sizeof(float);
+}
+
+extern "C" int ia_attn_bwd_bias(const void* q, const void* k, const void* v, int ld_qkv, const uint8_t* key_mask, const void* out,
+                                const void* d_out, int ld_o, const float* lse2, float* delta, void* dq, void* dk, void* dv, int ld_dqkv,
+                                float* dbias, void* workspace, size_t workspace_bytes, int B, int nh, int L, float scale, float drop_p,
+                                uint32_t seed, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!q || !k || !v || !out || !d_out || !lse2 || !delta || !dq || !dk || !dv || !dbias) return IA_ERR_ARG;
+  if (!workspace || workspace_bytes < ia_attn_bwd_bias_workspace_bytes(B, nh, L)) return IA_ERR_WORKSPACE;
+  AttnArgs a{};
+  int rc = fill_args(a, B, nh, L, L, ld_qkv, ld_qkv, ld_o, scale, drop_p, seed);
+  if (rc) return rc;
+  if ((ld_dqkv & 7) || ld_dqkv < nh * 64) return IA_ERR_ARG;
+  a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.o = (const bf16*)out; a.d_o = (const bf16*)d_out;
+  a.mask = key_mask; a.lse2 = const_cast<float*>(lse2); a.delta = delta;
+  a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.ld_dq = ld_dqkv; a.ld_dkv = ld_dqkv;
+  a.cs_part = (float*)workspace;
+  dim3 grid(((L + 127) / 128) * nh * B), blk(256);
+  if (a.thr16) {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, blk, 0, stream, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, blk, 0, stream, a);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, blk, 0, stream, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, blk, 0, stream, a);
+  }
+  rc = ia_check_launch();
+  if (rc) return rc;
+  return ia_sum_rows_f32((const float*)workspace, B * ((L + 127) / 128) * 4, 3 * nh * 64, dbias, 1, stream);
 }
 
 // Packed ("unpadded") self-attention: the token rows of all sequences lie back to back, sequence b owning rows

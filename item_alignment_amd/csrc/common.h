@@ -47,6 +47,22 @@ IA_DEV __amdgpu_buffer_rsrc_t ia_rsrc(const void* p, uint32_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
 
+// x[lane] + x[lane ^ 16] and x[lane] + x[lane ^ 32] through v_permlane16_swap / v_permlane32_swap (the instruction exchanges the odd
+// rows / upper half of its first register with the even rows / lower half of the second).  Inline asm on purpose: handed the same
+// value twice, __builtin_amdgcn_permlane16_swap came back from hipcc (ROCm 7.2) as `v_permlane16_swap v0, v8 ; v_add v0, v0, v0` --
+// the second result dropped, i.e. 2 * x[lane ^ 16] instead of the sum (seen in the attention column sums).  s_nop 1 = the two wait
+// states between a VALU write of an operand and the swap (guide T21).
+IA_DEV float ia_add_xor16(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+IA_DEV float ia_add_xor32(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+
 // wave-wide reductions (64 lanes) on DPP (no LDS round trips: __shfl_xor lowers to ds_bpermute_b32, ~100 cycles a step):
 // four in-row butterfly steps leave every lane with the total of its 16-lane row, the four row totals are then combined
 // through scalar registers.  The result is wave-uniform.

@@ -50,7 +50,7 @@ Scratch carve_scratch(const ia_layer_cfg* c, void* base) {
   s.gI = take(M * I * 2); s.gqkv = take(M * 3 * H * 2);
   s.delta = (float*)take((size_t)c->B * c->nh * c->L * 4);
   s.ws_bytes = max3(ia_ln_bwd_workspace_bytes((int)M, (int)H), ia_gemm_colsum_workspace_bytes((int)M, (int)I),
-                    ia_colsum_workspace_bytes((int)M, (int)(3 * H)));
+                    max3(ia_colsum_workspace_bytes((int)M, (int)(3 * H)), ia_attn_bwd_bias_workspace_bytes(c->B, c->nh, c->L), 0));
   s.ws = take(s.ws_bytes);
   // split-K partial sums of the four weight-gradient GEMMs (largest of them)
   s.gws_bytes = max3(ia_gemm_workspace_bytes((int)(3 * H), (int)H, (int)M, 1), ia_gemm_workspace_bytes((int)I, (int)H, (int)M, 1),
@@ -77,14 +77,18 @@ int attn_fwd(const ia_layer_cfg* c, const char* qkv, const uint8_t* key_mask, ch
   return ia_attn_fwd(qkv, qkv + (size_t)H * 2, qkv + (size_t)2 * H * 2, 3 * H, key_mask, ctx, H, lse, c->B, c->nh, c->L, scale, drop, seed, st);
 }
 
+// attention backward + the QKV bias gradient (+= into db_qkv): padded rows take the column sums out of the attention kernels'
+// epilogues, packed rows (cu_seqlens) keep the separate column-sum pass over [rows, 3H]
 int attn_bwd(const ia_layer_cfg* c, const char* qkv, const uint8_t* key_mask, const char* ctx, const char* dctx, const float* lse, float* delta,
-             char* gqkv, float scale, float drop, uint32_t seed, ia_stream_t st) {
+             char* gqkv, float* db_qkv, void* ws, size_t ws_bytes, float scale, float drop, uint32_t seed, ia_stream_t st) {
   const int H = c->H;
-  if (c->cu_seqlens)
-    return ia_attn_bwd_varlen(qkv, qkv + (size_t)H * 2, qkv + (size_t)2 * H * 2, 3 * H, c->cu_seqlens, c->total_tokens, ctx, dctx, H, lse, delta,
-                              gqkv, gqkv + (size_t)H * 2, gqkv + (size_t)2 * H * 2, 3 * H, c->B, c->nh, c->L, scale, drop, seed, st);
-  return ia_attn_bwd(qkv, qkv + (size_t)H * 2, qkv + (size_t)2 * H * 2, 3 * H, key_mask, ctx, dctx, H, lse, delta, gqkv, gqkv + (size_t)H * 2,
-                     gqkv + (size_t)2 * H * 2, 3 * H, c->B, c->nh, c->L, scale, drop, seed, st);
+  if (c->cu_seqlens) {
+    int rc = ia_attn_bwd_varlen(qkv, qkv + (size_t)H * 2, qkv + (size_t)2 * H * 2, 3 * H, c->cu_seqlens, c->total_tokens, ctx, dctx, H, lse, delta,
+                                gqkv, gqkv + (size_t)H * 2, gqkv + (size_t)2 * H * 2, 3 * H, c->B, c->nh, c->L, scale, drop, seed, st);
+    return rc ? rc : ia_colsum(gqkv, 3 * H, (int)rows_of(c), 3 * H, db_qkv, 1, ws, ws_bytes, st);
+  }
+  return ia_attn_bwd_bias(qkv, qkv + (size_t)H * 2, qkv + (size_t)2 * H * 2, 3 * H, key_mask, ctx, dctx, H, lse, delta, gqkv,
+                          gqkv + (size_t)H * 2, gqkv + (size_t)2 * H * 2, 3 * H, db_qkv, ws, ws_bytes, c->B, c->nh, c->L, scale, drop, seed, st);
 }
 
 }  // namespace
@@ -182,8 +186,7 @@ extern "C" int ia_layer_bwd2(const ia_layer_cfg* c, const ia_layer_weights* w, c
     const char* d_att = drop ? k.g1 : dz1buf;
     IA_TRY(ia_gemm_bf16(d_att, 1, H, s.ctx, 1, H, g->w_o, 1, H, H, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
     IA_TRY(ia_gemm_bf16(d_att, 0, H, w->w_o, 1, H, k.g2, 0, H, M, H, H, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
-    IA_TRY(attn_bwd(c, s.qkv, key_mask, s.ctx, k.g2, s.lse, k.delta, k.gqkv, scale, c->attn_drop, attn_seed, st));
-    IA_TRY(ia_colsum(k.gqkv, 3 * H, M, 3 * H, g->b_qkv, 1, k.ws, k.ws_bytes, st));
+    IA_TRY(attn_bwd(c, s.qkv, key_mask, s.ctx, k.g2, s.lse, k.delta, k.gqkv, g->b_qkv, k.ws, k.ws_bytes, scale, c->attn_drop, attn_seed, st));
     IA_TRY(ia_gemm_bf16(k.gqkv, 1, 3 * H, x, 1, H, g->w_qkv, 1, H, 3 * H, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
     if (dx2)   // split form: dx = the attention sub-block's data gradient, dx2 = dz1 (already written)
       IA_TRY(ia_gemm_bf16(k.gqkv, 0, 3 * H, w->w_qkv, 1, H, dx, 0, H, M, H, 3 * H, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
@@ -200,8 +203,7 @@ extern "C" int ia_layer_bwd2(const ia_layer_cfg* c, const ia_layer_weights* w, c
                      k.ws_bytes, 1, st));
     IA_TRY(ia_gemm_bf16(k.g1, 1, H, s.ctx, 1, H, g->w_o, 1, H, H, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
     IA_TRY(ia_gemm_bf16(k.g1, 0, H, w->w_o, 1, H, k.g2, 0, H, M, H, H, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
-    IA_TRY(attn_bwd(c, s.qkv, key_mask, s.ctx, k.g2, s.lse, k.delta, k.gqkv, scale, 0.f, 0, st));
-    IA_TRY(ia_colsum(k.gqkv, 3 * H, M, 3 * H, g->b_qkv, 1, k.ws, k.ws_bytes, st));
+    IA_TRY(attn_bwd(c, s.qkv, key_mask, s.ctx, k.g2, s.lse, k.delta, k.gqkv, g->b_qkv, k.ws, k.ws_bytes, scale, 0.f, 0, st));
     IA_TRY(ia_gemm_bf16(k.gqkv, 1, 3 * H, s.t0, 1, H, g->w_qkv, 1, H, 3 * H, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
     IA_TRY(ia_gemm_bf16(k.gqkv, 0, 3 * H, w->w_qkv, 1, H, k.g0, 0, H, M, H, 3 * H, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
     IA_TRY(ia_ln_bwd(k.g0, k.g1, x, s.mean1, s.rstd1, w->ln1_g, dx, nullptr, g->ln1_g, g->ln1_b, nullptr, M, H, 0.f, 0, 0, k.ws,

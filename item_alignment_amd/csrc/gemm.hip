@@ -693,14 +693,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs p) {
           float v = cs[r];
           v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x128, 0xF, 0xF,
                                                                      false));                    // row_ror:8   -> lane ^ 8
-          {                                                                                       // lane ^ 16 (rows 1,3 <-> rows 0,2)
-            const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-            v = __builtin_bit_cast(float, sw[0]) + __builtin_bit_cast(float, sw[1]);
-          }
-          {                                                                                       // lane ^ 32 (upper half <-> lower half)
-            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-            v = __builtin_bit_cast(float, sw[0]) + __builtin_bit_cast(float, sw[1]);
-          }
+          v = ia_add_xor32(ia_add_xor16(v));                                                      // lane ^ 16, lane ^ 32 (common.h)
           cs[r] = v;
         }
         if (rrow == 0 && n0 + c8 * 8 < p.N) {      // lanes 0..7: 8 consecutive columns each (two 16-byte stores, counted in PEND)
@@ -1087,14 +1080,7 @@ IA_DEV void drain_half(const GemmArgs& p, f32x16 (&acc)[4][4], int m0, int n0, c
       for (int r = 0; r < 8; ++r) {
         float v = cs[r];
         v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));
-        {
-          const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-          v = __builtin_bit_cast(float, sw[0]) + __builtin_bit_cast(float, sw[1]);
-        }
-        {
-          const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-          v = __builtin_bit_cast(float, sw[0]) + __builtin_bit_cast(float, sw[1]);
-        }
+        v = ia_add_xor32(ia_add_xor16(v));
         cs[r] = v;
       }
       if (rrow == 0 && n0 + c8 * 8 < p.N) {

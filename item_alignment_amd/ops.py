@@ -110,13 +110,21 @@ def attn_fwd(qkv, B, L, nh, *, key_mask=None, scale=0.125, drop_p=0.0, seed=0):
     return out, lse
 
 
-def attn_bwd(qkv, ctx, d_ctx, lse, B, L, nh, *, key_mask=None, scale=0.125, drop_p=0.0, seed=0):
+def attn_bwd(qkv, ctx, d_ctx, lse, B, L, nh, *, key_mask=None, scale=0.125, drop_p=0.0, seed=0, dbias=None):
+    """dbias (fp32 [3H], optional): += column sums of dqkv, i.e. the bias gradient of the fused QKV projection, out of the same launches"""
     lib = _lib.load()
     _need(qkv, BF16, "qkv"); _need(ctx, BF16, "ctx"); _need(d_ctx, BF16, "d_ctx"); _need(lse, F32, "lse")
     H = nh * 64
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, nh, L), device=qkv.device, dtype=F32)
     base, dbase = qkv.data_ptr(), dqkv.data_ptr()
+    if dbias is not None:
+        _need(dbias, F32, "dbias")
+        ws = torch.empty(lib.ia_attn_bwd_bias_workspace_bytes(B, nh, L), device=qkv.device, dtype=torch.uint8)
+        check(lib.ia_attn_bwd_bias(base, base + 2 * H, base + 4 * H, 3 * H, ptr(key_mask), ctx.data_ptr(), d_ctx.data_ptr(), H, lse.data_ptr(),
+                                   delta.data_ptr(), dbase, dbase + 2 * H, dbase + 4 * H, 3 * H, dbias.data_ptr(), ws.data_ptr(), ws.numel(),
+                                   B, nh, L, scale, drop_p, seed, stream_ptr()), "ia_attn_bwd_bias")
+        return dqkv
     check(lib.ia_attn_bwd(base, base + 2 * H, base + 4 * H, 3 * H, ptr(key_mask), ctx.data_ptr(), d_ctx.data_ptr(), H, lse.data_ptr(),
                           delta.data_ptr(), dbase, dbase + 2 * H, dbase + 4 * H, 3 * H, B, nh, L, scale, drop_p, seed, stream_ptr()),
           "ia_attn_bwd")

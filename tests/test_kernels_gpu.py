@@ -177,6 +177,27 @@ def test_attention_fwd_bwd(gpu, B, L, nh, masked):
         assert rel_err(got, want) < 3e-2, name
 
 
+@pytest.mark.parametrize("B,L,nh,masked,drop", [(3, 255, 4, True, 0.0), (2, 577, 3, False, 0.0), (2, 130, 2, True, 0.1), (1, 64, 1, False, 0.0)])
+def test_attention_bwd_bias_gradient(gpu, B, L, nh, masked, drop):
+    """ia_attn_bwd_bias: the QKV bias gradient out of the attention backward epilogues = column sums of the dqkv it stores (exactly the
+    stored bf16 values, fp32 sums), accumulated into dbias; dqkv itself is bit-identical to ia_attn_bwd's."""
+    from item_alignment_amd import ops
+    H = nh * 64
+    qkv = rnd((B * L, 3 * H), gpu, 1.0, 24)
+    dctx = rnd((B * L, H), gpu, 1.0, 25)
+    mask = None
+    if masked:
+        lens = torch.tensor([L - 7 * (i + 1) for i in range(B)])
+        mask = (torch.arange(L)[None, :] < lens[:, None]).to(torch.uint8).to(gpu)
+    ctx, lse = ops.attn_fwd(qkv, B, L, nh, key_mask=mask, drop_p=drop, seed=5)
+    plain = ops.attn_bwd(qkv, ctx, dctx, lse, B, L, nh, key_mask=mask, drop_p=drop, seed=5)
+    dbias = torch.full((3 * H,), 0.5, device=gpu, dtype=torch.float32)
+    fused = ops.attn_bwd(qkv, ctx, dctx, lse, B, L, nh, key_mask=mask, drop_p=drop, seed=5, dbias=dbias)
+    assert torch.equal(plain, fused)
+    want = 0.5 + fused.float().sum(0)
+    assert (dbias - want).abs().max().item() <= 1e-3 * (1.0 + want.abs().max().item())
+
+
 def test_attention_dropout_statistics(gpu):
     """Dropout on the attention probabilities: mean preserved, fwd/bwd use the same mask (checked by
     linearity: with V = const the output stays ~const)."""
