@@ -938,6 +938,7 @@ IA_DEV void drain_half_plain(const GemmArgs& p, f32x16 (&acc)[4][4], int m0, int
   static_assert(!(WITH_BIAS && BKS), "bias rows are laid out for the k-contiguous B fragment permutation");
   const int hh = lane_e >> 5, li = lane_e & 31, rrow = lane_e >> 3, c8 = lane_e & 7;
   auto stage = [&](int mi) {
+    char* const sl = stg + (mi & 1) * 4096;      // two 4-KiB slots per wave: block mi+1 is written while block mi is being read back
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       f32x16& a = acc[mi][NH * 2 + ni];
@@ -956,7 +957,7 @@ IA_DEV void drain_half_plain(const GemmArgs& p, f32x16 (&acc)[4][4], int m0, int
           if (WITH_BIAS) { t0 += bct[NH * 2 + ni][h8 * 2]; t1 += bct[NH * 2 + ni][h8 * 2 + 1]; }
           const bf16x8 v = {f2bf(t0[0]), f2bf(t0[1]), f2bf(t0[2]), f2bf(t0[3]), f2bf(t1[0]), f2bf(t1[1]), f2bf(t1[2]), f2bf(t1[3])};
           const int chunk = (ni * 32 + hh * 16 + h8 * 8) >> 3;
-          *reinterpret_cast<bf16x8*>(stg + li * 128 + ((chunk ^ (li & 7)) << 4)) = v;
+          *reinterpret_cast<bf16x8*>(sl + li * 128 + ((chunk ^ (li & 7)) << 4)) = v;
         }
       } else {             // four runs of 4 columns, 8 apart: 8-byte pieces
 #pragma unroll
@@ -966,7 +967,7 @@ IA_DEV void drain_half_plain(const GemmArgs& p, f32x16 (&acc)[4][4], int m0, int
           for (int j = 0; j < 4; ++j) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t0[j]) : "a"(a[rg * 4 + j]));
           const bf16x4 v = {f2bf(t0[0]), f2bf(t0[1]), f2bf(t0[2]), f2bf(t0[3])};
           const int col = ni * 32 + rg * 8 + hh * 4;
-          *reinterpret_cast<bf16x4*>(stg + li * 128 + (((col >> 3) ^ (li & 7)) << 4) + (col & 7) * 2) = v;
+          *reinterpret_cast<bf16x4*>(sl + li * 128 + (((col >> 3) ^ (li & 7)) << 4) + (col & 7) * 2) = v;
         }
       }
 #pragma unroll
@@ -978,15 +979,15 @@ IA_DEV void drain_half_plain(const GemmArgs& p, f32x16 (&acc)[4][4], int m0, int
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
     __builtin_amdgcn_wave_barrier();
+    const char* const sl = stg + (mi & 1) * 4096;
     bf16x8 v[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int row = it * 8 + rrow;
-      v[it] = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((c8 ^ (row & 7)) << 4));
+      v[it] = *reinterpret_cast<const bf16x8*>(sl + row * 128 + ((c8 ^ (row & 7)) << 4));
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
     __builtin_amdgcn_wave_barrier();
-    if (mi < 3) stage(mi + 1);
+    if (mi < 3) stage(mi + 1);        // the other slot: no wait for the reads above (LDS operations of a wave complete in order)
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int m = m0 + mi * 32 + it * 8 + rrow, n = n0 + c8 * 8;
