@@ -40,8 +40,8 @@ struct AttnArgs {
   float sc;                                       // softmax scale * log2(e)
   float scale;                                    // softmax scale
   uint32_t thr16; float inv_keep; uint32_t seed;
-  float* cs_part;                                 // backward, optional: [(b*ntile + tile)*4 + wave][3*nh*64] fp32 column sums of this wave's
-                                                  // dq | dk | dv block (the QKV bias gradient, summed over rows by ia_sum_rows_f32); null = off
+  float* cs_part;                                 // backward, optional: [b*ntile + tile][3*nh*64] fp32 column sums of this workgroup's
+                                                  // dq | dk | dv rows (the QKV bias gradient, summed over rows by ia_sum_rows_f32); null = off
 };
 
 // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): renumber them so that consecutive
@@ -165,8 +165,9 @@ IA_DEV bool drop_keep(uint32_t seed, uint32_t stream, int q, int key, uint32_t t
 // third of the forward kernel at L = 255.  Staged through a wave-private LDS slot (32 rows x 144 B: the 16-byte pad keeps the
 // 8-byte writes at two lanes per bank) the block leaves as whole 128-byte rows, 16 B per lane, 8 rows per instruction.
 constexpr int EPI_ROW = 144, EPI_SLOT = 32 * EPI_ROW;
-// cs_out != null: the 64 column sums of the block's stored rows (of the bf16 values as stored) go to cs_out[0..63] -- each lane adds up
-// its 8 columns over its 4 rows, lanes with equal lane&7 are folded with row_ror / permlane swaps (the GEMM column-sum epilogue's pattern).
+// cs_out != null (LDS): the 64 column sums of the block's stored rows (of the bf16 values as stored) go to cs_out[0..63] -- each lane adds
+// up its 8 columns over its 4 rows, lanes with equal lane&7 are folded with row_ror / permlane swaps (the GEMM column-sum epilogue's
+// pattern); the kernel adds the four waves' rows up behind a barrier and writes one row of the partial-sum matrix per workgroup.
 IA_DEV void store_block_rows(char* slot, const f32x16& a0, const f32x16& a1, float mul, bool zero, bf16* out, size_t ld, int nrows, int lane,
                              float* cs_out = nullptr) {
   const int hh = lane >> 5, lq = lane & 31;
@@ -212,7 +213,7 @@ IA_DEV void store_block_rows(char* slot, const f32x16& a0, const f32x16& a1, flo
     }
   }
 }
-// a wave without rows (past the end of the sequence) still owns a row of the partial-sum matrix: zeros
+// a wave without rows (past the end of the sequence) still contributes its (zero) row
 IA_DEV void zero_cs_row(float* cs_out, int lane) {
   if (lane < 16) *reinterpret_cast<f32x4*>(cs_out + lane * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
 }
@@ -539,9 +540,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  float* cs_row = p.cs_part ? p.cs_part + ((size_t)(b * ((p.Lq + 127) >> 7) + tile) * 4 + wave) * (3 * p.nh * 64) + h * 64 : nullptr;
-  if (!active) { if (cs_row) zero_cs_row(cs_row, lane); return; }
-  store_block_rows(smem + wave * EPI_SLOT, dq0, dq1, p.scale, false, p.dq + (qbase + q0) * p.ld_dq + h * 64, p.ld_dq, Lq - q0, lane, cs_row);
+  float* cs_lds = p.cs_part ? reinterpret_cast<float*>(smem + 4 * EPI_SLOT) + wave * 64 : nullptr;      // behind the four store slots
+  if (!active && !cs_lds) return;
+  if (active) store_block_rows(smem + wave * EPI_SLOT, dq0, dq1, p.scale, false, p.dq + (qbase + q0) * p.ld_dq + h * 64, p.ld_dq, Lq - q0, lane, cs_lds);
+  else zero_cs_row(cs_lds, lane);
+  if (cs_lds) {           // workgroup-uniform: one row of the partial-sum matrix per workgroup
+    __syncthreads();
+    if (wave == 0) {
+      const float* c = reinterpret_cast<const float*>(smem + 4 * EPI_SLOT);
+      p.cs_part[(size_t)(b * ((p.Lq + 127) >> 7) + tile) * (3 * p.nh * 64) + h * 64 + lane] = (c[lane] + c[64 + lane]) + (c[128 + lane] + c[192 + lane]);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------- backward: dK, dV
@@ -675,12 +684,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  float* cs_row = p.cs_part ? p.cs_part + ((size_t)(b * ((p.Lk + 127) >> 7) + tile) * 4 + wave) * (3 * p.nh * 64) + p.nh * 64 + h * 64 : nullptr;
-  if (!active) { if (cs_row) { zero_cs_row(cs_row, lane); zero_cs_row(cs_row + p.nh * 64, lane); } return; }
-  // a masked key's outputs are zero (its P is not bounded by the saved log-sum-exp, so the accumulators may hold inf / nan)
-  store_block_rows(smem + wave * 2 * EPI_SLOT, dk0, dk1, p.scale, !key_ok, p.dk + (rowbase + k0) * p.ld_dkv + h * 64, p.ld_dkv, L - k0, lane, cs_row);
-  store_block_rows(smem + (wave * 2 + 1) * EPI_SLOT, dv0, dv1, 1.f, !key_ok, p.dv + (rowbase + k0) * p.ld_dkv + h * 64, p.ld_dkv, L - k0, lane,
-                   cs_row ? cs_row + p.nh * 64 : nullptr);
+  float* cs_lds = p.cs_part ? reinterpret_cast<float*>(smem + 8 * EPI_SLOT) + wave * 128 : nullptr;     // behind the eight store slots: dk | dv sums
+  if (!active && !cs_lds) return;
+  if (active) {
+    // a masked key's outputs are zero (its P is not bounded by the saved log-sum-exp, so the accumulators may hold inf / nan)
+    store_block_rows(smem + wave * 2 * EPI_SLOT, dk0, dk1, p.scale, !key_ok, p.dk + (rowbase + k0) * p.ld_dkv + h * 64, p.ld_dkv, L - k0, lane, cs_lds);
+    store_block_rows(smem + (wave * 2 + 1) * EPI_SLOT, dv0, dv1, 1.f, !key_ok, p.dv + (rowbase + k0) * p.ld_dkv + h * 64, p.ld_dkv, L - k0, lane,
+                     cs_lds ? cs_lds + 64 : nullptr);
+  } else { zero_cs_row(cs_lds, lane); zero_cs_row(cs_lds + 64, lane); }
+  if (cs_lds) {
+    __syncthreads();
+    if (wave < 2) {         // wave 0: the dk columns, wave 1: the dv columns
+      const float* c = reinterpret_cast<const float*>(smem + 8 * EPI_SLOT) + wave * 64;
+      p.cs_part[(size_t)(b * ((p.Lk + 127) >> 7) + tile) * (3 * p.nh * 64) + (1 + wave) * p.nh * 64 + h * 64 + lane] =
+          (c[lane] + c[128 + lane]) + (c[256 + lane] + c[384 + lane]);
+    }
+  }
 }
 
 // packed_rows > 0: packed self-attention over that many token rows in total (AttnArgs::cu), Lq == Lk == longest sequence
@@ -767,11 +786,11 @@ extern "C" int ia_attn_bwd(const void* q, const void* k, const void* v, int ld_q
 }
 
 // ia_attn_bwd that also returns the bias gradient of the fused QKV projection: dbias[3*nh*64] (q | k | v order) += column sums of
-// dq, dk, dv over all tokens, taken from the rows as they are stored (each wave's 64 sums go to a row of the workspace matrix, one
+// dq, dk, dv over all tokens, taken from the rows as they are stored (each workgroup's sums go to a row of the workspace matrix, one
 // fixed-order fold afterwards: deterministic) -- the separate column-sum pass over [tokens, 3H] disappears from the layer backward.
 extern "C" size_t ia_attn_bwd_bias_workspace_bytes(int B, int nh, int L) {
   if (B <= 0 || nh <= 0 || L <= 0) return 0;
-  return (size_t)B * ((L + 127) / 128) * 4 * 3 * nh * 64 * sizeof(float);
+  return (size_t)B * ((L + 127) / 128) * 3 * nh * 64 * sizeof(float);
 }
 
 extern "C" int ia_attn_bwd_bias(const void* q, const void* k, const void* v, int ld_qkv, const uint8_t* key_mask, const void* out,
@@ -799,7 +818,7 @@ extern "C" int ia_attn_bwd_bias(const void* q, const void* k, const void* v, int
   }
   rc = ia_check_launch();
   if (rc) return rc;
-  return ia_sum_rows_f32((const float*)workspace, B * ((L + 127) / 128) * 4, 3 * nh * 64, dbias, 1, stream);
+  return ia_sum_rows_f32((const float*)workspace, B * ((L + 127) / 128), 3 * nh * 64, dbias, 1, stream);
 }
 
 // Packed ("unpadded") self-attention: the token rows of all sequences lie back to back, sequence b owning rows
