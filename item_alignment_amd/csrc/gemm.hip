@@ -1446,7 +1446,10 @@ static int gemm_core(const void* A, int a_kstrided, int lda, const void* B, int 
   const bool wgrad_form = a_kstrided && b_kstrided && c_is_f32 && epilogue == EPI_NONE;
   g.rsum_out = (wgrad_form && !big) ? (float*)C2 : nullptr;
   g.rsum_ws = nullptr;
-  if (c_is_f32 && pl.splits > 1 && workspace && workspace_bytes >= (size_t)groups * pl.splits * M * (N + (g.rsum_out ? 1 : 0)) * sizeof(float)) {
+  // split-K sums partial products: only the plain epilogue may be cut (a bias would be added once per k-slab -- the fp32 + bias form
+  // came out with 2-8 x the bias until round 2's edge-shape test)
+  if (c_is_f32 && epilogue == EPI_NONE && pl.splits > 1 && workspace &&
+      workspace_bytes >= (size_t)groups * pl.splits * M * (N + (g.rsum_out ? 1 : 0)) * sizeof(float)) {
     g.nk_per_split = (nk + pl.splits - 1) / pl.splits;
     g.splits = (nk + g.nk_per_split - 1) / g.nk_per_split;
     g.ws = (float*)workspace;

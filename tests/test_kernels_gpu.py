@@ -420,6 +420,27 @@ def test_gpu_image_pipeline_bit_exact(gpu, tmp_path, H, W, S):
     assert any(it.params.flip for it in items) and any(it.params.jitter[0][0] == 1 for it in items[:-1] if it.params.jitter)
 
 
+@pytest.mark.parametrize("M,N,K", [(1024, 1024, 64), (1024, 1024, 128), (1024, 768, 8), (1000, 520, 72), (3000, 4096, 64), (8200, 2056, 256),
+                                   (512, 512, 4104)])
+def test_gemm_one_wave_per_simd_kernel_edges(gpu, M, N, K):
+    """The T256W kernel (one wave per SIMD; serves the plain / bias / +residual / fp32 / weight-gradient forms of large GEMMs): one and
+    two k-tiles (its loop prefetches k-tile u+2 and reads k-tile u+1 ahead), ragged K, clipped M / N tiles (bias fetched before the
+    main loop only for full tiles, bf16-staged epilogue vs the fp32-staged fall-back), more tiles than workgroups."""
+    from item_alignment_amd import ops
+    a, w = rnd((M, K), gpu, 1.0, 61), rnd((N, K), gpu, 0.1, 62)
+    bias = torch.randn(N, device=gpu)
+    aux = rnd((M, N), gpu, 1.0, 63)
+    ref = a.float() @ w.float().t()
+    assert rel_err(ops.gemm(a, w), ref) < 2e-2
+    assert rel_err(ops.gemm(a, w, epilogue=ops.EPI_BIAS, bias=bias), ref + bias) < 2e-2
+    assert rel_err(ops.gemm(a, w, epilogue=ops.EPI_BIAS_ADD, bias=bias, aux=aux), ref + bias + aux.float()) < 2e-2
+    assert rel_err(ops.gemm(a, w, out_f32=True), ref) < 2e-3
+    assert rel_err(ops.gemm(a, w, epilogue=ops.EPI_BIAS, bias=bias, out_f32=True), ref + bias) < 2e-3
+    wt, at = w.t().contiguous(), a.t().contiguous()
+    assert rel_err(ops.gemm(a, wt, b_kstrided=True), ref) < 2e-2
+    assert rel_err(ops.gemm(at, wt, a_kstrided=True, b_kstrided=True, out_f32=True), ref) < 2e-3
+
+
 @pytest.mark.parametrize("M,N,K,epi", [(8200, 2056, 256, "none"), (8200, 2056, 320, "bias_gelu"), (16500, 1032, 192, "add")])
 def test_gemm_persistent_rounds_with_clipped_tiles(gpu, M, N, K, epi):
     """More than 256 output tiles (the T256 kernel loops over tiles per workgroup, keeps the previous tile's stores in

@@ -4,6 +4,8 @@
 #define IA_ATTN_SRC "../../item_alignment_amd/csrc/attention.hip"
 #endif
 #include IA_ATTN_SRC
+// the library's partial-sum fold (layernorm.hip), referenced by ia_attn_bwd_bias: not exercised by this harness
+int ia_sum_rows_f32(const float*, int, int, float*, int, hipStream_t) { return 0; }
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
