@@ -198,6 +198,51 @@ def test_attention_bwd_bias_gradient(gpu, B, L, nh, masked, drop):
     assert (dbias - want).abs().max().item() <= 1e-3 * (1.0 + want.abs().max().item())
 
 
+@pytest.mark.parametrize("B,L,nh", [(2, 128, 2), (1, 200, 3)])
+def test_attention_dropout_mask_is_the_same_in_forward_and_both_backward_kernels(gpu, B, L, nh):
+    """The dropped, rescaled probabilities A = P o M / keep are recovered from the forward kernel itself (V = shifted one-hot rows: the
+    output is then a 64-column window of A), the plain P from a run without dropout; the backward of the dropout run must equal the
+    closed form built from exactly that A (dV = A^T dO, dS = P o (M/keep o dP - delta)) -- i.e. the dQ and the dK/dV kernels regenerate
+    the forward's mask bit for bit."""
+    from item_alignment_amd import ops
+    H = nh * 64
+    drop, seed, scale = 0.25, 77, 0.125
+    qkv = rnd((B * L, 3 * H), gpu, 0.7, 31)
+    dctx = rnd((B * L, H), gpu, 1.0, 32)
+
+    def probs(drop_p):
+        A = torch.zeros((B, nh, L, L), device=gpu)
+        for j0 in range(0, L, 64):
+            t = qkv.clone().view(B, L, 3, nh, 64)
+            t[:, :, 2] = 0
+            for d in range(min(64, L - j0)):
+                t[:, j0 + d, 2, :, d] = 1.0
+            out, _ = ops.attn_fwd(t.view(B * L, 3 * H), B, L, nh, drop_p=drop_p, seed=seed)
+            w = min(64, L - j0)
+            A[:, :, :, j0:j0 + w] = out.float().view(B, L, nh, 64).permute(0, 2, 1, 3)[..., :w]
+        return A
+
+    P, A = probs(0.0), probs(drop)
+    keepmask = A > 0
+    frac = 1.0 - keepmask.float().mean().item() - (P <= 1e-30).float().mean().item()
+    assert abs(frac - drop) < 0.02, frac
+    ctx, lse = ops.attn_fwd(qkv, B, L, nh, drop_p=drop, seed=seed)
+    dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, B, L, nh, drop_p=drop, seed=seed).float().view(B, L, 3, nh, 64)
+    t = qkv.float().view(B, L, 3, nh, 64)
+    q, k, v = (t[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    do = dctx.float().view(B, L, nh, 64).permute(0, 2, 1, 3)
+    o = A @ v
+    assert rel_err(ctx.float().view(B, L, nh, 64).permute(0, 2, 1, 3), o) < 3e-2
+    Mk = torch.where(keepmask, A / P.clamp_min(1e-30), torch.zeros_like(A))          # M / keep
+    dp = Mk * (do @ v.transpose(-1, -2))
+    delta = (do * o).sum(-1, keepdim=True)
+    ds = P * (dp - delta)
+    want = [ds @ k * scale, ds.transpose(-1, -2) @ q * scale, A.transpose(-1, -2) @ do]
+    for i, name in enumerate("qkv"):
+        got = dqkv[:, :, i].permute(0, 2, 1, 3)
+        assert rel_err(got, want[i]) < 4e-2, name
+
+
 def test_attention_dropout_statistics(gpu):
     """Dropout on the attention probabilities: mean preserved, fwd/bwd use the same mask (checked by
     linearity: with V = const the output stays ~const)."""
