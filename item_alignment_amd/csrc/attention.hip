@@ -152,12 +152,10 @@ IA_DEV f32x16 zero16() {
 // row index inside a 32-row accumulator block for register r of lane-half hh
 #define ACC_ROW(r, hh) (((r) & 3) + 8 * ((r) >> 2) + 4 * (hh))
 
-// dropout keep decision for element (q, key) of stream (b, h)
-IA_DEV bool drop_keep(uint32_t seed, uint32_t stream, int q, int key, uint32_t thr16) {
-  const uint32_t r = ia_rng(seed, stream, (uint32_t)q * 1024u + ((uint32_t)key >> 1));
-  const uint32_t u = (key & 1) ? (r >> 16) : (r & 0xFFFFu);
-  return u >= thr16;
-}
+// dropout: element (q, key) of stream (b, h) is kept iff its 16-bit draw >= thr16; the draw is the low (even key) or high (odd key)
+// half of ia_rng_pair(row key of q, (key >> 1) * IA_RNG_PAIR_C) (common.h).  The three kernels assemble the pair constant from parts
+// they have for free (lane, tile, register index), so the loops carry no integer multiply beyond the one inside the mix.
+IA_DEV uint32_t pair_c_of(int key) { return ((uint32_t)key >> 1) * IA_RNG_PAIR_C; }
 
 // Epilogue store of a wave's 32 x 64 bf16 block that sits in two transposed accumulator blocks (a0: columns d = 0..31, a1: d = 32..63
 // of the output row this lane's column lane&31 stands for).  Written straight from the accumulators a lane owns 8-byte pieces of 32
@@ -229,7 +227,7 @@ constexpr float RESCALE_THR = 8.f;
 
 template <int BUF, bool DROPOUT>
 IA_DEV void fwd_tile(const AttnArgs& p, const char* smem, const bf16x8 (&qf)[4], uint32_t valid_lo, uint32_t valid_hi,
-                     float& m_ref, float& l_run, f32x16& o0, f32x16& o1, int lane, int q, int kt, uint32_t stream_id) {
+                     float& m_ref, float& l_run, f32x16& o0, f32x16& o1, int lane, int q, int kt, uint32_t rk) {
   const int hh = lane >> 5, lq = lane & 31;
   const char* sK = smem + BUF * 16384;
   f32x16 s0 = zero16(), s1 = zero16();
@@ -283,11 +281,14 @@ IA_DEV void fwd_tile(const AttnArgs& p, const char* smem, const bf16x8 (&qf)[4],
   }
   l_run += rs;
   if (DROPOUT) {
+    // key = kt*64 + ACC_ROW(r, hh) (+ 32 for the second block): pair constant = tile part (scalar) + lane part (hh) + immediate
+    const uint32_t tile_c = (uint32_t)(kt * 32) * IA_RNG_PAIR_C + (uint32_t)(2 * hh) * IA_RNG_PAIR_C;
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
-      const int kl = ACC_ROW(r, hh);   // even key, r+1 is the odd neighbour
-      const uint32_t ra = ia_rng(p.seed, stream_id, (uint32_t)q * 1024u + (uint32_t)((kt * 64 + kl) >> 1));
-      const uint32_t rb = ia_rng(p.seed, stream_id, (uint32_t)q * 1024u + (uint32_t)((kt * 64 + 32 + kl) >> 1));
+      constexpr uint32_t C = IA_RNG_PAIR_C;
+      const uint32_t imm = (uint32_t)(((r & 3) >> 1) + 4 * (r >> 2)) * C;      // (ACC_ROW(r, 0) >> 1) * C, r even
+      const uint32_t ra = ia_rng_pair(rk, tile_c + imm);
+      const uint32_t rb = ia_rng_pair(rk, tile_c + imm + 16u * C);
       if ((ra & 0xFFFFu) < p.thr16) s0[r] = 0.f;
       if ((ra >> 16) < p.thr16) s0[r + 1] = 0.f;
       if ((rb & 0xFFFFu) < p.thr16) s1[r] = 0.f;
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   float m_ref = 0.f, l_run = 0.f;
   f32x16 o0 = zero16(), o1 = zero16();
   const int nkt = (L + 63) >> 6;
-  const uint32_t stream_id = (uint32_t)(b * p.nh + h);
+  const uint32_t rk = DROPOUT ? ia_rng_row(p.seed, (uint32_t)(b * p.nh + h), (uint32_t)q) : 0u;      // row key of this lane's query
   auto prefetch = [&](int buf, int kt) {
     if (kt < nkt) {
       char* nb = smem + buf * 16384;
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
       const uint32_t valid_hi = __builtin_amdgcn_readfirstlane(s_valid[kt][1]);
       // a tile with no attendable key contributes nothing
       if ((valid_lo | valid_hi) != 0u)
-        fwd_tile<decltype(BUF)::value, DROPOUT>(p, smem, qf, valid_lo, valid_hi, m_ref, l_run, o0, o1, lane, q, kt, stream_id);
+        fwd_tile<decltype(BUF)::value, DROPOUT>(p, smem, qf, valid_lo, valid_hi, m_ref, l_run, o0, o1, lane, q, kt, rk);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 // applied once, when dQ is stored).
 template <bool DROPOUT>
 IA_DEV void dq_tile(const AttnArgs& p, const char* sK, const bf16x8 (&qf)[4], const bf16x8 (&gf)[4], uint32_t valid_lo,
-                    uint32_t valid_hi, float lse, float dlt, f32x16& dq0, f32x16& dq1, int lane, int q, int kt, uint32_t stream_id) {
+                    uint32_t valid_hi, float lse, float dlt, f32x16& dq0, f32x16& dq1, int lane, int q, int kt, uint32_t rk) {
   const int hh = lane >> 5, lq = lane & 31;
   const char* sKt = sK + 8192;
   const char* sV = sK + 16384;
@@ -428,18 +429,28 @@ IA_DEV void dq_tile(const AttnArgs& p, const char* sK, const bf16x8 (&qf)[4], co
     }
   }
   const float neg_lse = -lse;
+  const uint32_t tile_c = (uint32_t)(kt * 32) * IA_RNG_PAIR_C + (uint32_t)(2 * hh) * IA_RNG_PAIR_C;      // as in fwd_tile
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const float pa = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], p.sc, neg_lse));
-    const float pb = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], p.sc, neg_lse));
-    float da = dp0[r], db = dp1[r];
+  for (int r = 0; r < 16; r += 2) {
+    uint32_t ra = 0xFFFFFFFFu, rb = 0xFFFFFFFFu;       // one draw per pair of neighbouring keys (r, r+1)
     if (DROPOUT) {
-      const int kl = kt * 64 + ACC_ROW(r, hh);
-      da = drop_keep(p.seed, stream_id, q, kl, p.thr16) ? da * p.inv_keep : 0.f;
-      db = drop_keep(p.seed, stream_id, q, kl + 32, p.thr16) ? db * p.inv_keep : 0.f;
+      constexpr uint32_t C = IA_RNG_PAIR_C;
+      const uint32_t imm = (uint32_t)(((r & 3) >> 1) + 4 * (r >> 2)) * C;
+      ra = ia_rng_pair(rk, tile_c + imm);
+      rb = ia_rng_pair(rk, tile_c + imm + 16u * C);
     }
-    s0[r] = pa * (da - dlt);
-    s1[r] = pb * (db - dlt);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float pa = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r + e], p.sc, neg_lse));
+      const float pb = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r + e], p.sc, neg_lse));
+      float da = dp0[r + e], db = dp1[r + e];
+      if (DROPOUT) {
+        da = ((e ? ra >> 16 : ra & 0xFFFFu) >= p.thr16) ? da * p.inv_keep : 0.f;
+        db = ((e ? rb >> 16 : rb & 0xFFFFu) >= p.thr16) ? db * p.inv_keep : 0.f;
+      }
+      s0[r + e] = pa * (da - dlt);
+      s1[r + e] = pb * (db - dlt);
+    }
   }
   bf16x8 sf[4];
 #pragma unroll
@@ -488,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
   const int qc = q < Lq ? q : Lq - 1;
   const __amdgpu_buffer_rsrc_t rsK = ia_rsrc(p.k, p.kv_bytes);
   const __amdgpu_buffer_rsrc_t rsV = ia_rsrc(p.v, p.kv_bytes);
-  const uint32_t stream_id = (uint32_t)(b * p.nh + h);
+  const uint32_t rk = DROPOUT ? ia_rng_row(p.seed, (uint32_t)(b * p.nh + h), (uint32_t)q) : 0u;      // row key of this lane's query
   const int nkt = (L + 63) >> 6;
 
   // One memory round trip for the whole prologue: this wave's q / dO / o rows (wave-private 4 KiB slots behind ring slot 0), the
@@ -535,7 +546,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
       const uint32_t valid_lo = __builtin_amdgcn_readfirstlane(s_valid[kt][0]);
       const uint32_t valid_hi = __builtin_amdgcn_readfirstlane(s_valid[kt][1]);
       if ((valid_lo | valid_hi) != 0u)
-        dq_tile<DROPOUT>(p, smem + buf * 24576, qf, gf, valid_lo, valid_hi, lse, dlt, dq0, dq1, lane, q, kt, stream_id);
+        dq_tile<DROPOUT>(p, smem + buf * 24576, qf, gf, valid_lo, valid_hi, lse, dlt, dq0, dq1, lane, q, kt, rk);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -562,7 +573,8 @@ template <bool DROPOUT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   // per buffer: Q (b128) | Q (transpose-read) | dO (b128) | dO (transpose-read) | lse[64] | delta[64]
   constexpr int BUF = 32768 + 512;
-  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+  // + 1 KiB: under dropout every wave keeps the 64 row keys (ia_rng_row) of the current query tile in a private 256-byte slot
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF + 1024];
   const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, lk = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int tile, h, b;
@@ -586,6 +598,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   const __amdgpu_buffer_rsrc_t rsL = ia_rsrc(p.lse2 + ((size_t)b * p.nh + h) * p.Lq, (uint32_t)Lq * 4u);
   const __amdgpu_buffer_rsrc_t rsD = ia_rsrc(p.delta + ((size_t)b * p.nh + h) * p.Lq, (uint32_t)Lq * 4u);
   const uint32_t stream_id = (uint32_t)(b * p.nh + h);
+  // dropout draw of (q, key): key is this lane -> its pair constant and the half of the draw it reads are lane constants
+  const uint32_t pc = pair_c_of(key), ush = (uint32_t)(key & 1) * 16u;
+  uint32_t* const s_rk = reinterpret_cast<uint32_t*>(smem + 2 * BUF) + wave * 64;
 
   f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
   const int nqt = (Lq + 63) >> 6;
@@ -619,6 +634,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     const int buf = qt & 1;
     if (qt + 1 < nqt) stage_all(smem + (buf ^ 1) * BUF, qt + 1);
     if (active) {
+      if (DROPOUT) {      // row keys of this tile's 64 queries, one per lane (the wave's LDS operations complete in order: no barrier)
+        s_rk[lane] = ia_rng_row(p.seed, stream_id, (uint32_t)(qt * 64 + lane));
+        __builtin_amdgcn_wave_barrier();
+      }
       const char* sQ = smem + buf * BUF;
       const char* sG = sQ + 16384;
       const uint32_t qt0 = lds_addr(sQ + 8192) + tr_lane_off(lane, 0), qt1 = lds_addr(sQ + 8192) + tr_lane_off(lane, 32);
@@ -648,6 +667,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
           const int qoff = qs * 32 + 8 * rg + 4 * hh;              // 4 consecutive queries
           const f32x4 ls = *reinterpret_cast<const f32x4*>(sL + qoff);
           const f32x4 dl = *reinterpret_cast<const f32x4*>(sD + qoff);
+          u32x4 rkq = {0u, 0u, 0u, 0u};
+          if (DROPOUT) rkq = *reinterpret_cast<const u32x4*>(s_rk + qoff);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int r = rg * 4 + j;
@@ -655,7 +676,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
             float d = dp[r];
             float pd = pv;
             if (DROPOUT) {
-              const bool keep = drop_keep(p.seed, stream_id, qb + 8 * rg + 4 * hh + j, key, p.thr16);
+              const bool keep = ((ia_rng_pair(rkq[j], pc) >> ush) & 0xFFFFu) >= p.thr16;
               d = keep ? d * p.inv_keep : 0.f;
               pd = keep ? pv * p.inv_keep : 0.f;
             }

@@ -106,6 +106,18 @@ IA_DEV uint32_t ia_rng(uint32_t seed, uint32_t stream, uint32_t idx) {
   return ia_mix32(idx ^ ia_mix32(stream ^ (seed * 0x9E3779B9U)));
 }
 
+// Row-keyed variant for the attention dropout (element = (row q, column key) of stream (b, h)): one full mix per (stream, row) --
+// ia_rng_row, computed once per row -- and per PAIR of columns one xor + multiply + xorshift of the row key against the column
+// pair's constant (pair * IA_RNG_PAIR_C, assembled from lane / tile / immediate parts by the kernels so that no integer multiply
+// sits in the inner loops): 7 VALU issue slots per 32-bit draw instead of 15.  Statistics checked on 40 x 256 x 256 masks against
+// the two-round hash (keep rate, adjacent-key / adjacent-row / in-pair / cross-stream correlations, binomial row sums).
+constexpr uint32_t IA_RNG_PAIR_C = 0x9E3779B1U;
+IA_DEV uint32_t ia_rng_row(uint32_t seed, uint32_t stream, uint32_t row) { return ia_mix32(row ^ ia_mix32(stream ^ (seed * 0x9E3779B9U))); }
+IA_DEV uint32_t ia_rng_pair(uint32_t rowkey, uint32_t pair_c) {      // pair_c = (column >> 1) * IA_RNG_PAIR_C
+  const uint32_t h = (rowkey ^ pair_c) * 0x846ca68bU;
+  return h ^ (h >> 16);                                               // column & 1 ? high : low 16 bits
+}
+
 // erf-GELU (the reference's hidden_act = "gelu": x * Phi(x)).  erf comes from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7,
 // far below bf16 resolution) on one v_rcp + one v_exp, because the GELU epilogues run on the VALU in the shadow of no
 // MFMA work (libm erff costs ~2x as many instructions); exp(-x^2/2) is shared by Phi and the density phi.
