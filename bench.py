@@ -160,6 +160,12 @@ def main():
     args = ap.parse_args()
     if args.unpad:
         os.environ["IA_UNPAD"] = "1"
+    # stdout carries exactly ONE line, the result JSON of rank 0.  Native libraries write there too (RCCL prints a five-line version
+    # banner when the pool exports NCCL_DEBUG=VERSION): everything written to fd 1 during the run goes to stderr, the result line to the
+    # saved descriptor.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     from item_alignment_amd import _lib
     from item_alignment_amd import dist as iadist
@@ -301,9 +307,11 @@ def main():
                 res["cpu_baseline"] = cpu_baseline(cfg, args.image_model, args.cpu_pairs, args.cpu_steps, args.seed)
             except Exception as e:  # the baseline must never take the GPU number down with it
                 res["cpu_baseline"] = {"value": None, "unit": "item-pairs/sec", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
-        print(json.dumps(res), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(res) + "\n").encode())
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+    os.close(result_fd)
 
 
 if __name__ == "__main__":
