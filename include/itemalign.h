@@ -34,6 +34,10 @@ typedef struct ihipStream_t* ia_stream_t; /* hipStream_t */
 #define IA_ERR_UNSUPPORTED (-4)
 
 const char* ia_strerror(int code);
+/* Bumped whenever an entry point is added or the meaning of an argument / output changes (round 2 changed what IA_EPI_BIAS_GELU
+ * stores in C2 and what IA_EPI_DGELU expects in aux): a caller built against another header must not run on this library.
+ * item_alignment_amd/_lib.py refuses to load a library whose version differs from the one it was written for. */
+#define IA_ABI_VERSION 3
 int ia_abi_version(void);
 
 /* ---- GEMM: torch.nn.Linear forward / dgrad / wgrad (src/models/text.py:1241 -> RobertaLayer dense

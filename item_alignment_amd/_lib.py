@@ -127,6 +127,9 @@ SIGNATURES = {
 _lib = None
 
 
+ABI_VERSION = 3      # = IA_ABI_VERSION of include/itemalign.h (tests/test_cabi_symbols.py keeps the two in step)
+
+
 class ItemAlignError(RuntimeError):
     pass
 
@@ -148,6 +151,10 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so is stale
         fn.restype = res
         fn.argtypes = args
+    got = lib.ia_abi_version()
+    if got != ABI_VERSION:
+        raise ItemAlignError(f"{LIB_PATH} has ABI version {got}, this package needs {ABI_VERSION} (include/itemalign.h: IA_ABI_VERSION): "
+                             "stale build, run `make -C item_alignment_amd/csrc`")
     _lib = lib
     return lib
 

@@ -18,6 +18,7 @@
 //   attn_bwd_dkv (block owns 128 keys,   S orientation):     dV^T += dO^T P ; dK^T += Q^T dS
 #include "common.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -393,6 +394,329 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   store_block_rows(smem + wave * EPI_SLOT, o0, o1, inv, false, p.out + (qbase + q0) * p.ld_o + h * 64, p.ld_o, Lq - q0, lane);
 }
 
+// ------------------------------------------------------------------------------------------ forward, round 3
+// Same arithmetic and tile geometry (4 waves x 32 queries, 64-key tiles, S^T orientation) as attn_fwd_kernel above, restructured after
+// tools/abl/issue_model.hip had priced the instruction streams on an MI355X (profiles/r03_issue_model.txt):
+//  * the softmax is down to its 80 unavoidable VALU instructions per tile (32 exp2, 32 adds, 16 packed converts): the query fragments
+//    are pre-scaled by scale*log2(e) once per block, and -m_ref comes out of the matrix pipe as the C operand of the first QK^T MFMA
+//    (a 16-register block holding -m_ref), so an accumulator IS exp2's argument; no running maximum is taken at all -- m_ref only
+//    moves when a row's sum leaves [2^-60, 2^60] (rebase(): scores recomputed from the K tile still in the ring, true maximum taken);
+//    any reference cancels in O / l, and exp2 arguments stay far inside the fp32 exponent range;
+//  * masked / out-of-range keys get -1e30 from one extra MFMA per 32-key block (A = the penalty in k-slot 0 of the key's row, B = ones
+//    in k-slot 0) instead of 64 compare+select pairs (v_cmp 8.6 cycles, v_cndmask behind it 4.8: 13 cycles per select on one wave);
+//  * software pipelined inside the wave: QK^T of tile t+1 is issued under the softmax of tile t (two score blocks live), the V^T
+//    fragments of tile t and the K fragments of tile t+2 are in registers before the MFMAs that use them (asm reads, counted waits);
+//  * K ring of 4, V ring of 3 LDS slots; the DMA of K(t+3) / V(t+2) is issued at the top of iteration t and only K(t+2) is waited for
+//    there (counted vmcnt), one raw s_barrier per tile.
+#ifndef IA_F3_ABL
+#define IA_F3_ABL 0          // ablation bits for tools/abl/attn_dev.hip builds: 1 no K/V DMA in the loop, 2 no barrier, 4 no compute, 8 no exp, 16 no LDS reads
+#endif
+#ifndef IA_F3_PRESCALE
+#define IA_F3_PRESCALE 1     // 1: Q fragments carry scale * log2(e) (one more bf16 rounding of q, no multiply per score); 0: exp2(s * sc)
+#endif
+namespace fwd3 {
+constexpr bool PRESCALE = IA_F3_PRESCALE != 0;
+// LDS: K ring | V ring | [PIPE: Q staging, later the epilogue's row staging] | valid-key table.  Without PIPE the K ring is 3 deep as
+// well (the fragments of tile t+1 are read during tile t), Q is staged in the last V slot (first filled behind the first barrier) and
+// the epilogue rows in the K ring (behind a last barrier): 48 KiB, three workgroups per CU.
+template <bool PIPE>
+struct Cfg {
+  static constexpr int KRING = PIPE ? 4 : 3, VRING = 3;
+  // PIPE: K0..K3 | V0..V2 | Q / epilogue rows | table.   otherwise: K0 K1 | V0 V1 | K2 V2 (= Q staging, 16 KiB) | table
+  static constexpr int Q_OFF = PIPE ? (KRING + VRING) * 8192 : 32768;
+  static constexpr int EPI_OFF = PIPE ? Q_OFF : 0;
+  static constexpr int TAB_OFF = PIPE ? Q_OFF + 4 * EPI_SLOT : 49152;
+  static constexpr int SMEM = TAB_OFF + MAX_KT * 8;
+  static IA_DEV int k_slot(int kt) { const int s = kt % KRING; return PIPE ? s * 8192 : (s == 2 ? 32768 : s * 8192); }
+  static IA_DEV int v_slot(int kt) { const int s = kt % VRING; return PIPE ? (KRING + s) * 8192 : (s == 2 ? 40960 : 16384 + s * 8192); }
+};
+constexpr float L_LO = 8.6736174e-19f, L_HI = 1.1529215e18f;                      // 2^-60, 2^60
+constexpr float NEG_BIG = -1e30f;
+constexpr uint32_t NEG_BIG_BF16 = 0xF14Au;                                        // bf16(-1e30)
+
+template <int OFF>
+IA_DEV bf16x8 lds_read_b128(uint32_t addr) {
+  bf16x8 d;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+  return d;
+}
+// wait until at most N LDS operations issued after these eight fragments are outstanding
+template <int N>
+IA_DEV void frag_wait(bf16x8 (&f)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]) : "n"(N));
+}
+IA_DEV float swap32(float x) {      // the partner lane's (lane ^ 32) value
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return (threadIdx.x & 32) ? a : b;
+}
+IA_DEV f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+
+struct Lane {          // lane constants of the fragment reads
+  uint32_t ka[4];      // byte offset of this lane's K fragment (row lq, k-step kb) inside a K tile; the second 32-key block is +4096
+  uint32_t v0, v1;     // transpose-read offsets inside a V tile (d 0..31 / 32..63)
+};
+
+// all eight K fragments of a tile (kf[kb * 2 + blk])
+IA_DEV void read_k(bf16x8 (&kf)[8], const Lane& ln, uint32_t tile_addr) {
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    const uint32_t a = tile_addr + ln.ka[kb];
+    kf[kb * 2] = lds_read_b128<0>(a);
+    kf[kb * 2 + 1] = lds_read_b128<4096>(a);
+  }
+}
+
+// Scores of one 64-key tile against this wave's 32 queries: s = K (Q * scale * log2 e)^T [- m_ref] [- 1e30 on keys that may not be
+// attended].  The two optional terms come from one more MFMA per 32-key block whose A operand carries (penalty, 1) in k-slots 0 / 1 of
+// the key's row and whose B operand carries (1, -m_ref) in k-slots 0 / 1 of the query's column; a tile whose 64 keys are all
+// attendable in a wave that never left the reference 0 (the common case) starts from the inline constant 0 instead.
+// refw: this lane's B word {bf16 1.0, bf16 -m_ref} (lanes 32..63, which hold k-slots 8..15: 0).
+IA_DEV void qk_tile(f32x16& s0, f32x16& s1, const bf16x8 (&kf)[8], const bf16x8 (&qf)[4], bool plain, uint32_t refw, uint32_t valid_lo,
+                    uint32_t valid_hi, int lane) {
+  const f32x16 zero = zero16();
+  if (plain) {                                                                      // wave-uniform
+    s0 = mfma(kf[0], qf[0], zero);
+    s1 = mfma(kf[1], qf[0], zero);
+  } else {
+    const uint32_t low = (lane & 32) ? 0u : 1u;
+    const uint32_t bad0 = ((~valid_lo) >> (lane & 31)) & low, bad1 = ((~valid_hi) >> (lane & 31)) & low;
+    const u32x4 a0 = {bad0 * NEG_BIG_BF16 + low * 0x3F800000u, 0u, 0u, 0u}, a1 = {bad1 * NEG_BIG_BF16 + low * 0x3F800000u, 0u, 0u, 0u};
+    const u32x4 bw = {refw, 0u, 0u, 0u};
+    const f32x16 c0 = mfma(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, bw), zero);
+    const f32x16 c1 = mfma(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, bw), zero);
+    s0 = mfma(kf[0], qf[0], c0);
+    s1 = mfma(kf[1], qf[0], c1);
+  }
+#pragma unroll
+  for (int kb = 1; kb < 4; ++kb) {
+    s0 = mfma(kf[kb * 2], qf[kb], s0);
+    s1 = mfma(kf[kb * 2 + 1], qf[kb], s1);
+  }
+}
+
+struct Row {           // per-lane softmax state of its query (the partner lane ^ 32 holds the other half of the keys)
+  float m_ref, l_run;  // m_ref is a bf16-representable number (it travels through the matrix pipe as a bf16 operand)
+  uint32_t refw;       // {bf16 1.0, bf16 -m_ref} in lanes 0..31, 0 in lanes 32..63
+};
+
+// p = exp2(s [* sc]) in place; returns this lane's half of the tile's row sum
+IA_DEV float exp_sum(f32x16& s0, f32x16& s1, float sc) {
+  float ra = 0.f, rb = 0.f;
+  if (IA_F3_ABL & 8) return 1.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    s0[r] = __builtin_amdgcn_exp2f(PRESCALE ? s0[r] : s0[r] * sc);
+    s1[r] = __builtin_amdgcn_exp2f(PRESCALE ? s1[r] : s1[r] * sc);
+    ra += s0[r];
+    rb += s1[r];
+  }
+  return ra + rb;
+}
+
+// Rare: a row sum left [L_LO, L_HI] (or is not finite).  The tile's scores are recomputed from the K tile that is still in its ring
+// slot, the reference moves to the larger of the tile's maximum and the running log-sum-exp, everything accumulated so far follows.
+// snx0 / snx1: the next tile's scores, already formed against the old reference (null for the last tile).
+// sc: what exp2's argument is multiplied by (1 with pre-scaled queries); m_ref lives in the accumulators' units.
+IA_DEV float rebase(f32x16& s0, f32x16& s1, f32x16* snx0, f32x16* snx1, f32x16& o0, f32x16& o1, Row& row, const Lane& ln,
+                    uint32_t ktile_addr, const bf16x8 (&qf)[4], uint32_t valid_lo, uint32_t valid_hi, int lane, float sc) {
+  if (PRESCALE) sc = 1.f;
+  const float inv_sc = 1.f / sc;
+  bf16x8 kf[8];
+  read_k(kf, ln, ktile_addr);
+  frag_wait<0>(kf);
+  qk_tile(s0, s1, kf, qf, false, (lane & 32) ? 0u : 0x3F80u, valid_lo, valid_hi, lane);      // reference 0
+  float tm = NEG_BIG;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) tm = fmaxf(tm, fmaxf(s0[r], s1[r]));
+  tm = fmaxf(tm, swap32(tm));
+  const float l_prev = row.l_run + swap32(row.l_run);
+  const bool have_prev = l_prev > 0.f, have_tile = tm > 0.5f * NEG_BIG;
+  float m_new = row.m_ref;
+  if (have_prev) m_new = row.m_ref + __builtin_amdgcn_logf(l_prev) * inv_sc;      // v_log_f32 = log2
+  if (have_tile) m_new = have_prev ? fmaxf(m_new, tm) : tm;
+  m_new = bf2f(f2bf(m_new));
+  const float shift = row.m_ref - m_new;
+  const float alpha = have_prev ? __builtin_amdgcn_exp2f(shift * sc) : 0.f;
+  row.m_ref = m_new;
+  row.refw = (lane & 32) ? 0u : (0x3F80u | ((uint32_t)__builtin_bit_cast(uint16_t, f2bf(-m_new)) << 16));
+  row.l_run *= alpha;
+  float rs = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    s0[r] = __builtin_amdgcn_exp2f((s0[r] - m_new) * sc);
+    s1[r] = __builtin_amdgcn_exp2f((s1[r] - m_new) * sc);
+    rs += s0[r] + s1[r];
+    o0[r] *= alpha; o1[r] *= alpha;
+  }
+  if (snx0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { (*snx0)[r] += shift; (*snx1)[r] += shift; }
+  }
+  return rs;
+}
+}  // namespace fwd3
+
+// PIPE: the QK^T of tile t+1 runs under the softmax of tile t inside the wave (two score blocks live, 2 waves per SIMD); without it a wave
+// alternates an MFMA batch (PV of tile t, QK^T of tile t+1) with the softmax, and the waves sharing its SIMD fill the other pipe.
+template <bool DROPOUT, bool PIPE, int WPS>
+__global__ __launch_bounds__(256, WPS) void attn_fwd3_kernel(AttnArgs p) {
+  using namespace fwd3;
+  using C = Cfg<PIPE>;
+  constexpr int Q_OFF = C::Q_OFF, TAB_OFF = C::TAB_OFF;
+  constexpr int AHEAD = PIPE ? 2 : 1;                     // the K fragments requested during tile t are those of tile t + AHEAD
+  __shared__ __attribute__((aligned(16))) char smem[C::SMEM];
+  uint32_t (*s_valid)[2] = reinterpret_cast<uint32_t (*)[2]>(smem + TAB_OFF);
+  const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, lq = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int tile, h, b;
+  attn_block_coords(p, p.Lq, tile, h, b);
+  int Lq = p.Lq, L = p.Lk;
+  size_t qbase = (size_t)b * Lq, rowbase = (size_t)b * L;
+  if (p.cu) {
+    const int c0 = p.cu[b];
+    Lq = L = p.cu[b + 1] - c0;
+    qbase = rowbase = (size_t)c0;
+    if (tile * 128 >= Lq) return;
+  }
+  const int q0 = tile * 128 + wave * 32;
+  const bool active = q0 < Lq;
+  const int q = q0 + lq;
+  const __amdgpu_buffer_rsrc_t rsK = ia_rsrc(p.k, p.kv_bytes);
+  const __amdgpu_buffer_rsrc_t rsV = ia_rsrc(p.v, p.kv_bytes);
+  const uint32_t sbase = lds_addr(smem);
+  const int nkt_all = (L + 63) >> 6;
+
+  auto stage_k = [&](int kt) { stage64<false>(rsK, smem + C::k_slot(kt), rowbase + kt * 64, L - kt * 64, p.ld_kv, h * 64, tid, wave); };
+  auto stage_v = [&](int kt) { stage64<true>(rsV, smem + C::v_slot(kt), rowbase + kt * 64, L - kt * 64, p.ld_kv, h * 64, tid, wave); };
+
+  // ---- prologue: one round trip for Q, K0, V0, K1 and the mask bytes; K2 / V1 follow and stay in flight
+  char* qslot = smem + Q_OFF + wave * 4096;
+  stage_rows32(ia_rsrc(p.q, p.q_bytes), qslot, qbase + q0, Lq - q0, p.ld_q, h * 64, lane);
+  stage_k(0); stage_v(0); stage_k(1);
+  build_valid_table(p, s_valid, rowbase, L, lane, wave);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (PIPE) stage_k(2);
+  stage_v(1);
+  bf16x8 qf[4];
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    const bf16x8 raw = frag_b128(qslot, lq, kb * 2 + hh);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qf[kb][j] = PRESCALE ? f2bf(bf2f(raw[j]) * p.sc) : raw[j];
+  }
+  Lane ln;
+  {
+    const uint32_t a0 = (uint32_t)(lq * 128 + ((hh ^ swz_b128(lq)) << 4));
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) ln.ka[kb] = a0 ^ (uint32_t)(kb << 5);
+    ln.v0 = tr_lane_off(lane, 0); ln.v1 = tr_lane_off(lane, 32);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  // trailing tiles without any attendable key are never touched (right-padded batches); holes inside take the penalty path
+  int nkt = nkt_all;
+  while (nkt > 1 && (s_valid[nkt - 1][0] | s_valid[nkt - 1][1]) == 0u) --nkt;
+  nkt = __builtin_amdgcn_readfirstlane(nkt);
+
+  Row row{0.f, 0.f, hh ? 0u : 0x3F80u};
+  bool has_ref = false;                                  // wave-uniform: some row of this wave has left the reference 0
+  f32x16 o0 = zero16(), o1 = zero16();
+  f32x16 sa0, sa1, sb0, sb1;
+  bf16x8 kf[8];
+  if (active) {
+    read_k(kf, ln, sbase + C::k_slot(0));
+    if (PIPE) {
+      frag_wait<0>(kf);
+      const uint32_t v_lo = __builtin_amdgcn_readfirstlane(s_valid[0][0]), v_hi = __builtin_amdgcn_readfirstlane(s_valid[0][1]);
+      qk_tile(sa0, sa1, kf, qf, (v_lo & v_hi) == 0xFFFFFFFFu, row.refw, v_lo, v_hi, lane);
+      if (nkt > 1) read_k(kf, ln, sbase + C::k_slot(1));
+    }
+  }
+
+  // one tile.  PIPE: sc = scores of tile t (in), sn = scores of tile t+1 (out, unless LAST); otherwise sc is scratch, sn unused
+  auto tile_step = [&](auto LAST_T, f32x16& sc0, f32x16& sc1, f32x16& sn0, f32x16& sn1, int t) {
+    constexpr bool LAST = decltype(LAST_T)::value;
+    // K(t+2) has landed for this wave (V(t+1), issued behind it, may still be in flight), then for everybody
+    if (LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    if (!(IA_F3_ABL & 2)) __builtin_amdgcn_s_barrier();
+    if (!(IA_F3_ABL & 1)) {
+      if (t + AHEAD + 1 < nkt) stage_k(t + AHEAD + 1);
+      if (t + 2 < nkt) stage_v(t + 2);
+    }
+    if (!active || (IA_F3_ABL & 4)) return;
+    const uint32_t vt = sbase + (uint32_t)C::v_slot(t);
+    const uint32_t vb0 = vt + ln.v0, vb1 = vt + ln.v1;
+    const uint32_t cur_lo = __builtin_amdgcn_readfirstlane(s_valid[t][0]), cur_hi = __builtin_amdgcn_readfirstlane(s_valid[t][1]);
+    TrPair va, vb, vc, vd;
+    if (PIPE) {
+      if (!LAST) {
+        frag_wait<0>(kf);                                 // the K fragments of tile t+1, requested during the previous tile's PV
+        const uint32_t n_lo = __builtin_amdgcn_readfirstlane(s_valid[t + 1][0]), n_hi = __builtin_amdgcn_readfirstlane(s_valid[t + 1][1]);
+        qk_tile(sn0, sn1, kf, qf, !has_ref && (n_lo & n_hi) == 0xFFFFFFFFu, row.refw, n_lo, n_hi, lane);
+      }
+    } else {
+      frag_wait<0>(kf);                                   // the K fragments of tile t
+      qk_tile(sc0, sc1, kf, qf, !has_ref && (cur_lo & cur_hi) == 0xFFFFFFFFu, row.refw, cur_lo, cur_hi, lane);
+    }
+    float rs = exp_sum(sc0, sc1, p.sc);
+    {
+      float tot = row.l_run + rs;
+      tot += swap32(tot);
+      if (__builtin_expect(__ballot(!(tot >= L_LO && tot <= L_HI)) != 0ull, 0)) {
+        rs = rebase(sc0, sc1, (PIPE && !LAST) ? &sn0 : nullptr, (PIPE && !LAST) ? &sn1 : nullptr, o0, o1, row, ln,
+                    sbase + (uint32_t)C::k_slot(t), qf, cur_lo, cur_hi, lane, p.sc);
+        has_ref = true;
+      }
+    }
+    row.l_run += rs;
+    if (IA_F3_ABL & 16) {                                 // no LDS reads: whatever is in the K fragment registers stands in for V^T
+      va.lo0 = va.lo1 = vb.lo0 = vb.lo1 = vc.lo0 = vc.lo1 = vd.lo0 = vd.lo1 = __builtin_bit_cast(s16x8, kf[0]).lo;
+      va.hi0 = va.hi1 = vb.hi0 = vb.hi1 = vc.hi0 = vc.hi1 = vd.hi0 = vd.hi1 = __builtin_bit_cast(s16x8, kf[1]).hi;
+    } else {
+    tr_issue<0>(va, vb0, vb1);                            // the V^T fragments land under the conversions
+    tr_issue<16>(vb, vb0, vb1);
+    }
+    bf16x8 pf[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      pf[0][j] = f2bf(sc0[j]); pf[1][j] = f2bf(sc0[8 + j]);
+      pf[2][j] = f2bf(sc1[j]); pf[3][j] = f2bf(sc1[8 + j]);
+    }
+    tr_wait<4>(va);
+    o0 = mfma(va.a0(), pf[0], o0); o1 = mfma(va.a1(), pf[0], o1);
+    if (!(IA_F3_ABL & 16)) tr_issue<32>(vc, vb0, vb1);
+    tr_wait<4>(vb);
+    o0 = mfma(vb.a0(), pf[1], o0); o1 = mfma(vb.a1(), pf[1], o1);
+    if (!(IA_F3_ABL & 16)) tr_issue<48>(vd, vb0, vb1);
+    const bool more = !LAST && t + AHEAD < nkt && !(IA_F3_ABL & 16);
+    if (more) read_k(kf, ln, sbase + (uint32_t)C::k_slot(t + AHEAD));
+    if (more) { tr_wait<12>(vc); } else { tr_wait<4>(vc); }
+    o0 = mfma(vc.a0(), pf[2], o0); o1 = mfma(vc.a1(), pf[2], o1);
+    if (more) { tr_wait<8>(vd); } else { tr_wait<0>(vd); }
+    o0 = mfma(vd.a0(), pf[3], o0); o1 = mfma(vd.a1(), pf[3], o1);
+  };
+  if (PIPE) {
+    int t = 0;
+    for (;;) {
+      if (t + 1 >= nkt) { tile_step(std::true_type{}, sa0, sa1, sb0, sb1, t); break; }
+      tile_step(std::false_type{}, sa0, sa1, sb0, sb1, t); ++t;
+      if (t + 1 >= nkt) { tile_step(std::true_type{}, sb0, sb1, sa0, sa1, t); break; }
+      tile_step(std::false_type{}, sb0, sb1, sa0, sa1, t); ++t;
+    }
+  } else {
+    for (int t = 0; t + 1 < nkt; ++t) tile_step(std::false_type{}, sa0, sa1, sb0, sb1, t);
+    tile_step(std::true_type{}, sa0, sa1, sb0, sb1, nkt - 1);
+    __builtin_amdgcn_s_barrier();                         // the epilogue rows are staged in the K ring
+  }
+  if (!active) return;
+  const float l_tot = row.l_run + swap32(row.l_run);
+  const float inv = l_tot > 0.f ? p.inv_keep / l_tot : 0.f;
+  if (q < Lq && hh == 0 && p.lse2) p.lse2[((size_t)b * p.nh + h) * p.Lq + q] = row.m_ref * (PRESCALE ? 1.f : p.sc) + __builtin_amdgcn_logf(l_tot);
+  store_block_rows(smem + C::EPI_OFF + wave * EPI_SLOT, o0, o1, inv, false, p.out + (qbase + q0) * p.ld_o + h * 64, p.ld_o, Lq - q0, lane);
+}
+
 // ------------------------------------------------------------------------------------- backward: dQ
 // One 64-key tile for this wave's 32 queries: dQ^T += K^T dS^T with dS^T = P^T (dP^T - delta) (the softmax scale is
 // applied once, when dQ is stored).
@@ -745,6 +1069,12 @@ int fill_args(AttnArgs& a, int B, int nh, int Lq, int Lk, int ld_q, int ld_kv, i
   return IA_OK;
 }
 
+// development switch (round 3): IA_ATTN_FWD=2 runs the round-2 forward kernel for A/B measurements on one box
+int fwd_version() {
+  static const int v = [] { const char* e = getenv("IA_ATTN_FWD"); return e ? atoi(e) : 2; }();
+  return v;
+}
+
 }  // namespace
 
 // General form: Lq queries attend to Lk keys per (sequence, head).  q / out / d_out rows are b*Lq + i (strides ld_q,
@@ -762,6 +1092,9 @@ extern "C" int ia_attn_fwd_x(const void* q, int ld_q, const void* k, const void*
   a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.out = (bf16*)out; a.mask = key_mask; a.lse2 = lse2;
   dim3 grid(((Lq + 127) / 128) * nh * B), blk(256);
   if (a.thr16) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, blk, 0, stream, a);
+  else if (fwd_version() == 3) hipLaunchKernelGGL((attn_fwd3_kernel<false, false, 3>), grid, blk, 0, stream, a);
+  else if (fwd_version() == 4) hipLaunchKernelGGL((attn_fwd3_kernel<false, false, 2>), grid, blk, 0, stream, a);
+  else if (fwd_version() == 5) hipLaunchKernelGGL((attn_fwd3_kernel<false, true, 2>), grid, blk, 0, stream, a);
   else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, blk, 0, stream, a);
   return ia_check_launch();
 }

@@ -6,6 +6,7 @@
 // live in four flat arenas with identical element offsets; one launch walks a static chunk table
 // {offset, count, weight-decay flag} and also refreshes the bf16 shadow copy the GEMMs read.
 #include "common.h"
+#include "../../include/itemalign.h"
 #include <cstdio>
 
 namespace {
@@ -119,4 +120,4 @@ extern "C" const char* ia_strerror(int code) {
   return "unknown error";
 }
 
-extern "C" int ia_abi_version(void) { return 1; }
+extern "C" int ia_abi_version(void) { return IA_ABI_VERSION; }

@@ -11,8 +11,11 @@ Two executions of the same arithmetic:
   * host:  Pillow, inside __getitem__ (what the reference does);
   * GPU (--gpu_preproc):  the host only decodes and draws the random parameters (ImageParams travel with the frame), the
     resampling / jitter / normalisation run in csrc/image.hip, bit-identical to Pillow (tests/test_kernels_gpu.py).
-Random numbers come from one random.Random per dataset (the reference draws the crop from the global `random` module and the
-flip / jitter from torch's global generator: same distributions, not the same stream).
+Random numbers come from the global `random` module, like the reference's crop (its flip / jitter use torch's global generator:
+same distributions, not the same stream): DataLoader reseeds the global generators in every worker process and every epoch
+(base_seed + worker_id), so workers draw different augmentations and no epoch repeats another; train.py mixes the rank in.  A
+private random.Random(seed) is used only when a seed is passed (tests hand the host path, the GPU path and the restatement the
+same draw) -- a private generator inside the dataset object would be pickled to every worker in the same state.
 """
 import math
 import random
@@ -45,7 +48,11 @@ class ImageTransform:
     def __init__(self, size, is_training, hflip=0.5, color_jitter=None, seed=None):
         self.size, self.train, self.hflip = int(size), bool(is_training), float(hflip or 0.0)
         self.cj = None if color_jitter is None else float(color_jitter)
-        self.rng = random.Random(seed)
+        self._seeded = None if seed is None else random.Random(seed)
+
+    @property
+    def rng(self):
+        return self._seeded if self._seeded is not None else random
 
     # ---- random parameters
     def _crop_box(self, width, height):

@@ -42,9 +42,15 @@ def init_from_env(device_type="cuda"):
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = BACKEND or ("nccl" if device_type == "cuda" else "gloo")
         if device_type == "cuda":
-            torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
-        # generous collective timeout: a rank may legitimately wait for the others' data loading or checkpoint write
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(hours=2))
+            ndev = max(1, torch.cuda.device_count())
+            if local >= ndev and not BACKEND:
+                # production launches: one process per GPU.  (Tests put two ranks on one GPU over gloo: IA_DP_BACKEND.)
+                raise RuntimeError(f"LOCAL_RANK {local} but only {ndev} GPU(s) visible: launch one process per GPU")
+            torch.cuda.set_device(local % ndev)
+        # collective timeout: long enough for a rank that waits for the others' data loading or for rank 0's checkpoint write, short
+        # enough that a dead rank surfaces; IA_DP_TIMEOUT_MIN overrides it
+        minutes = float(os.environ.get("IA_DP_TIMEOUT_MIN", "30"))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=minutes))
     return rank, world, local
 
 
@@ -178,16 +184,32 @@ def all_reduce_scalar(x, op=None):
     return x
 
 
-def gather_interleaved(local, world):
-    """Rank r holds the items r, r + world, r + 2 world, ... of a sequence (numpy array): every rank gets the whole sequence back
-    in its original order."""
-    parts = [None] * world
-    dist.all_gather_object(parts, np.asarray(local))
-    n = sum(len(p) for p in parts)
-    out = np.empty((n,) + parts[0].shape[1:], dtype=parts[0].dtype)
-    for r, p in enumerate(parts):
-        out[r::world] = p
-    return out
+def gather_rows(local, device=None):
+    """Every rank hands in a float array [n_r, k] (n_r may differ from rank to rank and may be 0: the collates drop samples whose
+    image failed to load, data.py:44,84); every rank gets the concatenation over ranks (rank order) back.  Two tensor collectives
+    (row counts, then the rows padded to the longest shard): no pickling, and no assumption about which positions a rank scored."""
+    local = np.asarray(local if local is not None else [], dtype=np.float64)
+    k = local.shape[1] if local.ndim == 2 else 1
+    local = local.reshape(-1, k)
+    world = dist.get_world_size()
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    counts = torch.zeros(world, dtype=torch.int64, device=device)
+    mine = torch.tensor([local.shape[0], k], dtype=torch.int64, device=device)
+    shapes = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(shapes, mine)
+    counts = [int(t[0]) for t in shapes]
+    k = max(int(t[1]) for t in shapes)           # an empty shard does not know the row width
+    if local.shape[0] == 0:
+        local = local.reshape(0, k)
+    cap = max(counts)
+    if cap == 0:
+        return np.empty((0, k), dtype=np.float64)
+    buf = torch.zeros(cap, k, dtype=torch.float64, device=device)
+    buf[:local.shape[0]] = torch.from_numpy(local).to(device)
+    parts = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    return np.concatenate([p[:c].cpu().numpy() for p, c in zip(parts, counts)], axis=0)
 
 
 def all_reduce_grads(model, world):

@@ -112,8 +112,10 @@ def run(args, model, datasets, collate_fn, call_model, checkpoint_name, path_fie
         dl_kw["multiprocessing_context"] = "forkserver"
 
     def evaluate(dataset, tag):
-        """Scores the whole set.  Under data parallelism every rank scores positions rank::world and the pieces are gathered
-        (in the original order) on all ranks: no rank sits in a collective while another one evaluates alone."""
+        """Scores the whole set.  Under data parallelism every rank scores positions rank::world and the (score, label) rows of
+        all ranks are concatenated everywhere: no rank sits in a collective while another one evaluates alone.  The
+        P/R/F1 sweep does not depend on the order, and a rank may come back with fewer rows than it was dealt (the collates drop
+        samples whose image failed to load, data.py:44,84) or with none at all."""
         model.eval()
         n = len(dataset)
         mine = list(range(rank, n, world)) if world > 1 else None
@@ -132,8 +134,10 @@ def run(args, model, datasets, collate_fn, call_model, checkpoint_name, path_fie
                 probs_all = probs if probs_all is None else np.append(probs_all, probs)
                 labels_all = labels if labels_all is None else np.append(labels_all, labels)
         if world > 1:
-            probs_all, labels_all = iadist.gather_interleaved(probs_all, world), iadist.gather_interleaved(labels_all, world)
-        if rank != 0:
+            rows = np.empty((0, 2)) if probs_all is None else np.stack([np.asarray(probs_all, np.float64), np.asarray(labels_all, np.float64)], 1)
+            rows = iadist.gather_rows(rows)
+            probs_all, labels_all = rows[:, 0], rows[:, 1].astype(np.int64)
+        if rank != 0 or probs_all is None:
             return
         from sklearn.metrics import f1_score, precision_score, recall_score
         for threshold in np.arange(0.1, 1.0, 0.1):
@@ -169,7 +173,12 @@ def run(args, model, datasets, collate_fn, call_model, checkpoint_name, path_fie
         for epoch in range(int(args.start_epoch), int(args.num_train_epochs)):
             model.train()
             idx = iadist.shard_indices(len(train_ds), rank, world, args.seed + epoch, shuffle=True)
-            loader = DataLoader(Subset(train_ds, idx.tolist()), batch_size=per_rank, shuffle=False, collate_fn=collate_fn, **dl_kw)
+            # augmentation draws (data/transforms.py: the global `random`): a different stream per epoch and per rank, in the main
+            # process (num_workers 0) and, through the loader's base seed, in every worker (base_seed + worker_id)
+            aug_seed = (args.seed * 1000003 + epoch * 1009 + rank * 7919) & 0x7FFFFFFF
+            random.seed(aug_seed)
+            loader = DataLoader(Subset(train_ds, idx.tolist()), batch_size=per_rank, shuffle=False, collate_fn=collate_fn,
+                                generator=torch.Generator().manual_seed(aug_seed), **dl_kw)
             opt.zero_grad()
             for step, batch in enumerate(loader):
                 b = to_dev(batch[2:])

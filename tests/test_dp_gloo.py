@@ -63,11 +63,20 @@ def _worker(rank, world, port, out):
     dist.all_gather(gathered, shard)
     allidx = torch.cat(gathered)
     ok = ok and len(set(allidx.tolist())) == len(allidx) == 100
-    # sharded evaluation: rank r scores items r::world, every rank gets the whole sequence back in order
+    # sharded evaluation: every rank hands in the (score, label) rows it produced -- the counts may differ (dropped samples)
+    # and a shard may be empty -- and gets the concatenation of all ranks back
     import numpy as np
-    whole = np.arange(11, dtype=np.float32) * 0.5
-    back = iadist.gather_interleaved(whole[rank::world], world)
-    ok = ok and back.shape == whole.shape and bool((back == whole).all())
+    whole = np.stack([np.arange(11, dtype=np.float64) * 0.5, np.arange(11, dtype=np.float64) % 2], 1)
+    mine = whole[rank::world]
+    if rank == 1:
+        mine = mine[:-2]                      # two samples of rank 1 failed to load
+    back = iadist.gather_rows(mine)
+    want = np.concatenate([whole[0::world], whole[1::world][:-2]], 0)
+    ok = ok and back.shape == want.shape and bool((back == want).all())
+    back = iadist.gather_rows(whole[:3] if rank == 0 else None)      # rank 1 came back with nothing at all
+    ok = ok and back.shape == (3, 2) and bool((back == whole[:3]).all())
+    back = iadist.gather_rows(None)
+    ok = ok and back.shape[0] == 0
     # plain torch models (TextCNN): gradient averaging without an arena
     lin = torch.nn.Linear(3, 2)
     for p in lin.parameters():

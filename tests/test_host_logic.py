@@ -281,3 +281,26 @@ def test_attribute_pair_indices_match_reference_vectors():
             assert DS.attribute_pair_indices(c["input_ids"], fx["sep_token_id"]) == c["pair_indices"]
             n_pairs += len(c["pair_indices"])
     assert n_pairs > 20
+
+
+def test_image_transform_draws_follow_the_global_generator():
+    """Without an explicit seed the augmentation parameters come from the global `random` module, which DataLoader reseeds per worker
+    and per epoch (a private generator inside the dataset object was pickled to every worker in the same state, so
+    all workers drew the same crops and every epoch repeated them)."""
+    import pickle
+    import random
+    from item_alignment_amd.data.transforms import ImageTransform
+    tr = ImageTransform(64, True, hflip=0.5, color_jitter=0.4)
+    clone = pickle.loads(pickle.dumps(tr))            # what a forkserver worker receives
+    random.seed(1001)
+    a = [clone.draw(300, 200) for _ in range(4)]
+    random.seed(1002)                                  # another worker / another epoch
+    b = [clone.draw(300, 200) for _ in range(4)]
+    random.seed(1001)
+    c = [tr.draw(300, 200) for _ in range(4)]
+    assert a == c and a != b
+    seeded = ImageTransform(64, True, hflip=0.5, color_jitter=0.4, seed=5)
+    random.seed(1)
+    d = seeded.draw(300, 200)
+    random.seed(2)
+    assert ImageTransform(64, True, hflip=0.5, color_jitter=0.4, seed=5).draw(300, 200) == d
