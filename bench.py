@@ -52,14 +52,27 @@ def pmc_traffic(args):
     kb = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         out = tempfile.mkdtemp(prefix="ia_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+        # the same workload as the parent (--unpad / --full-length are forwarded), 1 + 1 steps, two resident batches only
         cmd = [rocprof, "--pmc", counter, "-d", out, "-o", "p", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
                "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-pmc", "--no-variants", "--pairs-per-gpu", str(args.pairs_per_gpu),
-               "--image-model", args.image_model, "--seed", str(args.seed)]
+               "--image-model", args.image_model, "--seed", str(args.seed), "--resident-batches", "2"]
+        cmd += (["--unpad"] if args.unpad else []) + (["--full-length"] if args.full_length else [])
         try:
             # a plain single-process child even when this run was started by a launcher (no inherited rendezvous)
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
                                                                      "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
-            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=420, check=True, cwd=out, env=env)
+            # own session: on a timeout the whole group goes (rocprofv3 is a wrapper; killing only it would leave the python child
+            # holding the GPU)
+            child = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=out, env=env, start_new_session=True)
+            try:
+                rc = child.wait(timeout=args.pmc_timeout)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(child.pid, signal.SIGKILL)
+                child.wait()
+                return None, f"{counter} pass timed out after {args.pmc_timeout} s"
+            if rc != 0:
+                return None, f"{counter} pass exited with {rc}"
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             tot, n = 0.0, 0
             for r in csv.DictReader(open(files[0])):
@@ -157,6 +170,8 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes behind roofline.traffic")
     ap.add_argument("--no-variants", action="store_true", help="skip the full-length / unpadded side measurements")
     ap.add_argument("--variant-steps", type=int, default=4)
+    ap.add_argument("--pmc-timeout", type=int, default=240, help="seconds per rocprofv3 --pmc child pass")
+    ap.add_argument("--resident-batches", type=int, default=RESIDENT_BATCHES, help="global batches generated up front and kept in HBM")
     args = ap.parse_args()
     if args.unpad:
         os.environ["IA_UNPAD"] = "1"
@@ -196,7 +211,7 @@ def main():
     # rank r owns pairs r::world of each global batch.  A default run (25 steps) never sees a batch twice.
     data = SyntheticCocaPairs(DATASET_PAIRS, image_size=cfg.image_size, seed=args.seed, full_length=args.full_length)
     perm = torch.randperm(DATASET_PAIRS, generator=torch.Generator().manual_seed(args.seed)).tolist()
-    n_batches = min(RESIDENT_BATCHES, DATASET_PAIRS // (B * world))
+    n_batches = max(1, min(args.resident_batches, n_steps, DATASET_PAIRS // (B * world)))
 
     def make_batches(ds, count):
         return [ds.batch([perm[g * B * world + rank + world * i] for i in range(B)], dev, device_images=True) for g in range(count)]
@@ -236,6 +251,7 @@ def main():
     dt = time.perf_counter() - t0
     ms, fl, nl = C.c_double(), C.c_double(), C.c_int()
     _lib.check(lib.ia_prof_end(C.byref(ms), C.byref(fl), C.byref(nl)), "ia_prof_end")
+    alg_bytes = lib.ia_prof_bytes()
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1 or iadist.FORCE:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -269,10 +285,23 @@ def main():
             variants["unpadded_text_tower"] = timed(batches, args.variant_steps, n_steps + 2 + args.variant_steps)
         finally:
             _text.UNPAD = False
+        # the image tower on a second HIP stream (IA_TOWER_STREAMS=1): the same arithmetic, the two towers' kernels
+        # overlap.  Not the headline because per-kernel roofline figures stop describing the kernels when two of them share the chip.
+        from item_alignment_amd.models import multimodal as _mm
+        if hasattr(_mm, "TOWER_STREAMS"):
+            _mm.TOWER_STREAMS = True
+            try:
+                variants["image_tower_on_second_stream"] = timed(batches, args.variant_steps, n_steps + 4 + 2 * args.variant_steps)
+            finally:
+                _mm.TOWER_STREAMS = False
 
     if rank == 0:
         pairs = B * world * args.steps
         achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        # which roof bounds the kernel: its algorithmic intensity (FLOP per byte, each operand moved once) against the ridge of the
+        # two peaks (2500 TFLOP/s dense bf16 MFMA, 8 TB/s HBM: 312.5 FLOP/B)
+        intensity = fl.value / alg_bytes if alg_bytes > 0 else float("inf")
+        bound = "mfma" if intensity >= 2500e12 / 8e12 else "hbm"
         res = {
             "metric": "item-pairs/sec (train step) RoBERTa-large+ViT-B two-tower", "value": pairs / dt, "unit": "item-pairs/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -286,11 +315,14 @@ def main():
             "model_tflops_per_gpu": None if args.unpad else pairs / dt * TRAIN_FLOPS_PER_PAIR / 1e12 / world,
             "mfma_fraction_whole_step": None if args.unpad else pairs / dt * TRAIN_FLOPS_PER_PAIR / 1e12 / world / 2500.0,
             "final_loss": final_loss,
-            "roofline": {"bound": "mfma", "kernel": WGRAD_KERNEL, "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s",
-                         "frac": achieved / 2500.0, "traffic": None, "launches": nl.value,
-                         "avg_launch_us": ms.value * 1e3 / max(1, nl.value)},
+            "roofline": ({"bound": "mfma", "kernel": WGRAD_KERNEL, "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s",
+                          "frac": achieved / 2500.0} if bound == "mfma" else
+                         {"bound": "hbm", "kernel": WGRAD_KERNEL, "achieved": alg_bytes / (ms.value * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                          "frac": alg_bytes / (ms.value * 1e-3) / 1e9 / 8000.0}),
             "variants": variants,
         }
+        res["roofline"].update({"traffic": None, "launches": nl.value, "avg_launch_us": ms.value * 1e3 / max(1, nl.value),
+                                "flop_per_byte": intensity, "algorithmic_bytes_per_launch": alg_bytes / max(1, nl.value)})
         res["config"]["dataset_pairs"] = DATASET_PAIRS
         res["config"]["resident_batches"] = n_batches
         if world == 1 and not args.no_pmc:

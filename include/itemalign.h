@@ -66,6 +66,7 @@ size_t ia_gemm_colsum_workspace_bytes(int M, int N);
  * recorded on the launch stream; used by bench.py for the roofline of the dominant kernel. */
 int ia_prof_begin(int variant, int max_launches);
 int ia_prof_end(double* total_ms, double* total_flops, int* launches);
+double ia_prof_bytes(void); /* algorithmic bytes of the recorded launches: A and B read once, C written once */
 
 /* ---- LayerNorm tails (RobertaSelfOutput / RobertaOutput: dense -> dropout -> +residual -> LayerNorm;
  * timm Block norm1/norm2).  z = residual + dropout(x + bias); y = LN(z).  z_out may alias x. */

@@ -37,6 +37,7 @@ SIGNATURES = {
     "ia_gemm_colsum_workspace_bytes": (sz, [i32, i32]),
     "ia_prof_begin": (i32, [i32, i32]),
     "ia_prof_end": (i32, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i32)]),
+    "ia_prof_bytes": (C.c_double, []),
     "ia_ln_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, u32, u32, vp]),
     "ia_ln_bwd_workspace_bytes": (sz, [i32, i32]),
     "ia_ln_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, u32, u32, vp, sz, i32, vp]),

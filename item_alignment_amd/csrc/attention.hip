@@ -395,19 +395,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------ forward, round 3
-// Same arithmetic and tile geometry (4 waves x 32 queries, 64-key tiles, S^T orientation) as attn_fwd_kernel above, restructured after
-// tools/abl/issue_model.hip had priced the instruction streams on an MI355X (profiles/r03_issue_model.txt):
-//  * the softmax is down to its 80 unavoidable VALU instructions per tile (32 exp2, 32 adds, 16 packed converts): the query fragments
-//    are pre-scaled by scale*log2(e) once per block, and -m_ref comes out of the matrix pipe as the C operand of the first QK^T MFMA
-//    (a 16-register block holding -m_ref), so an accumulator IS exp2's argument; no running maximum is taken at all -- m_ref only
-//    moves when a row's sum leaves [2^-60, 2^60] (rebase(): scores recomputed from the K tile still in the ring, true maximum taken);
-//    any reference cancels in O / l, and exp2 arguments stay far inside the fp32 exponent range;
-//  * masked / out-of-range keys get -1e30 from one extra MFMA per 32-key block (A = the penalty in k-slot 0 of the key's row, B = ones
-//    in k-slot 0) instead of 64 compare+select pairs (v_cmp 8.6 cycles, v_cndmask behind it 4.8: 13 cycles per select on one wave);
-//  * software pipelined inside the wave: QK^T of tile t+1 is issued under the softmax of tile t (two score blocks live), the V^T
-//    fragments of tile t and the K fragments of tile t+2 are in registers before the MFMAs that use them (asm reads, counted waits);
-//  * K ring of 4, V ring of 3 LDS slots; the DMA of K(t+3) / V(t+2) is issued at the top of iteration t and only K(t+2) is waited for
-//    there (counted vmcnt), one raw s_barrier per tile.
+// Same arithmetic and tile geometry (4 waves x 32 queries, 64-key tiles, S^T orientation) as attn_fwd_kernel above, rebuilt around
+// what tools/abl/issue_model.hip and the PMC passes of round 3 measured on an MI355X (profiles/r03_issue_model.txt,
+// r03_pmc_attention_fwd.txt): at head dim 64 the kernel is bound by instruction ISSUE -- the waves of a SIMD spent their time issuing
+// ~155 VALU + ~90 SALU instructions per 16 MFMAs -- so the loop is stripped to what the arithmetic needs:
+//  * softmax = 32 exp2 + 16 packed adds + 16 packed converts per tile.  The query fragments are pre-scaled by scale*log2(e) once per
+//    block, so an accumulator IS exp2's argument; no running maximum is taken: the reference m_ref starts at 0 and only moves when a
+//    row sum leaves [2^-100, 2^60] (rebase(): scores recomputed from the K tile still in its ring slot, true maximum taken) -- any
+//    reference cancels in O / l, and exp2 arguments stay far inside the fp32 exponent range;
+//  * masked / out-of-range keys and a moved reference enter through ONE extra MFMA per 32-key block (A = (penalty, 1) in k-slots 0 / 1
+//    of the key's row, B = (1, -m_ref) in k-slots 0 / 1 of the query's column) instead of 64 compare + select pairs (v_cmp 8.6 cycles,
+//    the v_cndmask behind it 4.8); tiles whose 64 keys are all attendable (a bit mask in an SGPR) start from the constant 0;
+//  * no address arithmetic in the loop: the K / V windows are per-sequence buffer descriptors (rows past the sequence read as zero by
+//    the bounds check), the tile is selected by the DMA's scalar offset, the ring slots are compile-time constants (loop unrolled by
+//    the ring depth 3) and every LDS read uses a lane-constant base register + an immediate;
+//  * all fragments are in registers before the MFMAs that use them (asm reads, counted lgkmcnt): the K fragments of tile t+1 and the
+//    V^T fragments of tile t arrive under the PV MFMAs / the conversions of tile t;
+//  * the DMA of tile t+2 is issued at the top of tile t and only K(t+1) is waited for there (counted vmcnt), one raw s_barrier per
+//    tile; 48 KiB of LDS and <= 168 VGPRs: three workgroups per CU.
 #ifndef IA_F3_ABL
 #define IA_F3_ABL 0          // ablation bits for tools/abl/attn_dev.hip builds: 1 no K/V DMA in the loop, 2 no barrier, 4 no compute, 8 no exp, 16 no LDS reads
 #endif
@@ -416,21 +421,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 #endif
 namespace fwd3 {
 constexpr bool PRESCALE = IA_F3_PRESCALE != 0;
-// LDS: K ring | V ring | [PIPE: Q staging, later the epilogue's row staging] | valid-key table.  Without PIPE the K ring is 3 deep as
-// well (the fragments of tile t+1 are read during tile t), Q is staged in the last V slot (first filled behind the first barrier) and
-// the epilogue rows in the K ring (behind a last barrier): 48 KiB, three workgroups per CU.
-template <bool PIPE>
-struct Cfg {
-  static constexpr int KRING = PIPE ? 4 : 3, VRING = 3;
-  // PIPE: K0..K3 | V0..V2 | Q / epilogue rows | table.   otherwise: K0 K1 | V0 V1 | K2 V2 (= Q staging, 16 KiB) | table
-  static constexpr int Q_OFF = PIPE ? (KRING + VRING) * 8192 : 32768;
-  static constexpr int EPI_OFF = PIPE ? Q_OFF : 0;
-  static constexpr int TAB_OFF = PIPE ? Q_OFF + 4 * EPI_SLOT : 49152;
-  static constexpr int SMEM = TAB_OFF + MAX_KT * 8;
-  static IA_DEV int k_slot(int kt) { const int s = kt % KRING; return PIPE ? s * 8192 : (s == 2 ? 32768 : s * 8192); }
-  static IA_DEV int v_slot(int kt) { const int s = kt % VRING; return PIPE ? (KRING + s) * 8192 : (s == 2 ? 40960 : 16384 + s * 8192); }
-};
-constexpr float L_LO = 8.6736174e-19f, L_HI = 1.1529215e18f;                      // 2^-60, 2^60
+// LDS: K0 K1 | V0 V1 | K2 V2 | valid-key table.  Q is staged in K2 + V2 (first filled behind the first barrier), the epilogue rows in
+// K0.. (behind a last barrier).
+constexpr int k_slot(int s) { return s == 2 ? 32768 : s * 8192; }
+constexpr int v_slot(int s) { return s == 2 ? 40960 : 16384 + s * 8192; }
+constexpr int Q_OFF = 32768, EPI_OFF = 0, TAB_OFF = 49152, SMEM = TAB_OFF + MAX_KT * 8;
+constexpr float L_HI = 1.1529215e18f;                                             // 2^60
+constexpr uint32_t L_LO_BITS = 0x0D800000u, L_HI_BITS = 0x5D800000u;              // bits of 2^-100, 2^60
 constexpr float NEG_BIG = -1e30f;
 constexpr uint32_t NEG_BIG_BF16 = 0xF14Au;                                        // bf16(-1e30)
 
@@ -452,25 +449,31 @@ IA_DEV float swap32(float x) {      // the partner lane's (lane ^ 32) value
 }
 IA_DEV f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 
-struct Lane {          // lane constants of the fragment reads
-  uint32_t ka[4];      // byte offset of this lane's K fragment (row lq, k-step kb) inside a K tile; the second 32-key block is +4096
-  uint32_t v0, v1;     // transpose-read offsets inside a V tile (d 0..31 / 32..63)
+struct Lane {          // lane constants (absolute LDS byte addresses of ring slot 0)
+  uint32_t ka[4];      // this lane's K fragment (row lq, k-step kb); the second 32-key block is +4096
+  uint32_t v0, v1;     // transpose-read bases of the V tile (d 0..31 / 32..63)
+  uint32_t dk0, dk1, dv0, dv1;      // DMA: byte offset of this lane's 16 bytes inside a K / V tile of the sequence (issue 0 / 1)
 };
 
-// all eight K fragments of a tile (kf[kb * 2 + blk])
-IA_DEV void read_k(bf16x8 (&kf)[8], const Lane& ln, uint32_t tile_addr) {
+// all eight K fragments of the tile in ring slot SLOT (kf[kb * 2 + blk])
+template <int SLOT>
+IA_DEV void read_k(bf16x8 (&kf)[8], const Lane& ln) {
 #pragma unroll
   for (int kb = 0; kb < 4; ++kb) {
-    const uint32_t a = tile_addr + ln.ka[kb];
-    kf[kb * 2] = lds_read_b128<0>(a);
-    kf[kb * 2 + 1] = lds_read_b128<4096>(a);
+    kf[kb * 2] = lds_read_b128<k_slot(SLOT)>(ln.ka[kb]);
+    kf[kb * 2 + 1] = lds_read_b128<k_slot(SLOT) + 4096>(ln.ka[kb]);
   }
+}
+// rows ROW0 .. ROW0+15 of the V tile in ring slot SLOT
+template <int SLOT, int ROW0>
+IA_DEV void read_v(TrPair& f, const Lane& ln) {
+  constexpr int O = v_slot(SLOT) + ROW0 * 128;
+  f.lo0 = tr_read<O>(ln.v0); f.hi0 = tr_read<O + 1024>(ln.v0);
+  f.lo1 = tr_read<O>(ln.v1); f.hi1 = tr_read<O + 1024>(ln.v1);
 }
 
 // Scores of one 64-key tile against this wave's 32 queries: s = K (Q * scale * log2 e)^T [- m_ref] [- 1e30 on keys that may not be
-// attended].  The two optional terms come from one more MFMA per 32-key block whose A operand carries (penalty, 1) in k-slots 0 / 1 of
-// the key's row and whose B operand carries (1, -m_ref) in k-slots 0 / 1 of the query's column; a tile whose 64 keys are all
-// attendable in a wave that never left the reference 0 (the common case) starts from the inline constant 0 instead.
+// attended].  The two optional terms come from one more MFMA per 32-key block (header comment); `plain` = neither is needed.
 // refw: this lane's B word {bf16 1.0, bf16 -m_ref} (lanes 32..63, which hold k-slots 8..15: 0).
 IA_DEV void qk_tile(f32x16& s0, f32x16& s1, const bf16x8 (&kf)[8], const bf16x8 (&qf)[4], bool plain, uint32_t refw, uint32_t valid_lo,
                     uint32_t valid_hi, int lane) {
@@ -495,36 +498,60 @@ IA_DEV void qk_tile(f32x16& s0, f32x16& s1, const bf16x8 (&kf)[8], const bf16x8 
   }
 }
 
+// Dropout on a register of two packed bf16 probabilities (keys 2i, 2i+1): h = their 32-bit draw (ia_rng_pair: low half = even key), kept
+// iff the 16-bit draw >= thr16.  No compare / select (v_cmp 8.6 cycles + v_cndmask on one wave): saturating packed subtract of thr16-1
+// (0 iff dropped), clamp to 0 / 1, integer multiply of the bf16 bit pattern.  thr1 = (thr16 - 1) in both halves.
+IA_DEV uint32_t drop_pair(uint32_t w, uint32_t h, uint32_t thr1) {
+  uint32_t d;
+  asm("v_pk_sub_u16 %0, %1, %2 clamp\n\tv_pk_min_u16 %0, %0, 1 op_sel_hi:[1,0]\n\tv_pk_mul_lo_u16 %0, %3, %0" : "=&v"(d) : "v"(h), "v"(thr1), "v"(w));
+  return d;
+}
+
 struct Row {           // per-lane softmax state of its query (the partner lane ^ 32 holds the other half of the keys)
   float m_ref, l_run;  // m_ref is a bf16-representable number (it travels through the matrix pipe as a bf16 operand)
   uint32_t refw;       // {bf16 1.0, bf16 -m_ref} in lanes 0..31, 0 in lanes 32..63
 };
 
-// p = exp2(s [* sc]) in place; returns this lane's half of the tile's row sum
-IA_DEV float exp_sum(f32x16& s0, f32x16& s1, float sc) {
-  float ra = 0.f, rb = 0.f;
-  if (IA_F3_ABL & 8) return 1.f;
+// p = exp2(s [* sc]) in place
+IA_DEV void exp_tile(f32x16& s0, f32x16& s1, float sc) {
+  if (IA_F3_ABL & 8) return;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     s0[r] = __builtin_amdgcn_exp2f(PRESCALE ? s0[r] : s0[r] * sc);
     s1[r] = __builtin_amdgcn_exp2f(PRESCALE ? s1[r] : s1[r] * sc);
-    ra += s0[r];
-    rb += s1[r];
+  }
+}
+// The probabilities as the B fragments of the PV MFMAs (bf16), and this lane's half of the tile's row sum taken from the ROUNDED values
+// (v_dot2c_f32_bf16 against packed ones, exact in fp32): O = sum(p^ v) / sum(p^) is then a convex combination of the v rows -- a row
+// with one attendable key returns that key's v exactly, and delta = rowsum(dO o) cancels against dP in the backward as it should.
+IA_DEV float pack_sum(bf16x8 (&pf)[4], const f32x16& s0, const f32x16& s1) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    pf[0][j] = f2bf(s0[j]); pf[1][j] = f2bf(s0[8 + j]);
+    pf[2][j] = f2bf(s1[j]); pf[3][j] = f2bf(s1[8 + j]);
+  }
+  // (the builtin, not inline asm: the dot instruction's result needs wait states before an ordinary VALU read, which only the
+  // compiler's hazard recognizer inserts)
+  float ra = 0.f, rb = 0.f;
+  const bf16x2 ones = {(bf16)1.0f, (bf16)1.0f};
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    const bf16x8 v = pf[n];
+    ra = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{v[0], v[1]}, ones, ra, false);
+    rb = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{v[2], v[3]}, ones, rb, false);
+    ra = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{v[4], v[5]}, ones, ra, false);
+    rb = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{v[6], v[7]}, ones, rb, false);
   }
   return ra + rb;
 }
 
-// Rare: a row sum left [L_LO, L_HI] (or is not finite).  The tile's scores are recomputed from the K tile that is still in its ring
-// slot, the reference moves to the larger of the tile's maximum and the running log-sum-exp, everything accumulated so far follows.
-// snx0 / snx1: the next tile's scores, already formed against the old reference (null for the last tile).
-// sc: what exp2's argument is multiplied by (1 with pre-scaled queries); m_ref lives in the accumulators' units.
-IA_DEV float rebase(f32x16& s0, f32x16& s1, f32x16* snx0, f32x16* snx1, f32x16& o0, f32x16& o1, Row& row, const Lane& ln,
-                    uint32_t ktile_addr, const bf16x8 (&qf)[4], uint32_t valid_lo, uint32_t valid_hi, int lane, float sc) {
+// Rare: a lane's row sum left [2^-100, 2^60] (or is not finite).  The tile's scores are recomputed (its K fragments are still in
+// their registers), the reference moves to the larger of the tile's maximum and the running log-sum-exp, everything accumulated so
+// far follows.  sc: what exp2's argument is multiplied by (1 with pre-scaled queries); m_ref lives in the accumulators' units.
+IA_DEV void rebase(f32x16& s0, f32x16& s1, f32x16& o0, f32x16& o1, Row& row, const bf16x8 (&kf)[8], const bf16x8 (&qf)[4], uint32_t valid_lo,
+                    uint32_t valid_hi, int lane, float sc) {
   if (PRESCALE) sc = 1.f;
   const float inv_sc = 1.f / sc;
-  bf16x8 kf[8];
-  read_k(kf, ln, ktile_addr);
-  frag_wait<0>(kf);
   qk_tile(s0, s1, kf, qf, false, (lane & 32) ? 0u : 0x3F80u, valid_lo, valid_hi, lane);      // reference 0
   float tm = NEG_BIG;
 #pragma unroll
@@ -541,31 +568,19 @@ IA_DEV float rebase(f32x16& s0, f32x16& s1, f32x16* snx0, f32x16* snx1, f32x16& 
   row.m_ref = m_new;
   row.refw = (lane & 32) ? 0u : (0x3F80u | ((uint32_t)__builtin_bit_cast(uint16_t, f2bf(-m_new)) << 16));
   row.l_run *= alpha;
-  float rs = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     s0[r] = __builtin_amdgcn_exp2f((s0[r] - m_new) * sc);
     s1[r] = __builtin_amdgcn_exp2f((s1[r] - m_new) * sc);
-    rs += s0[r] + s1[r];
     o0[r] *= alpha; o1[r] *= alpha;
   }
-  if (snx0) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { (*snx0)[r] += shift; (*snx1)[r] += shift; }
-  }
-  return rs;
 }
 }  // namespace fwd3
 
-// PIPE: the QK^T of tile t+1 runs under the softmax of tile t inside the wave (two score blocks live, 2 waves per SIMD); without it a wave
-// alternates an MFMA batch (PV of tile t, QK^T of tile t+1) with the softmax, and the waves sharing its SIMD fill the other pipe.
-template <bool DROPOUT, bool PIPE, int WPS>
+template <bool DROPOUT, int WPS>
 __global__ __launch_bounds__(256, WPS) void attn_fwd3_kernel(AttnArgs p) {
   using namespace fwd3;
-  using C = Cfg<PIPE>;
-  constexpr int Q_OFF = C::Q_OFF, TAB_OFF = C::TAB_OFF;
-  constexpr int AHEAD = PIPE ? 2 : 1;                     // the K fragments requested during tile t are those of tile t + AHEAD
-  __shared__ __attribute__((aligned(16))) char smem[C::SMEM];
+  __shared__ __attribute__((aligned(16))) char smem[SMEM];
   uint32_t (*s_valid)[2] = reinterpret_cast<uint32_t (*)[2]>(smem + TAB_OFF);
   const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, lq = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -582,22 +597,48 @@ __global__ __launch_bounds__(256, WPS) void attn_fwd3_kernel(AttnArgs p) {
   const int q0 = tile * 128 + wave * 32;
   const bool active = q0 < Lq;
   const int q = q0 + lq;
-  const __amdgpu_buffer_rsrc_t rsK = ia_rsrc(p.k, p.kv_bytes);
-  const __amdgpu_buffer_rsrc_t rsV = ia_rsrc(p.v, p.kv_bytes);
+  // this sequence's K / V rows of head h as buffer windows: rows >= L are out of range and arrive as zeros
+  const uint32_t win = (uint32_t)(((size_t)(L - 1) * p.ld_kv + 64) * 2);
+  const __amdgpu_buffer_rsrc_t rsK = ia_rsrc(p.k + rowbase * p.ld_kv + h * 64, win);
+  const __amdgpu_buffer_rsrc_t rsV = ia_rsrc(p.v + rowbase * p.ld_kv + h * 64, win);
   const uint32_t sbase = lds_addr(smem);
+  const uint32_t tile_bytes = (uint32_t)p.ld_kv * 128u;                            // 64 rows
   const int nkt_all = (L + 63) >> 6;
 
-  auto stage_k = [&](int kt) { stage64<false>(rsK, smem + C::k_slot(kt), rowbase + kt * 64, L - kt * 64, p.ld_kv, h * 64, tid, wave); };
-  auto stage_v = [&](int kt) { stage64<true>(rsV, smem + C::v_slot(kt), rowbase + kt * 64, L - kt * 64, p.ld_kv, h * 64, tid, wave); };
+  Lane ln;
+  {
+    const uint32_t a0 = (uint32_t)(lq * 128 + ((hh ^ swz_b128(lq)) << 4));
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) ln.ka[kb] = sbase + (a0 ^ (uint32_t)(kb << 5));
+    ln.v0 = sbase + tr_lane_off(lane, 0); ln.v1 = sbase + tr_lane_off(lane, 32);
+    const int r0 = tid >> 3, r1 = 32 + (tid >> 3), c = tid & 7;
+    ln.dk0 = (uint32_t)((r0 * p.ld_kv + (c ^ swz_b128(r0)) * 8) * 2); ln.dk1 = (uint32_t)((r1 * p.ld_kv + (c ^ swz_b128(r1)) * 8) * 2);
+    ln.dv0 = (uint32_t)((r0 * p.ld_kv + (c ^ swz_tr(r0)) * 8) * 2);   ln.dv1 = (uint32_t)((r1 * p.ld_kv + (c ^ swz_tr(r1)) * 8) * 2);
+  }
+  typedef __attribute__((address_space(3))) char lds_char;
+  lds_char* const lsm = (lds_char*)IA_LDS(smem);        // one flat -> LDS cast; DMA destinations are LDS-pointer arithmetic from here
+  // key tile kt into ring slot SLOT: two 16-byte-per-lane DMA issues per operand, tile selected by the scalar offset
+  auto stage_k = [&](auto SLOT_T, int kt) {
+    constexpr int S = decltype(SLOT_T)::value;
+    const uint32_t so = (uint32_t)kt * tile_bytes;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lsm + k_slot(S) + wave * 1024), 16, ln.dk0, so, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lsm + k_slot(S) + 4096 + wave * 1024), 16, ln.dk1, so, 0, 0);
+  };
+  auto stage_v = [&](auto SLOT_T, int kt) {
+    constexpr int S = decltype(SLOT_T)::value;
+    const uint32_t so = (uint32_t)kt * tile_bytes;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lsm + v_slot(S) + wave * 1024), 16, ln.dv0, so, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lsm + v_slot(S) + 4096 + wave * 1024), 16, ln.dv1, so, 0, 0);
+  };
+  using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>; using S2 = std::integral_constant<int, 2>;
 
-  // ---- prologue: one round trip for Q, K0, V0, K1 and the mask bytes; K2 / V1 follow and stay in flight
+  // ---- prologue: one round trip for Q, K0, V0, K1 and the mask bytes; V1 follows and stays in flight
   char* qslot = smem + Q_OFF + wave * 4096;
   stage_rows32(ia_rsrc(p.q, p.q_bytes), qslot, qbase + q0, Lq - q0, p.ld_q, h * 64, lane);
-  stage_k(0); stage_v(0); stage_k(1);
+  stage_k(S0{}, 0); stage_v(S0{}, 0); stage_k(S1{}, 1);
   build_valid_table(p, s_valid, rowbase, L, lane, wave);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (PIPE) stage_k(2);
-  stage_v(1);
+  stage_v(S1{}, 1);
   bf16x8 qf[4];
 #pragma unroll
   for (int kb = 0; kb < 4; ++kb) {
@@ -605,116 +646,109 @@ __global__ __launch_bounds__(256, WPS) void attn_fwd3_kernel(AttnArgs p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) qf[kb][j] = PRESCALE ? f2bf(bf2f(raw[j]) * p.sc) : raw[j];
   }
-  Lane ln;
-  {
-    const uint32_t a0 = (uint32_t)(lq * 128 + ((hh ^ swz_b128(lq)) << 4));
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) ln.ka[kb] = a0 ^ (uint32_t)(kb << 5);
-    ln.v0 = tr_lane_off(lane, 0); ln.v1 = tr_lane_off(lane, 32);
-  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  // trailing tiles without any attendable key are never touched (right-padded batches); holes inside take the penalty path
+  // trailing tiles without any attendable key are never touched (right-padded batches); bit t of `ragged`: tile t has a key that may
+  // not be attended (such tiles take the penalty MFMA)
   int nkt = nkt_all;
-  while (nkt > 1 && (s_valid[nkt - 1][0] | s_valid[nkt - 1][1]) == 0u) --nkt;
+  uint32_t ragged = 0u;
+  for (int t = 0; t < nkt_all; ++t) {
+    const uint32_t lo = s_valid[t][0], hi = s_valid[t][1];
+    if ((lo & hi) != 0xFFFFFFFFu) ragged |= 1u << t;
+    if ((lo | hi) != 0u) nkt = t + 1;
+  }
   nkt = __builtin_amdgcn_readfirstlane(nkt);
+  ragged = __builtin_amdgcn_readfirstlane(ragged);
 
+  const uint32_t rk = DROPOUT ? ia_rng_row(p.seed, (uint32_t)(b * p.nh + h), (uint32_t)q) : 0u;      // row key of this lane's query
+  const uint32_t thr1 = DROPOUT ? (p.thr16 - 1u) * 0x10001u : 0u;
   Row row{0.f, 0.f, hh ? 0u : 0x3F80u};
   bool has_ref = false;                                  // wave-uniform: some row of this wave has left the reference 0
   f32x16 o0 = zero16(), o1 = zero16();
-  f32x16 sa0, sa1, sb0, sb1;
   bf16x8 kf[8];
-  if (active) {
-    read_k(kf, ln, sbase + C::k_slot(0));
-    if (PIPE) {
-      frag_wait<0>(kf);
-      const uint32_t v_lo = __builtin_amdgcn_readfirstlane(s_valid[0][0]), v_hi = __builtin_amdgcn_readfirstlane(s_valid[0][1]);
-      qk_tile(sa0, sa1, kf, qf, (v_lo & v_hi) == 0xFFFFFFFFu, row.refw, v_lo, v_hi, lane);
-      if (nkt > 1) read_k(kf, ln, sbase + C::k_slot(1));
-    }
-  }
+  if (active) read_k<0>(kf, ln);
 
-  // one tile.  PIPE: sc = scores of tile t (in), sn = scores of tile t+1 (out, unless LAST); otherwise sc is scratch, sn unused
-  auto tile_step = [&](auto LAST_T, f32x16& sc0, f32x16& sc1, f32x16& sn0, f32x16& sn1, int t) {
-    constexpr bool LAST = decltype(LAST_T)::value;
-    // K(t+2) has landed for this wave (V(t+1), issued behind it, may still be in flight), then for everybody
+  // one tile (key tile t sits in ring slot SLOT = t % 3)
+  auto tile_step = [&](auto SLOT_T, int t) {
+    constexpr int SLOT = decltype(SLOT_T)::value;
+    using NEXT2 = std::integral_constant<int, (SLOT + 2) % 3>;
+    const bool LAST = t + 1 >= nkt;                       // wave-uniform
+    // K(t+1) has landed for this wave (V(t+1), issued behind it, may still be in flight), then for everybody
     if (LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     if (!(IA_F3_ABL & 2)) __builtin_amdgcn_s_barrier();
-    if (!(IA_F3_ABL & 1)) {
-      if (t + AHEAD + 1 < nkt) stage_k(t + AHEAD + 1);
-      if (t + 2 < nkt) stage_v(t + 2);
-    }
+    if (!(IA_F3_ABL & 1) && t + 2 < nkt) { stage_k(NEXT2{}, t + 2); stage_v(NEXT2{}, t + 2); }
     if (!active || (IA_F3_ABL & 4)) return;
-    const uint32_t vt = sbase + (uint32_t)C::v_slot(t);
-    const uint32_t vb0 = vt + ln.v0, vb1 = vt + ln.v1;
-    const uint32_t cur_lo = __builtin_amdgcn_readfirstlane(s_valid[t][0]), cur_hi = __builtin_amdgcn_readfirstlane(s_valid[t][1]);
-    TrPair va, vb, vc, vd;
-    if (PIPE) {
-      if (!LAST) {
-        frag_wait<0>(kf);                                 // the K fragments of tile t+1, requested during the previous tile's PV
-        const uint32_t n_lo = __builtin_amdgcn_readfirstlane(s_valid[t + 1][0]), n_hi = __builtin_amdgcn_readfirstlane(s_valid[t + 1][1]);
-        qk_tile(sn0, sn1, kf, qf, !has_ref && (n_lo & n_hi) == 0xFFFFFFFFu, row.refw, n_lo, n_hi, lane);
-      }
-    } else {
-      frag_wait<0>(kf);                                   // the K fragments of tile t
-      qk_tile(sc0, sc1, kf, qf, !has_ref && (cur_lo & cur_hi) == 0xFFFFFFFFu, row.refw, cur_lo, cur_hi, lane);
-    }
-    float rs = exp_sum(sc0, sc1, p.sc);
+    f32x16 s0, s1;
+    frag_wait<0>(kf);                                     // the K fragments of tile t
+    const bool plain = !has_ref && !((ragged >> t) & 1u);
+    uint32_t cur_lo = 0xFFFFFFFFu, cur_hi = 0xFFFFFFFFu;
+    if (!plain) { cur_lo = __builtin_amdgcn_readfirstlane(s_valid[t][0]); cur_hi = __builtin_amdgcn_readfirstlane(s_valid[t][1]); }
+    qk_tile(s0, s1, kf, qf, plain, row.refw, cur_lo, cur_hi, lane);
+    exp_tile(s0, s1, p.sc);
+    bf16x8 pf[4];
+    float rs = pack_sum(pf, s0, s1);
     {
-      float tot = row.l_run + rs;
-      tot += swap32(tot);
-      if (__builtin_expect(__ballot(!(tot >= L_LO && tot <= L_HI)) != 0ull, 0)) {
-        rs = rebase(sc0, sc1, (PIPE && !LAST) ? &sn0 : nullptr, (PIPE && !LAST) ? &sn1 : nullptr, o0, o1, row, ln,
-                    sbase + (uint32_t)C::k_slot(t), qf, cur_lo, cur_hi, lane, p.sc);
+      const float tot = row.l_run + rs;
+      if (__builtin_expect(__ballot(__builtin_bit_cast(uint32_t, tot) - L_LO_BITS > L_HI_BITS - L_LO_BITS) != 0ull, 0)) {
+        if (plain) { cur_lo = __builtin_amdgcn_readfirstlane(s_valid[t][0]); cur_hi = __builtin_amdgcn_readfirstlane(s_valid[t][1]); }
+        rebase(s0, s1, o0, o1, row, kf, qf, cur_lo, cur_hi, lane, p.sc);
+        rs = pack_sum(pf, s0, s1);
         has_ref = true;
       }
     }
     row.l_run += rs;
+    TrPair va, vb, vc, vd;
     if (IA_F3_ABL & 16) {                                 // no LDS reads: whatever is in the K fragment registers stands in for V^T
       va.lo0 = va.lo1 = vb.lo0 = vb.lo1 = vc.lo0 = vc.lo1 = vd.lo0 = vd.lo1 = __builtin_bit_cast(s16x8, kf[0]).lo;
       va.hi0 = va.hi1 = vb.hi0 = vb.hi1 = vc.hi0 = vc.hi1 = vd.hi0 = vd.hi1 = __builtin_bit_cast(s16x8, kf[1]).hi;
     } else {
-    tr_issue<0>(va, vb0, vb1);                            // the V^T fragments land under the conversions
-    tr_issue<16>(vb, vb0, vb1);
+      read_v<SLOT, 0>(va, ln);                            // the V^T fragments land under the dropout draws / the first MFMAs
+      read_v<SLOT, 16>(vb, ln);
     }
-    bf16x8 pf[4];
+    if (DROPOUT) {
+      // word i of pf[n] = keys (ACC_ROW(8 (n & 1) + 2 i), +1) of key block n >> 1: pair constant = tile part + lane part + immediate
+      const uint32_t tile_c = (uint32_t)(t * 32) * IA_RNG_PAIR_C + (uint32_t)(2 * hh) * IA_RNG_PAIR_C;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      pf[0][j] = f2bf(sc0[j]); pf[1][j] = f2bf(sc0[8 + j]);
-      pf[2][j] = f2bf(sc1[j]); pf[3][j] = f2bf(sc1[8 + j]);
+      for (int n = 0; n < 4; ++n) {
+        u32x4 w = __builtin_bit_cast(u32x4, pf[n]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          constexpr uint32_t C = IA_RNG_PAIR_C;
+          const int r = 8 * (n & 1) + 2 * i;
+          const uint32_t imm = (uint32_t)(((r & 3) >> 1) + 4 * (r >> 2) + 16 * (n >> 1)) * C;
+          w[i] = drop_pair(w[i], ia_rng_pair(rk, tile_c + imm), thr1);
+        }
+        pf[n] = __builtin_bit_cast(bf16x8, w);
+      }
     }
     tr_wait<4>(va);
     o0 = mfma(va.a0(), pf[0], o0); o1 = mfma(va.a1(), pf[0], o1);
-    if (!(IA_F3_ABL & 16)) tr_issue<32>(vc, vb0, vb1);
+    if (!(IA_F3_ABL & 16)) read_v<SLOT, 32>(vc, ln);
     tr_wait<4>(vb);
     o0 = mfma(vb.a0(), pf[1], o0); o1 = mfma(vb.a1(), pf[1], o1);
-    if (!(IA_F3_ABL & 16)) tr_issue<48>(vd, vb0, vb1);
-    const bool more = !LAST && t + AHEAD < nkt && !(IA_F3_ABL & 16);
-    if (more) read_k(kf, ln, sbase + (uint32_t)C::k_slot(t + AHEAD));
-    if (more) { tr_wait<12>(vc); } else { tr_wait<4>(vc); }
+    if (!(IA_F3_ABL & 16)) read_v<SLOT, 48>(vd, ln);
+    tr_wait<4>(vc);
     o0 = mfma(vc.a0(), pf[2], o0); o1 = mfma(vc.a1(), pf[2], o1);
-    if (more) { tr_wait<8>(vd); } else { tr_wait<0>(vd); }
+    tr_wait<0>(vd);
     o0 = mfma(vd.a0(), pf[3], o0); o1 = mfma(vd.a1(), pf[3], o1);
+    // the K fragments of tile t+1 land under the last MFMAs and the top of the next tile (no wait here depends on them)
+    if (!LAST && !(IA_F3_ABL & 16)) read_k<(SLOT + 1) % 3>(kf, ln);
   };
-  if (PIPE) {
+  {
     int t = 0;
     for (;;) {
-      if (t + 1 >= nkt) { tile_step(std::true_type{}, sa0, sa1, sb0, sb1, t); break; }
-      tile_step(std::false_type{}, sa0, sa1, sb0, sb1, t); ++t;
-      if (t + 1 >= nkt) { tile_step(std::true_type{}, sb0, sb1, sa0, sa1, t); break; }
-      tile_step(std::false_type{}, sb0, sb1, sa0, sa1, t); ++t;
+      tile_step(S0{}, t); if (++t >= nkt) break;
+      tile_step(S1{}, t); if (++t >= nkt) break;
+      tile_step(S2{}, t); if (++t >= nkt) break;
     }
-  } else {
-    for (int t = 0; t + 1 < nkt; ++t) tile_step(std::false_type{}, sa0, sa1, sb0, sb1, t);
-    tile_step(std::true_type{}, sa0, sa1, sb0, sb1, nkt - 1);
-    __builtin_amdgcn_s_barrier();                         // the epilogue rows are staged in the K ring
   }
+  __builtin_amdgcn_s_barrier();                           // the epilogue rows are staged in the K ring
   if (!active) return;
   const float l_tot = row.l_run + swap32(row.l_run);
   const float inv = l_tot > 0.f ? p.inv_keep / l_tot : 0.f;
   if (q < Lq && hh == 0 && p.lse2) p.lse2[((size_t)b * p.nh + h) * p.Lq + q] = row.m_ref * (PRESCALE ? 1.f : p.sc) + __builtin_amdgcn_logf(l_tot);
-  store_block_rows(smem + C::EPI_OFF + wave * EPI_SLOT, o0, o1, inv, false, p.out + (qbase + q0) * p.ld_o + h * 64, p.ld_o, Lq - q0, lane);
+  store_block_rows(smem + EPI_OFF + wave * EPI_SLOT, o0, o1, inv, false, p.out + (qbase + q0) * p.ld_o + h * 64, p.ld_o, Lq - q0, lane);
 }
 
 // ------------------------------------------------------------------------------------- backward: dQ
@@ -888,6 +922,260 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------- backward, round 3: dQ
+// The round-2 kernel above, rebuilt like the forward (issue-bound at head dim 64, so the loop carries only what the arithmetic needs):
+//  * S^T = K (Q scale log2e)^T - lse and dP^T - delta come out of the matrix pipe: the first MFMA of each chain takes a 16-register
+//    block holding -lse / -delta of the lane's query as its C operand (both are constants of the whole kernel), so P = exp2(acc) and
+//    dS = P * acc': 32 exp2 + 32 multiplies + 16 packed converts per 24 MFMAs; the query fragments are pre-scaled exactly as in the
+//    forward (the same bf16 rounding, so the recomputed P matches the forward's);
+//  * masked keys take the penalty MFMA (P = exp2(-1e30) = 0), no compare / select pairs;
+//  * per-sequence buffer windows + scalar DMA offsets + compile-time ring slots (3 stages of K | K for the transpose read | V), LDS
+//    reads on lane-constant bases with immediates, fragments of k-step kb+1 requested before the MFMAs of kb (asm reads, counted waits).
+// Dropout (text towers): dS = P (M / keep dP - delta); the draw of a key pair is turned into two 0 / 1 floats without compares
+// (saturating packed subtract, clamp, v_cvt_f32_ubyte).
+namespace bwd3 {
+using namespace fwd3;
+// One LDS image of a [64 rows][64 bf16] tile that BOTH read forms take without bank conflicts: the 16-byte chunk of row r is XORed
+// with swz_u(r).  ds_read_b128 (a lane group = 16 rows of one column chunk) needs 8 different values over the even (and the odd)
+// rows of its group; ds_read_b64_tr_b16 (a lane group = 4 rows x 32 bytes) needs rows r and r+2 to differ above bit 0.  With
+// x = (r >> 1) & 7, swz_u = ((x & 1) << 2) | (x >> 1) does both.  The round-2 kernels kept two copies of K (dQ kernel) and of Q and dO
+// (dK/dV kernel) in different layouts: a third / a half of their LDS-DMA traffic.
+IA_DEV int swz_u(int row) { const int x = (row >> 1) & 7; return ((x & 1) << 2) | (x >> 1); }
+// transpose-read lane offset inside such a tile (rows 0..7 of the 16-row step; rows 8..15 sit at (this ^ 32) + 1024)
+IA_DEV uint32_t tr_lane_off_u(int lane, int col0) {
+  const int p = lane & 15, G = lane >> 4;
+  const int row = 4 * (G >> 1) + (p >> 2);
+  const int col = col0 + 16 * (G & 1) + (p & 3) * 4;
+  return (uint32_t)(row * 128 + ((((col >> 3) ^ swz_u(row))) << 4) + (col & 7) * 2);
+}
+constexpr int STAGE = 16384;                         // K | V, both in the unified layout
+constexpr int DQ_ROWS_OFF = 3 * STAGE;               // 16 KiB: the prologue's q rows (dO / o rows go through stages 1 / 2)
+constexpr int DQ_TAB_OFF = DQ_ROWS_OFF + 16384, DQ_SMEM = DQ_TAB_OFF + MAX_KT * 8;
+template <int N>
+IA_DEV void frag_wait4(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+// rows ROW0 .. ROW0+15 of the unified-layout tile at byte offset BASE, read transposed (b0 / b1: tr_lane_off_u for d 0..31 / 32..63,
+// b0x / b1x = the same ^ 32: the swizzle of rows 8..15 differs in chunk bit 1)
+template <int BASE, int ROW0>
+IA_DEV void read_tr(TrPair& f, uint32_t b0, uint32_t b1, uint32_t b0x, uint32_t b1x) {
+  constexpr int O = BASE + ROW0 * 128;
+  f.lo0 = tr_read<O>(b0); f.hi0 = tr_read<O + 1024>(b0x);
+  f.lo1 = tr_read<O>(b1); f.hi1 = tr_read<O + 1024>(b1x);
+}
+// two 0 / 1 floats (low / high 16-bit draw >= thr16) out of a 32-bit draw; thr1 = (thr16 - 1) in both halves
+IA_DEV void keep_pair(uint32_t h, uint32_t thr1, float& k_lo, float& k_hi) {
+  uint32_t d;
+  asm("v_pk_sub_u16 %0, %1, %2 clamp\n\tv_pk_min_u16 %0, %0, 1 op_sel_hi:[1,0]" : "=v"(d) : "v"(h), "v"(thr1));
+  asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(k_lo) : "v"(d));
+  asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(k_hi) : "v"(d));
+}
+}  // namespace bwd3
+
+template <bool DROPOUT>
+__global__ __launch_bounds__(256, 2) void attn_bwd3_dq_kernel(AttnArgs p) {
+  using namespace bwd3;
+  __shared__ __attribute__((aligned(16))) char smem[DQ_SMEM];
+  uint32_t (*s_valid)[2] = reinterpret_cast<uint32_t (*)[2]>(smem + DQ_TAB_OFF);
+  const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, lq = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int tile, h, b;
+  attn_block_coords(p, p.Lq, tile, h, b);
+  int Lq = p.Lq, L = p.Lk;
+  size_t qbase = (size_t)b * Lq, rowbase = (size_t)b * L;
+  if (p.cu) {
+    const int c0 = p.cu[b];
+    Lq = L = p.cu[b + 1] - c0;
+    qbase = rowbase = (size_t)c0;
+    if (tile * 128 >= Lq) return;
+  }
+  const int q0 = tile * 128 + wave * 32;
+  const bool active = q0 < Lq;
+  const int q = q0 + lq;
+  const int qc = q < Lq ? q : Lq - 1;
+  const uint32_t win = (uint32_t)(((size_t)(L - 1) * p.ld_kv + 64) * 2);
+  const __amdgpu_buffer_rsrc_t rsK = ia_rsrc(p.k + rowbase * p.ld_kv + h * 64, win);
+  const __amdgpu_buffer_rsrc_t rsV = ia_rsrc(p.v + rowbase * p.ld_kv + h * 64, win);
+  const uint32_t sbase = lds_addr(smem);
+  const uint32_t tile_bytes = (uint32_t)p.ld_kv * 128u, half_bytes = (uint32_t)p.ld_kv * 64u;
+  const int nkt_all = (L + 63) >> 6;
+  // lane constants: fragment read bases (stage 0) and the DMA offsets of this lane's 16 bytes inside a tile
+  uint32_t ka[4], t0, t1, t0x, t1x, du;
+  {
+    const uint32_t a0 = (uint32_t)(lq * 128 + ((hh ^ swz_u(lq)) << 4));
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) ka[kb] = sbase + (a0 ^ (uint32_t)(kb << 5));
+    t0 = sbase + tr_lane_off_u(lane, 0); t1 = sbase + tr_lane_off_u(lane, 32); t0x = t0 ^ 32u; t1x = t1 ^ 32u;
+    const int r0 = tid >> 3, c = tid & 7;
+    du = (uint32_t)((r0 * p.ld_kv + (c ^ swz_u(r0)) * 8) * 2);
+  }
+  typedef __attribute__((address_space(3))) char lds_char;
+  lds_char* const lsm = (lds_char*)IA_LDS(smem);        // one flat -> LDS cast; DMA destinations are LDS-pointer arithmetic from here
+  auto stage_tile = [&](auto SLOT_T, int kt) {
+    constexpr int S = decltype(SLOT_T)::value * STAGE;
+    const uint32_t so = (uint32_t)kt * tile_bytes, so2 = so + half_bytes;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lsm + S + wave * 1024), 16, du, so, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lsm + S + 4096 + wave * 1024), 16, du, so2, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lsm + S + 8192 + wave * 1024), 16, du, so, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lsm + S + 12288 + wave * 1024), 16, du, so2, 0, 0);
+  };
+  using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>; using S2 = std::integral_constant<int, 2>;
+
+  // ---- prologue: one round trip for this wave's q / dO / o rows (q behind the ring, dO / o in stages 1 / 2), key tile 0, lse and
+  // the mask bytes
+  char* const rq = smem + DQ_ROWS_OFF + wave * 4096;
+  char* const rg = smem + STAGE + wave * 4096;
+  char* const ro = smem + 2 * STAGE + wave * 4096;
+  stage_rows32(ia_rsrc(p.q, p.q_bytes), rq, qbase + q0, Lq - q0, p.ld_q, h * 64, lane);
+  stage_rows32(ia_rsrc(p.d_o, p.o_bytes), rg, qbase + q0, Lq - q0, p.ld_o, h * 64, lane);
+  stage_rows32(ia_rsrc(p.o, p.o_bytes), ro, qbase + q0, Lq - q0, p.ld_o, h * 64, lane);
+  stage_tile(S0{}, 0);
+  const size_t sidx = ((size_t)b * p.nh + h) * p.Lq + qc;
+  const float lse = p.lse2[sidx];
+  build_valid_table(p, s_valid, rowbase, L, lane, wave);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  bf16x8 qf[4], gf[4];
+  float dlt = 0.f;                                      // delta = rowsum(dO * O): each lane of the pair (lane, lane ^ 32) holds half the columns
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    const bf16x8 raw = frag_b128(rq, lq, kb * 2 + hh);
+    gf[kb] = frag_b128(rg, lq, kb * 2 + hh);
+    const bf16x8 ov = frag_b128(ro, lq, kb * 2 + hh);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      dlt += bf2f(ov[j]) * bf2f(gf[kb][j]);
+      qf[kb][j] = PRESCALE ? f2bf(bf2f(raw[j]) * p.sc) : raw[j];
+    }
+  }
+  dlt += swap32(dlt);
+  if (active && hh == 0 && q < Lq) p.delta[sidx] = dlt;       // for the dK/dV kernel, which runs behind this one on the stream
+  f32x16 nl, nd;                                              // C operands: -lse, -delta (dropout: the mask sits between dP and delta)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { nl[r] = PRESCALE ? -lse : -lse / p.sc; nd[r] = DROPOUT ? 0.f : -dlt; }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int nkt = nkt_all;
+  uint32_t ragged = 0u;
+  for (int t = 0; t < nkt_all; ++t) {
+    const uint32_t lo = s_valid[t][0], hi = s_valid[t][1];
+    if ((lo & hi) != 0xFFFFFFFFu) ragged |= 1u << t;
+    if ((lo | hi) != 0u) nkt = t + 1;
+  }
+  nkt = __builtin_amdgcn_readfirstlane(nkt);
+  ragged = __builtin_amdgcn_readfirstlane(ragged);
+  if (nkt > 1) stage_tile(S1{}, 1);
+  const uint32_t rk = DROPOUT ? ia_rng_row(p.seed, (uint32_t)(b * p.nh + h), (uint32_t)q) : 0u;
+  const uint32_t thr1 = DROPOUT ? (p.thr16 - 1u) * 0x10001u : 0u;
+  f32x16 dq0 = zero16(), dq1 = zero16();
+
+  auto tile_step = [&](auto SLOT_T, int t) {
+    constexpr int SB = decltype(SLOT_T)::value * STAGE;
+    using NEXT2 = std::integral_constant<int, (decltype(SLOT_T)::value + 2) % 3>;
+    const bool LAST = t + 1 >= nkt;
+    // tile t has landed for this wave (tile t+1, issued behind it, may still be in flight), then for everybody
+    if (LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < nkt) stage_tile(NEXT2{}, t + 2);
+    if (!active) return;
+    bf16x8 xk0, xk1, xv0, xv1, yk0, yk1, yv0, yv1;        // K / V fragments of even / odd k-steps
+    auto rd = [&](auto KB, bf16x8& k0, bf16x8& k1, bf16x8& v0, bf16x8& v1) {
+      constexpr int kb = decltype(KB)::value;
+      k0 = lds_read_b128<SB>(ka[kb]); k1 = lds_read_b128<SB + 4096>(ka[kb]);
+      v0 = lds_read_b128<SB + 8192>(ka[kb]); v1 = lds_read_b128<SB + 12288>(ka[kb]);
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    rd(I0{}, xk0, xk1, xv0, xv1);
+    rd(I1{}, yk0, yk1, yv0, yv1);
+    f32x16 s0, s1, dp0, dp1;
+    const bool plain = !((ragged >> t) & 1u);
+    if (plain) {
+      frag_wait4<4>(xk0, xk1, xv0, xv1);
+      s0 = mfma(xk0, qf[0], nl); s1 = mfma(xk1, qf[0], nl);
+    } else {
+      const uint32_t v_lo = __builtin_amdgcn_readfirstlane(s_valid[t][0]), v_hi = __builtin_amdgcn_readfirstlane(s_valid[t][1]);
+      const uint32_t low = hh ? 0u : 1u;
+      const uint32_t bad0 = ((~v_lo) >> lq) & low, bad1 = ((~v_hi) >> lq) & low;
+      const u32x4 a0 = {bad0 * NEG_BIG_BF16, 0u, 0u, 0u}, a1 = {bad1 * NEG_BIG_BF16, 0u, 0u, 0u}, bw = {low * 0x3F80u, 0u, 0u, 0u};
+      const f32x16 c0 = mfma(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, bw), nl);
+      const f32x16 c1 = mfma(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, bw), nl);
+      frag_wait4<4>(xk0, xk1, xv0, xv1);
+      s0 = mfma(xk0, qf[0], c0); s1 = mfma(xk1, qf[0], c1);
+    }
+    dp0 = mfma(xv0, gf[0], nd); dp1 = mfma(xv1, gf[0], nd);
+    rd(I2{}, xk0, xk1, xv0, xv1);
+    frag_wait4<4>(yk0, yk1, yv0, yv1);
+    s0 = mfma(yk0, qf[1], s0); s1 = mfma(yk1, qf[1], s1); dp0 = mfma(yv0, gf[1], dp0); dp1 = mfma(yv1, gf[1], dp1);
+    rd(I3{}, yk0, yk1, yv0, yv1);
+    frag_wait4<4>(xk0, xk1, xv0, xv1);
+    s0 = mfma(xk0, qf[2], s0); s1 = mfma(xk1, qf[2], s1); dp0 = mfma(xv0, gf[2], dp0); dp1 = mfma(xv1, gf[2], dp1);
+    TrPair ta, tb, tc, td;                                // K^T fragments of the dQ MFMAs
+    read_tr<SB, 0>(ta, t0, t1, t0x, t1x);
+    read_tr<SB, 16>(tb, t0, t1, t0x, t1x);
+    frag_wait4<8>(yk0, yk1, yv0, yv1);
+    s0 = mfma(yk0, qf[3], s0); s1 = mfma(yk1, qf[3], s1); dp0 = mfma(yv0, gf[3], dp0); dp1 = mfma(yv1, gf[3], dp1);
+    // dS^T = P^T (dP^T - delta), P = exp2(s - lse)
+    if (DROPOUT) {
+      const uint32_t tile_c = (uint32_t)(t * 32) * IA_RNG_PAIR_C + (uint32_t)(2 * hh) * IA_RNG_PAIR_C;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        constexpr uint32_t C = IA_RNG_PAIR_C;
+        const uint32_t imm = (uint32_t)(((r & 3) >> 1) + 4 * (r >> 2)) * C;
+        float a_lo, a_hi, b_lo, b_hi;
+        keep_pair(ia_rng_pair(rk, tile_c + imm), thr1, a_lo, a_hi);
+        keep_pair(ia_rng_pair(rk, tile_c + imm + 16u * C), thr1, b_lo, b_hi);
+        s0[r] = __builtin_amdgcn_exp2f(PRESCALE ? s0[r] : s0[r] * p.sc) * __builtin_fmaf(dp0[r] * a_lo, p.inv_keep, -dlt);
+        s0[r + 1] = __builtin_amdgcn_exp2f(PRESCALE ? s0[r + 1] : s0[r + 1] * p.sc) * __builtin_fmaf(dp0[r + 1] * a_hi, p.inv_keep, -dlt);
+        s1[r] = __builtin_amdgcn_exp2f(PRESCALE ? s1[r] : s1[r] * p.sc) * __builtin_fmaf(dp1[r] * b_lo, p.inv_keep, -dlt);
+        s1[r + 1] = __builtin_amdgcn_exp2f(PRESCALE ? s1[r + 1] : s1[r + 1] * p.sc) * __builtin_fmaf(dp1[r + 1] * b_hi, p.inv_keep, -dlt);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0[r] = __builtin_amdgcn_exp2f(PRESCALE ? s0[r] : s0[r] * p.sc) * dp0[r];
+        s1[r] = __builtin_amdgcn_exp2f(PRESCALE ? s1[r] : s1[r] * p.sc) * dp1[r];
+      }
+    }
+    bf16x8 sf[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sf[0][j] = f2bf(s0[j]); sf[1][j] = f2bf(s0[8 + j]);
+      sf[2][j] = f2bf(s1[j]); sf[3][j] = f2bf(s1[8 + j]);
+    }
+    tr_wait<4>(ta);
+    dq0 = mfma(ta.a0(), sf[0], dq0); dq1 = mfma(ta.a1(), sf[0], dq1);
+    read_tr<SB, 32>(tc, t0, t1, t0x, t1x);
+    tr_wait<4>(tb);
+    dq0 = mfma(tb.a0(), sf[1], dq0); dq1 = mfma(tb.a1(), sf[1], dq1);
+    read_tr<SB, 48>(td, t0, t1, t0x, t1x);
+    tr_wait<4>(tc);
+    dq0 = mfma(tc.a0(), sf[2], dq0); dq1 = mfma(tc.a1(), sf[2], dq1);
+    tr_wait<0>(td);
+    dq0 = mfma(td.a0(), sf[3], dq0); dq1 = mfma(td.a1(), sf[3], dq1);
+  };
+  {
+    int t = 0;
+    for (;;) {
+      tile_step(S0{}, t); if (++t >= nkt) break;
+      tile_step(S1{}, t); if (++t >= nkt) break;
+      tile_step(S2{}, t); if (++t >= nkt) break;
+    }
+  }
+  __builtin_amdgcn_s_barrier();                           // the epilogue rows are staged in the ring
+  float* cs_lds = p.cs_part ? reinterpret_cast<float*>(smem + 4 * EPI_SLOT) + wave * 64 : nullptr;      // behind the four store slots
+  if (!active && !cs_lds) return;
+  if (active) store_block_rows(smem + wave * EPI_SLOT, dq0, dq1, p.scale, false, p.dq + (qbase + q0) * p.ld_dq + h * 64, p.ld_dq, Lq - q0, lane, cs_lds);
+  else zero_cs_row(cs_lds, lane);
+  if (cs_lds) {           // workgroup-uniform: one row of the partial-sum matrix per workgroup
+    __syncthreads();
+    if (wave == 0) {
+      const float* c = reinterpret_cast<const float*>(smem + 4 * EPI_SLOT);
+      p.cs_part[(size_t)(b * ((p.Lq + 127) >> 7) + tile) * (3 * p.nh * 64) + h * 64 + lane] = (c[lane] + c[64 + lane]) + (c[128 + lane] + c[192 + lane]);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------- backward: dK, dV
 // S orientation: rows = queries (accumulator registers), column = key = lane. A column of P / dS only ever reaches
 // that key's dK / dV, so the key mask needs no per-element work: a masked key's outputs are simply stored as zero.
@@ -1047,6 +1335,212 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------ backward, round 3: dK, dV
+// attn_bwd_dkv_kernel rebuilt on the same lines as attn_bwd3_dq_kernel.  S orientation (rows = queries in the accumulator registers,
+// column = key = lane), one 32-query sub tile at a time:
+//  * the wave's K / V fragments are negated (K also carries scale * log2 e) and the chains start from the +lse / +delta values of the
+//    sub tile's queries, read from LDS straight into the C operands: acc = lse - s, acc' = delta - dP, so P = exp2(-acc) (a source
+//    modifier) and -dS = P * acc': 16 exp2 + 16 multiplies + 16 packed converts per 16 MFMAs; the sign goes into the final scale of dK;
+//  * per-sequence buffer windows for the q / dO rows (rows past the sequence read as zeros: P = 1, dP = 0, dS = 0), scalar DMA
+//    offsets, compile-time ring slots, lane-constant LDS bases + immediates, fragments requested a k-step ahead.
+// A masked key's outputs are stored as zero (its P is not bounded by the saved log-sum-exp; the garbage stays in its own column).
+namespace bwd3 {
+constexpr int KV_STAGE = 16384 + 512;                // Q | dO (unified layout: b128 and transpose reads) | lse[64] | delta[64]
+constexpr int KV_SMEM = 3 * KV_STAGE + 1024 + 512;   // + under dropout: 64 row keys (ia_rng_row) of the current query tile per wave; + 2 spare DMA slots
+}
+
+template <bool DROPOUT>
+__global__ __launch_bounds__(256, 2) void attn_bwd3_dkv_kernel(AttnArgs p) {
+  using namespace bwd3;
+  __shared__ __attribute__((aligned(16))) char smem[KV_SMEM];
+  const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, lk = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int tile, h, b;
+  attn_block_coords(p, p.Lk, tile, h, b);
+  int Lq = p.Lq, L = p.Lk;
+  size_t qbase = (size_t)b * Lq, rowbase = (size_t)b * L;
+  if (p.cu) {
+    const int c0 = p.cu[b];
+    Lq = L = p.cu[b + 1] - c0;
+    qbase = rowbase = (size_t)c0;
+    if (tile * 128 >= L) return;
+  }
+  const int k0 = tile * 128 + wave * 32;
+  const bool active = k0 < L;
+  const int key = k0 + lk;
+  const int kc = key < L ? key : L - 1;
+  const bool key_ok = key < L && (p.mask == nullptr || p.mask[rowbase + kc] != 0);
+  const __amdgpu_buffer_rsrc_t rsQ = ia_rsrc(p.q + qbase * p.ld_q + h * 64, (uint32_t)(((size_t)(Lq - 1) * p.ld_q + 64) * 2));
+  const __amdgpu_buffer_rsrc_t rsG = ia_rsrc(p.d_o + qbase * p.ld_o + h * 64, (uint32_t)(((size_t)(Lq - 1) * p.ld_o + 64) * 2));
+  const __amdgpu_buffer_rsrc_t rsL = ia_rsrc(p.lse2 + ((size_t)b * p.nh + h) * p.Lq, (uint32_t)Lq * 4u);
+  const __amdgpu_buffer_rsrc_t rsD = ia_rsrc(p.delta + ((size_t)b * p.nh + h) * p.Lq, (uint32_t)Lq * 4u);
+  const uint32_t sbase = lds_addr(smem);
+  const uint32_t q_tile = (uint32_t)p.ld_q * 128u, q_half = (uint32_t)p.ld_q * 64u, g_tile = (uint32_t)p.ld_o * 128u, g_half = (uint32_t)p.ld_o * 64u;
+  const int nqt = (Lq + 63) >> 6;
+  // lane constants
+  uint32_t ka[4], t0, t1, t0x, t1x, dqu, dgu;
+  {
+    const uint32_t a0 = (uint32_t)(lk * 128 + ((hh ^ swz_u(lk)) << 4));
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) ka[kb] = sbase + (a0 ^ (uint32_t)(kb << 5));
+    t0 = sbase + tr_lane_off_u(lane, 0); t1 = sbase + tr_lane_off_u(lane, 32); t0x = t0 ^ 32u; t1x = t1 ^ 32u;
+    const int r0 = tid >> 3, c = tid & 7;
+    dqu = (uint32_t)((r0 * p.ld_q + (c ^ swz_u(r0)) * 8) * 2);
+    dgu = (uint32_t)((r0 * p.ld_o + (c ^ swz_u(r0)) * 8) * 2);
+  }
+  typedef __attribute__((address_space(3))) char lds_char;
+  lds_char* const lsm = (lds_char*)IA_LDS(smem);        // one flat -> LDS cast; DMA destinations are LDS-pointer arithmetic from here
+  auto stage_tile = [&](auto SLOT_T, int qt) {
+    constexpr int S = decltype(SLOT_T)::value * KV_STAGE;
+    const uint32_t sq = (uint32_t)qt * q_tile, sg = (uint32_t)qt * g_tile;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lsm + S + wave * 1024), 16, dqu, sq, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lsm + S + 4096 + wave * 1024), 16, dqu, sq + q_half, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (lsm + S + 8192 + wave * 1024), 16, dgu, sg, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (lsm + S + 12288 + wave * 1024), 16, dgu, sg + g_half, 0, 0);
+    // 64 x fp32 each, one 4-byte-per-lane DMA piece: wave 0 the lse values, wave 1 delta; waves 2 / 3 issue a piece of zeros into a
+    // spare slot, so that every wave has the same number of pieces in flight (the counted vmcnt waits assume it); out-of-range rows
+    // read as zero
+    {
+      const uint32_t o4 = wave < 2 ? (uint32_t)(qt * 64 + lane) * 4u : OOB;
+      lds_char* const dst = wave < 2 ? lsm + S + 16384 + wave * 256 : lsm + 3 * KV_STAGE + 1024 + (wave - 2) * 256;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wave == 1 ? rsD : rsL, dst, 4, o4, 0, 0, 0);
+    }
+  };
+  using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>; using S2 = std::integral_constant<int, 2>;
+  const uint32_t stream_id = (uint32_t)(b * p.nh + h);
+  const uint32_t pc = pair_c_of(key), ush = (uint32_t)(key & 1) * 16u;
+  const uint32_t thr1 = DROPOUT ? p.thr16 - 1u : 0u, seed = p.seed;
+  const float sc = p.sc, inv_keep = p.inv_keep;
+  typedef __attribute__((address_space(3))) uint32_t lds_u32;
+  typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+  lds_u32* const s_rk = (lds_u32*)IA_LDS(smem + 3 * KV_STAGE) + wave * 64;
+
+  // ---- prologue: this wave's 32 key rows of K and V through wave-private slots of stages 1-2, query tile 0 into stage 0
+  char* kslot = smem + KV_STAGE + wave * 8192;
+  stage_rows32(ia_rsrc(p.k, p.kv_bytes), kslot, rowbase + k0, L - k0, p.ld_kv, h * 64, lane);
+  stage_rows32(ia_rsrc(p.v, p.kv_bytes), kslot + 4096, rowbase + k0, L - k0, p.ld_kv, h * 64, lane);
+  stage_tile(S0{}, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    const bf16x8 kr = frag_b128(kslot, lk, kb * 2 + hh), vr = frag_b128(kslot + 4096, lk, kb * 2 + hh);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { kf[kb][j] = f2bf(-bf2f(kr[j]) * (PRESCALE ? p.sc : 1.f)); vf[kb][j] = f2bf(-bf2f(vr[j])); }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                           // the K / V row slots (stages 1-2) are free for query tiles
+  if (nqt > 1) stage_tile(S1{}, 1);
+  f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
+
+  auto tile_step = [&](auto SLOT_T, int qt) {
+    constexpr int SB = decltype(SLOT_T)::value * KV_STAGE;
+    using NEXT2 = std::integral_constant<int, (decltype(SLOT_T)::value + 2) % 3>;
+    // query tile qt has landed for this wave (tile qt+1, issued behind it: 5 pieces, may still be in flight), then for everybody
+    if (qt + 1 >= nqt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (qt + 2 < nqt) stage_tile(NEXT2{}, qt + 2);
+    if (!active) return;
+    if (DROPOUT) {      // row keys of this tile's 64 queries, one per lane (the wave's LDS operations complete in order: no barrier)
+      s_rk[lane] = ia_rng_row(seed, stream_id, (uint32_t)(qt * 64 + lane));
+      __builtin_amdgcn_wave_barrier();
+    }
+    auto sub_tile = [&](auto QS) {
+      constexpr int qs = decltype(QS)::value;
+      constexpr int QB = SB + qs * 4096, GB = SB + 8192 + qs * 4096;        // the sub tile's 32 rows of the Q / dO tiles
+      // C operands: +lse / +delta of the rows this lane's accumulator registers stand for (q = 8 rg + 4 hh + j)
+      f32x16 s, dp, dlr;
+      {
+        const float* sL = reinterpret_cast<const float*>(smem + SB + 16384) + qs * 32 + 4 * hh;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const f32x4 ls = *reinterpret_cast<const f32x4*>(sL + 8 * rg);
+          const f32x4 dl = *reinterpret_cast<const f32x4*>(sL + 64 + 8 * rg);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { s[rg * 4 + j] = PRESCALE ? ls[j] : ls[j] / sc; dlr[rg * 4 + j] = dl[j]; dp[rg * 4 + j] = DROPOUT ? 0.f : dl[j]; }
+        }
+      }
+      bf16x8 xq, xg, yq, yg;                              // Q / dO fragments of even / odd k-steps
+      xq = lds_read_b128<QB>(ka[0]); xg = lds_read_b128<GB>(ka[0]);
+      yq = lds_read_b128<QB>(ka[1]); yg = lds_read_b128<GB>(ka[1]);
+      asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xq), "+v"(xg));
+      s = mfma(xq, kf[0], s); dp = mfma(xg, vf[0], dp);
+      xq = lds_read_b128<QB>(ka[2]); xg = lds_read_b128<GB>(ka[2]);
+      asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(yq), "+v"(yg));
+      s = mfma(yq, kf[1], s); dp = mfma(yg, vf[1], dp);
+      yq = lds_read_b128<QB>(ka[3]); yg = lds_read_b128<GB>(ka[3]);
+      asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xq), "+v"(xg));
+      s = mfma(xq, kf[2], s); dp = mfma(xg, vf[2], dp);
+      TrPair g0, a0, g1, a1;                              // dO^T and Q^T fragments of the sub tile's two 16-query steps
+      read_tr<SB + 8192, qs * 32>(g0, t0, t1, t0x, t1x);
+      read_tr<SB, qs * 32>(a0, t0, t1, t0x, t1x);
+      asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(yq), "+v"(yg));
+      s = mfma(yq, kf[3], s); dp = mfma(yg, vf[3], dp);
+      read_tr<SB + 8192, qs * 32 + 16>(g1, t0, t1, t0x, t1x);
+      read_tr<SB, qs * 32 + 16>(a1, t0, t1, t0x, t1x);
+      bf16x8 pf[2], sf[2];
+      u32x4 rkq[4];
+      if (DROPOUT) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) rkq[rg] = *(const lds_u32x4*)(s_rk + qs * 32 + 8 * rg + 4 * hh);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(PRESCALE ? -s[r] : -s[r] * sc);      // exp2(s' - lse)
+        float pd = pv, nds;
+        if (DROPOUT) {
+          const uint32_t hsh = ia_rng_pair(rkq[r >> 2][r & 3], pc);
+          const uint32_t dr = (hsh >> ush) & 0xFFFFu;                                    // this key's half of the pair's draw
+          const float mk = __builtin_fminf(__builtin_fmaxf((float)((int)dr - (int)thr1), 0.f), 1.f);      // 0 iff dropped (draw < thr16), else 1
+          pd = pv * mk;
+          // dp = -dP here; -(M dP / keep - delta) = dp mk / keep + delta
+          nds = pv * __builtin_fmaf(dp[r] * mk, inv_keep, dlr[r]);
+        } else {
+          nds = pv * dp[r];
+        }
+        pf[r >> 3][r & 7] = f2bf(pd);
+        sf[r >> 3][r & 7] = f2bf(nds);
+      }
+      // dV^T[d][key] += dO^T[d][q] P[q][key] ; -dK^T[d][key] += Q^T[d][q] (-dS)[q][key]
+      tr_wait<12>(g0);
+      dv0 = mfma(g0.a0(), pf[0], dv0); dv1 = mfma(g0.a1(), pf[0], dv1);
+      tr_wait<8>(a0);
+      dk0 = mfma(a0.a0(), sf[0], dk0); dk1 = mfma(a0.a1(), sf[0], dk1);
+      tr_wait<4>(g1);
+      dv0 = mfma(g1.a0(), pf[1], dv0); dv1 = mfma(g1.a1(), pf[1], dv1);
+      tr_wait<0>(a1);
+      dk0 = mfma(a1.a0(), sf[1], dk0); dk1 = mfma(a1.a1(), sf[1], dk1);
+    };
+    sub_tile(std::integral_constant<int, 0>{});
+    if (qt * 64 + 32 < Lq) sub_tile(std::integral_constant<int, 1>{});
+  };
+  {
+    int qt = 0;
+    for (;;) {
+      tile_step(S0{}, qt); if (++qt >= nqt) break;
+      tile_step(S1{}, qt); if (++qt >= nqt) break;
+      tile_step(S2{}, qt); if (++qt >= nqt) break;
+    }
+  }
+  __builtin_amdgcn_s_barrier();                           // the epilogue rows are staged in the ring
+  float* cs_lds = p.cs_part ? reinterpret_cast<float*>(smem + 8 * EPI_SLOT) + wave * 128 : nullptr;     // behind the eight store slots: dk | dv sums
+  if (!active && !cs_lds) return;
+  if (active) {
+    store_block_rows(smem + wave * 2 * EPI_SLOT, dk0, dk1, -p.scale, !key_ok, p.dk + (rowbase + k0) * p.ld_dkv + h * 64, p.ld_dkv, L - k0, lane, cs_lds);
+    store_block_rows(smem + (wave * 2 + 1) * EPI_SLOT, dv0, dv1, DROPOUT ? p.inv_keep : 1.f, !key_ok, p.dv + (rowbase + k0) * p.ld_dkv + h * 64,
+                     p.ld_dkv, L - k0, lane, cs_lds ? cs_lds + 64 : nullptr);
+  } else { zero_cs_row(cs_lds, lane); zero_cs_row(cs_lds + 64, lane); }
+  if (cs_lds) {
+    __syncthreads();
+    if (wave < 2) {         // wave 0: the dk columns, wave 1: the dv columns
+      const float* c = reinterpret_cast<const float*>(smem + 8 * EPI_SLOT) + wave * 64;
+      p.cs_part[(size_t)(b * ((p.Lk + 127) >> 7) + tile) * (3 * p.nh * 64) + (1 + wave) * p.nh * 64 + h * 64 + lane] =
+          (c[lane] + c[128 + lane]) + (c[256 + lane] + c[384 + lane]);
+    }
+  }
+}
+
 // packed_rows > 0: packed self-attention over that many token rows in total (AttnArgs::cu), Lq == Lk == longest sequence
 int fill_args(AttnArgs& a, int B, int nh, int Lq, int Lk, int ld_q, int ld_kv, int ld_o, float scale, float drop_p, uint32_t seed,
               long packed_rows = 0) {
@@ -1069,10 +1563,32 @@ int fill_args(AttnArgs& a, int B, int nh, int Lq, int Lk, int ld_q, int ld_kv, i
   return IA_OK;
 }
 
-// development switch (round 3): IA_ATTN_FWD=2 runs the round-2 forward kernel for A/B measurements on one box
-int fwd_version() {
-  static const int v = [] { const char* e = getenv("IA_ATTN_FWD"); return e ? atoi(e) : 2; }();
+// development switches (round 3): IA_ATTN_FWD=2 / IA_ATTN_BWD=0 run the round-2 kernels for A/B measurements on one box
+int bwd_version() {
+  static const int v = [] { const char* e = getenv("IA_ATTN_BWD"); return e ? atoi(e) : 0; }();
   return v;
+}
+template <bool D> void launch_dkv(const AttnArgs& a, dim3 grid, hipStream_t st) {
+  if (bwd_version() & 2) hipLaunchKernelGGL(attn_bwd3_dkv_kernel<D>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(attn_bwd_dkv_kernel<D>, grid, dim3(256), 0, st, a);
+}
+template <bool D> void launch_dq(const AttnArgs& a, dim3 grid, hipStream_t st) {
+  if (bwd_version() & 1) hipLaunchKernelGGL(attn_bwd3_dq_kernel<D>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, grid, dim3(256), 0, st, a);
+}
+int fwd_version() {
+  static const int v = [] { const char* e = getenv("IA_ATTN_FWD"); return e ? atoi(e) : 3; }();
+  return v;
+}
+void launch_fwd(const AttnArgs& a, dim3 grid, hipStream_t stream) {
+  const dim3 blk(256);
+  if (fwd_version() == 2) {
+    if (a.thr16) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, blk, 0, stream, a);
+    else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, blk, 0, stream, a);
+  } else {
+    if (a.thr16) hipLaunchKernelGGL((attn_fwd3_kernel<true, 3>), grid, blk, 0, stream, a);
+    else hipLaunchKernelGGL((attn_fwd3_kernel<false, 3>), grid, blk, 0, stream, a);
+  }
 }
 
 }  // namespace
@@ -1091,11 +1607,7 @@ extern "C" int ia_attn_fwd_x(const void* q, int ld_q, const void* k, const void*
   if (rc) return rc;
   a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.out = (bf16*)out; a.mask = key_mask; a.lse2 = lse2;
   dim3 grid(((Lq + 127) / 128) * nh * B), blk(256);
-  if (a.thr16) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, blk, 0, stream, a);
-  else if (fwd_version() == 3) hipLaunchKernelGGL((attn_fwd3_kernel<false, false, 3>), grid, blk, 0, stream, a);
-  else if (fwd_version() == 4) hipLaunchKernelGGL((attn_fwd3_kernel<false, false, 2>), grid, blk, 0, stream, a);
-  else if (fwd_version() == 5) hipLaunchKernelGGL((attn_fwd3_kernel<false, true, 2>), grid, blk, 0, stream, a);
-  else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, blk, 0, stream, a);
+  launch_fwd(a, grid, stream);
   return ia_check_launch();
 }
 
@@ -1115,11 +1627,11 @@ extern "C" int ia_attn_bwd_x(const void* q, int ld_q, const void* k, const void*
   a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.ld_dq = ld_dq; a.ld_dkv = ld_dkv;
   dim3 gq(((Lq + 127) / 128) * nh * B), gk(((Lk + 127) / 128) * nh * B), blk(256);
   if (a.thr16) {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gq, blk, 0, stream, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, gk, blk, 0, stream, a);
+    launch_dq<true>(a, gq, stream);
+    launch_dkv<true>(a, gk, stream);
   } else {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gq, blk, 0, stream, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, gk, blk, 0, stream, a);
+    launch_dq<false>(a, gq, stream);
+    launch_dkv<false>(a, gk, stream);
   }
   return ia_check_launch();
 }
@@ -1164,11 +1676,11 @@ extern "C" int ia_attn_bwd_bias(const void* q, const void* k, const void* v, int
   a.cs_part = (float*)workspace;
   dim3 grid(((L + 127) / 128) * nh * B), blk(256);
   if (a.thr16) {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, blk, 0, stream, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, blk, 0, stream, a);
+    launch_dq<true>(a, grid, stream);
+    launch_dkv<true>(a, grid, stream);
   } else {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, blk, 0, stream, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, blk, 0, stream, a);
+    launch_dq<false>(a, grid, stream);
+    launch_dkv<false>(a, grid, stream);
   }
   rc = ia_check_launch();
   if (rc) return rc;
@@ -1187,9 +1699,8 @@ extern "C" int ia_attn_fwd_varlen(const void* q, const void* k, const void* v, i
   int rc = fill_args(a, B, nh, Lmax, Lmax, ld_qkv, ld_qkv, ld_o, scale, drop_p, seed, total_tokens);
   if (rc) return rc;
   a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.out = (bf16*)out; a.mask = nullptr; a.lse2 = lse2; a.cu = cu_seqlens;
-  dim3 grid(((Lmax + 127) / 128) * nh * B), blk(256);
-  if (a.thr16) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, blk, 0, stream, a);
-  else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, blk, 0, stream, a);
+  dim3 grid(((Lmax + 127) / 128) * nh * B);
+  launch_fwd(a, grid, stream);
   return ia_check_launch();
 }
 
@@ -1207,11 +1718,11 @@ extern "C" int ia_attn_bwd_varlen(const void* q, const void* k, const void* v, i
   a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.ld_dq = ld_dqkv; a.ld_dkv = ld_dqkv;
   dim3 grid(((Lmax + 127) / 128) * nh * B), blk(256);
   if (a.thr16) {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, blk, 0, stream, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, blk, 0, stream, a);
+    launch_dq<true>(a, grid, stream);
+    launch_dkv<true>(a, grid, stream);
   } else {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, blk, 0, stream, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, blk, 0, stream, a);
+    launch_dq<false>(a, grid, stream);
+    launch_dkv<false>(a, grid, stream);
   }
   return ia_check_launch();
 }

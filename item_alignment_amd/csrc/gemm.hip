@@ -1208,7 +1208,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 struct GemmProf {
   bool on = false;
   int variant = -1, n = 0, cap = 0;
-  double flops = 0.0;
+  double flops = 0.0, bytes = 0.0;      // algorithmic: 2 M N K, and A + B read once + C written once
   hipEvent_t* ev = nullptr;
 };
 GemmProf g_prof;
@@ -1363,6 +1363,7 @@ int launch(GemmArgs a, bool big, hipStream_t st) {
   if (rec) {
     (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st);
     g_prof.flops += 2.0 * a.M * a.N * a.K;
+    g_prof.bytes += 2.0 * ((double)a.M * a.K + (double)a.N * a.K) + (OUTF32 ? 4.0 : 2.0) * a.M * a.N;
     ++g_prof.n;
   }
   return ia_check_launch();
@@ -1520,7 +1521,7 @@ extern "C" int ia_prof_begin(int variant, int max_launches) {
       if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) return IA_ERR_LAUNCH;
     g_prof.cap = max_launches;
   }
-  g_prof.variant = variant; g_prof.n = 0; g_prof.flops = 0.0; g_prof.on = true;
+  g_prof.variant = variant; g_prof.n = 0; g_prof.flops = 0.0; g_prof.bytes = 0.0; g_prof.on = true;
   return IA_OK;
 }
 
@@ -1540,3 +1541,6 @@ extern "C" int ia_prof_end(double* total_ms, double* total_flops, int* launches)
   if (launches) *launches = g_prof.n;
   return IA_OK;
 }
+
+// algorithmic bytes (each operand read once, the output written once) of the launches recorded between ia_prof_begin / ia_prof_end
+extern "C" double ia_prof_bytes(void) { return g_prof.bytes; }

@@ -129,7 +129,13 @@ class GradBucketReducer:
                 if cur is not None and st != cur:
                     cur.wait_stream(st)
             if self.bf16:
-                stage = self.flat[s:e].to(torch.bfloat16)
+                # one pass fp32 -> bf16 into a staging slice (ia_cast_f32_to_bf16; torch's .to() only on CPU tensors, i.e. in the gloo tests)
+                stage = torch.empty(e - s, dtype=torch.bfloat16, device=self.flat.device)
+                if self.flat.is_cuda:
+                    from . import ops
+                    ops.cast_to_bf16(self.flat[s:e], stage)
+                else:
+                    stage.copy_(self.flat[s:e])
                 self.works.append((dist.all_reduce(stage, op=dist.ReduceOp.SUM, group=self.group, async_op=True), stage, s, e))
             else:
                 self.works.append((dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, s, e))
@@ -161,7 +167,11 @@ class GradBucketReducer:
         for w, stage, s, e in self.works:
             w.wait()
             if stage is not None:
-                self.flat[s:e].copy_(stage)
+                if self.flat.is_cuda:
+                    from . import ops
+                    ops.cast_to_f32(stage, self.flat[s:e])           # one pass back into the fp32 arena slice
+                else:
+                    self.flat[s:e].copy_(stage)
         self.reset()
         try:
             from .models import functional as Fn

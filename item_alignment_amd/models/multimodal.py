@@ -13,7 +13,7 @@ from .loss import apply_loss, make_loss
 from .text import PretrainedMixin, RobertaOneTower, RobertaTwoTower, adopt
 
 
-_TOWER_STREAMS = os.environ.get("IA_TOWER_STREAMS", "0") == "1"
+TOWER_STREAMS = os.environ.get("IA_TOWER_STREAMS", "0") == "1"      # module switch (bench.py flips it for its variant line)
 
 
 class RobertaImageModel(HipModule, PretrainedMixin):
@@ -258,7 +258,7 @@ class CoCaForItemAlignment(HipModule):
         # the other's work: +3.5 % pairs/s on the bench step (autograd replays each tower's backward on the stream its
         # forward used).  Off by default: concurrent kernels stretch each other's wall time, so per-kernel timings (the
         # bench's roofline leg, rocprofv3 averages) stop describing the kernels themselves.
-        two_streams = _TOWER_STREAMS and images_1.is_cuda
+        two_streams = TOWER_STREAMS and images_1.is_cuda
         images = torch.cat((images_1, images_2), dim=0)
 
         def image_tower():

@@ -1,0 +1,150 @@
+"""Parity at the BASELINE.json shapes themselves (round-2 verdict, weak #7): the golden fixtures cover every model at narrow widths;
+these run the real widths against the CPU oracle (oracle/ref_models.py, fp32) on the GPU box -- the 258 211 x 1024 PKGM entity
+table (a > 2^31-byte gather), eca_nfnet_l0 at 800 x 800, and one full-width CoCa pair (24-layer roberta_large at L = 255 + ViT-B/16
+at 384).  Weights are the models' own seeded initialisation copied into the oracle's state dict; eval mode (dropout off)."""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pytestmark = pytest.mark.gpu
+TOL = 5e-2
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-6)).item()
+
+
+def cosine(a, b):
+    a, b = a.float().cpu().flatten(), b.float().cpu().flatten()
+    return (torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)).item()
+
+
+def state_of(model, head_gain=1.0):
+    """the model's own (seeded) initialisation as the oracle's state dict; the pair head's weights are scaled up first so that the
+    logits are O(1) instead of the O(0.02) a fresh head produces (a relative tolerance on them then means something)"""
+    with torch.no_grad():
+        for k, v in model.named_parameters():
+            if k.startswith("classifier.") and k.endswith("weight"):
+                v.mul_(head_gain)
+    return {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+
+
+def test_c4_pkgm_large_full_entity_table(gpu):
+    """C4: PKGMOneTower, num_entities 258 211, kg_embedding_dim 1024, max_pvs 30 -> 220 embedded positions, H = 1024, 2 layers, B = 2
+    (reference src/models/base.py:347-392, text.py:720-783).  Loss, logits and the entity-table gradient rows against the oracle."""
+    import item_alignment_amd.models as M
+    from bench import roberta_large_config
+    from oracle import ref_models as O
+    S, P, B = 50, 30, 2
+    cfg = roberta_large_config(interaction_type="one_tower", max_seq_len=S, max_seq_len_pv=None, max_pvs=P, num_entities=258211,
+                               num_relations=1379, kg_embedding_dim=1024, entity_projection_bias=False, num_hidden_layers=2,
+                               hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    rs = np.random.RandomState(7)
+    L_ids, L_emb = 2 * (S + P + 1), 2 * (S + 2 * P)
+    ids = np.zeros((B, L_ids), dtype=np.int64); mask = np.zeros((B, L_emb), dtype=np.int64); tt = np.zeros((B, L_emb), dtype=np.int64)
+    ents = [[258210, 131072 + 7], [1, 200000]]            # the last row, a row past 2^31 bytes / 4, the first real row
+    for i in range(B):
+        for side in range(2):
+            n = int(rs.randint(8, S - 1))
+            o_ids, o_emb = side * (S + P + 1), side * (S + 2 * P)
+            ids[i, o_ids] = 101 if side == 0 else 102
+            ids[i, o_ids + 1:o_ids + 1 + n] = rs.randint(1000, 21128, size=n)
+            ids[i, o_ids + 1 + n] = 102
+            mask[i, o_emb:o_emb + n + 2] = 1
+            nrel = int(rs.randint(5, P + 1))
+            ids[i, o_ids + S] = ents[i][side]
+            ids[i, o_ids + S + 1:o_ids + S + 1 + nrel] = rs.randint(1, 1379, size=nrel)
+            mask[i, o_emb + S:o_emb + S + 2 * nrel] = 1
+            tt[i, o_emb:o_emb + S + 2 * P] = side
+    pos = np.tile(np.arange(L_emb), (B, 1))
+    labels = torch.tensor([1, 0])
+    torch.manual_seed(11)
+    model = M.PKGMOneTower(cfg)
+    sd = state_of(model, head_gain=20.0)
+    model = model.cuda().eval()
+    t = [torch.from_numpy(a) for a in (ids, mask, tt, pos)]
+    out = model(input_ids=t[0].cuda(), attention_mask=t[1].cuda(), token_type_ids=t[2].cuda(), position_ids=t[3].cuda(), labels=labels.cuda())
+    model.param_arena.zero_grad()
+    out.loss.backward()
+    torch.cuda.synchronize()
+    ent_key = next(k for k in sd if k.endswith("ent_emb.weight"))
+    rsd = {k: (v.requires_grad_(True) if k == ent_key or k.endswith("rel_emb.weight") or k.endswith("proj_mat.weight") else v) for k, v in sd.items()}
+    ref = O.pkgm_one_tower(rsd, cfg, *t, labels=labels, training=False)
+    ref.loss.backward()
+    assert abs(out.loss.item() - ref.loss.item()) < TOL * max(1.0, abs(ref.loss.item())), (out.loss.item(), ref.loss.item())
+    assert rel(out.logits.detach(), ref.logits.detach()) < TOL
+    got = dict(model.named_parameters())[ent_key].grad.float().cpu()
+    want = rsd[ent_key].grad
+    rows = sorted({e for pair in ents for e in pair})
+    # quirk A1 (normalize over a size-1 dim = sign) kills the entity gradient exactly; the touched rows and everything else must agree
+    assert torch.equal(got.abs().sum(1) > 0, want.abs().sum(1) > 0) or got[rows].abs().max() < 1e-6
+    assert (got[rows] - want[rows]).abs().max().item() <= TOL * max(want[rows].abs().max().item(), 1e-6) + 1e-6
+    for k in (next(k for k in sd if k.endswith("rel_emb.weight")), next(k for k in sd if k.endswith("proj_mat.weight"))):
+        g_, w_ = dict(model.named_parameters())[k].grad, rsd[k].grad
+        assert cosine(g_, w_) > 0.98, (k, cosine(g_, w_))
+        assert rel(g_, w_) < 0.10, (k, rel(g_, w_))
+
+
+def test_c3_eca_nfnet_l0_at_800(gpu):
+    """C3: NFNetTwoTower(eca_nfnet_l0) at 800 x 800, one pair (reference src/models/image.py:253-294; the tower is timm's, restated in
+    the oracle from its published definition -- parity unpinned by the reference).  Logits and the stem / last-stage
+    weight gradients against the fp32 oracle."""
+    import item_alignment_amd.models as M
+    from oracle import ref_models as O
+    cfg = SimpleNamespace(num_labels=2, hidden_dropout_prob=0.0, loss_type="ce", loss_margin=0.0, classification_method="cls", hidden_size=2304)
+    g = torch.Generator().manual_seed(3)
+    im1, im2 = torch.randn((1, 3, 800, 800), generator=g), torch.randn((1, 3, 800, 800), generator=g)
+    labels = torch.tensor([1])
+    torch.manual_seed(5)
+    model = M.NFNetTwoTower(cfg, M.create_model("eca_nfnet_l0"))
+    sd = state_of(model, head_gain=30.0)
+    model = model.cuda().eval()
+    out = model(im1.cuda(), im2.cuda(), labels.cuda())
+    model.param_arena.zero_grad()
+    out.loss.backward()
+    torch.cuda.synchronize()
+    keys = ["img_encoder.stem.conv1.weight", "img_encoder.stages.3.2.conv3.weight", "img_encoder.final_conv.weight"]
+    rsd = {k: (v.requires_grad_(True) if k in keys else v) for k, v in sd.items()}
+    ref = O.nfnet_two_tower(rsd, cfg, O.nfnet_cfg("eca_nfnet_l0"), im1, im2, labels=labels, training=False)
+    ref.loss.backward()
+    assert rel(out.logits.detach(), ref.logits.detach()) < TOL, rel(out.logits.detach(), ref.logits.detach())
+    assert abs(out.loss.item() - ref.loss.item()) < TOL * max(1.0, abs(ref.loss.item()))
+    params = dict(model.named_parameters())
+    for k in keys:
+        c = cosine(params[k].grad, rsd[k].grad)
+        assert c > 0.97, (k, c)
+        assert rel(params[k].grad, rsd[k].grad) < 0.25, (k, rel(params[k].grad, rsd[k].grad))
+
+
+def test_c5_full_width_coca_pair(gpu):
+    """C5: one full-width pair through CoCaForItemAlignment -- roberta_large (24 layers, H = 1024, L = 255) + ViT-B/16 at 384, ensemble
+    sum (reference src/models/multimodal.py:983-1045).  Loss and probabilities against the fp32 oracle."""
+    import item_alignment_amd.models as M
+    from bench import roberta_large_config
+    from item_alignment_amd.data.synthetic import SyntheticCocaPairs
+    from item_alignment_amd.models.image import VIT_CONFIGS
+    from oracle import ref_models as O
+    cfg = roberta_large_config(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    torch.manual_seed(2345)
+    model = M.CoCaForItemAlignment(cfg, M.create_model("vit_base_patch16_384"), M.RobertaModel(cfg))
+    sd = state_of(model)                                  # the summed CLS vectors are large: the fresh head already gives O(1) logits
+    model = model.cuda().eval()
+    data = SyntheticCocaPairs(2, image_size=384, seed=9)
+    b = data.batch([0, 1], "cuda")
+    with torch.no_grad():
+        out = model(*b[:10], labels=b[10])
+    torch.cuda.synchronize()
+    s_, p_, d_, depth, h_ = VIT_CONFIGS["vit_base_patch16_384"]
+    vcfg = SimpleNamespace(embed_dim=d_, depth=depth, num_heads=h_, patch_size=p_, eps=1e-6)
+    bc = data.batch([0, 1], "cpu")
+    with torch.no_grad():
+        ref = O.coca_item_alignment(sd, cfg, vcfg, *bc[:10], labels=bc[10], training=False)
+    assert abs(out.loss.item() - ref.loss.item()) < TOL * max(1.0, abs(ref.loss.item())), (out.loss.item(), ref.loss.item())
+    assert rel(out.logits, ref.logits) < TOL, (out.logits, ref.logits)
+    assert (out.probs.float().cpu() - ref.probs).abs().max().item() < TOL

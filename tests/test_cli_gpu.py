@@ -274,3 +274,24 @@ def test_finetune_text_under_torchrun_rccl(gpu, tmp_path):
     dirs = os.listdir(out)
     assert len(dirs) == 1 and any(f.endswith("epoch-0.bin") for f in os.listdir(os.path.join(out, dirs[0])))
     assert "f1=" in r.stderr and "loss:" in r.stderr
+
+
+def test_bench_single_gpu_with_forced_collectives(gpu):
+    """bench.py --gpus 1 under IA_DP_FORCE_COLLECTIVES=1 (RCCL initialised, every gradient bucket all-reduced although there is one
+    rank: the exact multi-GPU code path on a 1-GPU box): exactly one JSON line on stdout, n_gpus 1."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IA_DP_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29731")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-pmc",
+                        "--no-cpu-baseline", "--no-variants", "--pairs-per-gpu", "16"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 1 and res["steps"] == 2 and res["value"] > 0
+    assert res["roofline"]["bound"] in ("mfma", "hbm") and res["roofline"]["frac"] > 0

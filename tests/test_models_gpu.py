@@ -161,8 +161,8 @@ def test_coca_sum_two_streams(gpu):
     case = load_case("coca_sum")
     v = vit_cfg(case)
     cfg = cfg_of(case)
-    old = multimodal._TOWER_STREAMS
-    multimodal._TOWER_STREAMS = True
+    old = multimodal.TOWER_STREAMS
+    multimodal.TOWER_STREAMS = True
     try:
         text = M.RobertaModel(cfg)
         vit = M.VisionTransformer(img_size=v.image_size, patch_size=v.patch_size, embed_dim=v.embed_dim, depth=v.depth, num_heads=v.num_heads)
@@ -177,7 +177,7 @@ def test_coca_sum_two_streams(gpu):
             model.param_arena.adamw_step(0.0)   # lr 0: exercises the join before the optimiser without moving the weights
         assert len(model.param_arena.side_streams) == 1
     finally:
-        multimodal._TOWER_STREAMS = old
+        multimodal.TOWER_STREAMS = old
 
 
 def test_coca_cross_attn(gpu):
