@@ -60,6 +60,16 @@ IA_DEV void attn_block_coords(const AttnArgs& p, int len, int& tile, int& h, int
   h = w % p.nh; b = w / p.nh;
 }
 
+// the same with `rows` queries (keys) per workgroup instead of 128
+IA_DEV void attn_block_coords_n(const AttnArgs& p, int len, int rows, int& tile, int& h, int& b) {
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int per = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  int w = (xcd < r ? xcd * (per + 1) : r * (per + 1) + (xcd - r) * per) + idx;
+  const int nt = (len + rows - 1) / rows;
+  tile = w % nt; w /= nt;
+  h = w % p.nh; b = w / p.nh;
+}
+
 // Per 64-key tile, the ballot of attendable keys (in range and not masked), built once per workgroup: a mask byte
 // fetched inside the tile loop would make the wave wait for the next tile's LDS-DMA as well (vmcnt is in-order).
 constexpr int MAX_KT = 32;   // L <= 2048
@@ -413,9 +423,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 //    V^T fragments of tile t arrive under the PV MFMAs / the conversions of tile t;
 //  * the DMA of tile t+2 is issued at the top of tile t and only K(t+1) is waited for there (counted vmcnt), one raw s_barrier per
 //    tile; 48 KiB of LDS and <= 168 VGPRs: three workgroups per CU.
-#ifndef IA_F3_ABL
-#define IA_F3_ABL 0          // ablation bits for tools/abl/attn_dev.hip builds: 1 no K/V DMA in the loop, 2 no barrier, 4 no compute, 8 no exp, 16 no LDS reads
-#endif
 #ifndef IA_F3_PRESCALE
 #define IA_F3_PRESCALE 1     // 1: Q fragments carry scale * log2(e) (one more bf16 rounding of q, no multiply per score); 0: exp2(s * sc)
 #endif
@@ -472,31 +479,31 @@ IA_DEV void read_v(TrPair& f, const Lane& ln) {
   f.lo1 = tr_read<O>(ln.v1); f.hi1 = tr_read<O + 1024>(ln.v1);
 }
 
-// Scores of one 64-key tile against this wave's 32 queries: s = K (Q * scale * log2 e)^T [- m_ref] [- 1e30 on keys that may not be
-// attended].  The two optional terms come from one more MFMA per 32-key block (header comment); `plain` = neither is needed.
-// refw: this lane's B word {bf16 1.0, bf16 -m_ref} (lanes 32..63, which hold k-slots 8..15: 0).
-IA_DEV void qk_tile(f32x16& s0, f32x16& s1, const bf16x8 (&kf)[8], const bf16x8 (&qf)[4], bool plain, uint32_t refw, uint32_t valid_lo,
-                    uint32_t valid_hi, int lane) {
+// Scores of one 32-key block against this wave's 32 queries: s = K (Q * scale * log2 e)^T [- m_ref] [- 1e30 on keys that may not be
+// attended].  The two optional terms come from one more MFMA (header comment); `plain` = neither is needed.  k0..k3: the block's K
+// fragments of the four k-steps.  refw: this lane's B word {bf16 1.0, bf16 -m_ref} (lanes 32..63, which hold k-slots 8..15: 0).
+IA_DEV void qk_block(f32x16& s, const bf16x8& k0, const bf16x8& k1, const bf16x8& k2, const bf16x8& k3, const bf16x8 (&qf)[4], bool plain,
+                     uint32_t refw, uint32_t valid, int lane) {
   const f32x16 zero = zero16();
   if (plain) {                                                                      // wave-uniform
-    s0 = mfma(kf[0], qf[0], zero);
-    s1 = mfma(kf[1], qf[0], zero);
+    s = mfma(k0, qf[0], zero);
   } else {
     const uint32_t low = (lane & 32) ? 0u : 1u;
-    const uint32_t bad0 = ((~valid_lo) >> (lane & 31)) & low, bad1 = ((~valid_hi) >> (lane & 31)) & low;
-    const u32x4 a0 = {bad0 * NEG_BIG_BF16 + low * 0x3F800000u, 0u, 0u, 0u}, a1 = {bad1 * NEG_BIG_BF16 + low * 0x3F800000u, 0u, 0u, 0u};
+    const uint32_t bad = ((~valid) >> (lane & 31)) & low;
+    const u32x4 a = {bad * NEG_BIG_BF16 + low * 0x3F800000u, 0u, 0u, 0u};
     const u32x4 bw = {refw, 0u, 0u, 0u};
-    const f32x16 c0 = mfma(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, bw), zero);
-    const f32x16 c1 = mfma(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, bw), zero);
-    s0 = mfma(kf[0], qf[0], c0);
-    s1 = mfma(kf[1], qf[0], c1);
+    const f32x16 c = mfma(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bw), zero);
+    s = mfma(k0, qf[0], c);
   }
-#pragma unroll
-  for (int kb = 1; kb < 4; ++kb) {
-    s0 = mfma(kf[kb * 2], qf[kb], s0);
-    s1 = mfma(kf[kb * 2 + 1], qf[kb], s1);
-  }
+  s = mfma(k1, qf[1], s);
+  s = mfma(k2, qf[2], s);
+  s = mfma(k3, qf[3], s);
 }
+
+struct Row {           // per-lane softmax state of its query (the partner lane ^ 32 holds the other half of the keys)
+  float m_ref, l_run;  // m_ref is a bf16-representable number (it travels through the matrix pipe as a bf16 operand)
+  uint32_t refw;       // {bf16 1.0, bf16 -m_ref} in lanes 0..31, 0 in lanes 32..63
+};
 
 // Dropout on a register of two packed bf16 probabilities (keys 2i, 2i+1): h = their 32-bit draw (ia_rng_pair: low half = even key), kept
 // iff the 16-bit draw >= thr16.  No compare / select (v_cmp 8.6 cycles + v_cndmask on one wave): saturating packed subtract of thr16-1
@@ -507,61 +514,47 @@ IA_DEV uint32_t drop_pair(uint32_t w, uint32_t h, uint32_t thr1) {
   return d;
 }
 
-struct Row {           // per-lane softmax state of its query (the partner lane ^ 32 holds the other half of the keys)
-  float m_ref, l_run;  // m_ref is a bf16-representable number (it travels through the matrix pipe as a bf16 operand)
-  uint32_t refw;       // {bf16 1.0, bf16 -m_ref} in lanes 0..31, 0 in lanes 32..63
-};
-
 // p = exp2(s [* sc]) in place
-IA_DEV void exp_tile(f32x16& s0, f32x16& s1, float sc) {
-  if (IA_F3_ABL & 8) return;
+IA_DEV void exp_block(f32x16& s, float sc) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    s0[r] = __builtin_amdgcn_exp2f(PRESCALE ? s0[r] : s0[r] * sc);
-    s1[r] = __builtin_amdgcn_exp2f(PRESCALE ? s1[r] : s1[r] * sc);
-  }
+  for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(PRESCALE ? s[r] : s[r] * sc);
 }
-// The probabilities as the B fragments of the PV MFMAs (bf16), and this lane's half of the tile's row sum taken from the ROUNDED values
-// (v_dot2c_f32_bf16 against packed ones, exact in fp32): O = sum(p^ v) / sum(p^) is then a convex combination of the v rows -- a row
-// with one attendable key returns that key's v exactly, and delta = rowsum(dO o) cancels against dP in the backward as it should.
-IA_DEV float pack_sum(bf16x8 (&pf)[4], const f32x16& s0, const f32x16& s1) {
+// The block's probabilities as the B fragments of its two PV k-steps (bf16), and this lane's part of the row sum taken from the
+// ROUNDED values (v_dot2c_f32_bf16 against packed ones, exact in fp32): O = sum(p^ v) / sum(p^) is then a convex combination of the v
+// rows -- a row with one attendable key returns that key's v exactly, and delta = rowsum(dO o) cancels against dP in the backward as
+// it should.  (The builtin, not inline asm: the dot instruction's result needs wait states before an ordinary VALU read, which only
+// the compiler's hazard recognizer inserts.)
+IA_DEV float pack_sum(bf16x8& pa, bf16x8& pb, const f32x16& s) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    pf[0][j] = f2bf(s0[j]); pf[1][j] = f2bf(s0[8 + j]);
-    pf[2][j] = f2bf(s1[j]); pf[3][j] = f2bf(s1[8 + j]);
-  }
-  // (the builtin, not inline asm: the dot instruction's result needs wait states before an ordinary VALU read, which only the
-  // compiler's hazard recognizer inserts)
+  for (int j = 0; j < 8; ++j) { pa[j] = f2bf(s[j]); pb[j] = f2bf(s[8 + j]); }
   float ra = 0.f, rb = 0.f;
   const bf16x2 ones = {(bf16)1.0f, (bf16)1.0f};
 #pragma unroll
-  for (int n = 0; n < 4; ++n) {
-    const bf16x8 v = pf[n];
-    ra = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{v[0], v[1]}, ones, ra, false);
-    rb = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{v[2], v[3]}, ones, rb, false);
-    ra = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{v[4], v[5]}, ones, ra, false);
-    rb = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{v[6], v[7]}, ones, rb, false);
+  for (int i = 0; i < 8; i += 2) {
+    ra = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{pa[i], pa[i + 1]}, ones, ra, false);
+    rb = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{pb[i], pb[i + 1]}, ones, rb, false);
   }
   return ra + rb;
 }
 
-// Rare: a lane's row sum left [2^-100, 2^60] (or is not finite).  The tile's scores are recomputed (its K fragments are still in
-// their registers), the reference moves to the larger of the tile's maximum and the running log-sum-exp, everything accumulated so
-// far follows.  sc: what exp2's argument is multiplied by (1 with pre-scaled queries); m_ref lives in the accumulators' units.
-IA_DEV void rebase(f32x16& s0, f32x16& s1, f32x16& o0, f32x16& o1, Row& row, const bf16x8 (&kf)[8], const bf16x8 (&qf)[4], uint32_t valid_lo,
-                    uint32_t valid_hi, int lane, float sc) {
+// Rare: a lane's row sum left [2^-100, 2^60] (or is not finite) at this block.  The block's scores are recomputed (its K fragments are
+// still in their registers), the reference moves to the larger of the block's maximum and the running log-sum-exp, everything
+// accumulated so far follows; `other`: scores of the tile's second block, already formed against the old reference (or null).
+// sc: what exp2's argument is multiplied by (1 with pre-scaled queries); m_ref lives in the accumulators' units.
+IA_DEV void rebase(f32x16& s, f32x16* other, f32x16& o0, f32x16& o1, Row& row, const bf16x8& k0, const bf16x8& k1, const bf16x8& k2,
+                   const bf16x8& k3, const bf16x8 (&qf)[4], uint32_t valid, int lane, float sc) {
   if (PRESCALE) sc = 1.f;
   const float inv_sc = 1.f / sc;
-  qk_tile(s0, s1, kf, qf, false, (lane & 32) ? 0u : 0x3F80u, valid_lo, valid_hi, lane);      // reference 0
+  qk_block(s, k0, k1, k2, k3, qf, false, (lane & 32) ? 0u : 0x3F80u, valid, lane);      // reference 0
   float tm = NEG_BIG;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) tm = fmaxf(tm, fmaxf(s0[r], s1[r]));
+  for (int r = 0; r < 16; ++r) tm = fmaxf(tm, s[r]);
   tm = fmaxf(tm, swap32(tm));
   const float l_prev = row.l_run + swap32(row.l_run);
-  const bool have_prev = l_prev > 0.f, have_tile = tm > 0.5f * NEG_BIG;
+  const bool have_prev = l_prev > 0.f, have_blk = tm > 0.5f * NEG_BIG;
   float m_new = row.m_ref;
   if (have_prev) m_new = row.m_ref + __builtin_amdgcn_logf(l_prev) * inv_sc;      // v_log_f32 = log2
-  if (have_tile) m_new = have_prev ? fmaxf(m_new, tm) : tm;
+  if (have_blk) m_new = have_prev ? fmaxf(m_new, tm) : tm;
   m_new = bf2f(f2bf(m_new));
   const float shift = row.m_ref - m_new;
   const float alpha = have_prev ? __builtin_amdgcn_exp2f(shift * sc) : 0.f;
@@ -570,33 +563,40 @@ IA_DEV void rebase(f32x16& s0, f32x16& s1, f32x16& o0, f32x16& o1, Row& row, con
   row.l_run *= alpha;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    s0[r] = __builtin_amdgcn_exp2f((s0[r] - m_new) * sc);
-    s1[r] = __builtin_amdgcn_exp2f((s1[r] - m_new) * sc);
+    s[r] = __builtin_amdgcn_exp2f((s[r] - m_new) * sc);
     o0[r] *= alpha; o1[r] *= alpha;
+  }
+  if (other) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) (*other)[r] += shift;
   }
 }
 }  // namespace fwd3
 
-template <bool DROPOUT, int WPS>
-__global__ __launch_bounds__(256, WPS) void attn_fwd3_kernel(AttnArgs p) {
+// QB = 32-query blocks per wave: with 2, a workgroup owns 256 queries and every K / V^T fragment read from LDS feeds two MFMAs -- the
+// per-tile costs that are neither MFMA nor softmax (LDS-DMA issue and latency, barrier, fragment reads) and the per-workgroup
+// prologue / epilogue are spent once per 32 MFMAs instead of once per 16 (profiles/r03_attention_fwd_notes.txt).
+template <bool DROPOUT, int QB>
+__global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void attn_fwd3_kernel(AttnArgs p) {
   using namespace fwd3;
-  __shared__ __attribute__((aligned(16))) char smem[SMEM];
+  constexpr int ROWS = 128 * QB;                          // queries per workgroup
+  constexpr int QX_OFF = SMEM;                            // QB = 2: the second query block's staging rows (16 KiB) behind the table
+  __shared__ __attribute__((aligned(16))) char smem[SMEM + (QB - 1) * 16384];
   uint32_t (*s_valid)[2] = reinterpret_cast<uint32_t (*)[2]>(smem + TAB_OFF);
   const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, lq = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int tile, h, b;
-  attn_block_coords(p, p.Lq, tile, h, b);
+  attn_block_coords_n(p, p.Lq, ROWS, tile, h, b);
   int Lq = p.Lq, L = p.Lk;
   size_t qbase = (size_t)b * Lq, rowbase = (size_t)b * L;
   if (p.cu) {
     const int c0 = p.cu[b];
     Lq = L = p.cu[b + 1] - c0;
     qbase = rowbase = (size_t)c0;
-    if (tile * 128 >= Lq) return;
+    if (tile * ROWS >= Lq) return;
   }
-  const int q0 = tile * 128 + wave * 32;
+  const int q0 = tile * ROWS + wave * 32 * QB;            // this wave's first query (block qb: + 32 qb)
   const bool active = q0 < Lq;
-  const int q = q0 + lq;
   // this sequence's K / V rows of head h as buffer windows: rows >= L are out of range and arrive as zeros
   const uint32_t win = (uint32_t)(((size_t)(L - 1) * p.ld_kv + 64) * 2);
   const __amdgpu_buffer_rsrc_t rsK = ia_rsrc(p.k + rowbase * p.ld_kv + h * 64, win);
@@ -633,38 +633,52 @@ __global__ __launch_bounds__(256, WPS) void attn_fwd3_kernel(AttnArgs p) {
   using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>; using S2 = std::integral_constant<int, 2>;
 
   // ---- prologue: one round trip for Q, K0, V0, K1 and the mask bytes; V1 follows and stays in flight
-  char* qslot = smem + Q_OFF + wave * 4096;
-  stage_rows32(ia_rsrc(p.q, p.q_bytes), qslot, qbase + q0, Lq - q0, p.ld_q, h * 64, lane);
+  {
+    const __amdgpu_buffer_rsrc_t rsQ = ia_rsrc(p.q, p.q_bytes);
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+      stage_rows32(rsQ, smem + (qb ? QX_OFF : Q_OFF) + wave * 4096, qbase + q0 + 32 * qb, Lq - q0 - 32 * qb, p.ld_q, h * 64, lane);
+  }
   stage_k(S0{}, 0); stage_v(S0{}, 0); stage_k(S1{}, 1);
   build_valid_table(p, s_valid, rowbase, L, lane, wave);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   stage_v(S1{}, 1);
-  bf16x8 qf[4];
+  bf16x8 qf[QB][4];
 #pragma unroll
-  for (int kb = 0; kb < 4; ++kb) {
-    const bf16x8 raw = frag_b128(qslot, lq, kb * 2 + hh);
+  for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) qf[kb][j] = PRESCALE ? f2bf(bf2f(raw[j]) * p.sc) : raw[j];
-  }
+    for (int kb = 0; kb < 4; ++kb) {
+      const bf16x8 raw = frag_b128(smem + (qb ? QX_OFF : Q_OFF) + wave * 4096, lq, kb * 2 + hh);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[qb][kb][j] = PRESCALE ? f2bf(bf2f(raw[j]) * p.sc) : raw[j];
+    }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  // trailing tiles without any attendable key are never touched (right-padded batches); bit t of `ragged`: tile t has a key that may
-  // not be attended (such tiles take the penalty MFMA)
+  // trailing tiles without any attendable key are never touched (right-padded batches); bit t of rag0 / rag1: the first / second
+  // 32-key block of tile t has a key that may not be attended (such blocks take the penalty MFMA)
   int nkt = nkt_all;
-  uint32_t ragged = 0u;
+  uint32_t rag0 = 0u, rag1 = 0u;
   for (int t = 0; t < nkt_all; ++t) {
     const uint32_t lo = s_valid[t][0], hi = s_valid[t][1];
-    if ((lo & hi) != 0xFFFFFFFFu) ragged |= 1u << t;
+    if (lo != 0xFFFFFFFFu) rag0 |= 1u << t;
+    if (hi != 0xFFFFFFFFu) rag1 |= 1u << t;
     if ((lo | hi) != 0u) nkt = t + 1;
   }
   nkt = __builtin_amdgcn_readfirstlane(nkt);
-  ragged = __builtin_amdgcn_readfirstlane(ragged);
+  rag0 = __builtin_amdgcn_readfirstlane(rag0);
+  rag1 = __builtin_amdgcn_readfirstlane(rag1);
 
-  const uint32_t rk = DROPOUT ? ia_rng_row(p.seed, (uint32_t)(b * p.nh + h), (uint32_t)q) : 0u;      // row key of this lane's query
+  uint32_t rk[QB];                                        // dropout: row keys of this lane's queries
+  Row row[QB];
+  f32x16 o[QB][2];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    rk[qb] = DROPOUT ? ia_rng_row(p.seed, (uint32_t)(b * p.nh + h), (uint32_t)(q0 + 32 * qb + lq)) : 0u;
+    row[qb] = Row{0.f, 0.f, hh ? 0u : 0x3F80u};
+    o[qb][0] = zero16(); o[qb][1] = zero16();
+  }
   const uint32_t thr1 = DROPOUT ? (p.thr16 - 1u) * 0x10001u : 0u;
-  Row row{0.f, 0.f, hh ? 0u : 0x3F80u};
   bool has_ref = false;                                  // wave-uniform: some row of this wave has left the reference 0
-  f32x16 o0 = zero16(), o1 = zero16();
   bf16x8 kf[8];
   if (active) read_k<0>(kf, ln);
 
@@ -676,64 +690,76 @@ __global__ __launch_bounds__(256, WPS) void attn_fwd3_kernel(AttnArgs p) {
     // K(t+1) has landed for this wave (V(t+1), issued behind it, may still be in flight), then for everybody
     if (LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    if (!(IA_F3_ABL & 2)) __builtin_amdgcn_s_barrier();
-    if (!(IA_F3_ABL & 1) && t + 2 < nkt) { stage_k(NEXT2{}, t + 2); stage_v(NEXT2{}, t + 2); }
-    if (!active || (IA_F3_ABL & 4)) return;
-    f32x16 s0, s1;
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < nkt) { stage_k(NEXT2{}, t + 2); stage_v(NEXT2{}, t + 2); }
+    if (!active) return;
+    // The tile is worked in its two 32-key blocks: the softmax of one block (VALU) has the MFMAs of the other beside it.
+    f32x16 s[QB][2];
     frag_wait<0>(kf);                                     // the K fragments of tile t
-    const bool plain = !has_ref && !((ragged >> t) & 1u);
+    const bool plain0 = !has_ref && !((rag0 >> t) & 1u), plain1 = !has_ref && !((rag1 >> t) & 1u);
     uint32_t cur_lo = 0xFFFFFFFFu, cur_hi = 0xFFFFFFFFu;
-    if (!plain) { cur_lo = __builtin_amdgcn_readfirstlane(s_valid[t][0]); cur_hi = __builtin_amdgcn_readfirstlane(s_valid[t][1]); }
-    qk_tile(s0, s1, kf, qf, plain, row.refw, cur_lo, cur_hi, lane);
-    exp_tile(s0, s1, p.sc);
-    bf16x8 pf[4];
-    float rs = pack_sum(pf, s0, s1);
-    {
-      const float tot = row.l_run + rs;
+    if (!plain0 || !plain1) { cur_lo = __builtin_amdgcn_readfirstlane(s_valid[t][0]); cur_hi = __builtin_amdgcn_readfirstlane(s_valid[t][1]); }
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) qk_block(s[qb][0], kf[0], kf[2], kf[4], kf[6], qf[qb], plain0, row[qb].refw, cur_lo, lane);
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) qk_block(s[qb][1], kf[1], kf[3], kf[5], kf[7], qf[qb], plain1, row[qb].refw, cur_hi, lane);
+    TrPair va, vb, vc, vd;
+    read_v<SLOT, 0>(va, ln);
+    read_v<SLOT, 16>(vb, ln);
+    bf16x8 pf[QB][2];                                     // the current block's probabilities (two PV k-steps)
+    const uint32_t tile_c = DROPOUT ? (uint32_t)(t * 32) * IA_RNG_PAIR_C + (uint32_t)(2 * hh) * IA_RNG_PAIR_C : 0u;
+    // one block's probabilities: exp2, pack + row sum, range check (rare: rebase), dropout
+    auto softmax_block = [&](auto BLK, auto QBI, bool plain_b, uint32_t valid_b) {
+      constexpr int blk = decltype(BLK)::value, qb = decltype(QBI)::value;
+      f32x16& sc = s[qb][blk];
+      exp_block(sc, p.sc);
+      float rs = pack_sum(pf[qb][0], pf[qb][1], sc);
+      const float tot = row[qb].l_run + rs;
       if (__builtin_expect(__ballot(__builtin_bit_cast(uint32_t, tot) - L_LO_BITS > L_HI_BITS - L_LO_BITS) != 0ull, 0)) {
-        if (plain) { cur_lo = __builtin_amdgcn_readfirstlane(s_valid[t][0]); cur_hi = __builtin_amdgcn_readfirstlane(s_valid[t][1]); }
-        rebase(s0, s1, o0, o1, row, kf, qf, cur_lo, cur_hi, lane, p.sc);
-        rs = pack_sum(pf, s0, s1);
+        if (plain_b) valid_b = __builtin_amdgcn_readfirstlane(s_valid[t][blk]);
+        rebase(sc, blk == 0 ? &s[qb][1] : nullptr, o[qb][0], o[qb][1], row[qb], kf[blk], kf[2 + blk], kf[4 + blk], kf[6 + blk], qf[qb], valid_b,
+               lane, p.sc);
+        rs = pack_sum(pf[qb][0], pf[qb][1], sc);
         has_ref = true;
       }
-    }
-    row.l_run += rs;
-    TrPair va, vb, vc, vd;
-    if (IA_F3_ABL & 16) {                                 // no LDS reads: whatever is in the K fragment registers stands in for V^T
-      va.lo0 = va.lo1 = vb.lo0 = vb.lo1 = vc.lo0 = vc.lo1 = vd.lo0 = vd.lo1 = __builtin_bit_cast(s16x8, kf[0]).lo;
-      va.hi0 = va.hi1 = vb.hi0 = vb.hi1 = vc.hi0 = vc.hi1 = vd.hi0 = vd.hi1 = __builtin_bit_cast(s16x8, kf[1]).hi;
-    } else {
-      read_v<SLOT, 0>(va, ln);                            // the V^T fragments land under the dropout draws / the first MFMAs
-      read_v<SLOT, 16>(vb, ln);
-    }
-    if (DROPOUT) {
-      // word i of pf[n] = keys (ACC_ROW(8 (n & 1) + 2 i), +1) of key block n >> 1: pair constant = tile part + lane part + immediate
-      const uint32_t tile_c = (uint32_t)(t * 32) * IA_RNG_PAIR_C + (uint32_t)(2 * hh) * IA_RNG_PAIR_C;
+      row[qb].l_run += rs;
+      if (DROPOUT) {
+        // word i of pf[qb][n] = keys (ACC_ROW(8 n + 2 i), +1) of the block: pair constant = tile part + lane part + immediate
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        u32x4 w = __builtin_bit_cast(u32x4, pf[n]);
+        for (int n = 0; n < 2; ++n) {
+          u32x4 w = __builtin_bit_cast(u32x4, pf[qb][n]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          constexpr uint32_t C = IA_RNG_PAIR_C;
-          const int r = 8 * (n & 1) + 2 * i;
-          const uint32_t imm = (uint32_t)(((r & 3) >> 1) + 4 * (r >> 2) + 16 * (n >> 1)) * C;
-          w[i] = drop_pair(w[i], ia_rng_pair(rk, tile_c + imm), thr1);
+          for (int i = 0; i < 4; ++i) {
+            constexpr uint32_t C = IA_RNG_PAIR_C;
+            const int r = 8 * n + 2 * i;
+            const uint32_t imm = (uint32_t)(((r & 3) >> 1) + 4 * (r >> 2) + 16 * blk) * C;
+            w[i] = drop_pair(w[i], ia_rng_pair(rk[qb], tile_c + imm), thr1);
+          }
+          pf[qb][n] = __builtin_bit_cast(bf16x8, w);
         }
-        pf[n] = __builtin_bit_cast(bf16x8, w);
       }
-    }
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    softmax_block(I0{}, I0{}, plain0, cur_lo);
+    if (QB == 2) softmax_block(I0{}, I1{}, plain0, cur_lo);
     tr_wait<4>(va);
-    o0 = mfma(va.a0(), pf[0], o0); o1 = mfma(va.a1(), pf[0], o1);
-    if (!(IA_F3_ABL & 16)) read_v<SLOT, 32>(vc, ln);
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) { o[qb][0] = mfma(va.a0(), pf[qb][0], o[qb][0]); o[qb][1] = mfma(va.a1(), pf[qb][0], o[qb][1]); }
+    read_v<SLOT, 32>(vc, ln);
     tr_wait<4>(vb);
-    o0 = mfma(vb.a0(), pf[1], o0); o1 = mfma(vb.a1(), pf[1], o1);
-    if (!(IA_F3_ABL & 16)) read_v<SLOT, 48>(vd, ln);
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) { o[qb][0] = mfma(vb.a0(), pf[qb][1], o[qb][0]); o[qb][1] = mfma(vb.a1(), pf[qb][1], o[qb][1]); }
+    read_v<SLOT, 48>(vd, ln);
+    softmax_block(I1{}, I0{}, plain1, cur_hi);
+    if (QB == 2) softmax_block(I1{}, I1{}, plain1, cur_hi);
     tr_wait<4>(vc);
-    o0 = mfma(vc.a0(), pf[2], o0); o1 = mfma(vc.a1(), pf[2], o1);
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) { o[qb][0] = mfma(vc.a0(), pf[qb][0], o[qb][0]); o[qb][1] = mfma(vc.a1(), pf[qb][0], o[qb][1]); }
     tr_wait<0>(vd);
-    o0 = mfma(vd.a0(), pf[3], o0); o1 = mfma(vd.a1(), pf[3], o1);
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) { o[qb][0] = mfma(vd.a0(), pf[qb][1], o[qb][0]); o[qb][1] = mfma(vd.a1(), pf[qb][1], o[qb][1]); }
     // the K fragments of tile t+1 land under the last MFMAs and the top of the next tile (no wait here depends on them)
-    if (!LAST && !(IA_F3_ABL & 16)) read_k<(SLOT + 1) % 3>(kf, ln);
+    if (!LAST) read_k<(SLOT + 1) % 3>(kf, ln);
   };
   {
     int t = 0;
@@ -743,12 +769,19 @@ __global__ __launch_bounds__(256, WPS) void attn_fwd3_kernel(AttnArgs p) {
       tile_step(S2{}, t); if (++t >= nkt) break;
     }
   }
-  __builtin_amdgcn_s_barrier();                           // the epilogue rows are staged in the K ring
+  __builtin_amdgcn_s_barrier();                           // the epilogue rows are staged in the ring
   if (!active) return;
-  const float l_tot = row.l_run + swap32(row.l_run);
-  const float inv = l_tot > 0.f ? p.inv_keep / l_tot : 0.f;
-  if (q < Lq && hh == 0 && p.lse2) p.lse2[((size_t)b * p.nh + h) * p.Lq + q] = row.m_ref * (PRESCALE ? 1.f : p.sc) + __builtin_amdgcn_logf(l_tot);
-  store_block_rows(smem + EPI_OFF + wave * EPI_SLOT, o0, o1, inv, false, p.out + (qbase + q0) * p.ld_o + h * 64, p.ld_o, Lq - q0, lane);
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int qq0 = q0 + 32 * qb;
+    if (qq0 >= Lq) break;                                 // wave-uniform
+    const float l_tot = row[qb].l_run + swap32(row[qb].l_run);
+    const float inv = l_tot > 0.f ? p.inv_keep / l_tot : 0.f;
+    if (qq0 + lq < Lq && hh == 0 && p.lse2)
+      p.lse2[((size_t)b * p.nh + h) * p.Lq + qq0 + lq] = row[qb].m_ref * (PRESCALE ? 1.f : p.sc) + __builtin_amdgcn_logf(l_tot);
+    store_block_rows(smem + EPI_OFF + (wave * QB + qb) * EPI_SLOT, o[qb][0], o[qb][1], inv, false, p.out + (qbase + qq0) * p.ld_o + h * 64, p.ld_o,
+                     Lq - qq0, lane);
+  }
 }
 
 // ------------------------------------------------------------------------------------- backward: dQ
@@ -1090,20 +1123,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_dq_kernel(AttnArgs p) {
     rd(I1{}, yk0, yk1, yv0, yv1);
     f32x16 s0, s1, dp0, dp1;
     const bool plain = !((ragged >> t) & 1u);
-    if (plain) {
-      frag_wait4<4>(xk0, xk1, xv0, xv1);
-      s0 = mfma(xk0, qf[0], nl); s1 = mfma(xk1, qf[0], nl);
-    } else {
+    frag_wait4<4>(xk0, xk1, xv0, xv1);
+    s0 = mfma(xk0, qf[0], nl); s1 = mfma(xk1, qf[0], nl);
+    dp0 = mfma(xv0, gf[0], nd); dp1 = mfma(xv1, gf[0], nd);
+    if (!plain) {
+      // masked keys: one more accumulate step adds -1e30 to their rows (A = the penalty in k-slot 0 of the key's row, B = 1.0 in
+      // k-slot 0 of every query).  The fragment registers of the reads in flight are not touched in here: a wait that sat on the
+      // far side of a branch from its read once had the register allocator copy a fragment before its data had arrived
+      // (tools/lint_asm_waits.py checks the compiled kernels for exactly that).
       const uint32_t v_lo = __builtin_amdgcn_readfirstlane(s_valid[t][0]), v_hi = __builtin_amdgcn_readfirstlane(s_valid[t][1]);
       const uint32_t low = hh ? 0u : 1u;
       const uint32_t bad0 = ((~v_lo) >> lq) & low, bad1 = ((~v_hi) >> lq) & low;
       const u32x4 a0 = {bad0 * NEG_BIG_BF16, 0u, 0u, 0u}, a1 = {bad1 * NEG_BIG_BF16, 0u, 0u, 0u}, bw = {low * 0x3F80u, 0u, 0u, 0u};
-      const f32x16 c0 = mfma(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, bw), nl);
-      const f32x16 c1 = mfma(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, bw), nl);
-      frag_wait4<4>(xk0, xk1, xv0, xv1);
-      s0 = mfma(xk0, qf[0], c0); s1 = mfma(xk1, qf[0], c1);
+      s0 = mfma(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, bw), s0);
+      s1 = mfma(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, bw), s1);
     }
-    dp0 = mfma(xv0, gf[0], nd); dp1 = mfma(xv1, gf[0], nd);
     rd(I2{}, xk0, xk1, xv0, xv1);
     frag_wait4<4>(yk0, yk1, yv0, yv1);
     s0 = mfma(yk0, qf[1], s0); s1 = mfma(yk1, qf[1], s1); dp0 = mfma(yv0, gf[1], dp0); dp1 = mfma(yv1, gf[1], dp1);
@@ -1565,7 +1599,7 @@ int fill_args(AttnArgs& a, int B, int nh, int Lq, int Lk, int ld_q, int ld_kv, i
 
 // development switches (round 3): IA_ATTN_FWD=2 / IA_ATTN_BWD=0 run the round-2 kernels for A/B measurements on one box
 int bwd_version() {
-  static const int v = [] { const char* e = getenv("IA_ATTN_BWD"); return e ? atoi(e) : 0; }();
+  static const int v = [] { const char* e = getenv("IA_ATTN_BWD"); return e ? atoi(e) : 3; }();      // bit 0: round-3 dQ kernel, bit 1: round-3 dK/dV kernel
   return v;
 }
 template <bool D> void launch_dkv(const AttnArgs& a, dim3 grid, hipStream_t st) {
@@ -1577,17 +1611,26 @@ template <bool D> void launch_dq(const AttnArgs& a, dim3 grid, hipStream_t st) {
   else hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, grid, dim3(256), 0, st, a);
 }
 int fwd_version() {
-  static const int v = [] { const char* e = getenv("IA_ATTN_FWD"); return e ? atoi(e) : 3; }();
+  // 2: round-2 kernel, 3: 128 queries per workgroup, 4: 256, default 0: by shape
+  static const int v = [] { const char* e = getenv("IA_ATTN_FWD"); return e ? atoi(e) : 0; }();
   return v;
 }
+// grid: the workgroup count for 128 queries per workgroup (the round-2 geometry); the 256-query kernel derives its own
 void launch_fwd(const AttnArgs& a, dim3 grid, hipStream_t stream) {
   const dim3 blk(256);
-  if (fwd_version() == 2) {
+  const int v = fwd_version();
+  if (v == 2) {
     if (a.thr16) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, blk, 0, stream, a);
     else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, blk, 0, stream, a);
+  } else if (v == 3 || (v != 4 && ((a.Lq - 1) & 255) < 128)) {
+    // 128 queries per workgroup when the last 256-query block would be less than half full (ViT: 577 = 2 x 256 + 65); measured
+    // (profiles/r03_attention_variants.txt): 256-query workgroups are 3-6 % faster at L = 220 / 255, equal at 510, 3 % slower at 577
+    if (a.thr16) hipLaunchKernelGGL((attn_fwd3_kernel<true, 1>), grid, blk, 0, stream, a);
+    else hipLaunchKernelGGL((attn_fwd3_kernel<false, 1>), grid, blk, 0, stream, a);
   } else {
-    if (a.thr16) hipLaunchKernelGGL((attn_fwd3_kernel<true, 3>), grid, blk, 0, stream, a);
-    else hipLaunchKernelGGL((attn_fwd3_kernel<false, 3>), grid, blk, 0, stream, a);
+    const dim3 g2(((a.Lq + 255) / 256) * a.nh * a.B);
+    if (a.thr16) hipLaunchKernelGGL((attn_fwd3_kernel<true, 2>), g2, blk, 0, stream, a);
+    else hipLaunchKernelGGL((attn_fwd3_kernel<false, 2>), g2, blk, 0, stream, a);
   }
 }
 

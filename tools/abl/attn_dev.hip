@@ -1,6 +1,8 @@
 // Development harness for the attention kernels (no torch): includes attention.hip, checks the forward (and backward) against an fp32
 // host reference on a few (sequence, head) pairs and times the launches.  Kernel variants are picked with IA_ATTN_FWD / IA_ATTN_BWD.
-// usage: attn_dev B L nh [mode: 0 fwd, 1 bwd] [drop] [amp: input std * 4] [masked: 0 none, 1 right padding + a hole] [check: 1]
+// usage: attn_dev B L nh [mode: 0 fwd, 1 bwd] [drop] [amp: input std * 4] [masked: 0 none, 1 right padding + a hole]
+//        [check: 0 time only, 1 compare sampled (sequence, head) pairs with the host reference, N >= 2: also N launches whose whole
+//         output is scanned for non-finite / absurd entries -- rare timing-dependent faults do not show up in the sampled check]
 #ifndef IA_ATTN_SRC
 #define IA_ATTN_SRC "../../item_alignment_amd/csrc/attention.hip"
 #endif
@@ -39,7 +41,7 @@ int main(int argc, char** argv) {
     }
   }
   void *qkv, *out, *dout, *dqkv; float *lse, *delta; uint8_t* mask;
-  hipMalloc(&qkv, T * 3 * H * 2); hipMalloc(&out, T * H * 2); hipMalloc(&dout, T * H * 2); hipMalloc(&dqkv, T * 3 * H * 2);
+  hipMalloc(&qkv, T * 3 * H * 2 + (4u << 20)); hipMemset(qkv, 0, T * 3 * H * 2 + (4u << 20)); hipMalloc(&out, T * H * 2); hipMalloc(&dout, T * H * 2); hipMalloc(&dqkv, T * 3 * H * 2);
   hipMalloc(&lse, (size_t)B * nh * L * 4); hipMalloc(&delta, (size_t)B * nh * L * 4); hipMalloc(&mask, T);
   hipMemcpy(qkv, h.data(), T * 3 * H * 2, hipMemcpyHostToDevice);
   hipMemcpy(dout, hdo.data(), T * H * 2, hipMemcpyHostToDevice);
@@ -120,6 +122,21 @@ int main(int argc, char** argv) {
     best = std::min(best, ms); tot += ms;
   }
   const double us = tot * 1000 / 60, usb = best * 1000 / 20; const double fl = (mode == 0 ? 4.0 : 10.0) * B * nh * (double)L * L * 64;
+  for (int rep = 0; rep < (check >= 3 ? check : check >= 2 ? 1 : 0); ++rep) {   // whole-tensor scan of a launch: non-finite or absurd entries
+    std::vector<uint16_t> hg(mode == 1 ? T * 3 * H : T * H);
+    if (mode == 0) fwd(); else bwd();
+    hipDeviceSynchronize();
+    hipMemcpy(hg.data(), mode == 1 ? dqkv : out, hg.size() * 2, hipMemcpyDeviceToHost);
+    const size_t ld = mode == 1 ? 3 * H : H; size_t nbad = 0;
+    for (size_t i = 0; i < hg.size(); ++i) {
+      const float v = bf2f_h(hg[i]);
+      if (!(std::fabs(v) < 1e3f)) {
+        if (nbad < 2) printf("   bad %g at row %zu (b %zu, i %zu) col %zu (part %zu head %zu d %zu)\n", v, i / ld, i / ld / L, i / ld % L, i % ld, i % ld / H, i % H / 64, i % 64);
+        ++nbad;
+      }
+    }
+    printf("[%s] scan: %zu bad of %zu\n", tag, nbad, hg.size());
+  }
   printf("[%s] mode=%d B=%d L=%d nh=%d drop=%.2f masked=%d: %.1f us avg (%.1f best)  %.1f TF/s\n", tag, mode, B, L, nh, drop, masked, us, usb, fl / us * 1e-6);
   return 0;
 }

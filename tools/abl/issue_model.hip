@@ -97,6 +97,19 @@ __global__ __launch_bounds__(256 * WAVES) void kern(const float* in, int iters, 
 #pragma unroll
         for (int i = 0; i < K; ++i) filler<FILL>(x, u, c, d, m * K + i);
       }
+    } else if (ROLES == 3 || ROLES == 4) {
+      // the attention loop's own shape, free running: every wave alternates a batch of NM MFMAs with NM * K fillers whose inputs are
+      // the accumulators (so the batch must have drained); ROLES 4: waves 4-7 start with the filler batch (anti-phase)
+      if (ROLES == 4 && wave >= 4 && it == 0) {
+#pragma unroll
+        for (int i = 0; i < NM * K; ++i) filler<FILL>(x, u, c, d, i);
+      }
+#pragma unroll
+      for (int m = 0; m < NM; ++m) MFMA(acc[m % NACC], a, b);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[r]) : "v"(acc[r & (NACC - 1)][r]));      // wait for the MFMAs
+#pragma unroll
+      for (int i = 0; i < NM * K; ++i) filler<FILL>(x, u, c, d, i);
     } else if (ROLES == 2) {
       // ping-pong: waves 0-3 {MFMA phase, barrier, filler phase, barrier}, waves 4-7 the opposite order
       if (wave < 4) {
@@ -155,7 +168,7 @@ void run(const char* what) {
   for (int b = 0; b < 256; ++b) for (int w = 0; w < 4 * WAVES; ++w) { if (w < 4) { lo += h[b * 16 + w]; ++nlo; } else { hi += h[b * 16 + w]; ++nhi; } }
   lo /= nlo * (double)iters; if (nhi) hi /= nhi * (double)iters;
   const int nmf = NM ? NM : 0, nfl = NM ? NM * K : 16 * K;
-  printf("%-44s waves/SIMD %d  %s  cyc/iter w0-3 %8.1f", what, WAVES, ROLES == 1 ? "roles" : ROLES == 2 ? "pingp" : "     ", lo);
+  printf("%-44s waves/SIMD %d  %s  cyc/iter w0-3 %8.1f", what, WAVES, ROLES == 1 ? "roles" : ROLES == 2 ? "pingp" : ROLES == 3 ? "batch" : ROLES == 4 ? "batcA" : "     ", lo);
   if (nhi) printf("  w4-7 %8.1f", hi); else printf("               ");
   if (nmf) printf("  | per MFMA %6.1f", lo / nmf);
   if (nfl) printf("  | per filler %6.2f", (nhi && ROLES == 1 ? hi : lo) / nfl);
@@ -205,6 +218,11 @@ int main() {
   printf("== roles: waves 0-3 MFMA only, waves 4-7 fillers only (same SIMDs) ==\n");
   run<16, 5, 0, 2, 2, 1>("16 mfma | 80 fma"); run<16, 8, 0, 2, 2, 1>("16 mfma | 128 fma"); run<16, 10, 4, 2, 2, 1>("16 mfma | 160 mix"); run<16, 16, 0, 2, 2, 1>("16 mfma | 256 fma");
   printf("== phase-alternating: 8 MFMAs back to back, then 8*K fillers (what a non-interleaved loop does) ==\n");
+  printf("== batches: every wave {16 MFMA, wait, 16*K fillers}, free running (batch) / waves 4-7 starting half a period late (batcA) ==\n");
+  run<16, 5, 4, 2, 1, 3>("1 wave: 16 mfma then 80 mix"); run<16, 5, 4, 2, 2, 3>("2 waves: 16 mfma then 80 mix"); run<16, 5, 4, 2, 2, 4>("2 waves anti-phase start");
+  run<16, 5, 4, 2, 3, 3>("3 waves: 16 mfma then 80 mix");
+  run<16, 8, 4, 2, 2, 3>("2 waves: 16 mfma then 128 mix"); run<16, 8, 4, 2, 2, 4>("2 waves anti-phase: 128 mix");
+  run<8, 5, 4, 2, 2, 3>("2 waves: 8 mfma then 40 mix"); run<8, 5, 4, 2, 3, 3>("3 waves: 8 mfma then 40 mix");
   run<16, 5, 0, 2, 2, 2>("16 mfma / 80 fma per wave"); run<16, 8, 0, 2, 2, 2>("16 mfma / 128 fma per wave"); run<16, 5, 4, 2, 2, 2>("16 mfma / 80 mix per wave");
   run<16, 8, 4, 2, 2, 2>("16 mfma / 128 mix per wave"); run<16, 10, 4, 2, 2, 2>("16 mfma / 160 mix per wave");
   return 0;

@@ -1,0 +1,8 @@
+#!/bin/bash
+cd "$(dirname "$0")"
+export IA_ATTN_BWD=1 IA_ATTN_FWD=2
+for d in "$@"; do
+echo "== DBG=$d"
+./attn_dev_d$d.bin 64 577 12 1 0 1 0 40 | grep -v "rel err" | grep -c "scan: 0 bad"
+./attn_dev_d$d.bin 64 577 12 1 0 1 0 40 | grep -v "rel err" | grep "bad" | grep -v "scan: 0" | head -8
+done
