@@ -82,10 +82,17 @@ def test_c4_pkgm_large_full_entity_table(gpu):
     got = dict(model.named_parameters())[ent_key].grad.float().cpu()
     want = rsd[ent_key].grad
     rows = sorted({e for pair in ents for e in pair})
-    # quirk A1 (normalize over a size-1 dim = sign) kills the entity gradient exactly; the touched rows and everything else must agree
-    assert torch.equal(got.abs().sum(1) > 0, want.abs().sum(1) > 0) or got[rows].abs().max() < 1e-6
-    assert (got[rows] - want[rows]).abs().max().item() <= TOL * max(want[rows].abs().max().item(), 1e-6) + 1e-6
-    for k in (next(k for k in sd if k.endswith("rel_emb.weight")), next(k for k in sd if k.endswith("proj_mat.weight"))):
+    rel_key = next(k for k in sd if k.endswith("rel_emb.weight"))
+    # quirk A1 (F.normalize over a size-1 dim = sign(x)) has zero gradient: the HIP path returns exact zeros for the entity rows.  The
+    # oracle differentiates x / max(|x|, eps) in fp32, whose two cancelling terms leave rounding noise of order eps_fp32 / |x| per
+    # element (|x| goes down to 2e-6 in a fresh table: 2^-9 here) -- bounded against the scale of the relation-table gradient.
+    untouched = torch.ones(got.shape[0], dtype=torch.bool); untouched[rows] = False
+    assert got[untouched].abs().max().item() == 0.0 and want[untouched].abs().max().item() == 0.0
+    if got[rows].abs().max().item() < 1e-6:
+        assert want[rows].abs().max().item() < 0.02 * rsd[rel_key].grad.abs().max().item(), want[rows].abs().max().item()
+    else:
+        assert (got[rows] - want[rows]).abs().max().item() <= TOL * want[rows].abs().max().item() + 1e-6
+    for k in (rel_key, next(k for k in sd if k.endswith("proj_mat.weight"))):
         g_, w_ = dict(model.named_parameters())[k].grad, rsd[k].grad
         assert cosine(g_, w_) > 0.98, (k, cosine(g_, w_))
         assert rel(g_, w_) < 0.10, (k, rel(g_, w_))
@@ -103,6 +110,10 @@ def test_c3_eca_nfnet_l0_at_800(gpu):
     labels = torch.tensor([1])
     torch.manual_seed(5)
     model = M.NFNetTwoTower(cfg, M.create_model("eca_nfnet_l0"))
+    with torch.no_grad():                                  # timm starts conv3.gain at 0 (the residual branches are off in a fresh
+        for k, v in model.named_parameters():              # net): switch them on so that all 12 blocks take part, as after training
+            if k.endswith("conv3.gain"):
+                v.fill_(1.0)
     sd = state_of(model, head_gain=30.0)
     model = model.cuda().eval()
     out = model(im1.cuda(), im2.cuda(), labels.cuda())
@@ -111,9 +122,20 @@ def test_c3_eca_nfnet_l0_at_800(gpu):
     torch.cuda.synchronize()
     keys = ["img_encoder.stem.conv1.weight", "img_encoder.stages.3.2.conv3.weight", "img_encoder.final_conv.weight"]
     rsd = {k: (v.requires_grad_(True) if k in keys else v) for k, v in sd.items()}
-    ref = O.nfnet_two_tower(rsd, cfg, O.nfnet_cfg("eca_nfnet_l0"), im1, im2, labels=labels, training=False)
+    ncfg = O.nfnet_cfg("eca_nfnet_l0")
+    f1 = O.nfnet_global_pool(O.nfnet_forward_features(rsd, "img_encoder", ncfg, im1))
+    f2 = O.nfnet_global_pool(O.nfnet_forward_features(rsd, "img_encoder", ncfg, im2))
+    ref = O.image_two_tower(rsd, cfg, f1, f2, labels, False)          # = nfnet_two_tower, with the pooled features kept
     ref.loss.backward()
-    assert rel(out.logits.detach(), ref.logits.detach()) < TOL, rel(out.logits.detach(), ref.logits.detach())
+    # the tower: pooled 2304-d features of both images (measured at 800 x 800: every stage within 2 % of the oracle's maximum)
+    with torch.no_grad():
+        feats = model._embed(torch.cat((im1, im2)).cuda())
+    want_f = torch.cat((f1, f2)).detach()
+    assert rel(feats, want_f) < 0.03, rel(feats, want_f)
+    assert cosine(feats, want_f) > 0.9995, cosine(feats, want_f)
+    # the head: a fresh pair head's logits are a small difference of large sums over 3 x 2304 feature terms (0.05 and 0.22 here with
+    # the x30 weights), so the features' bf16 error reaches them amplified by the head's gain: absolute tolerance, like the loss
+    assert (out.logits.detach().float().cpu() - ref.logits.detach()).abs().max().item() < TOL, (out.logits, ref.logits)
     assert abs(out.loss.item() - ref.loss.item()) < TOL * max(1.0, abs(ref.loss.item()))
     params = dict(model.named_parameters())
     for k in keys:
