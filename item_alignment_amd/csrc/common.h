@@ -130,6 +130,29 @@ IA_DEV void gelu_parts(float x, float& cdf, float& pdf) {
   cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
   pdf = 0.3989422804014327f * e;
 }
+// The same pair for the GEMM epilogues (FFN1 forward: 128 outputs per thread behind every 256 x 256 tile, no MFMA work to hide
+// behind), two outputs at a time on the packed fp32 pipe:  Phi(x) ~ sigmoid(x (c0 + c1 u + c2 u^2)), u = min(x^2, U_MAX), the odd
+// polynomial fitted to the erf form on [-8, 8] (tools/fit_gelu.py: |gelu - x Phi(x)| <= 3.0e-5, |gelu' error| <= 1.1e-4, a tenth of
+// a bf16 ulp at the magnitudes where it matters).  U_MAX = c1 / (2 |c2|) is where the fitted polynomial peaks (|x| = 7.27, the
+// sigmoid is 1 - 6e-12 there); beyond it the argument keeps growing linearly instead of following the polynomial back down.
+// 12 issue slots per output (6 packed, 1 min, exp2 + rcp, 2 converts) against 21 for the A&S form above.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+IA_DEV void gelu_pair(f32x2_t x, f32x2_t& act, f32x2_t& der) {
+  constexpr float L2E = 1.4426950408889634f;
+  constexpr float C0 = 1.5949398799788077f, C1 = 0.07403000634661838f, C2 = -0.0007007124749191571f;
+  constexpr float U_MAX = C1 / (2.f * 0.0007007124749191571f);
+  f32x2_t u = x * x;
+  u[0] = __builtin_fminf(u[0], U_MAX); u[1] = __builtin_fminf(u[1], U_MAX);
+  const f32x2_t np = (u * (-C2 * L2E) + (-C1 * L2E)) * u + (-C0 * L2E);      // -log2(e) p(u)
+  const f32x2_t t = x * np;
+  const f32x2_t e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};    // exp(-x p): inf for very negative x -> s = 0
+  const f32x2_t den = e + 1.0f;
+  const f32x2_t s = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  act = x * s;
+  const f32x2_t q = (u * (5.f * C2) + (3.f * C1)) * u + C0;                  // d/dx [x p(x^2)]
+  const f32x2_t r = 1.0f - s;
+  der = (act * r) * q + s;
+}
 IA_DEV float gelu_erf(float x) { float c, d; gelu_parts(x, c, d); return x * c; }
 IA_DEV float gelu_erf_grad(float x) { float c, d; gelu_parts(x, c, d); return c + x * d; }
 

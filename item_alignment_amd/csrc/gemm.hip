@@ -79,16 +79,15 @@ IA_DEV void epi_store4(const GemmArgs& p, int m, int n, f32x4 v) {
     v += b;
   }
   if (EPI == EPI_BIAS_GELU) {
-    // C = gelu(pre), C2 = gelu'(pre), both of the bf16-rounded pre-activation: the derivative shares the exp / rcp of the
-    // activation (two more multiply-adds here) and turns the data-gradient epilogue (EPI_DGELU) into one multiply per element
+    // C = gelu(pre), C2 = gelu'(pre): the derivative shares the exp / rcp of the activation (gelu_pair, common.h) and turns the
+    // data-gradient epilogue (EPI_DGELU) into one multiply per element
     bf16x4 der;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float x = bf2f(f2bf(v[r]));
-      float c, d;
-      gelu_parts(x, c, d);
-      v[r] = x * c;
-      der[r] = f2bf(__builtin_fmaf(x, d, c));
+    for (int r = 0; r < 4; r += 2) {
+      f32x2_t a, d;
+      gelu_pair(f32x2_t{v[r], v[r + 1]}, a, d);
+      v[r] = a[0]; v[r + 1] = a[1];
+      der[r] = f2bf(d[0]); der[r + 1] = f2bf(d[1]);
     }
     *reinterpret_cast<bf16x4*>(p.C2 + (size_t)m * p.ldc + n) = der;
   }
@@ -146,13 +145,12 @@ IA_DEV void epi_store8(const GemmArgs& p, int m, int n, f32x4 lo, f32x4 hi, f32x
   if (EPI == EPI_BIAS_GELU) {   // see epi_store4
     bf16x8 der;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const float x = bf2f(f2bf(v[r]));
-      float c, d;
-      if (p.dbg & 512) { c = x; d = x; } else
-      gelu_parts(x, c, d);
-      v[r] = x * c;
-      der[r] = f2bf(__builtin_fmaf(x, d, c));
+    for (int r = 0; r < 8; r += 2) {
+      f32x2_t a, d;
+      if (p.dbg & 512) { a = f32x2_t{v[r], v[r + 1]}; d = a; } else
+      gelu_pair(f32x2_t{v[r], v[r + 1]}, a, d);
+      v[r] = a[0]; v[r + 1] = a[1];
+      der[r] = f2bf(d[0]); der[r + 1] = f2bf(d[1]);
     }
     gstore16(((p.dbg & 1024) ? reinterpret_cast<bf16*>(p.C) : p.C2) + (size_t)m * p.ldc + n, der);
   }

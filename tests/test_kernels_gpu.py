@@ -37,6 +37,31 @@ def test_gemm_nt_epilogues(gpu, M, N, K):
     assert rel_err(ops.gemm(a, w, out_f32=True), ref) < 2e-3
 
 
+@pytest.mark.parametrize("M,N", [(256, 256), (512, 128), (77, 64)])
+def test_gemm_gelu_epilogue_accuracy(gpu, M, N):
+    """The FFN1 epilogue's GELU pair against the exact erf form (reference hidden_act = "gelu") at chosen pre-activations.  The GEMM is
+    x = 1 * bias (A = a one-hot column, W = ones in that column), so every output is exactly the bf16-exact bias value: a sweep over
+    [-12, 12] including the outliers past the range the sigmoid-form polynomial was fitted on.  Bounds: the fit's own error
+    (3e-5 / 1.1e-4, tools/fit_gelu.py) plus half a bf16 ulp of the stored result."""
+    from item_alignment_amd import ops
+    K = 64
+    a = torch.zeros((M, K), device=gpu, dtype=torch.bfloat16); a[:, 0] = 1
+    w = torch.zeros((N, K), device=gpu, dtype=torch.bfloat16)           # x[m][n] = bias[n] exactly
+    xs = torch.linspace(-12, 12, N, device=gpu).to(torch.bfloat16).float()
+    xs[0], xs[-1] = -30.0, 30.0
+    act, der = ops.gemm(a, w, epilogue=ops.EPI_BIAS_GELU, bias=xs)
+    x64 = xs.double().cpu()
+    Phi = 0.5 * (1 + torch.erf(x64 / 2 ** 0.5))
+    want_act = x64 * Phi
+    want_der = Phi + x64 * torch.exp(-x64 * x64 / 2) / (2 * torch.pi) ** 0.5
+    for got, want, fit_err in ((act, want_act, 3.0e-5), (der, want_der, 1.1e-4)):
+        g = got.double().cpu()
+        assert torch.isfinite(g).all()
+        assert (g - g[0:1]).abs().max().item() == 0.0                     # every row saw the same pre-activations
+        tol = fit_err * 1.2 + want.abs() * 2.0 ** -8
+        assert ((g[0] - want).abs() <= tol).all(), ((g[0] - want).abs() - tol).max().item()
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 192, 256), (1000, 1024, 3072), (510, 64, 192)])
 def test_gemm_nn_dgrad(gpu, M, N, K):
     """dX = dY W: A k-contiguous, B = W[K(red)][N] k-strided."""
