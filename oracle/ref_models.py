@@ -23,12 +23,38 @@ import torch.nn.functional as F
 # --------------------------------------------------------------------------------------------- basics
 
 
+# Storage-rounding mode (tests only): inside `with rounding(torch.bfloat16):` the text-encoder functions round their tensors where
+# the HIP engine keeps them in bf16 -- GEMM weights (the engine multiplies bf16 shadows of the fp32 masters), every linear / LayerNorm /
+# GELU output, the attention probabilities fed to P V -- while accumulation, softmax, LayerNorm statistics and the loss stay fp32, as
+# on the GPU.  The casts are differentiable (the gradient passes through, itself rounded), so the gradients of this mode carry the
+# noise bf16 storage puts on an fp32 computation: the yardstick the GPU gradient tolerances are justified against
+# (tests/test_models_gpu.py).  It does not reproduce the engine's roundings bit for bit (accumulation orders differ).
+_ROUND = None
+
+
+class rounding:
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global _ROUND
+        self.prev, _ROUND = _ROUND, self.dtype
+
+    def __exit__(self, *exc):
+        global _ROUND
+        _ROUND = self.prev
+
+
+def _r(x):
+    return x if _ROUND is None else x.to(_ROUND).to(torch.float32)
+
+
 def linear(x, sd, prefix, bias=True):
-    return F.linear(x, sd[prefix + ".weight"], sd[prefix + ".bias"] if bias and (prefix + ".bias") in sd else None)
+    return _r(F.linear(x, _r(sd[prefix + ".weight"]), sd[prefix + ".bias"] if bias and (prefix + ".bias") in sd else None))
 
 
 def layer_norm(x, sd, prefix, eps):
-    return F.layer_norm(x, x.shape[-1:], sd[prefix + ".weight"], sd[prefix + ".bias"], eps)
+    return _r(F.layer_norm(x, x.shape[-1:], sd[prefix + ".weight"], sd[prefix + ".bias"], eps))
 
 
 def dropout(x, p, training):
@@ -67,8 +93,8 @@ def bert_self_attention(x, sd, p, cfg, ext_mask, training):
     s = torch.matmul(q, k.transpose(-1, -2)) * (dh ** -0.5)
     if ext_mask is not None:
         s = s + ext_mask
-    a = dropout(torch.softmax(s, dim=-1), cfg.attention_probs_dropout_prob, training)
-    ctx = torch.matmul(a, v).transpose(1, 2).reshape(B, L, H)
+    a = _r(dropout(torch.softmax(s, dim=-1), cfg.attention_probs_dropout_prob, training))
+    ctx = _r(torch.matmul(a, v).transpose(1, 2).reshape(B, L, H))
     # RobertaSelfOutput: dense -> dropout -> LayerNorm(h + input)
     h = dropout(linear(ctx, sd, p + ".output.dense"), cfg.hidden_dropout_prob, training)
     return layer_norm(h + x, sd, p + ".output.LayerNorm", cfg.layer_norm_eps)
@@ -77,7 +103,7 @@ def bert_self_attention(x, sd, p, cfg, ext_mask, training):
 def bert_layer(x, sd, p, cfg, ext_mask, training):
     """transformers RobertaLayer = attention + RobertaIntermediate (erf GELU) + RobertaOutput."""
     a = bert_self_attention(x, sd, p + ".attention", cfg, ext_mask, training)
-    h = F.gelu(linear(a, sd, p + ".intermediate.dense"))
+    h = _r(F.gelu(linear(a, sd, p + ".intermediate.dense")))
     h = dropout(linear(h, sd, p + ".output.dense"), cfg.hidden_dropout_prob, training)
     return layer_norm(h + a, sd, p + ".output.LayerNorm", cfg.layer_norm_eps)
 

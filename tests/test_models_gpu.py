@@ -14,7 +14,27 @@ TOL = 5e-2
 COS_MIN = 0.99           # gradient direction; see check().  Measured (tools/parity_report.py, profiles/r02_parity_report.txt): median 1.0000
 # tensors measured below 0.99: a bias gradient that is a sum over the few tokens of a 3-sample batch (cancellation), bf16 ReLU gates
 COS_EXCEPTIONS = {("roberta_two_tower_ce", "roberta.embeddings.LayerNorm.bias"): 0.97}
+# gradient magnitude: |got - want|_max / |want|_max.  The bar is 0.10, or four times the deviation the CPU oracle itself shows when
+# it rounds its tensors to bf16 where the engine stores bf16 (oracle.ref_models.rounding: weights, linear / LayerNorm / GELU outputs,
+# attention probabilities, and the gradients flowing back through them) -- whichever is larger.  The fixtures are 3-sample batches:
+# sums over a handful of tokens with cancellation (an embedding LayerNorm bias) move by 6 - 40 % under that rounding alone
+# (measured: roberta_two_tower_ce LayerNorm.bias 0.42, everything else 0.01 - 0.07); the engine rounds a few more tensors than the
+# oracle mode does (dS ahead of the dQ / dK MFMAs, the saved GELU derivative), hence the factor.
+GRAD_REL = 0.10
+NOISE_FACTOR = 4.0
+# towers the rounding mode does not cover (convolutions): named bounds.  resnet stem: BatchNorm batch statistics over 3 images in bf16.
+REL_EXCEPTIONS = {("resnet_two_tower", "img_encoder.stem.conv.weight"): 0.25}
 MEASURED = []            # (case, kind, key, value) of everything check() compared: printed by tools/parity_report.py
+
+
+def bf16_noise(case):
+    """per-tensor deviation of the oracle's own gradients under bf16 storage rounding from its fp32 gradients (= the fixture's)"""
+    from golden_util import run_oracle
+    from oracle import ref_models as O
+    sd = weights(case, requires_grad=True)
+    with O.rounding(torch.bfloat16):
+        run_oracle(case, sd).loss.backward()
+    return {k: rel(sd[k].grad, want) for k, want in case.grads.items() if sd[k].grad is not None}
 
 
 def rel(a, b):
@@ -53,8 +73,9 @@ def check(case, out, model, tol=TOL, cos_min=None):
         torch.cuda.synchronize()
         params = dict(model.named_parameters())
         # gradients pass through bf16 activations (B = 3 samples, so little averaging): direction must agree
-        # (cosine >= 0.99) and magnitude within 0.25 of the reference's max; kernel-level backward parity is
-        # checked much tighter in test_kernels_gpu.py / test_engine_gpu.py against same-precision inputs.
+        # (cosine >= 0.99) and magnitude within GRAD_REL / the measured bf16 storage noise (above); kernel-level backward
+        # parity is checked much tighter in test_kernels_gpu.py / test_engine_gpu.py against same-precision inputs.
+        noise = bf16_noise(case)
         for k, want in case.grads.items():
             got = params[k].grad
             assert torch.isfinite(got).all(), k
@@ -63,7 +84,9 @@ def check(case, out, model, tol=TOL, cos_min=None):
             MEASURED.append((case.name, "grad cos", k, c))
             MEASURED.append((case.name, "grad rel", k, rel(got, want)))
             assert c > min(cos_min, COS_EXCEPTIONS.get((case.name, k), 1.0)), (case.name, "grad cosine", k, c)
-            assert rel(got, want) < 0.25, (case.name, "grad", k, rel(got, want))
+            bound = max(GRAD_REL, NOISE_FACTOR * noise.get(k, 0.0), REL_EXCEPTIONS.get((case.name, k), 0.0))
+            MEASURED.append((case.name, "grad bf16-noise", k, noise.get(k, 0.0)))
+            assert rel(got, want) < bound, (case.name, "grad", k, rel(got, want), "bound", bound)
 
 
 def g(case, k):
@@ -555,3 +578,74 @@ def test_coca_with_unpadding_enabled(gpu, monkeypatch):
     monkeypatch.setattr(T, "UNPAD", True)
     test_coca_sum(gpu)
     test_coca_cross_attn(gpu)
+
+
+def test_train_step_with_dropout_on(gpu):
+    """Dropout ON (the bench configuration: hidden 0.1, attention 0.1) through the whole RobertaTwoTower train step.  The engine's masks
+    come from a counter-based generator keyed by (step seed, layer, element) -- not torch's stream -- so the reference's masks cannot
+    be reproduced bit for bit; what must hold: (a) the same step seed gives the bit-identical loss and gradients (embedding tables: to
+    atomic-add order), a different seed does not; (b) over 64 seeds the mean loss and the mean gradient of the pair head agree with the oracle's (training=True, torch
+    dropout, 64 seeds of its own) within two standard errors of the difference (loss: plus the bf16 bias measured with dropout off)."""
+    from golden_util import run_oracle
+    from item_alignment_amd.models import functional as Fn
+    case = load_case("roberta_two_tower_ce")
+    assert case.cfg.hidden_dropout_prob == 0.1 and case.cfg.attention_probs_dropout_prob == 0.1
+    model = build(case, "RobertaTwoTower").train()
+    key = "classifier.out_proj.weight"
+    args = dict(input_ids_1=g(case, "input_ids_1"), attention_mask_1=g(case, "attention_mask_1"), token_type_ids_1=g(case, "token_type_ids_1"),
+                input_ids_2=g(case, "input_ids_2"), attention_mask_2=g(case, "attention_mask_2"), token_type_ids_2=g(case, "token_type_ids_2"),
+                labels=g(case, "labels"))
+
+    def hip_step(seed):
+        Fn.set_step_seed(seed)
+        model.param_arena.zero_grad()
+        out = model(**args)
+        out.loss.backward()
+        torch.cuda.synchronize()
+        return out.loss.detach().float().cpu().clone(), {k: p.grad.detach().float().cpu().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    l0, g0 = hip_step(1234)
+    l1, g1 = hip_step(1234)
+    # bit for bit: the loss and every gradient except the three embedding tables, whose rows are accumulated with fp32 atomic adds
+    # in arrival order (embed_ln_bwd_kernel; torch's own embedding backward on a GPU does the same): those repeat to ~1e-7 relative
+    tables = [k for k in g0 if k.startswith("roberta.embeddings.") and k.endswith("_embeddings.weight")]
+    assert len(tables) == 3
+    assert torch.equal(l0, l1), "same step seed must reproduce the loss bit for bit"
+    for k in g0:
+        if k in tables:
+            assert (g0[k] - g1[k]).abs().max().item() <= 2e-6 * g0[k].abs().max().item(), k
+        else:
+            assert torch.equal(g0[k], g1[k]), ("same step seed must reproduce this gradient bit for bit", k)
+    l2, g2 = hip_step(99)
+    assert not torch.equal(l0, l2) and not torch.equal(g0[key], g2[key])
+    model.eval()
+    le, _ = hip_step(0)                                                     # dropout off: differs from every dropout-on step
+    assert not torch.equal(le, l0)
+    model.train()
+
+    n = 64
+    hl, hg = [], []
+    for s in range(n):
+        l, gr = hip_step(1000 + 7 * s)
+        hl.append(l.item()); hg.append(gr[key])
+    ol, og = [], []
+    for s in range(n):
+        torch.manual_seed(5000 + s)
+        sd = weights(case, requires_grad=True)
+        out = run_oracle(case, sd, training=True)
+        out.loss.backward()
+        ol.append(out.loss.item()); og.append(sd[key].grad.clone())
+    hl, ol = torch.tensor(hl, dtype=torch.float64), torch.tensor(ol, dtype=torch.float64)
+    assert hl.std() > 1e-3 and ol.std() > 1e-3                              # dropout really is on in both
+    se = (hl.var() / n + ol.var() / n).sqrt().item()
+    bias = 5e-3                                                             # |loss - oracle loss| with dropout off is 3e-3 on this fixture
+    assert abs(hl.mean().item() - ol.mean().item()) <= 2 * se + bias, (hl.mean().item(), ol.mean().item(), se)
+    hg, og = torch.stack(hg).double(), torch.stack(og).double()
+    # per element of the pair head's weight gradient (2 x 256): z = |difference of the two sample means| / its standard error.
+    # Two samplers of the same distribution give |N(0, 1)| scores: mean 0.80, 95 % below 2, the largest of 512 around 3.1
+    # (measured with 128 seeds: 0.85 / 0.953 / 3.08); a wrong keep probability or a missing 1 / (1 - p) shifts every one of them.
+    z = (hg.mean(0) - og.mean(0)).abs() / (hg.var(0) / n + og.var(0) / n).sqrt()
+    assert z.mean().item() < 1.05, z.mean().item()
+    assert (z < 2).double().mean().item() > 0.90, (z < 2).double().mean().item()
+    assert z.max().item() < 5.0, z.max().item()
+    assert abs(hl.std().item() / ol.std().item() - 1.0) < 0.35             # the spread over masks matches too (0.162 vs 0.158 at 128 seeds)
