@@ -37,7 +37,7 @@ const char* ia_strerror(int code);
 /* Bumped whenever an entry point is added or the meaning of an argument / output changes (round 2 changed what IA_EPI_BIAS_GELU
  * stores in C2 and what IA_EPI_DGELU expects in aux): a caller built against another header must not run on this library.
  * item_alignment_amd/_lib.py refuses to load a library whose version differs from the one it was written for. */
-#define IA_ABI_VERSION 3
+#define IA_ABI_VERSION 4
 int ia_abi_version(void);
 
 /* ---- GEMM: torch.nn.Linear forward / dgrad / wgrad (src/models/text.py:1241 -> RobertaLayer dense
@@ -175,6 +175,9 @@ int ia_ws_conv_weight_bwd(const float* dwhat, const float* w, const float* gain,
 /* y = silu(x) * scale ; dx = dy * scale * silu'(x) (+ dadd) over n bf16 elements */
 int ia_silu_fwd(const void* x, void* y, size_t n, float scale, ia_stream_t stream);
 int ia_silu_bwd(const void* dy, const void* x, const void* dadd, void* dx, size_t n, float scale, ia_stream_t stream);
+/* the same with a second consumer of y: dx = (dy + dy2) * scale * silu'(x) [+ dadd] -- the SiLU output of a downsampling NormFreeBlock
+   feeds conv1 and the projected shortcut (timm nfnet.py NormFreeBlock.forward); replaces autograd's separate gradient add */
+int ia_silu_bwd_sum(const void* dy, const void* dy2, const void* x, const void* dadd, void* dx, size_t n, float scale, ia_stream_t stream);
 /* AvgPool2d(2, 2, ceil_mode=True, count_include_pad=False) on NHWC */
 int ia_avgpool2_fwd(const void* x, void* y, int B, int H, int W, int C, ia_stream_t stream);
 int ia_avgpool2_bwd(const void* dy, void* dx, int B, int H, int W, int C, ia_stream_t stream);

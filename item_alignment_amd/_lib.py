@@ -69,6 +69,7 @@ SIGNATURES = {
     "ia_ws_conv_weight_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     "ia_silu_fwd": (i32, [vp, vp, sz, f32, vp]),
     "ia_silu_bwd": (i32, [vp, vp, vp, vp, sz, f32, vp]),
+    "ia_silu_bwd_sum": (i32, [vp, vp, vp, vp, vp, sz, f32, vp]),
     "ia_avgpool2_fwd": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ia_avgpool2_bwd": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ia_gap_workspace_bytes": (sz, [i32, i32, i32]),
@@ -128,7 +129,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 3      # = IA_ABI_VERSION of include/itemalign.h (tests/test_cabi_symbols.py keeps the two in step)
+ABI_VERSION = 4      # = IA_ABI_VERSION of include/itemalign.h (tests/test_cabi_symbols.py keeps the two in step)
 
 
 class ItemAlignError(RuntimeError):

@@ -135,18 +135,22 @@ __global__ __launch_bounds__(256) void silu_fwd_kernel(const bf16* __restrict__ 
   *reinterpret_cast<bf16x8*>(y + i * 8) = o;
 }
 
-__global__ __launch_bounds__(256) void silu_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x, const bf16* __restrict__ dadd,
-                                                       bf16* __restrict__ dx, size_t n8, float scale) {
+// dx = (dy [+ dy2]) * scale * silu'(x) [+ dadd]: dy2 = the gradient of a second consumer of y (the projected shortcut of a
+// downsampling NormFreeBlock reads the same activation as conv1), dadd = the gradient of an identity shortcut that bypassed the SiLU
+__global__ __launch_bounds__(256) void silu_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ dy2, const bf16* __restrict__ x,
+                                                       const bf16* __restrict__ dadd, bf16* __restrict__ dx, size_t n8, float scale) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n8) return;
   const bf16x8 g = *reinterpret_cast<const bf16x8*>(dy + i * 8), v = *reinterpret_cast<const bf16x8*>(x + i * 8);
-  bf16x8 e;
+  bf16x8 e, g2;
   if (dadd) e = *reinterpret_cast<const bf16x8*>(dadd + i * 8);
+  if (dy2) g2 = *reinterpret_cast<const bf16x8*>(dy2 + i * 8);
   bf16x8 o;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const float a = bf2f(v[j]), sg = 1.f / (1.f + __expf(-a));
-    o[j] = f2bf(bf2f(g[j]) * scale * sg * (1.f + a * (1.f - sg)) + (dadd ? bf2f(e[j]) : 0.f));
+    const float gy = bf2f(g[j]) + (dy2 ? bf2f(g2[j]) : 0.f);
+    o[j] = f2bf(gy * scale * sg * (1.f + a * (1.f - sg)) + (dadd ? bf2f(e[j]) : 0.f));
   }
   *reinterpret_cast<bf16x8*>(dx + i * 8) = o;
 }
@@ -546,7 +550,16 @@ extern "C" int ia_silu_fwd(const void* x, void* y, size_t n, float scale, hipStr
 extern "C" int ia_silu_bwd(const void* dy, const void* x, const void* dadd, void* dx, size_t n, float scale, hipStream_t stream) {
   (void)hipGetLastError();
   if (!dy || !x || !dx || !n || (n & 7)) return IA_ERR_ARG;
-  hipLaunchKernelGGL(silu_bwd_kernel, dim3(blocks_of(n >> 3)), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)x, (const bf16*)dadd, (bf16*)dx, n >> 3, scale);
+  hipLaunchKernelGGL(silu_bwd_kernel, dim3(blocks_of(n >> 3)), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)nullptr, (const bf16*)x, (const bf16*)dadd,
+                     (bf16*)dx, n >> 3, scale);
+  return ia_check_launch();
+}
+
+extern "C" int ia_silu_bwd_sum(const void* dy, const void* dy2, const void* x, const void* dadd, void* dx, size_t n, float scale, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dy || !dy2 || !x || !dx || !n || (n & 7)) return IA_ERR_ARG;
+  hipLaunchKernelGGL(silu_bwd_kernel, dim3(blocks_of(n >> 3)), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)dy2, (const bf16*)x, (const bf16*)dadd,
+                     (bf16*)dx, n >> 3, scale);
   return ia_check_launch();
 }
 

@@ -187,8 +187,9 @@ class SiluPadFn(torch.autograd.Function):
 
 
 class SiluFn(torch.autograd.Function):
-    """y = silu(x) * scale.  With `passthrough`, also hands x back as a second output (the identity shortcut of a
-    NormFreeBlock) so that both gradients are combined inside ia_silu_bwd instead of by a torch add."""
+    """y = silu(x) * scale.  passthrough = True: also hands x back as a second output (the identity shortcut of a NormFreeBlock);
+    passthrough = 2: hands y out twice (a downsampling block's activation feeds conv1 and the projected shortcut).  Either way the
+    two gradients are combined inside the SiLU backward kernel instead of by a separate torch add over the feature map."""
 
     @staticmethod
     def forward(ctx, x, scale, passthrough):
@@ -196,14 +197,30 @@ class SiluFn(torch.autograd.Function):
         x = x.contiguous()
         y = torch.empty_like(x)
         check(lib.ia_silu_fwd(x.data_ptr(), y.data_ptr(), x.numel(), scale, stream_ptr()), "ia_silu_fwd")
-        ctx.x, ctx.scale = x, scale
+        ctx.x, ctx.scale, ctx.mode = x, scale, passthrough
         ctx.set_materialize_grads(False)
+        if passthrough == 2:
+            return y, y.view_as(y)
         return (y, x.view_as(x)) if passthrough else y
 
     @staticmethod
-    def backward(ctx, dy, dpass=None):
+    def backward(ctx, dy, dother=None):
         lib = _lib.load()
         x = ctx.x
+        if ctx.mode == 2:
+            if dy is None or dother is None:
+                dy = dy if dother is None else dother
+                if dy is None:
+                    return None, None, None
+                dother = None
+            dx = torch.empty_like(x)
+            if dother is None:
+                check(lib.ia_silu_bwd(dy.contiguous().data_ptr(), x.data_ptr(), None, dx.data_ptr(), x.numel(), ctx.scale, stream_ptr()), "ia_silu_bwd")
+            else:
+                check(lib.ia_silu_bwd_sum(dy.contiguous().data_ptr(), dother.contiguous().data_ptr(), x.data_ptr(), None, dx.data_ptr(), x.numel(),
+                                          ctx.scale, stream_ptr()), "ia_silu_bwd_sum")
+            return dx, None, None
+        dpass = dother
         if dy is None:
             return dpass, None, None
         dx = torch.empty_like(x)
@@ -382,8 +399,9 @@ class NormFreeBlock(nn.Module):
     def forward(self, f):
         act = lambda g: FeatureMap(SiluFn.apply(g.t, 1.0, False), g.B, g.H, g.W)
         if self.downsample is not None:
-            out = FeatureMap(SiluFn.apply(f.t, self.beta, False), f.B, f.H, f.W)
-            shortcut = self.downsample(out).t
+            ya, yb = SiluFn.apply(f.t, self.beta, 2)
+            out = FeatureMap(ya, f.B, f.H, f.W)
+            shortcut = self.downsample(FeatureMap(yb, f.B, f.H, f.W)).t
         else:
             o, shortcut = SiluFn.apply(f.t, self.beta, True)
             out = FeatureMap(o, f.B, f.H, f.W)
