@@ -12,12 +12,20 @@ rc = pytest.main([os.path.join(ROOT, "tests", "test_models_gpu.py"), "-q", "-m",
 T = sys.modules.get("test_models_gpu")
 rows = sorted(set(T.MEASURED)) if T is not None else []
 print(f"\npytest exit code {rc}; {len(rows)} measurements")
-print(f"{'fixture':36s} {'kind':9s} {'tensor':62s} value")
+print(f"{'fixture':36s} {'kind':15s} {'tensor':62s} value")
 for case, kind, key, val in rows:
-    print(f"{case:36s} {kind:9s} {key:62s} {val:.4f}")
+    print(f"{case:36s} {kind:15s} {key:62s} {val:.4f}")
 cos = [v for _, k, _, v in rows if k == "grad cos"]
 if cos:
     print(f"\ngradient cosine: min {min(cos):.4f}, median {sorted(cos)[len(cos) // 2]:.4f} over {len(cos)} tensors")
+gr = {(c, t): v for c, k, t, v in rows if k == "grad rel"}
+nz = {(c, t): v for c, k, t, v in rows if k == "grad bf16-noise"}
+if gr:
+    worst = sorted(gr.items(), key=lambda kv: -kv[1])[:8]
+    print(f"gradient magnitude error (of the reference's max): max {max(gr.values()):.4f}, median {sorted(gr.values())[len(gr) // 2]:.4f}; "
+          "largest, with the oracle's own bf16-storage noise on the same tensor:")
+    for (c, t), v in worst:
+        print(f"    {c:34s} {t:58s} {v:.4f}   noise {nz.get((c, t), 0.0):.4f}")
 rels = [v for _, k, _, v in rows if k == "out rel"]
 if rels:
     print(f"output relative error: max {max(rels):.4f}, median {sorted(rels)[len(rels) // 2]:.4f} over {len(rels)} tensors")
