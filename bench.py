@@ -39,7 +39,7 @@ TRAIN_FLOPS_PER_PAIR = 1.628e12      # 3 x (2 x text(255) + 2 
 WGRAD_VARIANT = 1101                 # gemm_kernel<A k-strided, B k-strided, EPI_NONE, fp32 out>  (dW = dY^T X)
 WGRAD_KERNEL = "t256w::gemm_kernel<true, true, 0, true> (+ splitk_reduce_kernel)"
 DATASET_PAIRS = 50_000               # size of the synthetic pair set the batches are drawn from
-RESIDENT_BATCHES = 32
+RESIDENT_BATCHES = 16                # global batches kept in HBM (4096 pairs at the default 256 per GPU; 0.9 GB each per rank)
 
 
 def pmc_traffic(args):
@@ -158,7 +158,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs-per-gpu", type=int, default=128)
+    # 256 pairs per GPU = 211 GiB of the 288 GB at the peak of a default run (activations of both towers for backward, 13 resident
+    # batches, weights + AdamW state); per pair 2-3 % faster than 128 (the step's fixed costs -- optimizer, embedding backward, reduces --
+    # and the GEMMs' tile-round tails amortise over twice the rows): 535.9 / 545.8 / 550.6 pairs/s at 128 / 192 / 256 on one box
+    ap.add_argument("--pairs-per-gpu", type=int, default=256)
     ap.add_argument("--image-model", default="vit_base_patch16_384")
     ap.add_argument("--seed", type=int, default=2345)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -207,7 +210,7 @@ def main():
     B = args.pairs_per_gpu
     n_steps = args.warmup + args.steps
     # a 50 000-pair synthetic set; the run walks a seeded permutation of it in global batches of B * world pairs,
-    # RESIDENT_BATCHES of them generated device-side and resident in HBM before timing starts (14.5 GB at 128 pairs per GPU);
+    # RESIDENT_BATCHES of them generated device-side and resident in HBM before timing starts (0.9 GB per 256-pair batch);
     # rank r owns pairs r::world of each global batch.  A default run (25 steps) never sees a batch twice.
     data = SyntheticCocaPairs(DATASET_PAIRS, image_size=cfg.image_size, seed=args.seed, full_length=args.full_length)
     perm = torch.randperm(DATASET_PAIRS, generator=torch.Generator().manual_seed(args.seed)).tolist()
@@ -325,6 +328,7 @@ def main():
                                 "flop_per_byte": intensity, "algorithmic_bytes_per_launch": alg_bytes / max(1, nl.value)})
         res["config"]["dataset_pairs"] = DATASET_PAIRS
         res["config"]["resident_batches"] = n_batches
+        res["peak_hbm_gib"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)      # this rank, incl. the resident batches
         if world == 1 and not args.no_pmc:
             # free this process's HBM first: the child runs build their own model and batches
             del batches
