@@ -406,13 +406,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 
 // ------------------------------------------------------------------------------------------ forward, round 3
 // Same arithmetic and tile geometry (4 waves x 32 queries, 64-key tiles, S^T orientation) as attn_fwd_kernel above, rebuilt around
-// what tools/abl/issue_model.hip and the PMC passes of round 3 measured on an MI355X (profiles/r03_issue_model.txt,
-// r03_pmc_attention_fwd.txt): at head dim 64 the kernel is bound by instruction ISSUE -- the waves of a SIMD spent their time issuing
-// ~155 VALU + ~90 SALU instructions per 16 MFMAs -- so the loop is stripped to what the arithmetic needs:
+// what tools/abl/issue_model.hip and the PMC passes of round 3 measured on an MI355X (profiles/r03_issue_model.txt, r03_pmc_mfma.csv):
+// at head dim 64 the kernel is bound by instruction ISSUE -- the waves of a SIMD spent their time issuing ~155 VALU + ~90 SALU
+// instructions per 16 MFMAs -- so the loop is stripped to what the arithmetic needs:
 //  * softmax = 32 exp2 + 16 packed adds + 16 packed converts per tile.  The query fragments are pre-scaled by scale*log2(e) once per
 //    block, so an accumulator IS exp2's argument; no running maximum is taken: the reference m_ref starts at 0 and only moves when a
-//    row sum leaves [2^-100, 2^60] (rebase(): scores recomputed from the K tile still in its ring slot, true maximum taken) -- any
-//    reference cancels in O / l, and exp2 arguments stay far inside the fp32 exponent range;
+//    row sum leaves [2^-100, 2^60] (rebase(): the block's scores recomputed from the K fragments still in registers, true maximum
+//    taken) -- any reference cancels in O / l, and exp2 arguments stay far inside the fp32 exponent range;
 //  * masked / out-of-range keys and a moved reference enter through ONE extra MFMA per 32-key block (A = (penalty, 1) in k-slots 0 / 1
 //    of the key's row, B = (1, -m_ref) in k-slots 0 / 1 of the query's column) instead of 64 compare + select pairs (v_cmp 8.6 cycles,
 //    the v_cndmask behind it 4.8); tiles whose 64 keys are all attendable (a bit mask in an SGPR) start from the constant 0;
@@ -422,7 +422,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 //  * all fragments are in registers before the MFMAs that use them (asm reads, counted lgkmcnt): the K fragments of tile t+1 and the
 //    V^T fragments of tile t arrive under the PV MFMAs / the conversions of tile t;
 //  * the DMA of tile t+2 is issued at the top of tile t and only K(t+1) is waited for there (counted vmcnt), one raw s_barrier per
-//    tile; 48 KiB of LDS and <= 168 VGPRs: three workgroups per CU.
+//    tile; QB = 1 (32 queries per wave): 48 KiB of LDS and <= 168 VGPRs, three workgroups per CU; QB = 2 (64 queries per wave, half
+//    the K / V traffic per MFMA): 64 KiB and <= 251 VGPRs, two per CU -- launch_fwd picks by how full the last 256-query block is.
 #ifndef IA_F3_PRESCALE
 #define IA_F3_PRESCALE 1     // 1: Q fragments carry scale * log2(e) (one more bf16 rounding of q, no multiply per score); 0: exp2(s * sc)
 #endif
