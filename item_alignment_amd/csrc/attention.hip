@@ -576,7 +576,7 @@ IA_DEV void rebase(f32x16& s, f32x16* other, f32x16& o0, f32x16& o1, Row& row, c
 
 // QB = 32-query blocks per wave: with 2, a workgroup owns 256 queries and every K / V^T fragment read from LDS feeds two MFMAs -- the
 // per-tile costs that are neither MFMA nor softmax (LDS-DMA issue and latency, barrier, fragment reads) and the per-workgroup
-// prologue / epilogue are spent once per 32 MFMAs instead of once per 16 (profiles/r03_attention_fwd_notes.txt).
+// prologue / epilogue are spent once per 32 MFMAs instead of once per 16 (measured: profiles/r03_attention_variants.txt).
 template <bool DROPOUT, int QB>
 __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void attn_fwd3_kernel(AttnArgs p) {
   using namespace fwd3;
