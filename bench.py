@@ -196,8 +196,11 @@ def main():
     rank, world, local = iadist.init_from_env("cuda")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    # one process per GPU; IA_DP_BACKEND (tests: two gloo ranks sharing one GPU) folds surplus local ranks onto the visible devices,
+    # exactly as dist.init_from_env does
+    dev_index = local % max(1, torch.cuda.device_count()) if iadist.BACKEND else local
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     cfg = roberta_large_config()
     model = build_model(cfg, args.image_model, args.seed).to(dev).train()

@@ -295,3 +295,30 @@ def test_bench_single_gpu_with_forced_collectives(gpu):
     res = json.loads(lines[0])
     assert res["n_gpus"] == 1 and res["steps"] == 2 and res["value"] > 0
     assert res["roofline"]["bound"] in ("mfma", "hbm") and res["roofline"]["frac"] > 0
+
+
+def test_bench_two_ranks_under_the_launcher(gpu):
+    """bench.py launched the way the driver launches it for N > 1 (python -m torch.distributed.run --nproc-per-node 2 ... bench.py
+    --gpus 2): rank / device selection, the rank-sharded synthetic batches, the bucketed gradient all-reduce, the barrier +
+    max-over-ranks timing and rank 0's single JSON line.  One GPU here, so both ranks share it over gloo (IA_DP_BACKEND); on a
+    multi-GPU node the same path runs over RCCL with one process per GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IA_DP_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "IA_DP_FORCE_COLLECTIVES"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29733",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-pmc", "--no-cpu-baseline", "--no-variants",
+           "--pairs-per-gpu", "16"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 32 and res["config"]["parallelism"] == "dp2"
+    assert res["value"] > 0 and res["scaling"] == "weak"
+    import math
+    assert math.isfinite(res["final_loss"])
