@@ -8,7 +8,7 @@ fp32 master weights, on synthetic pairs (BASELINE.json metric)
 
 One JSON line on rank 0.  `value` = pairs processed by ALL ranks / max-over-ranks wall time of the K timed
 steps (inputs resident in HBM, weak scaling: per-GPU batch fixed).  The batches are drawn without replacement from the
-50 000-pair synthetic set of SURVEY §8(d) (32 resident global batches, never repeated inside a default run).  Extra objects:
+50 000-pair synthetic set of SURVEY §8(d) (16 resident global batches; longer runs walk them again).  Extra objects:
   roofline     the dominant kernel (by summed time: the wgrad GEMM instantiation), timed per launch with HIP
                events on its launch stream inside the timed region: achieved = algorithmic FLOPs / time; `traffic` = HBM
                bytes per launch from two rocprofv3 --pmc child passes of this same command (FETCH_SIZE x 2 on gfx950 +
@@ -64,13 +64,24 @@ def pmc_traffic(args):
             # own session: on a timeout the whole group goes (rocprofv3 is a wrapper; killing only it would leave the python child
             # holding the GPU)
             child = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=out, env=env, start_new_session=True)
+            import signal
+            # the child lives in its own session: if THIS process is told to stop while a pass runs (driver timeout, Ctrl-C), take the
+            # child's group down first -- it holds its own model in HBM
+            def on_term(signum, frame, child=child):
+                kill_group(child)
+                raise SystemExit(128 + signum)
+            old = {sg: signal.signal(sg, on_term) for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP)}
             try:
                 rc = child.wait(timeout=args.pmc_timeout)
             except subprocess.TimeoutExpired:
-                import signal
-                os.killpg(child.pid, signal.SIGKILL)
-                child.wait()
+                kill_group(child)
                 return None, f"{counter} pass timed out after {args.pmc_timeout} s"
+            except BaseException:
+                kill_group(child)
+                raise
+            finally:
+                for sg, h in old.items():
+                    signal.signal(sg, h)
             if rc != 0:
                 return None, f"{counter} pass exited with {rc}"
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
@@ -153,6 +164,39 @@ def cpu_baseline(cfg, image_model, pairs, steps, seed):
                       f"{torch.get_num_threads()} torch threads)"}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher environment: run `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+    as a child process (never an exec: see the harness rules on processes that have initialised the GPU; this parent has not, but a
+    child keeps that true by construction) on a free loopback port, and pass its stdout -- rank 0's one JSON line -- through."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return child.wait()
+    except BaseException:
+        kill_group(child)
+        raise
+
+
+def kill_group(child):
+    import signal
+    try:
+        os.killpg(child.pid, signal.SIGKILL)
+    except (ProcessLookupError, PermissionError):
+        pass
+    try:
+        child.wait(timeout=10)
+    except Exception:
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,6 +220,10 @@ def main():
     ap.add_argument("--pmc-timeout", type=int, default=240, help="seconds per rocprofv3 --pmc child pass")
     ap.add_argument("--resident-batches", type=int, default=RESIDENT_BATCHES, help="global batches generated up front and kept in HBM")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # started bare (`python bench.py --gpus N`): this process has not touched the GPU (no torch.cuda call so far) and never will --
+        # it starts the N ranks as a CHILD launcher, forwards rank 0's single JSON line and returns the launcher's exit code
+        raise SystemExit(self_launch(args.gpus))
     if args.unpad:
         os.environ["IA_UNPAD"] = "1"
     # stdout carries exactly ONE line, the result JSON of rank 0.  Native libraries write there too (RCCL prints a five-line version
@@ -214,7 +262,8 @@ def main():
     n_steps = args.warmup + args.steps
     # a 50 000-pair synthetic set; the run walks a seeded permutation of it in global batches of B * world pairs,
     # RESIDENT_BATCHES of them generated device-side and resident in HBM before timing starts (0.9 GB per 256-pair batch);
-    # rank r owns pairs r::world of each global batch.  A default run (25 steps) never sees a batch twice.
+    # rank r owns pairs r::world of each global batch.  A run of more than RESIDENT_BATCHES steps (warm-up included) walks the resident
+    # batches again from the start (13 steps by default: no repeat; the driver's 3 + 20: batches 0-6 are seen twice).
     data = SyntheticCocaPairs(DATASET_PAIRS, image_size=cfg.image_size, seed=args.seed, full_length=args.full_length)
     perm = torch.randperm(DATASET_PAIRS, generator=torch.Generator().manual_seed(args.seed)).tolist()
     n_batches = max(1, min(args.resident_batches, n_steps, DATASET_PAIRS // (B * world)))
@@ -264,8 +313,9 @@ def main():
     dt = tmax.item()
     final_loss = float(loss.detach())
 
-    def timed(pool, k, first):
+    def timed(pool, k, first, pairs_per_rank=None):
         """k more steps on `pool` (2 untimed first), max over ranks, like the headline region"""
+        pairs_per_rank = B if pairs_per_rank is None else pairs_per_rank
         for i in range(2):
             step(first + i, pool)
         torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
@@ -276,12 +326,19 @@ def main():
         tm = torch.tensor([time.perf_counter() - t], device=dev, dtype=torch.float64)
         if world > 1 or iadist.FORCE:
             torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
-        return {"value": B * world * k / tm.item(), "unit": "item-pairs/sec", "ms_per_step": tm.item() / k * 1e3, "steps": k}
+        return {"value": pairs_per_rank * world * k / tm.item(), "unit": "item-pairs/sec", "ms_per_step": tm.item() / k * 1e3, "steps": k,
+                "pairs_per_gpu": pairs_per_rank}
 
     variants = None
     if not args.no_variants and not args.unpad and not args.full_length:
         from item_alignment_amd.models import text as _text
         variants = {}
+        # SURVEY 8(d)'s smallest batch: 16 pairs per GPU = a step of ~30 ms, where the 1.64 GB gradient all-reduce is a third of the
+        # step instead of 2 % -- the point of the scaling curve that actually exercises the bucket overlap
+        if B > 16:
+            small = [data.batch([perm[g * 16 * world + rank + world * i] for i in range(16)], dev, device_images=True) for g in range(4)]
+            variants["pairs_per_gpu_16"] = timed(small, 4 * args.variant_steps, n_steps, pairs_per_rank=16)
+            del small
         full = SyntheticCocaPairs(B * world * 2, image_size=cfg.image_size, seed=args.seed + 1, full_length=True)
         pool = [full.batch([g * B * world + rank + world * i for i in range(B)], dev, device_images=True) for g in range(2)]
         variants["full_length_sequences"] = timed(pool, args.variant_steps, n_steps)

@@ -74,19 +74,21 @@ def collate_image(inputs):
 def collate_multimodal(inputs):
     """reference data.py:98-128 (RoBERTa + image embeddings, one tower)."""
     pos = [i["position_ids"] for i in inputs if "position_ids" in i]
-    return ([i["src_item_id"] for i in inputs], [i["tgt_item_id"] for i in inputs], _t([i["image_indices"] for i in inputs]),
-            _t([i["src_image_emb"] for i in inputs], torch.float32), _t([i["tgt_image_emb"] for i in inputs], torch.float32),
+    return ([i["src_item_id"] for i in inputs], [i["tgt_item_id"] for i in inputs], _t([i["image_index"] for i in inputs if "image_index" in i]),
+            _t([i["src_img_emb"] for i in inputs], torch.float32), _t([i["tgt_img_emb"] for i in inputs], torch.float32),
             _t([i["input_ids"] for i in inputs]), _t([i["token_type_ids"] for i in inputs]), _t([i["attention_mask"] for i in inputs]),
             _t(pos) if pos else None, _t([i["labels"] for i in inputs]))
 
 
 def collate_multimodal_two_tower(inputs):
-    """reference data.py:131-169."""
+    """reference data.py:131-169 (the same position_ids tensor, or None, sits in both towers' slots)."""
+    pos = [i["position_ids"] for i in inputs if "position_ids" in i]
+    pos = _t(pos) if pos else None
     return ([i["src_item_id"] for i in inputs], [i["tgt_item_id"] for i in inputs],
-            _t([i["input_ids_1"] for i in inputs]), _t([i["attention_mask_1"] for i in inputs]), _t([i["token_type_ids_1"] for i in inputs]), None,
-            _t([i["src_image_emb"] for i in inputs], torch.float32),
-            _t([i["input_ids_2"] for i in inputs]), _t([i["attention_mask_2"] for i in inputs]), _t([i["token_type_ids_2"] for i in inputs]), None,
-            _t([i["tgt_image_emb"] for i in inputs], torch.float32), _t([i["labels"] for i in inputs]))
+            _t([i["input_ids_1"] for i in inputs]), _t([i["attention_mask_1"] for i in inputs]), _t([i["token_type_ids_1"] for i in inputs]), pos,
+            _t([i["src_img_emb"] for i in inputs], torch.float32),
+            _t([i["input_ids_2"] for i in inputs]), _t([i["attention_mask_2"] for i in inputs]), _t([i["token_type_ids_2"] for i in inputs]), pos,
+            _t([i["tgt_img_emb"] for i in inputs], torch.float32), _t([i["labels"] for i in inputs]))
 
 
 def collate_coca_pair(inputs):
@@ -214,18 +216,22 @@ class _PKGMBase(Dataset):
         return ids[:1 + self.max_pvs]
 
     def _text(self, title, first_id, type_id):
+        """reference pad_text_sequence (data.py:370-378): padding positions carry mask 0 AND token type 0"""
         ids = self.tk.convert_tokens_to_ids(self.tk.tokenize(title))[:self.max_seq_len - 2]
         ids = [first_id] + ids + [self.tk.sep_token_id]
         n = len(ids)
         pad = self.max_seq_len - n
-        return ids + [0] * pad, [1] * n + [0] * pad, [type_id] * self.max_seq_len
+        return ids + [0] * pad, [1] * n + [0] * pad, [type_id] * n + [0] * pad
 
     def _kg(self, ids, type_id):
-        """reference pad_kg_sequence: 1 entity + max_pvs relations as ids; masks / types cover 2*max_pvs embedded rows."""
-        n_rel = max(len(ids) - 1, 0)
+        """reference pad_kg_sequence (data.py:380-389): 1 entity + max_pvs relations as ids; masks / types cover 2*max_pvs embedded
+        rows, padding rows typed 0.  An item without any attribute has no entity id either and trips the reference's own length
+        assertion (data.py:351-356): the same AssertionError here."""
+        assert len(ids) >= 1, "PKGM sample without attributes (reference data.py:355 asserts on it too)"
+        n_rel = len(ids) - 1
         ids = ids + [0] * (1 + self.max_pvs - len(ids))
         mask = [1] * (2 * n_rel) + [0] * (2 * (self.max_pvs - n_rel))
-        return ids, mask, [type_id] * (2 * self.max_pvs)
+        return ids, mask, [type_id] * (2 * n_rel) + [0] * (2 * (self.max_pvs - n_rel))
 
 
 class PKGMOneTowerDataset(_PKGMBase):
@@ -253,61 +259,68 @@ class PKGMTwoTowerDataset(_PKGMBase):
         label, src_id, _sc, src_title, src_pvs, tgt_id, _tc, tgt_title, tgt_pvs = self.data[item]
         st, sm, stt = self._text(src_title, self.tk.cls_token_id, 0)
         tt, tm, ttt = self._text(tgt_title, self.tk.cls_token_id, 0)
-        sk, skm, skt = self._kg(self._kg_ids(src_id, src_pvs), 0)
-        tk_, tkm, tkt = self._kg(self._kg_ids(tgt_id, tgt_pvs), 0)
+        sk, skm, skt = self._kg(self._kg_ids(src_id, src_pvs), 1)              # data.py:432 / :465: KG rows are typed 1 in both towers
+        tk_, tkm, tkt = self._kg(self._kg_ids(tgt_id, tgt_pvs), 1)
         return {"input_ids_1": st + sk, "attention_mask_1": sm + skm, "token_type_ids_1": stt + skt,
                 "input_ids_2": tt + tk_, "attention_mask_2": tm + tkm, "token_type_ids_2": ttt + tkt,
                 "position_ids": list(range(self.max_seq_len + 2 * self.max_pvs)), "labels": int(label), "src_item_id": src_id,
                 "tgt_item_id": tgt_id}
 
 
-class RobertaImageOneTowerDataset(Dataset):
-    """reference data.py:623-679: text pair with an [unused99] image token after each [CLS]/[SEP] + the two
-    pre-extracted image embeddings (data rows carry them as JSON lists)."""
+def _img_emb(text):
+    """reference data.py:669: the row carries the pre-extracted image embedding as comma-separated floats (a JSON list is accepted too)"""
+    if not isinstance(text, str):
+        return [float(v) for v in text]
+    return [float(v) for v in text.strip().lstrip("[").rstrip("]").split(",")]
 
-    def __init__(self, data, text_tokenizer, max_seq_len, max_seq_len_pv=None, ensemble="begin"):
+
+def _image_item_text(tokenizer, title, pvs, max_seq_len, max_seq_len_pv, ensemble):
+    text, L = _item_text(tokenizer, title, pvs, max_seq_len, max_seq_len_pv)
+    if ensemble == "begin":                                   # data.py:650-652: [unused99] [SEP] in front of the item's text
+        text = " ".join((IMG_TOKEN, tokenizer.sep_token, text))
+    return text, L
+
+
+class RobertaImageOneTowerDataset(Dataset):
+    """reference data.py:623-679: the text pair, with `ensemble="begin"` an [unused99] [SEP] image slot in front of each item's text,
+    + the two pre-extracted image embeddings; `image_index` = position of the SECOND image token (begin only)."""
+
+    def __init__(self, data, text_tokenizer, max_seq_len, ensemble, max_seq_len_pv=None):
         self.data, self.tk, self.max_seq_len, self.max_seq_len_pv, self.ensemble = data, text_tokenizer, max_seq_len, max_seq_len_pv, ensemble
 
     def __len__(self):
         return len(self.data)
 
     def __getitem__(self, item):
-        import json
         label, src_id, src_title, src_pvs, src_emb, tgt_id, tgt_title, tgt_pvs, tgt_emb = self.data[item]
-        src_text, L = _item_text(self.tk, src_title, src_pvs, self.max_seq_len, self.max_seq_len_pv)
-        tgt_text, _ = _item_text(self.tk, tgt_title, tgt_pvs, self.max_seq_len, self.max_seq_len_pv)
-        if self.ensemble == "begin":
-            src_text, tgt_text = " ".join((IMG_TOKEN, src_text)), " ".join((IMG_TOKEN, tgt_text))
+        src_text, L = _image_item_text(self.tk, src_title, src_pvs, self.max_seq_len, self.max_seq_len_pv, self.ensemble)
+        tgt_text, _ = _image_item_text(self.tk, tgt_title, tgt_pvs, self.max_seq_len, self.max_seq_len_pv, self.ensemble)
         rec = dict(_tok(self.tk, src_text, 2 * L, text_pair=tgt_text))
-        img_pos = [i for i, t in enumerate(rec["input_ids"]) if t == IMG_TOKEN_ID]
-        rec.update(image_indices=img_pos[1] if len(img_pos) > 1 else 0, src_image_emb=json.loads(src_emb) if isinstance(src_emb, str) else src_emb,
-                   tgt_image_emb=json.loads(tgt_emb) if isinstance(tgt_emb, str) else tgt_emb, labels=int(label), src_item_id=src_id,
-                   tgt_item_id=tgt_id)
+        rec.update(labels=int(label), src_item_id=src_id, tgt_item_id=tgt_id, src_img_emb=_img_emb(src_emb), tgt_img_emb=_img_emb(tgt_emb))
+        if self.ensemble == "begin":
+            first = rec["input_ids"].index(IMG_TOKEN_ID)
+            rec["image_index"] = rec["input_ids"].index(IMG_TOKEN_ID, first + 1)      # ValueError when truncation lost it, as in the reference
         return rec
 
 
 class RobertaImageTwoTowerDataset(Dataset):
     """reference data.py:682-753."""
 
-    def __init__(self, data, text_tokenizer, max_seq_len, max_seq_len_pv=None, ensemble="begin"):
+    def __init__(self, data, text_tokenizer, max_seq_len, ensemble, max_seq_len_pv=None):
         self.data, self.tk, self.max_seq_len, self.max_seq_len_pv, self.ensemble = data, text_tokenizer, max_seq_len, max_seq_len_pv, ensemble
 
     def __len__(self):
         return len(self.data)
 
     def __getitem__(self, item):
-        import json
         label, src_id, src_title, src_pvs, src_emb, tgt_id, tgt_title, tgt_pvs, tgt_emb = self.data[item]
-        src_text, L = _item_text(self.tk, src_title, src_pvs, self.max_seq_len, self.max_seq_len_pv)
-        tgt_text, _ = _item_text(self.tk, tgt_title, tgt_pvs, self.max_seq_len, self.max_seq_len_pv)
-        if self.ensemble == "begin":
-            src_text, tgt_text = " ".join((IMG_TOKEN, src_text)), " ".join((IMG_TOKEN, tgt_text))
+        src_text, L = _image_item_text(self.tk, src_title, src_pvs, self.max_seq_len, self.max_seq_len_pv, self.ensemble)
+        tgt_text, _ = _image_item_text(self.tk, tgt_title, tgt_pvs, self.max_seq_len, self.max_seq_len_pv, self.ensemble)
         s, t = _tok(self.tk, src_text, L), _tok(self.tk, tgt_text, L)
-        return {"input_ids_1": s["input_ids"], "token_type_ids_1": s["token_type_ids"], "attention_mask_1": s["attention_mask"],
-                "input_ids_2": t["input_ids"], "token_type_ids_2": t["token_type_ids"], "attention_mask_2": t["attention_mask"],
-                "src_image_emb": json.loads(src_emb) if isinstance(src_emb, str) else src_emb,
-                "tgt_image_emb": json.loads(tgt_emb) if isinstance(tgt_emb, str) else tgt_emb, "labels": int(label), "src_item_id": src_id,
-                "tgt_item_id": tgt_id}
+        return {"input_ids_1": s["input_ids"], "input_ids_2": t["input_ids"], "token_type_ids_1": s["token_type_ids"],
+                "token_type_ids_2": t["token_type_ids"], "attention_mask_1": s["attention_mask"], "attention_mask_2": t["attention_mask"],
+                "labels": int(label), "src_item_id": src_id, "tgt_item_id": tgt_id, "src_img_emb": _img_emb(src_emb),
+                "tgt_img_emb": _img_emb(tgt_emb), "image_index": 0}
 
 
 class RawImage:

@@ -36,14 +36,14 @@ def state_of(model, head_gain=1.0):
 
 
 def test_c4_pkgm_large_full_entity_table(gpu):
-    """C4: PKGMOneTower, num_entities 258 211, kg_embedding_dim 1024, max_pvs 30 -> 220 embedded positions, H = 1024, 2 layers, B = 2
+    """C4: PKGMOneTower, num_entities 258 211, kg_embedding_dim 1024, max_pvs 30 -> 220 embedded positions, H = 1024, all 24 layers, B = 2
     (reference src/models/base.py:347-392, text.py:720-783).  Loss, logits and the entity-table gradient rows against the oracle."""
     import item_alignment_amd.models as M
     from bench import roberta_large_config
     from oracle import ref_models as O
     S, P, B = 50, 30, 2
     cfg = roberta_large_config(interaction_type="one_tower", max_seq_len=S, max_seq_len_pv=None, max_pvs=P, num_entities=258211,
-                               num_relations=1379, kg_embedding_dim=1024, entity_projection_bias=False, num_hidden_layers=2,
+                               num_relations=1379, kg_embedding_dim=1024, entity_projection_bias=False, num_hidden_layers=24,
                                hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
     rs = np.random.RandomState(7)
     L_ids, L_emb = 2 * (S + P + 1), 2 * (S + 2 * P)
@@ -146,7 +146,10 @@ def test_c3_eca_nfnet_l0_at_800(gpu):
 
 def test_c5_full_width_coca_pair(gpu):
     """C5: one full-width pair through CoCaForItemAlignment -- roberta_large (24 layers, H = 1024, L = 255) + ViT-B/16 at 384, ensemble
-    sum (reference src/models/multimodal.py:983-1045).  Loss and probabilities against the fp32 oracle."""
+    sum (reference src/models/multimodal.py:983-1045).  Loss, probabilities AND the backward pass against the fp32 oracle: gradients of
+    the pair head, the first and the last text layer's query projection, the ViT's first qkv projection and the patch embedding (the
+    deepest points of both towers' backward chains -- a fault in any attention / GEMM / LayerNorm backward kernel on the way down
+    shows up there)."""
     import item_alignment_amd.models as M
     from bench import roberta_large_config
     from item_alignment_amd.data.synthetic import SyntheticCocaPairs
@@ -159,14 +162,37 @@ def test_c5_full_width_coca_pair(gpu):
     model = model.cuda().eval()
     data = SyntheticCocaPairs(2, image_size=384, seed=9)
     b = data.batch([0, 1], "cuda")
-    with torch.no_grad():
-        out = model(*b[:10], labels=b[10])
+    model.param_arena.zero_grad()
+    out = model(*b[:10], labels=b[10])
+    out.loss.backward()
     torch.cuda.synchronize()
     s_, p_, d_, depth, h_ = VIT_CONFIGS["vit_base_patch16_384"]
     vcfg = SimpleNamespace(embed_dim=d_, depth=depth, num_heads=h_, patch_size=p_, eps=1e-6)
     bc = data.batch([0, 1], "cpu")
-    with torch.no_grad():
-        ref = O.coca_item_alignment(sd, cfg, vcfg, *bc[:10], labels=bc[10], training=False)
+
+    def key(*parts):
+        hits = [k for k in sd if all(p_ in k for p_ in parts)]
+        assert len(hits) == 1, (parts, hits)
+        return hits[0]
+    keys = [key("classifier", "out_proj.weight"), key("layer.0.", "self.query.weight"), key("layer.23.", "self.query.weight"),
+            key("blocks.0.", "attn.qkv.weight"), key("patch_embed.proj.weight")]
+    rsd = {k: (v.requires_grad_(True) if k in keys else v) for k, v in sd.items()}
+    ref = O.coca_item_alignment(rsd, cfg, vcfg, *bc[:10], labels=bc[10], training=False)
+    ref.loss.backward()
     assert abs(out.loss.item() - ref.loss.item()) < TOL * max(1.0, abs(ref.loss.item())), (out.loss.item(), ref.loss.item())
-    assert rel(out.logits, ref.logits) < TOL, (out.logits, ref.logits)
-    assert (out.probs.float().cpu() - ref.probs).abs().max().item() < TOL
+    assert rel(out.logits.detach(), ref.logits.detach()) < TOL, (out.logits, ref.logits)
+    assert (out.probs.detach().float().cpu() - ref.probs.detach()).abs().max().item() < TOL
+    params = dict(model.named_parameters())
+    report = {}
+    for k in keys:
+        g_, w_ = params[k].grad, rsd[k].grad
+        assert torch.isfinite(g_).all(), k
+        report[k] = (cosine(g_, w_), rel(g_, w_))
+    print("C5 full-width gradients (cosine, rel):", report)
+    for k, (c, r) in report.items():
+        assert c >= 0.99, (k, c, r)
+        assert r <= 0.10, (k, c, r)
+    # every parameter of both towers received a finite gradient (a poisoned row anywhere in the backward would be non-finite here)
+    for k, v in params.items():
+        if v.grad is not None:
+            assert torch.isfinite(v.grad).all(), k

@@ -322,3 +322,26 @@ def test_bench_two_ranks_under_the_launcher(gpu):
     assert res["value"] > 0 and res["scaling"] == "weak"
     import math
     assert math.isfinite(res["final_loss"])
+
+
+def test_bench_gpus_2_launches_itself(gpu):
+    """`python bench.py --gpus 2 ...` with NO launcher environment: the parent must start the two ranks itself (as child processes,
+    before it touches the GPU), forward rank 0's single JSON line and return 0.  One GPU here: both ranks share it over gloo."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IA_DP_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "IA_DP_FORCE_COLLECTIVES", "GROUP_RANK", "ROLE_RANK",
+              "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-pmc", "--no-cpu-baseline",
+           "--no-variants", "--pairs-per-gpu", "16"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 32 and res["config"]["parallelism"] == "dp2"
+    assert res["value"] > 0 and res["scaling"] == "weak"

@@ -304,3 +304,43 @@ def test_image_transform_draws_follow_the_global_generator():
     d = seeded.draw(300, 200)
     random.seed(2)
     assert ImageTransform(64, True, hflip=0.5, color_jitter=0.4, seed=5).draw(300, 200) == d
+
+
+def test_bench_self_launch_builds_a_child_launcher_command(monkeypatch):
+    """bench.py --gpus N started bare must hand the SAME arguments to `python -m torch.distributed.run --nproc-per-node N` as a child
+    process (never an exec) on a loopback rendezvous, and return the child's exit code."""
+    import importlib.util
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    class FakeChild:
+        pid = 1
+
+        def wait(self, timeout=None):
+            return 7
+
+    def fake_popen(cmd, env=None, start_new_session=False, **kw):
+        seen["cmd"], seen["env"], seen["session"] = cmd, env, start_new_session
+        return FakeChild()
+    monkeypatch.setattr(bench.subprocess, "Popen", fake_popen)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert bench.self_launch(4) == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    i = cmd.index(os.path.join(root, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert seen["session"] and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # main() takes that route before importing the engine or touching torch.cuda
+    monkeypatch.setattr(bench, "self_launch", lambda n: 5)
+    import pytest
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 5
