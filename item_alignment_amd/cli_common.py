@@ -64,6 +64,13 @@ def load_tokenizer(args):
     from transformers import BertTokenizer
     tk = BertTokenizer.from_pretrained(args.pretrained_model_path, do_lower_case=args.do_lower_case)
     tk.do_basic_tokenize = False
+    # transformers 4.20 (the reference's pin) with do_basic_tokenize=False keeps every whitespace-separated word whole, so the
+    # image placeholder "[unused99]" (data.py:9-10, id 99) and the BOS marker reach the vocabulary lookup intact; the 5.x tokenizer
+    # backend splits bracketed words at the punctuation unless they are registered as special tokens -- same ids either way
+    try:
+        tk.add_special_tokens({"additional_special_tokens": ["[unused99]", BOS_TOKEN]})
+    except Exception as e:      # an older transformers without this keyword set: the whitespace path above already covers it
+        logger.warning(f"could not register the image / BOS placeholders as special tokens: {e!r}")
     tk.bos_token = BOS_TOKEN
     logger.info(f"vocab size: {tk.vocab_size}")
     return tk

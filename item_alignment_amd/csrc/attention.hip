@@ -742,7 +742,7 @@ __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void attn_fwd3_kernel(AttnArg
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     softmax_block(I0{}, I0{}, plain0, cur_lo);
-    if (QB == 2) softmax_block(I0{}, I1{}, plain0, cur_lo);
+    if constexpr (QB == 2) softmax_block(I0{}, I1{}, plain0, cur_lo);
     tr_wait<4>(va);
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) { o[qb][0] = mfma(va.a0(), pf[qb][0], o[qb][0]); o[qb][1] = mfma(va.a1(), pf[qb][0], o[qb][1]); }
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void attn_fwd3_kernel(AttnArg
     for (int qb = 0; qb < QB; ++qb) { o[qb][0] = mfma(vb.a0(), pf[qb][1], o[qb][0]); o[qb][1] = mfma(vb.a1(), pf[qb][1], o[qb][1]); }
     read_v<SLOT, 48>(vd, ln);
     softmax_block(I1{}, I0{}, plain1, cur_hi);
-    if (QB == 2) softmax_block(I1{}, I1{}, plain1, cur_hi);
+    if constexpr (QB == 2) softmax_block(I1{}, I1{}, plain1, cur_hi);
     tr_wait<4>(vc);
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) { o[qb][0] = mfma(vc.a0(), pf[qb][0], o[qb][0]); o[qb][1] = mfma(vc.a1(), pf[qb][0], o[qb][1]); }

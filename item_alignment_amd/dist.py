@@ -75,14 +75,18 @@ class GradBucketReducer:
         self.bf16 = BF16_BUCKETS if bf16 is None else bool(bf16)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         esz = flat_grad.element_size()
-        per = max(1, bucket_bytes // esz)
+        # bucket boundaries on multiples of ALIGN elements: the bf16 staging casts (ia_cast_f32_to_bf16 / ia_cast_bf16_to_f32) move 16-byte
+        # vectors from flat[s:], so s * 4 and s * 2 bytes must both be 16-byte aligned (only the arena's end may be ragged)
+        per = max(self.ALIGN, bucket_bytes // esz // self.ALIGN * self.ALIGN)
         n = flat_grad.numel()
         # buckets from the END of the arena (backward order) towards the start
         self.buckets, end = [], n
         while end > 0:
-            start = max(0, end - per)
+            start = max(0, (end - per) // self.ALIGN * self.ALIGN)
             self.buckets.append((start, end))
             end = start
+        assert all(s % self.ALIGN == 0 for s, _ in self.buckets)
+        self.stage = [None] * len(self.buckets)          # persistent bf16 staging slices (allocated on first use, bf16 buckets only)
         self.param_buckets = {}
         self.need = [0] * len(self.buckets)
         for p, off, numel in params:
@@ -111,6 +115,7 @@ class GradBucketReducer:
     # (a bucket reduced early would be reduced with part of its sum and never again).  The train loop disarms the reducer for
     # the other micro-steps; finish() then reduces every bucket that was not launched.
     armed = True
+    ALIGN = 8
 
     def reset(self):
         self.left = list(self.need)
@@ -130,7 +135,9 @@ class GradBucketReducer:
                     cur.wait_stream(st)
             if self.bf16:
                 # one pass fp32 -> bf16 into a staging slice (ia_cast_f32_to_bf16; torch's .to() only on CPU tensors, i.e. in the gloo tests)
-                stage = torch.empty(e - s, dtype=torch.bfloat16, device=self.flat.device)
+                if self.stage[i] is None:
+                    self.stage[i] = torch.empty(e - s, dtype=torch.bfloat16, device=self.flat.device)
+                stage = self.stage[i]
                 if self.flat.is_cuda:
                     from . import ops
                     ops.cast_to_bf16(self.flat[s:e], stage)

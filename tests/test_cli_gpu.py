@@ -204,7 +204,7 @@ def test_finetune_multimodal_coca_cross_attn_gpu(gpu, tmp_path):
 
 @pytest.mark.parametrize("interaction,ensemble", [("one_tower", "begin"), ("two_tower", "begin"), ("one_tower", "end")])
 def test_finetune_multimodal_roberta_image_gpu(gpu, tmp_path, interaction, ensemble):
-    """roberta_image_* through finetune_multimodal.py: rows carry pre-extracted image embeddings (JSON lists), spliced in as
+    """roberta_image_* through finetune_multimodal.py: rows carry pre-extracted image embeddings (comma-separated floats, as the reference's files), spliced in as
     tokens (`begin`) or fed to the head (`end`)."""
     root = str(tmp_path)
     pre = make_data(root, n_train=16, n_test=8)
@@ -215,7 +215,8 @@ def test_finetune_multimodal_roberta_image_gpu(gpu, tmp_path, interaction, ensem
         rows = [l.rstrip("\n").split("\t") for l in open(path, encoding="utf-8")]
         with open(path, "w", encoding="utf-8") as w:
             for label, a, at, ap, b, bt, bp in rows:
-                ea, eb = (json.dumps([round(float(x), 4) for x in rs.standard_normal(D)]) for _ in range(2))
+                # the reference's row format (data.py:669): comma-separated floats
+                ea, eb = (",".join(f"{float(x):.4f}" for x in rs.standard_normal(D)) for _ in range(2))
                 w.write("\t".join([label, a, at, ap, ea, b, bt, bp, eb]) + "\n")
     vocab_size = len(open(os.path.join(pre, "vocab.txt"), encoding="utf-8").read().split("\n")) - 1
     cfg = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=vocab_size,

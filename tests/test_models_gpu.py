@@ -14,27 +14,43 @@ TOL = 5e-2
 COS_MIN = 0.99           # gradient direction; see check().  Measured (tools/parity_report.py, profiles/r02_parity_report.txt): median 1.0000
 # tensors measured below 0.99: a bias gradient that is a sum over the few tokens of a 3-sample batch (cancellation), bf16 ReLU gates
 COS_EXCEPTIONS = {("roberta_two_tower_ce", "roberta.embeddings.LayerNorm.bias"): 0.97}
-# gradient magnitude: |got - want|_max / |want|_max.  The bar is 0.10, or four times the deviation the CPU oracle itself shows when
-# it rounds its tensors to bf16 where the engine stores bf16 (oracle.ref_models.rounding: weights, linear / LayerNorm / GELU outputs,
-# attention probabilities, and the gradients flowing back through them) -- whichever is larger.  The fixtures are 3-sample batches:
-# sums over a handful of tokens with cancellation (an embedding LayerNorm bias) move by 6 - 40 % under that rounding alone
-# (measured: roberta_two_tower_ce LayerNorm.bias 0.42, everything else 0.01 - 0.07); the engine rounds a few more tensors than the
-# oracle mode does (dS ahead of the dQ / dK MFMAs, the saved GELU derivative), hence the factor.
-GRAD_REL = 0.10
-NOISE_FACTOR = 4.0
-# towers the rounding mode does not cover (convolutions): named bounds.  resnet stem: BatchNorm batch statistics over 3 images in bf16.
-REL_EXCEPTIONS = {("resnet_two_tower", "img_encoder.stem.conv.weight"): 0.25}
+# gradient magnitude: |got - want|_max / |want|_max <= 5e-2 (north_star's bf16 bar), against the reference's fp32 gradients (the fixture)
+# or -- when the fixture's 3-sample batch makes the tensor a small difference of large sums -- against the gradients the CPU oracle
+# produces when it rounds to bf16 where the engine stores bf16 (oracle.ref_models.rounding: weights, linear / LayerNorm / GELU outputs,
+# attention probabilities, and the gradients flowing back through them), i.e. against a same-precision run of the reference
+# arithmetic.  No multiplier on either.  Tensors that pass neither are named below with the value measured on an MI355X
+# (tools/parity_report.py -> profiles/r04_parity_report.txt) and bounded at 1.25 x that value.
+GRAD_REL = 5e-2
+REL_EXCEPTIONS = {
+    # conv towers: the rounding mode does not cover convolutions; BatchNorm batch statistics over 3 images / ReLU gates in bf16
+    ("resnet_two_tower", "img_encoder.stem.conv.weight"): 0.191,
+    ("resnet_two_tower", "img_encoder.stages.3.blocks.0.conv3.weight"): 0.072,
+    # 3-sample fixtures, bias / head gradients that are sums over a handful of tokens with cancellation
+    ("roberta_two_tower_ce", "roberta.embeddings.LayerNorm.bias"): 0.229,
+    ("roberta_two_tower_cosine", "roberta.embeddings.LayerNorm.bias"): 0.091,
+    ("roberta_two_tower_euclidean", "roberta.embeddings.LayerNorm.bias"): 0.088,
+    ("roberta_two_tower_euclidean", "classifier.out_proj.weight"): 0.121,
+    ("roberta_two_tower_euclidean", "roberta.encoder.layer.1.attention.self.value.weight"): 0.088,
+    ("roberta_two_tower_cosine", "roberta.encoder.layer.1.attention.self.value.weight"): 0.052,
+    ("roberta_two_tower_ce", "classifier.out_proj.weight"): 0.060,
+    ("roberta_one_tower_cls_ce", "classifier.dense.weight"): 0.083,
+    ("roberta_one_tower_cls_ce", "classifier.out_proj.weight"): 0.054,
+    ("roberta_one_tower_cls_ce", "roberta.embeddings.position_embeddings.weight"): 0.054,
+    ("roberta_one_tower_cls_ce", "roberta.embeddings.word_embeddings.weight"): 0.054,
+    ("roberta_image_two_tower_begin", "classifier.out_proj.weight"): 0.055,
+}
+EXCEPTION_HEADROOM = 1.25
 MEASURED = []            # (case, kind, key, value) of everything check() compared: printed by tools/parity_report.py
 
 
-def bf16_noise(case):
-    """per-tensor deviation of the oracle's own gradients under bf16 storage rounding from its fp32 gradients (= the fixture's)"""
+def bf16_oracle_grads(case):
+    """the oracle's gradients under bf16 storage rounding (same inputs, same weights as the fixture)"""
     from golden_util import run_oracle
     from oracle import ref_models as O
     sd = weights(case, requires_grad=True)
     with O.rounding(torch.bfloat16):
         run_oracle(case, sd).loss.backward()
-    return {k: rel(sd[k].grad, want) for k, want in case.grads.items() if sd[k].grad is not None}
+    return {k: sd[k].grad for k in case.grads if sd[k].grad is not None}
 
 
 def rel(a, b):
@@ -72,21 +88,29 @@ def check(case, out, model, tol=TOL, cos_min=None):
         out.loss.backward()
         torch.cuda.synchronize()
         params = dict(model.named_parameters())
-        # gradients pass through bf16 activations (B = 3 samples, so little averaging): direction must agree
-        # (cosine >= 0.99) and magnitude within GRAD_REL / the measured bf16 storage noise (above); kernel-level backward
-        # parity is checked much tighter in test_kernels_gpu.py / test_engine_gpu.py against same-precision inputs.
-        noise = bf16_noise(case)
+        # direction: cosine >= 0.99 against the fp32 reference gradient; magnitude: GRAD_REL (above).  Kernel-level backward parity is
+        # checked tighter in test_kernels_gpu.py / test_engine_gpu.py against same-precision inputs.
+        same_precision = None
         for k, want in case.grads.items():
             got = params[k].grad
             assert torch.isfinite(got).all(), k
             a, b = got.float().cpu().flatten(), want.float().flatten()
             c = (torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)).item()
+            r32 = rel(got, want)
             MEASURED.append((case.name, "grad cos", k, c))
-            MEASURED.append((case.name, "grad rel", k, rel(got, want)))
+            MEASURED.append((case.name, "grad rel", k, r32))
             assert c > min(cos_min, COS_EXCEPTIONS.get((case.name, k), 1.0)), (case.name, "grad cosine", k, c)
-            bound = max(GRAD_REL, NOISE_FACTOR * noise.get(k, 0.0), REL_EXCEPTIONS.get((case.name, k), 0.0))
-            MEASURED.append((case.name, "grad bf16-noise", k, noise.get(k, 0.0)))
-            assert rel(got, want) < bound, (case.name, "grad", k, rel(got, want), "bound", bound)
+            if r32 <= GRAD_REL:
+                continue
+            if same_precision is None:
+                same_precision = bf16_oracle_grads(case)
+            r16 = ((got.float().cpu() - same_precision[k]).abs().max() / (want.abs().max() + 1e-6)).item() if k in same_precision else float("inf")
+            MEASURED.append((case.name, "grad rel-bf16-oracle", k, r16))
+            if r16 <= GRAD_REL:
+                continue
+            named = REL_EXCEPTIONS.get((case.name, k))
+            assert named is not None and min(r32, r16) <= EXCEPTION_HEADROOM * named, (case.name, "grad", k, "vs fp32", r32, "vs bf16 oracle", r16,
+                                                                                        "named bound", named)
 
 
 def g(case, k):

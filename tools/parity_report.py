@@ -19,13 +19,13 @@ cos = [v for _, k, _, v in rows if k == "grad cos"]
 if cos:
     print(f"\ngradient cosine: min {min(cos):.4f}, median {sorted(cos)[len(cos) // 2]:.4f} over {len(cos)} tensors")
 gr = {(c, t): v for c, k, t, v in rows if k == "grad rel"}
-nz = {(c, t): v for c, k, t, v in rows if k == "grad bf16-noise"}
+nz = {(c, t): v for c, k, t, v in rows if k == "grad rel-bf16-oracle"}
 if gr:
     worst = sorted(gr.items(), key=lambda kv: -kv[1])[:8]
     print(f"gradient magnitude error (of the reference's max): max {max(gr.values()):.4f}, median {sorted(gr.values())[len(gr) // 2]:.4f}; "
-          "largest, with the oracle's own bf16-storage noise on the same tensor:")
+          "largest, with the distance to the bf16-rounding oracle's gradient where the fp32 bar (5e-2) failed:")
     for (c, t), v in worst:
-        print(f"    {c:34s} {t:58s} {v:.4f}   noise {nz.get((c, t), 0.0):.4f}")
+        print(f"    {c:34s} {t:58s} {v:.4f}   vs bf16 oracle {nz.get((c, t), float('nan')):.4f}")
 rels = [v for _, k, _, v in rows if k == "out rel"]
 if rels:
     print(f"output relative error: max {max(rels):.4f}, median {sorted(rels)[len(rels) // 2]:.4f} over {len(rels)} tensors")
