@@ -1576,6 +1576,407 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_dkv_kernel(AttnArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------- backward, round 4: ONE kernel for L <= 256
+// Self-attention backward of a whole (sequence, head) item by one 512-thread workgroup (8 waves, two per SIMD), persistent over
+// items.  dQ, dK and dV come out of ONE evaluation of S, P, dP and dS per 32 x 32 block: 20 MFMA-equivalents per block instead of the
+// 12 + 16 of the dQ / dK,dV kernel pair, one exp2 per score instead of two, and q, k, v, dO, o are read from HBM once (the pair reads
+// q, k, v, dO twice).  Layout of the work:
+//  * wave w owns key block w (32 keys; L <= 256 -> at most 8 blocks): its K / V fragments sit in registers as the B operands of
+//    S = Q' K^T and dP = dO V^T (S orientation of the dK/dV kernels: rows = queries in the accumulator registers, column = key =
+//    lane), dK and dV accumulate in registers over the item's query blocks;
+//  * the query blocks (Q | dO | O rows, lse) stream through a 4-deep LDS ring, one block per step, fetched 4 steps ahead by LDS-DMA
+//    (continuously across items); before a block is published, the waves that fetched its pieces prepare it: Q <- bf16(Q * scale *
+//    log2 e) in place (exactly the forward's pre-scaled operand, so the recomputed P is the forward's P), delta = rowsum(dO o O);
+//  * dQ needs the contraction over the keys, i.e. over lanes AND waves: every wave writes its -dS block (bf16, [key][query]) into
+//    an exchange slot; behind the step's barrier wave (dq, qh) forms the 16 x 16 tile dQ^T[16 dq .. +16][16 qh .. +16] of the step's
+//    query block with MFMA 16x16x32 over all key blocks (A = K^T fragments held in registers for the whole item, B = transpose
+//    reads of the exchange slots) and stores it; one workgroup barrier per step;
+//  * the next item's K / V / mask bytes are fetched into a stage during the current item, so nothing but the very first fill is
+//    exposed.  No global load is issued inside the loop except through LDS-DMA (a register load would drain the in-order VMEM
+//    queue), and every wait on the DMA is a counted vmcnt that is exact or stricter than needed whether or not stores are counted.
+// Deterministic (no atomics).  A masked / out-of-range key gets +1e30 on its column's reference (P = 0 exactly).
+namespace bwdf {
+using namespace bwd3;
+constexpr int NW = 8, RING = 4;
+// ring slot: Q | dO | O rows of one 32-query block (4 KiB each, unified layout) | lse[32] | delta[32] | dropout row keys[32]
+constexpr int SL_Q = 0, SL_G = 4096, SL_O = 8192, SL_LSE = 12288, SL_DLT = SL_LSE + 128, SL_RK = SL_LSE + 256, SLOT = SL_LSE + 512;
+constexpr int KST = 0, VST = 32768, RING_OFF = 65536, X_OFF = RING_OFF + RING * SLOT;
+constexpr int XP = 72, XT = 32 * XP;                 // exchange tile [32 keys][32 queries] bf16, 72-byte rows (conflict-free b64 writes)
+static_assert(2 * XT == EPI_SLOT, "a wave's two exchange tiles double as its epilogue staging slot");
+constexpr int CS_OFF = X_OFF + NW * 2 * XT;          // column sums: 8 x (dk[64] | dv[64]) + 8 x dq tile[16] floats
+constexpr int MSK_OFF = CS_OFF + NW * 128 * 4 + NW * 16 * 4;      // the next item's attendable-key bits: 8 words (one per key block), 256 B reserved
+constexpr int DUMMY_OFF = MSK_OFF + 256;             // 8 x 256 B: targets of the count-equalising out-of-range DMA pieces
+constexpr int F_SMEM = DUMMY_OFF + NW * 256;
+static_assert(F_SMEM <= 160 * 1024, "LDS budget");
+constexpr float PEN = 1e30f;
+
+IA_DEV f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+IA_DEV bf16x8 join(s16x4 lo, s16x4 hi) { s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; return __builtin_bit_cast(bf16x8, r); }
+template <int N> IA_DEV void wait2(s16x4& a, s16x4& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
+IA_DEV bf16x8 frag_u(const char* s, int row, int chunk) {
+  return *reinterpret_cast<const bf16x8*>(s + row * 128 + ((chunk ^ swz_u(row)) << 4));
+}
+// wait until at most n VMEM operations of this wave are outstanding (n is wave-uniform, one of the values the schedule uses)
+IA_DEV void wait_vm(int n) {
+  if (n >= 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+  else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+}  // namespace bwdf
+
+template <bool DROPOUT>
+__global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnArgs p) {
+  using namespace bwdf;
+  __shared__ __attribute__((aligned(128))) char smem[F_SMEM];
+  const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, lk = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = p.Lq, nb = (L + 31) >> 5, nh = p.nh;
+  // items (sequence, head), head fastest; every XCD takes a contiguous run of items (the heads of a sequence share its token rows)
+  const int nitems = p.B * nh;
+  const int xcd = blockIdx.x & 7, wslot = blockIdx.x >> 3, wpx = gridDim.x >> 3;
+  const int per_x = (nitems + 7) >> 3;
+  const int x_lo = xcd * per_x, x_hi = (x_lo + per_x < nitems) ? x_lo + per_x : nitems;
+  const int first_item = x_lo + wslot;
+  if (first_item >= x_hi) return;
+  const int cnt = (x_hi - first_item + wpx - 1) / wpx;
+  auto item_of = [&](int n) { return n < cnt ? first_item + n * wpx : -1; };
+
+  const uint32_t sbase = lds_addr(smem);
+  typedef __attribute__((address_space(3))) char lds_char;
+  lds_char* const lsm = (lds_char*)IA_LDS(smem);
+
+  // ---- lane constants
+  // fragment read bases inside a ring slot (slot offset added per step; RING_OFF and SLOT are multiples of 128, so the k-step /
+  // row-half XORs of 32 / 64 / 96 bytes can be applied to the absolute address): b128 reads of row lk, k-step 0; transpose reads
+  // of columns 0 .. 31 (t0) and 32 .. 63 (t0 + t1d)
+  const uint32_t ka0 = sbase + RING_OFF + (uint32_t)(lk * 128 + ((hh ^ swz_u(lk)) << 4));
+  const uint32_t t0 = sbase + RING_OFF + tr_lane_off_u(lane, 0), t1d = tr_lane_off_u(lane, 32) - tr_lane_off_u(lane, 0);
+  const int dqt = wave & 3, qh = wave >> 2;               // this wave's dQ^T tile: d 16 dqt .. +16, queries 16 qh .. +16 of the block
+  const int g4 = lane >> 4, p16 = lane & 15;
+  // transpose-read bases for MFMA 16x16x32 operands: 16-lane group g4 reads rows 4 g4 .. +3 (second read: + 16 rows) of 16 columns
+  const uint32_t ktb = sbase + KST + (uint32_t)((4 * g4 + (p16 >> 2)) * 128 + ((((16 * dqt + 4 * (p16 & 3)) >> 3) ^ swz_u(4 * g4 + (p16 >> 2))) << 4) +
+                                                ((4 * (p16 & 3)) & 7) * 2);
+  const uint32_t xrb = sbase + X_OFF + (uint32_t)((4 * g4 + (p16 >> 2)) * XP + (16 * qh + 4 * (p16 & 3)) * 2);
+  const int xwo = X_OFF + wave * 2 * XT + lk * XP + hh * 8;      // this lane's row of the wave's exchange tile
+  const int r8 = lane >> 3, c8 = lane & 7;                // DMA piece: 8 rows x 8 chunks of 16 bytes
+  // ---- DMA issue.  An item's rows are addressed through per-item buffer windows (base = the item's first row and head column,
+  // size = up to the end of its last row): rows >= L and the pieces of items past the end read as zeros without per-lane selects,
+  // and the only lane-dependent operand is the piece-local offset (row r8 of the piece, swizzled chunk).  Piece pc of a 32-row block
+  // covers rows 8 pc .. 8 pc + 7: swz_u of odd pieces = swz_u of even pieces | 2, i.e. the lane offset XOR 32 bytes.
+  // Every wave issues the same number of pieces at every point of the schedule (out-of-range dummies fill up), so one set of counted
+  // waits serves all waves.
+  const uint32_t lo_q = (uint32_t)((r8 * p.ld_q + ((c8 ^ swz_u(r8)) << 3)) * 2);
+  const uint32_t lo_kv = (uint32_t)((r8 * p.ld_kv + ((c8 ^ swz_u(r8)) << 3)) * 2);
+  const uint32_t lo_o = (uint32_t)((r8 * p.ld_o + ((c8 ^ swz_u(r8)) << 3)) * 2);
+  const uint32_t lo_w = lane < 32 ? (uint32_t)lane * 4u : OOB;      // 32 words
+  const uint32_t lo_m = lane < 8 ? (uint32_t)lane * 4u : OOB;       // 8 words
+  auto window = [&](const bf16* base, size_t row0, int ld, int col0, bool ok) {
+    return ia_rsrc(base + row0 * ld + col0, ok ? (uint32_t)(((size_t)(L - 1) * ld + 64) * 2) : 0u);
+  };
+  // ring pieces of query block j of item `it` into ring slot `slot`: 2 pieces per wave
+  auto issue_ring = [&](int it, int j, int slot) {
+    const bool ok = it >= 0;
+    const int b = ok ? it / nh : 0, h = ok ? it - b * nh : 0;
+    const size_t row0 = (size_t)b * L;
+    const int so = RING_OFF + slot * SLOT;
+    if (wave < 4) {
+      const uint32_t vo = lo_q ^ (uint32_t)((wave & 1) << 5);
+      const __amdgpu_buffer_rsrc_t wq = window(p.q, row0, p.ld_q, h * 64, ok);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wq, lsm + so + SL_Q + wave * 1024, 16, vo, (uint32_t)((j * 32 + wave * 8) * p.ld_q * 2), 0, 0);
+      const bool real = wave == 0 && ok;
+      const __amdgpu_buffer_rsrc_t wl = ia_rsrc(p.lse2 + (size_t)(ok ? it : 0) * L, real ? (uint32_t)L * 4u : 0u);
+      const int dst = wave == 0 ? so + SL_LSE : DUMMY_OFF + wave * 256;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wl, lsm + dst, 4, lo_w, (uint32_t)(j * 128), 0, 0);
+    } else {
+      const int pc = wave - 4;
+      const uint32_t vo = lo_o ^ (uint32_t)((pc & 1) << 5), sof = (uint32_t)((j * 32 + pc * 8) * p.ld_o * 2);
+      const __amdgpu_buffer_rsrc_t wg = window(p.d_o, row0, p.ld_o, h * 64, ok), wo = window(p.o, row0, p.ld_o, h * 64, ok);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wg, lsm + so + SL_G + pc * 1024, 16, vo, sof, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wo, lsm + so + SL_O + pc * 1024, 16, vo, sof, 0, 0);
+    }
+  };
+  // K / V rows and the attendable-key words of item `it` into the stage: 9 pieces per wave (its own key block + a word piece)
+  auto issue_kv = [&](int it) {
+    const bool ok = it >= 0;
+    const int b = ok ? it / nh : 0, h = ok ? it - b * nh : 0;
+    const size_t row0 = (size_t)b * L;
+    const __amdgpu_buffer_rsrc_t wk = window(p.k, row0, p.ld_kv, h * 64, ok), wv = window(p.v, row0, p.ld_kv, h * 64, ok);
+#pragma unroll
+    for (int pc = 0; pc < 4; ++pc) {
+      const uint32_t vo = lo_kv ^ (uint32_t)((pc & 1) << 5), sof = (uint32_t)((wave * 32 + pc * 8) * p.ld_kv * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wk, lsm + KST + wave * 4096 + pc * 1024, 16, vo, sof, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wv, lsm + VST + wave * 4096 + pc * 1024, 16, vo, sof, 0, 0);
+    }
+    // attendable-key bits per sequence: 8 words (bit i of word k: key 32 k + i in range and not masked), built by
+    // attn_key_bits_kernel into the `delta` scratch the pair kernels use for their hand-over (this kernel needs none)
+    const bool real = wave == 0 && ok;
+    const __amdgpu_buffer_rsrc_t wm = ia_rsrc(reinterpret_cast<const uint32_t*>(p.delta) + b * 8, real ? 32u : 0u);
+    const int dst = wave == 0 ? MSK_OFF : DUMMY_OFF + wave * 256;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wm, lsm + dst, 4, lo_m, 0, 0, 0);
+  };
+  // preparation of a landed block by the waves that fetched its pieces (before the barrier that publishes it)
+  auto prep = [&](int it, int j, int slot) {
+    char* const sl = smem + RING_OFF + slot * SLOT;
+    if (wave < 4) {
+      bf16x8* const qp = reinterpret_cast<bf16x8*>(sl + SL_Q + wave * 1024 + lane * 16);
+      bf16x8 v = *qp;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = f2bf(bf2f(v[i]) * p.sc);
+      *qp = v;
+      if (DROPOUT && wave == 1 && lane < 32)
+        *reinterpret_cast<uint32_t*>(sl + SL_RK + lane * 4) = ia_rng_row(p.seed, (uint32_t)(it < 0 ? 0 : it), (uint32_t)(j * 32 + lane));
+    } else {
+      const bf16x8 gv = *reinterpret_cast<const bf16x8*>(sl + SL_G + (wave - 4) * 1024 + lane * 16);
+      const bf16x8 ov = *reinterpret_cast<const bf16x8*>(sl + SL_O + (wave - 4) * 1024 + lane * 16);
+      float d = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) d += bf2f(gv[i]) * bf2f(ov[i]);
+      d += ia_dpp<0xB1>(d); d += ia_dpp<0x4E>(d); d += ia_dpp<0x141>(d);      // the 8 lanes of a row
+      if (c8 == 0) *reinterpret_cast<float*>(sl + SL_DLT + ((wave - 4) * 8 + r8) * 4) = d;
+    }
+  };
+
+  const uint32_t thr1 = DROPOUT ? p.thr16 - 1u : 0u;
+  const float inv_keep = p.inv_keep;
+  const int ntile = (L + 127) >> 7;
+
+  // ---- prologue: stage of item 0, ring blocks 0 .. RING-1, preparation of block 0
+  int pn = 0, pj = 0;                                     // producer cursor (item ordinal, block)
+  issue_kv(item_of(0));
+#pragma unroll 1
+  for (int s = 0; s < RING; ++s) {
+    issue_ring(item_of(pn), pj, s);
+    if (++pj == nb) { pj = 0; ++pn; }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  prep(item_of(0), 0, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  bf16x8 kf[4], vf[4], KT[8];
+  f32x16 dk0, dk1, dv0, dv1;
+  f32x4 csq;
+  bool key_ok = false, mine = false;
+  uint32_t vbits = 0u;                                    // bit k: key block k has an attendable key
+  float pen = 0.f;
+  bool any_bad = false;
+  uint32_t pc = 0u, ush = 0u;
+  int cn = 0, cj = 0;                                     // consumer cursor
+#pragma unroll 1
+  for (int g = 0;; ++g) {
+    const int it = item_of(cn);
+    const int b = it / nh, h = it - b * nh;
+    const size_t row0 = (size_t)b * L;
+    const int slot = g & (RING - 1), par = g & 1;
+    const bool first = cj == 0, last = cj == nb - 1;
+    if (first) {
+      // ---- item start: this wave's K / V fragments (B operands), the K^T fragments of its dQ tile, the mask
+      const char* kb_ = smem + KST + wave * 4096;
+      const char* vb_ = smem + VST + wave * 4096;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const bf16x8 kr = frag_u(kb_, lk, kb * 2 + hh), vr = frag_u(vb_, lk, kb * 2 + hh);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { kf[kb][i] = f2bf(-bf2f(kr[i])); vf[kb][i] = f2bf(-bf2f(vr[i])); }
+      }
+      {
+        s16x4 lo[8], hi[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { lo[k] = tr_read<0>(ktb + k * 4096); hi[k] = tr_read<2048>(ktb + k * 4096); }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]));
+        asm volatile("" : "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]), "+v"(hi[4]), "+v"(hi[5]), "+v"(hi[6]), "+v"(hi[7]));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) KT[k] = join(lo[k], hi[k]);
+      }
+      const int key = wave * 32 + lk;
+      // attendable keys of the item: one word per key block (from the stage)
+      {
+        const uint32_t* const mw = reinterpret_cast<const uint32_t*>(smem + MSK_OFF);
+        uint32_t vb = 0u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) vb |= (mw[k] != 0u ? 1u : 0u) << k;
+        vbits = __builtin_amdgcn_readfirstlane(vb);
+        key_ok = ((mw[wave] >> lk) & 1u) != 0u;
+      }
+      mine = ((vbits >> wave) & 1u) != 0u;                // this wave's key block takes part
+      pen = key_ok ? 0.f : PEN;
+      any_bad = __ballot(!key_ok) != 0ull;
+      pc = pair_c_of(key); ush = (uint32_t)(key & 1) * 16u;
+      dk0 = zero16(); dk1 = zero16(); dv0 = zero16(); dv1 = zero16();
+      csq = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // ---- part A: S, dP, P, dS of (query block cj, this wave's key block); dV, dK; -dS to the exchange slot
+    if (mine) {
+      const uint32_t so = (uint32_t)(slot * SLOT);
+      f32x16 s, dp;
+      const float* const sL = reinterpret_cast<const float*>(smem + RING_OFF + slot * SLOT + SL_LSE) + 4 * hh;
+      {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const f32x4 ls = *reinterpret_cast<const f32x4*>(sL + 8 * rg);
+          const f32x4 dl = *reinterpret_cast<const f32x4*>(sL + 32 + 8 * rg);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { s[rg * 4 + j] = ls[j]; dp[rg * 4 + j] = DROPOUT ? 0.f : dl[j]; }
+        }
+        if (any_bad) {                                    // wave-uniform: masked / out-of-range keys end up with P = exp2(-1e30) = 0
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[r] += pen;
+        }
+      }
+      const uint32_t k0_ = ka0 + so;
+      bf16x8 xq, xg, yq, yg;
+      xq = lds_read_b128<SL_Q>(k0_); xg = lds_read_b128<SL_G>(k0_);
+      yq = lds_read_b128<SL_Q>(k0_ ^ 32u); yg = lds_read_b128<SL_G>(k0_ ^ 32u);
+      asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xq), "+v"(xg));
+      s = mfma(xq, kf[0], s); dp = mfma(xg, vf[0], dp);
+      xq = lds_read_b128<SL_Q>(k0_ ^ 64u); xg = lds_read_b128<SL_G>(k0_ ^ 64u);
+      asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(yq), "+v"(yg));
+      s = mfma(yq, kf[1], s); dp = mfma(yg, vf[1], dp);
+      yq = lds_read_b128<SL_Q>(k0_ ^ 96u); yg = lds_read_b128<SL_G>(k0_ ^ 96u);
+      asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xq), "+v"(xg));
+      s = mfma(xq, kf[2], s); dp = mfma(xg, vf[2], dp);
+      const uint32_t a0_ = t0 + so, a1_ = a0_ + t1d, a0x = a0_ ^ 32u, a1x = a1_ ^ 32u;
+      TrPair g0, q0, g1, q1;                              // dO^T and Q'^T fragments of the block's two 16-query steps
+      read_tr<SL_G, 0>(g0, a0_, a1_, a0x, a1x);
+      read_tr<SL_Q, 0>(q0, a0_, a1_, a0x, a1x);
+      asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(yq), "+v"(yg));
+      s = mfma(yq, kf[3], s); dp = mfma(yg, vf[3], dp);
+      bf16x8 pf[2], sf[2];
+      const uint32_t* const rkp = reinterpret_cast<const uint32_t*>(smem + RING_OFF + slot * SLOT + SL_RK) + 4 * hh;
+      // probabilities and -dS of 8 accumulator rows (one 16-query MFMA step): HALF = 0 / 1
+      auto half = [&](auto HALF) {
+        constexpr int hf = decltype(HALF)::value;
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          const int r = hf * 8 + rr;
+          const float pv = __builtin_amdgcn_exp2f(-s[r]); // exp2(q' . k - lse)
+          float pd = pv, nds;
+          if (DROPOUT) {
+            const int qo = 8 * (r >> 2) + (r & 3);        // this register's query inside the block, minus 4 hh
+            const uint32_t dr = (ia_rng_pair(rkp[qo], pc) >> ush) & 0xFFFFu;
+            const float mk = __builtin_fminf(__builtin_fmaxf((float)((int)dr - (int)thr1), 0.f), 1.f);      // 0 iff dropped
+            pd = pv * mk;
+            nds = pv * __builtin_fmaf(dp[r] * mk, inv_keep, sL[32 + qo]);      // dp = -dP: -(M dP / keep - delta)
+          } else {
+            nds = pv * dp[r];                             // dp = delta - dP
+          }
+          pf[hf][rr] = f2bf(pd);
+          sf[hf][rr] = f2bf(nds);
+        }
+        // -dS^T to the exchange slot: row = key (this lane), two groups of 4 consecutive queries
+        char* const xw = smem + xwo + par * XT + hf * 32;
+        *reinterpret_cast<bf16x4*>(xw) = bf16x4{sf[hf][0], sf[hf][1], sf[hf][2], sf[hf][3]};
+        *reinterpret_cast<bf16x4*>(xw + 16) = bf16x4{sf[hf][4], sf[hf][5], sf[hf][6], sf[hf][7]};
+      };
+      half(std::integral_constant<int, 0>{});
+      // the second step's fragments are requested only now: the first step's MFMAs run under the second half's exp2 / multiplies
+      read_tr<SL_G, 16>(g1, a0_, a1_, a0x, a1x);
+      read_tr<SL_Q, 16>(q1, a0_, a1_, a0x, a1x);
+      tr_wait<12>(g0);
+      dv0 = mfma(g0.a0(), pf[0], dv0); dv1 = mfma(g0.a1(), pf[0], dv1);
+      tr_wait<8>(q0);
+      dk0 = mfma(q0.a0(), sf[0], dk0); dk1 = mfma(q0.a1(), sf[0], dk1);
+      half(std::integral_constant<int, 1>{});
+      tr_wait<4>(g1);
+      dv0 = mfma(g1.a0(), pf[1], dv0); dv1 = mfma(g1.a1(), pf[1], dv1);
+      tr_wait<0>(q1);
+      dk0 = mfma(q1.a0(), sf[1], dk0); dk1 = mfma(q1.a1(), sf[1], dk1);
+    }
+    // ---- the next block: wait for this wave's pieces of it, prepare it, publish everything with the step's barrier
+    {
+      int n = 4;
+      if (last) n = nb == 2 ? 2 : 4;
+      else if (cj == 1 || cj == 2) n = 13;
+      wait_vm(n);
+      int nn = cn, nj = cj + 1;
+      if (nj == nb) { nj = 0; ++nn; }
+      prep(item_of(nn), nj, (g + 1) & (RING - 1));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (first) issue_kv(item_of(cn + 1));
+    issue_ring(item_of(pn), pj, slot);
+    if (++pj == nb) { pj = 0; ++pn; }
+    // ---- part C: this wave's 16 x 16 tile of -dQ^T of query block cj, contraction over all key blocks
+    {
+      const uint32_t xr = xrb + par * XT;
+      s16x4 lo[8], hi[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { lo[k] = tr_read<0>(xr + k * 2 * XT); hi[k] = tr_read<16 * XP>(xr + k * 2 * XT); }
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#define IA_DQ_STEP(k, n)                                                                                   \
+      wait2<n>(lo[k], hi[k]);                                                                              \
+      if ((vbits >> k) & 1u) acc = mfma16(KT[k], join(lo[k], hi[k]), acc);
+      IA_DQ_STEP(0, 14) IA_DQ_STEP(1, 12) IA_DQ_STEP(2, 10) IA_DQ_STEP(3, 8) IA_DQ_STEP(4, 6) IA_DQ_STEP(5, 4) IA_DQ_STEP(6, 2) IA_DQ_STEP(7, 0)
+#undef IA_DQ_STEP
+      // lane (query n = p16 of the half, rows d = 16 dqt + 4 g4 .. +3): 8 bytes of row q
+      const int q = cj * 32 + 16 * qh + p16;
+      bf16x4 o4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { o4[i] = f2bf(-p.scale * acc[i]); }
+      if (q < L) {
+        *reinterpret_cast<bf16x4*>(p.dq + (row0 + q) * p.ld_dq + h * 64 + 16 * dqt + 4 * g4) = o4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) csq[i] += bf2f(o4[i]);
+      }
+    }
+    if (!last) { ++cj; continue; }
+    // ---- item end: dK, dV through the wave's exchange tiles (free once every wave is past part C), column sums
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    float* const cs_w = reinterpret_cast<float*>(smem + CS_OFF) + wave * 128;
+    if (wave < nb) {
+      // dK = scale sum dS q = -(1 / log2 e) sum (-dS) q'   (q' = q scale log2 e)
+      store_block_rows(smem + X_OFF + wave * EPI_SLOT, dk0, dk1, -1.f / LOG2E, false, p.dk + (row0 + wave * 32) * p.ld_dkv + h * 64, p.ld_dkv,
+                       L - wave * 32, lane, p.cs_part ? cs_w : nullptr);
+      store_block_rows(smem + X_OFF + wave * EPI_SLOT, dv0, dv1, DROPOUT ? inv_keep : 1.f, false, p.dv + (row0 + wave * 32) * p.ld_dkv + h * 64,
+                       p.ld_dkv, L - wave * 32, lane, p.cs_part ? cs_w + 64 : nullptr);
+    } else if (p.cs_part) { zero_cs_row(cs_w, lane); zero_cs_row(cs_w + 64, lane); }
+    if (p.cs_part) {                                      // workgroup-uniform
+      // dq: the tile's column sums over its 16 queries (lanes with equal g4), then the two query halves (waves dqt, dqt + 4)
+      // (lane-derived addresses of this once-per-item block are rebuilt from an opaque copy of the lane id: hoisted out of the item
+      // loop they were spilled, and a scratch reload drains the whole in-order VMEM queue -- the look-ahead DMA -- with vmcnt(0))
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      float* const cq = reinterpret_cast<float*>(smem + CS_OFF + NW * 128 * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) csq[i] = row16_sum(csq[i]);
+      if ((ln & 15) == 0) *reinterpret_cast<f32x4*>(cq + wave * 16 + 4 * (ln >> 4)) = csq;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      float* const dst = p.cs_part + (size_t)(b * ntile) * (3 * nh * 64) + h * 64 + ln;
+      if (wave == 0) {
+        dst[0] = cq[(ln >> 4) * 16 + (ln & 15)] + cq[((ln >> 4) + 4) * 16 + (ln & 15)];
+      } else if (wave == 1 || wave == 2) {
+        const float* c = reinterpret_cast<const float*>(smem + CS_OFF) + (wave - 1) * 64 + ln;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += c[w * 128];
+        dst[wave * nh * 64] = t;
+      } else if (wave == 3 && ntile == 2) {               // the pair kernels write one row per 128-row tile: keep the workspace shape
+        float* const z = p.cs_part + (size_t)(b * ntile + 1) * (3 * nh * 64) + h * 64 + ln;
+        z[0] = 0.f; z[nh * 64] = 0.f; z[2 * nh * 64] = 0.f;
+      }
+    }
+    if (++cn == cnt) break;
+    cj = 0;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the look-ahead pieces still in flight target this workgroup's LDS
+}
+
+// bit i of word [b][k] = key 32 k + i of sequence b may be attended (in range, mask byte != 0); 8 words per sequence (L <= 256)
+__global__ void attn_key_bits_kernel(const uint8_t* mask, uint32_t* bits, int L) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int key = k * 64 + lane;
+    const bool ok = key < L && (mask == nullptr || mask[(size_t)b * L + key] != 0);
+    const uint64_t bal = __ballot(ok);
+    if (lane == 0) { bits[b * 8 + 2 * k] = (uint32_t)bal; bits[b * 8 + 2 * k + 1] = (uint32_t)(bal >> 32); }
+  }
+}
+
 // packed_rows > 0: packed self-attention over that many token rows in total (AttnArgs::cu), Lq == Lk == longest sequence
 int fill_args(AttnArgs& a, int B, int nh, int Lq, int Lk, int ld_q, int ld_kv, int ld_o, float scale, float drop_p, uint32_t seed,
               long packed_rows = 0) {
@@ -1600,7 +2001,8 @@ int fill_args(AttnArgs& a, int B, int nh, int Lq, int Lk, int ld_q, int ld_kv, i
 
 // development switches (round 3): IA_ATTN_FWD=2 / IA_ATTN_BWD=0 run the round-2 kernels for A/B measurements on one box
 int bwd_version() {
-  static const int v = [] { const char* e = getenv("IA_ATTN_BWD"); return e ? atoi(e) : 3; }();      // bit 0: round-3 dQ kernel, bit 1: round-3 dK/dV kernel
+  // bit 0: round-3 dQ kernel, bit 1: round-3 dK/dV kernel, bit 2: the fused one-kernel backward where it applies (L <= 256)
+  static const int v = [] { const char* e = getenv("IA_ATTN_BWD"); return e ? atoi(e) : 7; }();
   return v;
 }
 template <bool D> void launch_dkv(const AttnArgs& a, dim3 grid, hipStream_t st) {
@@ -1610,6 +2012,15 @@ template <bool D> void launch_dkv(const AttnArgs& a, dim3 grid, hipStream_t st) 
 template <bool D> void launch_dq(const AttnArgs& a, dim3 grid, hipStream_t st) {
   if (bwd_version() & 1) hipLaunchKernelGGL(attn_bwd3_dq_kernel<D>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, grid, dim3(256), 0, st, a);
+}
+// The fused backward serves plain self-attention (one length for queries and keys, padded rows) of 33 .. 256 tokens
+bool fused_applies(const AttnArgs& a) { return (bwd_version() & 4) && a.cu == nullptr && a.Lq == a.Lk && a.Lq > 32 && a.Lq <= 256 && a.delta != nullptr; }
+void launch_fused(const AttnArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(attn_key_bits_kernel, dim3(a.B), dim3(64), 0, st, a.mask, reinterpret_cast<uint32_t*>(a.delta), a.Lk);
+  const int per_x = (a.B * a.nh + 7) / 8;
+  const dim3 grid(8 * (per_x < 32 ? per_x : 32));        // one 512-thread workgroup per CU, a multiple of the 8 XCDs
+  if (a.thr16) hipLaunchKernelGGL(attn_bwd_fused_kernel<true>, grid, dim3(512), 0, st, a);
+  else hipLaunchKernelGGL(attn_bwd_fused_kernel<false>, grid, dim3(512), 0, st, a);
 }
 int fwd_version() {
   // 2: round-2 kernel, 3: 128 queries per workgroup, 4: 256, default 0: by shape
@@ -1670,7 +2081,9 @@ extern "C" int ia_attn_bwd_x(const void* q, int ld_q, const void* k, const void*
   a.mask = key_mask; a.lse2 = const_cast<float*>(lse2); a.delta = delta;
   a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.ld_dq = ld_dq; a.ld_dkv = ld_dkv;
   dim3 gq(((Lq + 127) / 128) * nh * B), gk(((Lk + 127) / 128) * nh * B), blk(256);
-  if (a.thr16) {
+  if (fused_applies(a)) {
+    launch_fused(a, stream);
+  } else if (a.thr16) {
     launch_dq<true>(a, gq, stream);
     launch_dkv<true>(a, gk, stream);
   } else {
@@ -1719,7 +2132,9 @@ extern "C" int ia_attn_bwd_bias(const void* q, const void* k, const void* v, int
   a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.ld_dq = ld_dqkv; a.ld_dkv = ld_dqkv;
   a.cs_part = (float*)workspace;
   dim3 grid(((L + 127) / 128) * nh * B), blk(256);
-  if (a.thr16) {
+  if (fused_applies(a)) {
+    launch_fused(a, stream);
+  } else if (a.thr16) {
     launch_dq<true>(a, grid, stream);
     launch_dkv<true>(a, grid, stream);
   } else {

@@ -189,6 +189,10 @@ def test_c5_full_width_coca_pair(gpu):
         assert torch.isfinite(g_).all(), k
         report[k] = (cosine(g_, w_), rel(g_, w_))
     print("C5 full-width gradients (cosine, rel):", report)
+    os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "c5_full_width_gradients.txt"), "w") as f:
+        for k, (c, r) in report.items():
+            f.write(f"{k}: cosine {c:.4f} rel {r:.4f}\n")
     for k, (c, r) in report.items():
         assert c >= 0.99, (k, c, r)
         assert r <= 0.10, (k, c, r)
