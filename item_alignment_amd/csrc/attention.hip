@@ -1373,7 +1373,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
 // ------------------------------------------------------------------------------ backward, round 3: dK, dV
 // attn_bwd_dkv_kernel rebuilt on the same lines as attn_bwd3_dq_kernel.  S orientation (rows = queries in the accumulator registers,
 // column = key = lane), one 32-query sub tile at a time:
-//  * the wave's K / V fragments are negated (K also carries scale * log2 e) and the chains start from the +lse / +delta values of the
+//  * the wave's K / V fragments are negated (round 4: the scale * log2 e sits on the Q tile, rounded in LDS exactly as the forward
+//    rounds its pre-scaled query fragments) and the chains start from the +lse / +delta values of the
 //    sub tile's queries, read from LDS straight into the C operands: acc = lse - s, acc' = delta - dP, so P = exp2(-acc) (a source
 //    modifier) and -dS = P * acc': 16 exp2 + 16 multiplies + 16 packed converts per 16 MFMAs; the sign goes into the final scale of dK;
 //  * per-sequence buffer windows for the q / dO rows (rows past the sequence read as zeros: P = 1, dP = 0, dS = 0), scalar DMA
@@ -1461,7 +1462,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_dkv_kernel(AttnArgs p) {
   for (int kb = 0; kb < 4; ++kb) {
     const bf16x8 kr = frag_b128(kslot, lk, kb * 2 + hh), vr = frag_b128(kslot + 4096, lk, kb * 2 + hh);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { kf[kb][j] = f2bf(-bf2f(kr[j]) * (PRESCALE ? p.sc : 1.f)); vf[kb][j] = f2bf(-bf2f(vr[j])); }
+    for (int j = 0; j < 8; ++j) { kf[kb][j] = f2bf(-bf2f(kr[j])); vf[kb][j] = f2bf(-bf2f(vr[j])); }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                           // the K / V row slots (stages 1-2) are free for query tiles
@@ -1474,6 +1475,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_dkv_kernel(AttnArgs p) {
     // query tile qt has landed for this wave (tile qt+1, issued behind it: 5 pieces, may still be in flight), then for everybody
     if (qt + 1 >= nqt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    if (PRESCALE) {
+      // Q <- bf16(Q * scale * log2 e) in place, each wave on the two 1-KiB pieces it fetched: exactly the operand the forward and
+      // the dQ kernel multiply with K, so the P recomputed here is the P the saved log-sum-exp and delta belong to (round 3 scaled
+      // the K fragments instead: a different rounding of every score, P rows that no longer sum to one)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        bf16x8* const qp = reinterpret_cast<bf16x8*>(smem + SB + i * 4096 + wave * 1024 + lane * 16);
+        bf16x8 v = *qp;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) * sc);
+        *qp = v;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     if (qt + 2 < nqt) stage_tile(NEXT2{}, qt + 2);
     if (!active) return;
@@ -1562,7 +1577,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_dkv_kernel(AttnArgs p) {
   float* cs_lds = p.cs_part ? reinterpret_cast<float*>(smem + 8 * EPI_SLOT) + wave * 128 : nullptr;     // behind the eight store slots: dk | dv sums
   if (!active && !cs_lds) return;
   if (active) {
-    store_block_rows(smem + wave * 2 * EPI_SLOT, dk0, dk1, -p.scale, !key_ok, p.dk + (rowbase + k0) * p.ld_dkv + h * 64, p.ld_dkv, L - k0, lane, cs_lds);
+    // dK = scale sum dS q; the accumulators hold sum (-dS) q' with q' = q scale log2 e
+    store_block_rows(smem + wave * 2 * EPI_SLOT, dk0, dk1, PRESCALE ? -1.f / LOG2E : -p.scale, !key_ok, p.dk + (rowbase + k0) * p.ld_dkv + h * 64, p.ld_dkv,
+                     L - k0, lane, cs_lds);
     store_block_rows(smem + (wave * 2 + 1) * EPI_SLOT, dv0, dv1, DROPOUT ? p.inv_keep : 1.f, !key_ok, p.dv + (rowbase + k0) * p.ld_dkv + h * 64,
                      p.ld_dkv, L - k0, lane, cs_lds ? cs_lds + 64 : nullptr);
   } else { zero_cs_row(cs_lds, lane); zero_cs_row(cs_lds + 64, lane); }
@@ -1595,8 +1612,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_dkv_kernel(AttnArgs p) {
 //    exposed.  No global load is issued inside the loop except through LDS-DMA (a register load would drain the in-order VMEM
 //    queue), and every wait on the DMA is a counted vmcnt that is exact or stricter than needed whether or not stores are counted.
 // Deterministic (no atomics).  A masked / out-of-range key gets +1e30 on its column's reference (P = 0 exactly).
+#ifndef IA_FUSED_SWAP
+#define IA_FUSED_SWAP 1      // 1: the second wave of every SIMD runs its part A one step ahead inside an item (below); 0: all waves in step
+#endif
+#ifndef IA_FUSED_ABL
+#define IA_FUSED_ABL 0       // development: timing ablations of the fused backward (tools/abl/run_fused_abl.sh); results are wrong when != 0
+#endif
 namespace bwdf {
 using namespace bwd3;
+constexpr int ABL = IA_FUSED_ABL;
 constexpr int NW = 8, RING = 4;
 // ring slot: Q | dO | O rows of one 32-query block (4 KiB each, unified layout) | lse[32] | delta[32] | dropout row keys[32]
 constexpr int SL_Q = 0, SL_G = 4096, SL_O = 8192, SL_LSE = 12288, SL_DLT = SL_LSE + 128, SL_RK = SL_LSE + 256, SLOT = SL_LSE + 512;
@@ -1640,7 +1664,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnArgs p) {
   const int first_item = x_lo + wslot;
   if (first_item >= x_hi) return;
   const int cnt = (x_hi - first_item + wpx - 1) / wpx;
-  auto item_of = [&](int n) { return n < cnt ? first_item + n * wpx : -1; };
+  // item cursors carry (item, sequence, head) and advance by the workgroup stride without divisions
+  struct Cur { int it, b, h; };
+  const int wpx_b = wpx / nh, wpx_h = wpx - wpx_b * nh;
+  auto adv = [&](Cur& c) { c.it += wpx; c.b += wpx_b; c.h += wpx_h; if (c.h >= nh) { c.h -= nh; ++c.b; } };
 
   const uint32_t sbase = lds_addr(smem);
   typedef __attribute__((address_space(3))) char lds_char;
@@ -1652,6 +1679,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnArgs p) {
   // of columns 0 .. 31 (t0) and 32 .. 63 (t0 + t1d)
   const uint32_t ka0 = sbase + RING_OFF + (uint32_t)(lk * 128 + ((hh ^ swz_u(lk)) << 4));
   const uint32_t t0 = sbase + RING_OFF + tr_lane_off_u(lane, 0), t1d = tr_lane_off_u(lane, 32) - tr_lane_off_u(lane, 0);
+  const int grp = wave >> 2;                              // the two waves of a SIMD (w, w + 4) are in different groups
   const int dqt = wave & 3, qh = wave >> 2;               // this wave's dQ^T tile: d 16 dqt .. +16, queries 16 qh .. +16 of the block
   const int g4 = lane >> 4, p16 = lane & 15;
   // transpose-read bases for MFMA 16x16x32 operands: 16-lane group g4 reads rows 4 g4 .. +3 (second read: + 16 rows) of 16 columns
@@ -1660,60 +1688,55 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnArgs p) {
   const uint32_t xrb = sbase + X_OFF + (uint32_t)((4 * g4 + (p16 >> 2)) * XP + (16 * qh + 4 * (p16 & 3)) * 2);
   const int xwo = X_OFF + wave * 2 * XT + lk * XP + hh * 8;      // this lane's row of the wave's exchange tile
   const int r8 = lane >> 3, c8 = lane & 7;                // DMA piece: 8 rows x 8 chunks of 16 bytes
-  // ---- DMA issue.  An item's rows are addressed through per-item buffer windows (base = the item's first row and head column,
-  // size = up to the end of its last row): rows >= L and the pieces of items past the end read as zeros without per-lane selects,
-  // and the only lane-dependent operand is the piece-local offset (row r8 of the piece, swizzled chunk).  Piece pc of a 32-row block
-  // covers rows 8 pc .. 8 pc + 7: swz_u of odd pieces = swz_u of even pieces | 2, i.e. the lane offset XOR 32 bytes.
-  // Every wave issues the same number of pieces at every point of the schedule (out-of-range dummies fill up), so one set of counted
-  // waits serves all waves.
+  // ---- DMA issue.  Every tensor keeps ONE descriptor base; per item only its size field moves: "up to the end of the item's last
+  // row of this head", so rows >= L and the pieces of items past the end read as zeros without per-lane selects, the item / block /
+  // piece position is the instruction's scalar offset, and the only lane-dependent operand is the piece-local offset (row r8 of the
+  // piece, swizzled chunk).  Piece pc of a 32-row block covers rows 8 pc .. 8 pc + 7: swz_u of odd pieces = swz_u of even pieces | 2,
+  // i.e. the lane offset XOR 32 bytes.  Every wave issues the same number of pieces at every point of the schedule (out-of-range
+  // dummies fill up), so one set of counted waits serves all waves.
   const uint32_t lo_q = (uint32_t)((r8 * p.ld_q + ((c8 ^ swz_u(r8)) << 3)) * 2);
   const uint32_t lo_kv = (uint32_t)((r8 * p.ld_kv + ((c8 ^ swz_u(r8)) << 3)) * 2);
   const uint32_t lo_o = (uint32_t)((r8 * p.ld_o + ((c8 ^ swz_u(r8)) << 3)) * 2);
   const uint32_t lo_w = lane < 32 ? (uint32_t)lane * 4u : OOB;      // 32 words
   const uint32_t lo_m = lane < 8 ? (uint32_t)lane * 4u : OOB;       // 8 words
-  auto window = [&](const bf16* base, size_t row0, int ld, int col0, bool ok) {
-    return ia_rsrc(base + row0 * ld + col0, ok ? (uint32_t)(((size_t)(L - 1) * ld + 64) * 2) : 0u);
-  };
-  // ring pieces of query block j of item `it` into ring slot `slot`: 2 pieces per wave
-  auto issue_ring = [&](int it, int j, int slot) {
-    const bool ok = it >= 0;
-    const int b = ok ? it / nh : 0, h = ok ? it - b * nh : 0;
-    const size_t row0 = (size_t)b * L;
+  // bytes from the tensor's base to the end of row L-1 of the item's head column block; 0 for an item past the end
+  auto lim = [&](const Cur& c, int ld) { return c.it < x_hi ? (uint32_t)((((uint32_t)c.b * L + L - 1) * ld + c.h * 64 + 64) * 2) : 0u; };
+  auto org = [&](const Cur& c, int ld, int row) { return (uint32_t)((((uint32_t)c.b * L + row) * ld + c.h * 64) * 2); };
+  // ring pieces of query block j of item c into ring slot `slot`: 2 pieces per wave
+  auto issue_ring = [&](const Cur& c, int j, int slot) {
     const int so = RING_OFF + slot * SLOT;
     if (wave < 4) {
       const uint32_t vo = lo_q ^ (uint32_t)((wave & 1) << 5);
-      const __amdgpu_buffer_rsrc_t wq = window(p.q, row0, p.ld_q, h * 64, ok);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wq, lsm + so + SL_Q + wave * 1024, 16, vo, (uint32_t)((j * 32 + wave * 8) * p.ld_q * 2), 0, 0);
-      const bool real = wave == 0 && ok;
-      const __amdgpu_buffer_rsrc_t wl = ia_rsrc(p.lse2 + (size_t)(ok ? it : 0) * L, real ? (uint32_t)L * 4u : 0u);
+      const __amdgpu_buffer_rsrc_t wq = ia_rsrc(p.q, lim(c, p.ld_q));
+      const uint32_t sof = org(c, p.ld_q, j * 32 + wave * 8);      // (a lambda call written directly as a builtin argument makes hipcc
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wq, lsm + so + SL_Q + wave * 1024, 16, vo, sof, 0, 0);      // drop the kernel's host stub)
+      const bool real = wave == 0 && c.it < x_hi;
+      const __amdgpu_buffer_rsrc_t wl = ia_rsrc(p.lse2, real ? (uint32_t)(c.it * L + L) * 4u : 0u);
       const int dst = wave == 0 ? so + SL_LSE : DUMMY_OFF + wave * 256;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wl, lsm + dst, 4, lo_w, (uint32_t)(j * 128), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wl, lsm + dst, 4, lo_w, (uint32_t)(c.it * L + j * 32) * 4u, 0, 0);
     } else {
       const int pc = wave - 4;
-      const uint32_t vo = lo_o ^ (uint32_t)((pc & 1) << 5), sof = (uint32_t)((j * 32 + pc * 8) * p.ld_o * 2);
-      const __amdgpu_buffer_rsrc_t wg = window(p.d_o, row0, p.ld_o, h * 64, ok), wo = window(p.o, row0, p.ld_o, h * 64, ok);
+      const uint32_t vo = lo_o ^ (uint32_t)((pc & 1) << 5), sof = org(c, p.ld_o, j * 32 + pc * 8);
+      const __amdgpu_buffer_rsrc_t wg = ia_rsrc(p.d_o, lim(c, p.ld_o)), wo = ia_rsrc(p.o, lim(c, p.ld_o));
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wg, lsm + so + SL_G + pc * 1024, 16, vo, sof, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wo, lsm + so + SL_O + pc * 1024, 16, vo, sof, 0, 0);
     }
   };
-  // K / V rows and the attendable-key words of item `it` into the stage: 9 pieces per wave (its own key block + a word piece)
-  auto issue_kv = [&](int it) {
-    const bool ok = it >= 0;
-    const int b = ok ? it / nh : 0, h = ok ? it - b * nh : 0;
-    const size_t row0 = (size_t)b * L;
-    const __amdgpu_buffer_rsrc_t wk = window(p.k, row0, p.ld_kv, h * 64, ok), wv = window(p.v, row0, p.ld_kv, h * 64, ok);
+  // K / V rows and the attendable-key words of item c into the stage: 9 pieces per wave (its own key block + a word piece)
+  auto issue_kv = [&](const Cur& c) {
+    const __amdgpu_buffer_rsrc_t wk = ia_rsrc(p.k, lim(c, p.ld_kv)), wv = ia_rsrc(p.v, lim(c, p.ld_kv));
 #pragma unroll
     for (int pc = 0; pc < 4; ++pc) {
-      const uint32_t vo = lo_kv ^ (uint32_t)((pc & 1) << 5), sof = (uint32_t)((wave * 32 + pc * 8) * p.ld_kv * 2);
+      const uint32_t vo = lo_kv ^ (uint32_t)((pc & 1) << 5), sof = org(c, p.ld_kv, wave * 32 + pc * 8);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wk, lsm + KST + wave * 4096 + pc * 1024, 16, vo, sof, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wv, lsm + VST + wave * 4096 + pc * 1024, 16, vo, sof, 0, 0);
     }
     // attendable-key bits per sequence: 8 words (bit i of word k: key 32 k + i in range and not masked), built by
     // attn_key_bits_kernel into the `delta` scratch the pair kernels use for their hand-over (this kernel needs none)
-    const bool real = wave == 0 && ok;
-    const __amdgpu_buffer_rsrc_t wm = ia_rsrc(reinterpret_cast<const uint32_t*>(p.delta) + b * 8, real ? 32u : 0u);
+    const bool real = wave == 0 && c.it < x_hi;
+    const __amdgpu_buffer_rsrc_t wm = ia_rsrc(p.delta, real ? (uint32_t)(c.b * 8 + 8) * 4u : 0u);
     const int dst = wave == 0 ? MSK_OFF : DUMMY_OFF + wave * 256;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(wm, lsm + dst, 4, lo_m, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wm, lsm + dst, 4, lo_m, (uint32_t)c.b * 32u, 0, 0);
   };
   // preparation of a landed block by the waves that fetched its pieces (before the barrier that publishes it)
   auto prep = [&](int it, int j, int slot) {
@@ -1725,7 +1748,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnArgs p) {
       for (int i = 0; i < 8; ++i) v[i] = f2bf(bf2f(v[i]) * p.sc);
       *qp = v;
       if (DROPOUT && wave == 1 && lane < 32)
-        *reinterpret_cast<uint32_t*>(sl + SL_RK + lane * 4) = ia_rng_row(p.seed, (uint32_t)(it < 0 ? 0 : it), (uint32_t)(j * 32 + lane));
+        *reinterpret_cast<uint32_t*>(sl + SL_RK + lane * 4) = ia_rng_row(p.seed, (uint32_t)it, (uint32_t)(j * 32 + lane));
     } else {
       const bf16x8 gv = *reinterpret_cast<const bf16x8*>(sl + SL_G + (wave - 4) * 1024 + lane * 16);
       const bf16x8 ov = *reinterpret_cast<const bf16x8*>(sl + SL_O + (wave - 4) * 1024 + lane * 16);
@@ -1742,15 +1765,17 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnArgs p) {
   const int ntile = (L + 127) >> 7;
 
   // ---- prologue: stage of item 0, ring blocks 0 .. RING-1, preparation of block 0
-  int pn = 0, pj = 0;                                     // producer cursor (item ordinal, block)
-  issue_kv(item_of(0));
+  Cur prod{first_item, first_item / nh, first_item % nh}; // producer cursor of the ring (item, block pj)
+  Cur cons = prod, kvn = prod;                            // consumer cursor; the item whose K / V is staged next
+  int pj = 0;
+  issue_kv(kvn); adv(kvn);
 #pragma unroll 1
   for (int s = 0; s < RING; ++s) {
-    issue_ring(item_of(pn), pj, s);
-    if (++pj == nb) { pj = 0; ++pn; }
+    issue_ring(prod, pj, s);
+    if (++pj == nb) { pj = 0; adv(prod); }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  prep(item_of(0), 0, 0);
+  prep(cons.it, 0, 0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
@@ -1762,205 +1787,251 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnArgs p) {
   float pen = 0.f;
   bool any_bad = false;
   uint32_t pc = 0u, ush = 0u;
-  int cn = 0, cj = 0;                                     // consumer cursor
+  // One trip per step g, closed by the step's barrier: part C of step g-1 (this wave's dQ tile from all exchange slots, which the
+  // previous barrier published), then part A of step g (S, dP, P, dS of this wave's key block, dV, dK, -dS to the exchange slot).
+  // Run like that by all eight waves, the two waves of a SIMD hit the matrix pipe together and leave it idle together (measured:
+  // MFMA busy 19 %, every part's time adding up).  So the second wave of every SIMD (waves 4 .. 7) runs its part A one step AHEAD:
+  // behind the barrier of trip g it already does part A of step g+1 -- whose block that barrier has just published -- and in trip
+  // g+1 only part C.  One wave's exp2 / multiply / convert stretch then has the other's MFMA stretch beside it (626 against 667 us
+  // at 512 x 255 x 16).  Every wave still arrives at every barrier once; the dependencies are the same ones (part C of step g needs
+  // every wave's part A of step g in front of barrier g: group 1 finished it a trip earlier; an exchange tile is rewritten two steps
+  // later, behind the barrier every reader arrives at after reading it).  At an item boundary the run-ahead pauses: the epilogue
+  // needs dK / dV and part C the K^T fragments of the old item before the item start overwrites them.
+  const int G = cnt * nb;
+  int cj = 0;                                             // block of step g inside its item
+  Cur prev = cons;                                        // item of step g-1
+  int pcj = 0;                                            // its block
 #pragma unroll 1
   for (int g = 0;; ++g) {
-    const int it = item_of(cn);
-    const int b = it / nh, h = it - b * nh;
-    const size_t row0 = (size_t)b * L;
-    const int slot = g & (RING - 1), par = g & 1;
+    const bool haveA = g < G;
     const bool first = cj == 0, last = cj == nb - 1;
-    if (first) {
-      // ---- item start: this wave's K / V fragments (B operands), the K^T fragments of its dQ tile, the mask
-      const char* kb_ = smem + KST + wave * 4096;
-      const char* vb_ = smem + VST + wave * 4096;
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {
-        const bf16x8 kr = frag_u(kb_, lk, kb * 2 + hh), vr = frag_u(vb_, lk, kb * 2 + hh);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { kf[kb][i] = f2bf(-bf2f(kr[i])); vf[kb][i] = f2bf(-bf2f(vr[i])); }
-      }
+    auto part_a = [&](int ga, bool first_a) {
       {
-        s16x4 lo[8], hi[8];
+        const int slot = ga & (RING - 1), par = ga & 1;
+        if (first_a) {
+          // ---- item start: this wave's K / V fragments (B operands), the K^T fragments of its dQ tile, the mask
+          const char* kb_ = smem + KST + wave * 4096;
+          const char* vb_ = smem + VST + wave * 4096;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { lo[k] = tr_read<0>(ktb + k * 4096); hi[k] = tr_read<2048>(ktb + k * 4096); }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]));
-        asm volatile("" : "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]), "+v"(hi[4]), "+v"(hi[5]), "+v"(hi[6]), "+v"(hi[7]));
+          for (int kb = 0; kb < 4; ++kb) {
+            const bf16x8 kr = frag_u(kb_, lk, kb * 2 + hh), vr = frag_u(vb_, lk, kb * 2 + hh);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) KT[k] = join(lo[k], hi[k]);
-      }
-      const int key = wave * 32 + lk;
-      // attendable keys of the item: one word per key block (from the stage)
-      {
-        const uint32_t* const mw = reinterpret_cast<const uint32_t*>(smem + MSK_OFF);
-        uint32_t vb = 0u;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) vb |= (mw[k] != 0u ? 1u : 0u) << k;
-        vbits = __builtin_amdgcn_readfirstlane(vb);
-        key_ok = ((mw[wave] >> lk) & 1u) != 0u;
-      }
-      mine = ((vbits >> wave) & 1u) != 0u;                // this wave's key block takes part
-      pen = key_ok ? 0.f : PEN;
-      any_bad = __ballot(!key_ok) != 0ull;
-      pc = pair_c_of(key); ush = (uint32_t)(key & 1) * 16u;
-      dk0 = zero16(); dk1 = zero16(); dv0 = zero16(); dv1 = zero16();
-      csq = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    // ---- part A: S, dP, P, dS of (query block cj, this wave's key block); dV, dK; -dS to the exchange slot
-    if (mine) {
-      const uint32_t so = (uint32_t)(slot * SLOT);
-      f32x16 s, dp;
-      const float* const sL = reinterpret_cast<const float*>(smem + RING_OFF + slot * SLOT + SL_LSE) + 4 * hh;
-      {
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const f32x4 ls = *reinterpret_cast<const f32x4*>(sL + 8 * rg);
-          const f32x4 dl = *reinterpret_cast<const f32x4*>(sL + 32 + 8 * rg);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { s[rg * 4 + j] = ls[j]; dp[rg * 4 + j] = DROPOUT ? 0.f : dl[j]; }
-        }
-        if (any_bad) {                                    // wave-uniform: masked / out-of-range keys end up with P = exp2(-1e30) = 0
-#pragma unroll
-          for (int r = 0; r < 16; ++r) s[r] += pen;
-        }
-      }
-      const uint32_t k0_ = ka0 + so;
-      bf16x8 xq, xg, yq, yg;
-      xq = lds_read_b128<SL_Q>(k0_); xg = lds_read_b128<SL_G>(k0_);
-      yq = lds_read_b128<SL_Q>(k0_ ^ 32u); yg = lds_read_b128<SL_G>(k0_ ^ 32u);
-      asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xq), "+v"(xg));
-      s = mfma(xq, kf[0], s); dp = mfma(xg, vf[0], dp);
-      xq = lds_read_b128<SL_Q>(k0_ ^ 64u); xg = lds_read_b128<SL_G>(k0_ ^ 64u);
-      asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(yq), "+v"(yg));
-      s = mfma(yq, kf[1], s); dp = mfma(yg, vf[1], dp);
-      yq = lds_read_b128<SL_Q>(k0_ ^ 96u); yg = lds_read_b128<SL_G>(k0_ ^ 96u);
-      asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xq), "+v"(xg));
-      s = mfma(xq, kf[2], s); dp = mfma(xg, vf[2], dp);
-      const uint32_t a0_ = t0 + so, a1_ = a0_ + t1d, a0x = a0_ ^ 32u, a1x = a1_ ^ 32u;
-      TrPair g0, q0, g1, q1;                              // dO^T and Q'^T fragments of the block's two 16-query steps
-      read_tr<SL_G, 0>(g0, a0_, a1_, a0x, a1x);
-      read_tr<SL_Q, 0>(q0, a0_, a1_, a0x, a1x);
-      asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(yq), "+v"(yg));
-      s = mfma(yq, kf[3], s); dp = mfma(yg, vf[3], dp);
-      bf16x8 pf[2], sf[2];
-      const uint32_t* const rkp = reinterpret_cast<const uint32_t*>(smem + RING_OFF + slot * SLOT + SL_RK) + 4 * hh;
-      // probabilities and -dS of 8 accumulator rows (one 16-query MFMA step): HALF = 0 / 1
-      auto half = [&](auto HALF) {
-        constexpr int hf = decltype(HALF)::value;
-#pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-          const int r = hf * 8 + rr;
-          const float pv = __builtin_amdgcn_exp2f(-s[r]); // exp2(q' . k - lse)
-          float pd = pv, nds;
-          if (DROPOUT) {
-            const int qo = 8 * (r >> 2) + (r & 3);        // this register's query inside the block, minus 4 hh
-            const uint32_t dr = (ia_rng_pair(rkp[qo], pc) >> ush) & 0xFFFFu;
-            const float mk = __builtin_fminf(__builtin_fmaxf((float)((int)dr - (int)thr1), 0.f), 1.f);      // 0 iff dropped
-            pd = pv * mk;
-            nds = pv * __builtin_fmaf(dp[r] * mk, inv_keep, sL[32 + qo]);      // dp = -dP: -(M dP / keep - delta)
-          } else {
-            nds = pv * dp[r];                             // dp = delta - dP
+            for (int i = 0; i < 8; ++i) { kf[kb][i] = f2bf(-bf2f(kr[i])); vf[kb][i] = f2bf(-bf2f(vr[i])); }
           }
-          pf[hf][rr] = f2bf(pd);
-          sf[hf][rr] = f2bf(nds);
+          {
+            s16x4 lo[8], hi[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { lo[k] = tr_read<0>(ktb + k * 4096); hi[k] = tr_read<2048>(ktb + k * 4096); }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]));
+            asm volatile("" : "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]), "+v"(hi[4]), "+v"(hi[5]), "+v"(hi[6]), "+v"(hi[7]));
+#pragma unroll
+            for (int k = 0; k < 8; ++k) KT[k] = join(lo[k], hi[k]);
+          }
+          const int key = wave * 32 + lk;
+          // attendable keys of the item: one word per key block (from the stage)
+          {
+            const uint32_t* const mw = reinterpret_cast<const uint32_t*>(smem + MSK_OFF);
+            uint32_t vb = 0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) vb |= (mw[k] != 0u ? 1u : 0u) << k;
+            vbits = __builtin_amdgcn_readfirstlane(vb);
+            key_ok = ((mw[wave] >> lk) & 1u) != 0u;
+          }
+          mine = ((vbits >> wave) & 1u) != 0u;            // this wave's key block takes part
+          pen = key_ok ? 0.f : PEN;
+          any_bad = __ballot(!key_ok) != 0ull;
+          pc = pair_c_of(key); ush = (uint32_t)(key & 1) * 16u;
+          dk0 = zero16(); dk1 = zero16(); dv0 = zero16(); dv1 = zero16();
+          csq = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        // -dS^T to the exchange slot: row = key (this lane), two groups of 4 consecutive queries
-        char* const xw = smem + xwo + par * XT + hf * 32;
-        *reinterpret_cast<bf16x4*>(xw) = bf16x4{sf[hf][0], sf[hf][1], sf[hf][2], sf[hf][3]};
-        *reinterpret_cast<bf16x4*>(xw + 16) = bf16x4{sf[hf][4], sf[hf][5], sf[hf][6], sf[hf][7]};
-      };
-      half(std::integral_constant<int, 0>{});
-      // the second step's fragments are requested only now: the first step's MFMAs run under the second half's exp2 / multiplies
-      read_tr<SL_G, 16>(g1, a0_, a1_, a0x, a1x);
-      read_tr<SL_Q, 16>(q1, a0_, a1_, a0x, a1x);
-      tr_wait<12>(g0);
-      dv0 = mfma(g0.a0(), pf[0], dv0); dv1 = mfma(g0.a1(), pf[0], dv1);
-      tr_wait<8>(q0);
-      dk0 = mfma(q0.a0(), sf[0], dk0); dk1 = mfma(q0.a1(), sf[0], dk1);
-      half(std::integral_constant<int, 1>{});
-      tr_wait<4>(g1);
-      dv0 = mfma(g1.a0(), pf[1], dv0); dv1 = mfma(g1.a1(), pf[1], dv1);
-      tr_wait<0>(q1);
-      dk0 = mfma(q1.a0(), sf[1], dk0); dk1 = mfma(q1.a1(), sf[1], dk1);
-    }
+        // ---- part A of step g
+        if (mine) {
+          const uint32_t so = (uint32_t)(slot * SLOT);
+          f32x16 s, dp;
+          const float* const sL = reinterpret_cast<const float*>(smem + RING_OFF + slot * SLOT + SL_LSE) + 4 * hh;
+          {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+              const f32x4 ls = *reinterpret_cast<const f32x4*>(sL + 8 * rg);
+              const f32x4 dl = *reinterpret_cast<const f32x4*>(sL + 32 + 8 * rg);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { s[rg * 4 + j] = ls[j]; dp[rg * 4 + j] = DROPOUT ? 0.f : dl[j]; }
+            }
+            if (any_bad) {                                // wave-uniform: masked / out-of-range keys end up with P = exp2(-1e30) = 0
+#pragma unroll
+              for (int r = 0; r < 16; ++r) s[r] += pen;
+            }
+          }
+          const uint32_t k0_ = ka0 + so;
+          bf16x8 xq, xg, yq, yg;
+          if (!(ABL & 128)) {
+          xq = lds_read_b128<SL_Q>(k0_); xg = lds_read_b128<SL_G>(k0_);
+          yq = lds_read_b128<SL_Q>(k0_ ^ 32u); yg = lds_read_b128<SL_G>(k0_ ^ 32u);
+          asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xq), "+v"(xg));
+          s = mfma(xq, kf[0], s); dp = mfma(xg, vf[0], dp);
+          xq = lds_read_b128<SL_Q>(k0_ ^ 64u); xg = lds_read_b128<SL_G>(k0_ ^ 64u);
+          asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(yq), "+v"(yg));
+          s = mfma(yq, kf[1], s); dp = mfma(yg, vf[1], dp);
+          yq = lds_read_b128<SL_Q>(k0_ ^ 96u); yg = lds_read_b128<SL_G>(k0_ ^ 96u);
+          asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xq), "+v"(xg));
+          s = mfma(xq, kf[2], s); dp = mfma(xg, vf[2], dp);
+          }
+          const uint32_t a0_ = t0 + so, a1_ = a0_ + t1d, a0x = a0_ ^ 32u, a1x = a1_ ^ 32u;
+          TrPair g0, q0, g1, q1;                          // dO^T and Q'^T fragments of the block's two 16-query steps
+          if (!(ABL & 64)) {
+          read_tr<SL_G, 0>(g0, a0_, a1_, a0x, a1x);
+          read_tr<SL_Q, 0>(q0, a0_, a1_, a0x, a1x);
+          }
+          if (!(ABL & 128)) {
+          asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(yq), "+v"(yg));
+          s = mfma(yq, kf[3], s); dp = mfma(yg, vf[3], dp);
+          }
+          bf16x8 pf[2], sf[2];
+          const uint32_t* const rkp = reinterpret_cast<const uint32_t*>(smem + RING_OFF + slot * SLOT + SL_RK) + 4 * hh;
+          // probabilities and -dS of 8 accumulator rows (one 16-query MFMA step): HALF = 0 / 1
+          auto half = [&](auto HALF) {
+            constexpr int hf = decltype(HALF)::value;
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+              const int r = hf * 8 + rr;
+              const float pv = (ABL & 2) ? s[r] : __builtin_amdgcn_exp2f(-s[r]);      // exp2(q' . k - lse)
+              float pd = pv, nds;
+              if (ABL & 2) nds = dp[r];
+              else if (DROPOUT) {
+                const int qo = 8 * (r >> 2) + (r & 3);    // this register's query inside the block, minus 4 hh
+                const uint32_t dr = (ia_rng_pair(rkp[qo], pc) >> ush) & 0xFFFFu;
+                const float mk = __builtin_fminf(__builtin_fmaxf((float)((int)dr - (int)thr1), 0.f), 1.f);      // 0 iff dropped
+                pd = pv * mk;
+                nds = pv * __builtin_fmaf(dp[r] * mk, inv_keep, sL[32 + qo]);      // dp = -dP: -(M dP / keep - delta)
+              } else {
+                nds = pv * dp[r];                         // dp = delta - dP
+              }
+              pf[hf][rr] = f2bf(pd);
+              sf[hf][rr] = f2bf(nds);
+            }
+            // -dS^T to the exchange slot: row = key (this lane), two groups of 4 consecutive queries
+            char* const xw = smem + xwo + par * XT + hf * 32;
+            if (!(ABL & 8)) {
+            *reinterpret_cast<bf16x4*>(xw) = bf16x4{sf[hf][0], sf[hf][1], sf[hf][2], sf[hf][3]};
+            *reinterpret_cast<bf16x4*>(xw + 16) = bf16x4{sf[hf][4], sf[hf][5], sf[hf][6], sf[hf][7]};
+            }
+          };
+          half(std::integral_constant<int, 0>{});
+          // the second step's fragments are requested only now: the first step's MFMAs run under the second half's exp2 / multiplies
+          if (!(ABL & 64)) {
+          read_tr<SL_G, 16>(g1, a0_, a1_, a0x, a1x);
+          read_tr<SL_Q, 16>(q1, a0_, a1_, a0x, a1x);
+          tr_wait<12>(g0);
+          dv0 = mfma(g0.a0(), pf[0], dv0); dv1 = mfma(g0.a1(), pf[0], dv1);
+          tr_wait<8>(q0);
+          dk0 = mfma(q0.a0(), sf[0], dk0); dk1 = mfma(q0.a1(), sf[0], dk1);
+          }
+          half(std::integral_constant<int, 1>{});
+          if (!(ABL & 64)) {
+          tr_wait<4>(g1);
+          dv0 = mfma(g1.a0(), pf[1], dv0); dv1 = mfma(g1.a1(), pf[1], dv1);
+          tr_wait<0>(q1);
+          dk0 = mfma(q1.a0(), sf[1], dk0); dk1 = mfma(q1.a1(), sf[1], dk1);
+          } else { dv0[0] += bf2f(pf[0][0]) + bf2f(pf[1][0]); dk0[0] += bf2f(sf[0][0]) + bf2f(sf[1][0]); }
+        }
+      }
+    };
+    // ---- the other half of the interval: look-ahead DMA, part C of step g-1, and at an item boundary the epilogue
+    auto part_c = [&]() {
+      if (haveA && g >= 1 && !(ABL & 16)) {
+        // the slot of step g-1 is free (every wave passed the barrier behind its part A): block g+3 goes there; the stage is free once
+        // every wave has read it, i.e. behind the barrier of the item's first step
+        if (cj == 1) { issue_kv(kvn); adv(kvn); }
+        issue_ring(prod, pj, (g - 1) & (RING - 1));
+        if (++pj == nb) { pj = 0; adv(prod); }
+      }
+      if (g == 0) return;
+      {
+        const uint32_t xr = xrb + ((g - 1) & 1) * XT;
+        s16x4 lo[8], hi[8];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (!(ABL & 1)) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { lo[k] = tr_read<0>(xr + k * 2 * XT); hi[k] = tr_read<16 * XP>(xr + k * 2 * XT); }
+#define IA_DQ_STEP(k, n)                                                                                   \
+        wait2<n>(lo[k], hi[k]);                                                                            \
+        if ((vbits >> k) & 1u) acc = mfma16(KT[k], join(lo[k], hi[k]), acc);
+        IA_DQ_STEP(0, 14) IA_DQ_STEP(1, 12) IA_DQ_STEP(2, 10) IA_DQ_STEP(3, 8) IA_DQ_STEP(4, 6) IA_DQ_STEP(5, 4) IA_DQ_STEP(6, 2) IA_DQ_STEP(7, 0)
+#undef IA_DQ_STEP
+        }
+        // lane (query n = p16 of the half, rows d = 16 dqt + 4 g4 .. +3): 8 bytes of row q
+        const int q = pcj * 32 + 16 * qh + p16;
+        bf16x4 o4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { o4[i] = f2bf(-p.scale * acc[i]); }
+        if (q < L) {
+          *reinterpret_cast<bf16x4*>(p.dq + ((size_t)prev.b * L + q) * p.ld_dq + prev.h * 64 + 16 * dqt + 4 * g4) = o4;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) csq[i] += bf2f(o4[i]);
+        }
+      }
+      if (!first) return;
+      // ---- item end (of the item of step g-1): dK, dV through the wave's exchange tiles (free once every wave is past part C),
+      // column sums
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const size_t row0 = (size_t)prev.b * L;
+      float* const cs_w = reinterpret_cast<float*>(smem + CS_OFF) + wave * 128;
+      if (wave < nb) {
+        // dK = scale sum dS q = -(1 / log2 e) sum (-dS) q'   (q' = q scale log2 e)
+        store_block_rows(smem + X_OFF + wave * EPI_SLOT, dk0, dk1, -1.f / LOG2E, false, p.dk + (row0 + wave * 32) * p.ld_dkv + prev.h * 64, p.ld_dkv,
+                         L - wave * 32, lane, p.cs_part ? cs_w : nullptr);
+        store_block_rows(smem + X_OFF + wave * EPI_SLOT, dv0, dv1, DROPOUT ? inv_keep : 1.f, false, p.dv + (row0 + wave * 32) * p.ld_dkv + prev.h * 64,
+                         p.ld_dkv, L - wave * 32, lane, p.cs_part ? cs_w + 64 : nullptr);
+      } else if (p.cs_part) { zero_cs_row(cs_w, lane); zero_cs_row(cs_w + 64, lane); }
+      if (p.cs_part) {                                    // workgroup-uniform
+        // dq: the tile's column sums over its 16 queries (lanes with equal g4), then the two query halves (waves dqt, dqt + 4)
+        // (lane-derived addresses of this once-per-item block are rebuilt from an opaque copy of the lane id: hoisted out of the item
+        // loop they were spilled, and a scratch reload drains the whole in-order VMEM queue -- the look-ahead DMA -- with vmcnt(0))
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        float* const cq = reinterpret_cast<float*>(smem + CS_OFF + NW * 128 * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) csq[i] = row16_sum(csq[i]);
+        if ((ln & 15) == 0) *reinterpret_cast<f32x4*>(cq + wave * 16 + 4 * (ln >> 4)) = csq;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        float* const dst = p.cs_part + (size_t)(prev.b * ntile) * (3 * nh * 64) + prev.h * 64 + ln;
+        if (wave == 0) {
+          dst[0] = cq[(ln >> 4) * 16 + (ln & 15)] + cq[((ln >> 4) + 4) * 16 + (ln & 15)];
+        } else if (wave == 1 || wave == 2) {
+          const float* c = reinterpret_cast<const float*>(smem + CS_OFF) + (wave - 1) * 64 + ln;
+          float t = 0.f;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) t += c[w * 128];
+          dst[wave * nh * 64] = t;
+        } else if (wave == 3 && ntile == 2) {             // the pair kernels write one row per 128-row tile: keep the workspace shape
+          float* const z = p.cs_part + (size_t)(prev.b * ntile + 1) * (3 * nh * 64) + prev.h * 64 + ln;
+          z[0] = 0.f; z[nh * 64] = 0.f; z[2 * nh * 64] = 0.f;
+        }
+      }
+    };
+    part_c();
+    if (!haveA) break;
+    if (!IA_FUSED_SWAP || grp == 0 || first) part_a(g, first);
     // ---- the next block: wait for this wave's pieces of it, prepare it, publish everything with the step's barrier
     {
+      // pieces issued after the ones waited for: the ring pieces of this and the previous interval (4), plus the 9 stage pieces when
+      // they went out in one of them (block 1 / 2 of the item); at an item's last step the stage pieces must have landed as well
       int n = 4;
       if (last) n = nb == 2 ? 2 : 4;
       else if (cj == 1 || cj == 2) n = 13;
       wait_vm(n);
-      int nn = cn, nj = cj + 1;
-      if (nj == nb) { nj = 0; ++nn; }
-      prep(item_of(nn), nj, (g + 1) & (RING - 1));
+      int nj = cj + 1;
+      Cur nc = cons;
+      if (nj == nb) { nj = 0; adv(nc); }
+      if (!(ABL & 4)) prep(nc.it, nj, (g + 1) & (RING - 1));
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (first) issue_kv(item_of(cn + 1));
-    issue_ring(item_of(pn), pj, slot);
-    if (++pj == nb) { pj = 0; ++pn; }
-    // ---- part C: this wave's 16 x 16 tile of -dQ^T of query block cj, contraction over all key blocks
-    {
-      const uint32_t xr = xrb + par * XT;
-      s16x4 lo[8], hi[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) { lo[k] = tr_read<0>(xr + k * 2 * XT); hi[k] = tr_read<16 * XP>(xr + k * 2 * XT); }
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#define IA_DQ_STEP(k, n)                                                                                   \
-      wait2<n>(lo[k], hi[k]);                                                                              \
-      if ((vbits >> k) & 1u) acc = mfma16(KT[k], join(lo[k], hi[k]), acc);
-      IA_DQ_STEP(0, 14) IA_DQ_STEP(1, 12) IA_DQ_STEP(2, 10) IA_DQ_STEP(3, 8) IA_DQ_STEP(4, 6) IA_DQ_STEP(5, 4) IA_DQ_STEP(6, 2) IA_DQ_STEP(7, 0)
-#undef IA_DQ_STEP
-      // lane (query n = p16 of the half, rows d = 16 dqt + 4 g4 .. +3): 8 bytes of row q
-      const int q = cj * 32 + 16 * qh + p16;
-      bf16x4 o4;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { o4[i] = f2bf(-p.scale * acc[i]); }
-      if (q < L) {
-        *reinterpret_cast<bf16x4*>(p.dq + (row0 + q) * p.ld_dq + h * 64 + 16 * dqt + 4 * g4) = o4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) csq[i] += bf2f(o4[i]);
-      }
-    }
-    if (!last) { ++cj; continue; }
-    // ---- item end: dK, dV through the wave's exchange tiles (free once every wave is past part C), column sums
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    float* const cs_w = reinterpret_cast<float*>(smem + CS_OFF) + wave * 128;
-    if (wave < nb) {
-      // dK = scale sum dS q = -(1 / log2 e) sum (-dS) q'   (q' = q scale log2 e)
-      store_block_rows(smem + X_OFF + wave * EPI_SLOT, dk0, dk1, -1.f / LOG2E, false, p.dk + (row0 + wave * 32) * p.ld_dkv + h * 64, p.ld_dkv,
-                       L - wave * 32, lane, p.cs_part ? cs_w : nullptr);
-      store_block_rows(smem + X_OFF + wave * EPI_SLOT, dv0, dv1, DROPOUT ? inv_keep : 1.f, false, p.dv + (row0 + wave * 32) * p.ld_dkv + h * 64,
-                       p.ld_dkv, L - wave * 32, lane, p.cs_part ? cs_w + 64 : nullptr);
-    } else if (p.cs_part) { zero_cs_row(cs_w, lane); zero_cs_row(cs_w + 64, lane); }
-    if (p.cs_part) {                                      // workgroup-uniform
-      // dq: the tile's column sums over its 16 queries (lanes with equal g4), then the two query halves (waves dqt, dqt + 4)
-      // (lane-derived addresses of this once-per-item block are rebuilt from an opaque copy of the lane id: hoisted out of the item
-      // loop they were spilled, and a scratch reload drains the whole in-order VMEM queue -- the look-ahead DMA -- with vmcnt(0))
-      int ln = lane;
-      asm volatile("" : "+v"(ln));
-      float* const cq = reinterpret_cast<float*>(smem + CS_OFF + NW * 128 * 4);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) csq[i] = row16_sum(csq[i]);
-      if ((ln & 15) == 0) *reinterpret_cast<f32x4*>(cq + wave * 16 + 4 * (ln >> 4)) = csq;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      float* const dst = p.cs_part + (size_t)(b * ntile) * (3 * nh * 64) + h * 64 + ln;
-      if (wave == 0) {
-        dst[0] = cq[(ln >> 4) * 16 + (ln & 15)] + cq[((ln >> 4) + 4) * 16 + (ln & 15)];
-      } else if (wave == 1 || wave == 2) {
-        const float* c = reinterpret_cast<const float*>(smem + CS_OFF) + (wave - 1) * 64 + ln;
-        float t = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) t += c[w * 128];
-        dst[wave * nh * 64] = t;
-      } else if (wave == 3 && ntile == 2) {               // the pair kernels write one row per 128-row tile: keep the workspace shape
-        float* const z = p.cs_part + (size_t)(b * ntile + 1) * (3 * nh * 64) + h * 64 + ln;
-        z[0] = 0.f; z[nh * 64] = 0.f; z[2 * nh * 64] = 0.f;
-      }
-    }
-    if (++cn == cnt) break;
-    cj = 0;
+    if (!(ABL & 32)) __builtin_amdgcn_s_barrier();
+    if (IA_FUSED_SWAP && grp != 0 && !last) part_a(g + 1, false);      // group 1 runs one part A ahead inside an item
+    prev = cons; pcj = cj;
+    if (++cj == nb) { cj = 0; adv(cons); }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the look-ahead pieces still in flight target this workgroup's LDS
 }

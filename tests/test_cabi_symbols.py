@@ -48,3 +48,14 @@ def test_error_codes_without_touching_the_gpu():
     assert lib.ia_gemm_workspace_bytes(1024, 1024, 32640, 1) > 0
     assert lib.ia_gemm_workspace_bytes(1024, 1024, 32640, 0) == 0
     assert lib.ia_ln_bwd_workspace_bytes(1000, 1024) == 250 * 3 * 1024 * 4
+
+
+def test_library_has_no_undefined_kernel_stubs():
+    """A shared library links with undefined symbols: a kernel whose host-side launch stub hipcc failed to emit (seen when a lambda
+    call is written directly as an argument of a builtin inside a template kernel) would only fail at the first launch."""
+    import os
+    import subprocess
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "item_alignment_amd", "libitemalign_hip.so")
+    out = subprocess.run(["nm", "-C", "-u", lib], capture_output=True, text=True, check=True).stdout
+    bad = [ln for ln in out.splitlines() if "__device_stub__" in ln]
+    assert not bad, bad
