@@ -348,6 +348,28 @@ def main():
             variants["unpadded_text_tower"] = timed(batches, args.variant_steps, n_steps + 2 + args.variant_steps)
         finally:
             _text.UNPAD = False
+        # evaluation / prediction throughput (reference finetune_multimodal.py:470-563 runs the model under no_grad): forward-only
+        # layers (ia_layer_fwd_infer: nothing written for a backward pass), same batch size
+        def eval_pass(k):
+            model.eval()
+            try:
+                with torch.no_grad():
+                    for i in range(2):
+                        model(*batches[i % len(batches)][:10], labels=batches[i % len(batches)][10])
+                    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+                    t = time.perf_counter()
+                    for i in range(k):
+                        b = batches[i % len(batches)]
+                        model(*b[:10], labels=b[10])
+                    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+                    tm = torch.tensor([time.perf_counter() - t], device=dev, dtype=torch.float64)
+            finally:
+                model.train()
+            if world > 1 or iadist.FORCE:
+                torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
+            return {"value": B * world * k / tm.item(), "unit": "item-pairs/sec", "ms_per_step": tm.item() / k * 1e3, "steps": k, "pairs_per_gpu": B,
+                    "what": "forward + loss only (model.eval(), no_grad)"}
+        variants["eval_forward_only"] = eval_pass(args.variant_steps)
         # the image tower on a second HIP stream (IA_TOWER_STREAMS=1): the same arithmetic, the two towers' kernels
         # overlap.  Not the headline because per-kernel roofline figures stop describing the kernels when two of them share the chip.
         from item_alignment_amd.models import multimodal as _mm

@@ -37,7 +37,7 @@ const char* ia_strerror(int code);
 /* Bumped whenever an entry point is added or the meaning of an argument / output changes (round 2 changed what IA_EPI_BIAS_GELU
  * stores in C2 and what IA_EPI_DGELU expects in aux): a caller built against another header must not run on this library.
  * item_alignment_amd/_lib.py refuses to load a library whose version differs from the one it was written for. */
-#define IA_ABI_VERSION 4
+#define IA_ABI_VERSION 5
 int ia_abi_version(void);
 
 /* ---- GEMM: torch.nn.Linear forward / dgrad / wgrad (src/models/text.py:1241 -> RobertaLayer dense
@@ -52,6 +52,7 @@ int ia_abi_version(void);
 #define IA_EPI_BIAS_ADD 5  /* + bias + aux */
 #define IA_EPI_DGELU_COLSUM 6 /* IA_EPI_DGELU, and C2 (fp32 [N]) += column sums of C: the bias gradient of the Linear in front of the GELU
                                * (row-major C with ldc == N; workspace >= ia_gemm_colsum_workspace_bytes(M, N)) */
+#define IA_EPI_BIAS_GELU_ACT 7 /* forward-only IA_EPI_BIAS_GELU: C = gelu_erf(bf16(acc + bias)), nothing else is evaluated or stored (ABI 5) */
 int ia_gemm_bf16(const void* A, int a_kstrided, int lda, const void* B, int b_kstrided, int ldb, void* C, int c_is_f32, int ldc,
                  int M, int N, int K, int epilogue, const float* bias, const void* aux, int ldaux, void* C2, int accumulate,
                  void* workspace, size_t workspace_bytes, ia_stream_t stream);
@@ -364,10 +365,15 @@ typedef struct {
 /* per-layer activation stash (saved by forward, read by backward) and shared backward scratch */
 size_t ia_layer_stash_bytes(const ia_layer_cfg* cfg);
 size_t ia_layer_bwd_scratch_bytes(const ia_layer_cfg* cfg);
-/* x [M,H] bf16 -> y [M,H] bf16.  key_mask [B,L] uint8 or NULL.  stash may be NULL for inference
- * (then `scratch` of ia_layer_stash_bytes is used transiently and nothing is kept). */
+/* x [M,H] bf16 -> y [M,H] bf16.  key_mask [B,L] uint8 or NULL.  stash (ia_layer_stash_bytes) receives what ia_layer_bwd needs. */
 int ia_layer_fwd(const ia_layer_cfg* cfg, const ia_layer_weights* w, const void* x, const uint8_t* key_mask, void* y, void* stash,
                  ia_stream_t stream);
+/* Forward only (evaluation / prediction; reference finetune_multimodal.py:470-563, 661-775 run the model under no_grad): the layer
+ * without anything kept for a backward pass -- no gelu' stream, no pre-LayerNorm sums, dropout off whatever cfg says.  `scratch`
+ * (>= ia_layer_infer_scratch_bytes) is transient: every layer of a stack may be handed the same buffer.  (ABI 5) */
+size_t ia_layer_infer_scratch_bytes(const ia_layer_cfg* cfg);
+int ia_layer_fwd_infer(const ia_layer_cfg* cfg, const ia_layer_weights* w, const void* x, const uint8_t* key_mask, void* y, void* scratch,
+                       size_t scratch_bytes, ia_stream_t stream);
 /* dy [M,H] bf16 -> dx [M,H] bf16 (dx may alias dy); parameter gradients accumulate into g. */
 int ia_layer_bwd(const ia_layer_cfg* cfg, const ia_layer_weights* w, const ia_layer_grads* g, const void* x, const uint8_t* key_mask,
                  const void* y, const void* stash, const void* dy, void* dx, void* scratch, size_t scratch_bytes, ia_stream_t stream);

@@ -122,6 +122,8 @@ SIGNATURES = {
     "ia_layer_stash_bytes": (sz, [C.POINTER(LayerCfg)]),
     "ia_layer_bwd_scratch_bytes": (sz, [C.POINTER(LayerCfg)]),
     "ia_layer_fwd": (i32, [C.POINTER(LayerCfg), C.POINTER(LayerWeights), vp, vp, vp, vp, vp]),
+    "ia_layer_infer_scratch_bytes": (sz, [C.POINTER(LayerCfg)]),
+    "ia_layer_fwd_infer": (i32, [C.POINTER(LayerCfg), C.POINTER(LayerWeights), vp, vp, vp, vp, sz, vp]),
     "ia_layer_bwd": (i32, [C.POINTER(LayerCfg), C.POINTER(LayerWeights), C.POINTER(LayerGrads), vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "ia_layer_bwd2": (i32, [C.POINTER(LayerCfg), C.POINTER(LayerWeights), C.POINTER(LayerGrads), vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
 }
@@ -129,7 +131,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 4      # = IA_ABI_VERSION of include/itemalign.h (tests/test_cabi_symbols.py keeps the two in step)
+ABI_VERSION = 5      # = IA_ABI_VERSION of include/itemalign.h (tests/test_cabi_symbols.py keeps the two in step)
 
 
 class ItemAlignError(RuntimeError):

@@ -153,6 +153,18 @@ IA_DEV void gelu_pair(f32x2_t x, f32x2_t& act, f32x2_t& der) {
   const f32x2_t r = 1.0f - s;
   der = (act * r) * q + s;
 }
+// the activation alone (forward-only layers): 8 issue slots per output
+IA_DEV f32x2_t gelu_act_pair(f32x2_t x) {
+  constexpr float L2E = 1.4426950408889634f;
+  constexpr float C0 = 1.5949398799788077f, C1 = 0.07403000634661838f, C2 = -0.0007007124749191571f;
+  constexpr float U_MAX = C1 / (2.f * 0.0007007124749191571f);
+  f32x2_t u = x * x;
+  u[0] = __builtin_fminf(u[0], U_MAX); u[1] = __builtin_fminf(u[1], U_MAX);
+  const f32x2_t t = x * ((u * (-C2 * L2E) + (-C1 * L2E)) * u + (-C0 * L2E));
+  const f32x2_t e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+  const f32x2_t den = e + 1.0f;
+  return x * f32x2_t{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+}
 IA_DEV float gelu_erf(float x) { float c, d; gelu_parts(x, c, d); return x * c; }
 IA_DEV float gelu_erf_grad(float x) { float c, d; gelu_parts(x, c, d); return c + x * d; }
 

@@ -142,6 +142,60 @@ extern "C" int ia_layer_fwd(const ia_layer_cfg* c, const ia_layer_weights* w, co
   return IA_OK;
 }
 
+// ---- forward only (evaluation / prediction, reference finetune_multimodal.py:470-563, 661-775): the same launches as ia_layer_fwd
+// minus everything that exists for the backward pass -- no gelu'(pre-activation) stream (IA_EPI_BIAS_GELU_ACT), no pre-LayerNorm
+// sums z, no dropout -- in a transient scratch that every layer of a stack can share.
+namespace {
+struct Infer { char* qkv; char* ctx; char* t0; char* t1; char* h; float* lse; float* mean; float* rstd; size_t bytes; };
+Infer carve_infer(const ia_layer_cfg* c, void* base) {
+  const size_t M = rows_of(c), H = c->H, I = c->I;
+  char* p = (char*)base;
+  Infer s;
+  auto take = [&](size_t b) { char* r = p; p += al(b); return r; };
+  s.qkv = take(M * 3 * H * 2); s.ctx = take(M * H * 2); s.t0 = take(M * H * 2); s.t1 = take(M * H * 2); s.h = take(M * I * 2);
+  s.lse = (float*)take((size_t)c->B * c->nh * c->L * 4);
+  s.mean = (float*)take(M * 4); s.rstd = (float*)take(M * 4);
+  s.bytes = (size_t)(p - (char*)base);
+  return s;
+}
+}  // namespace
+
+extern "C" size_t ia_layer_infer_scratch_bytes(const ia_layer_cfg* cfg) {
+  (void)hipGetLastError();
+  if (!cfg_ok(cfg)) return 0;
+  return carve_infer(cfg, nullptr).bytes;
+}
+
+extern "C" int ia_layer_fwd_infer(const ia_layer_cfg* c, const ia_layer_weights* w, const void* x, const uint8_t* key_mask, void* y,
+                                  void* scratch, size_t scratch_bytes, ia_stream_t st) {
+  (void)hipGetLastError();
+  if (!cfg_ok(c) || !w || !x || !y || !scratch) return IA_ERR_ARG;
+  if (scratch_bytes < ia_layer_infer_scratch_bytes(c)) return IA_ERR_WORKSPACE;
+  const int M = (int)rows_of(c), H = c->H, I = c->I;
+  const Infer s = carve_infer(c, scratch);
+  const float scale = 0.125f;
+  if (!c->pre_ln) {
+    IA_TRY(ia_gemm_bf16(x, 0, H, w->w_qkv, 0, H, s.qkv, 0, 3 * H, M, 3 * H, H, IA_EPI_BIAS, w->b_qkv, nullptr, 0, nullptr, 0, nullptr, 0, st));
+    IA_TRY(attn_fwd(c, s.qkv, key_mask, s.ctx, s.lse, scale, 0.f, 0, st));
+    IA_TRY(ia_gemm_bf16(s.ctx, 0, H, w->w_o, 0, H, s.t0, 0, H, M, H, H, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
+    IA_TRY(ia_ln_fwd(s.t0, w->b_o, x, nullptr, s.t1, s.mean, s.rstd, w->ln1_g, w->ln1_b, M, H, c->eps, 0.f, 0, 0, st));
+    IA_TRY(ia_gemm_bf16(s.t1, 0, H, w->w_fc1, 0, H, s.h, 0, I, M, I, H, IA_EPI_BIAS_GELU_ACT, w->b_fc1, nullptr, 0, nullptr, 0, nullptr, 0, st));
+    IA_TRY(ia_gemm_bf16(s.h, 0, I, w->w_fc2, 0, I, s.t0, 0, H, M, H, I, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
+    IA_TRY(ia_ln_fwd(s.t0, w->b_fc2, s.t1, nullptr, y, s.mean, s.rstd, w->ln2_g, w->ln2_b, M, H, c->eps, 0.f, 0, 0, st));
+  } else {
+    IA_TRY(ia_ln_fwd(x, nullptr, nullptr, nullptr, s.t0, s.mean, s.rstd, w->ln1_g, w->ln1_b, M, H, c->eps, 0.f, 0, 0, st));
+    IA_TRY(ia_gemm_bf16(s.t0, 0, H, w->w_qkv, 0, H, s.qkv, 0, 3 * H, M, 3 * H, H, IA_EPI_BIAS, w->b_qkv, nullptr, 0, nullptr, 0, nullptr, 0, st));
+    IA_TRY(attn_fwd(c, s.qkv, key_mask, s.ctx, s.lse, scale, 0.f, 0, st));
+    // x1 = x + ctx Wo^T + b_o is formed by the LayerNorm kernel exactly as in ia_layer_fwd (same roundings: evaluation reproduces the
+    // training forward bit for bit when dropout is off); t1 receives x1, the fc2 epilogue's residual
+    IA_TRY(ia_gemm_bf16(s.ctx, 0, H, w->w_o, 0, H, s.t1, 0, H, M, H, H, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
+    IA_TRY(ia_ln_fwd(s.t1, w->b_o, x, s.t1, s.t0, s.mean, s.rstd, w->ln2_g, w->ln2_b, M, H, c->eps, 0.f, 0, 0, st));
+    IA_TRY(ia_gemm_bf16(s.t0, 0, H, w->w_fc1, 0, H, s.h, 0, I, M, I, H, IA_EPI_BIAS_GELU_ACT, w->b_fc1, nullptr, 0, nullptr, 0, nullptr, 0, st));
+    IA_TRY(ia_gemm_bf16(s.h, 0, I, w->w_fc2, 0, I, y, 0, H, M, H, I, IA_EPI_BIAS_ADD, w->b_fc2, s.t1, H, nullptr, 0, nullptr, 0, st));
+  }
+  return IA_OK;
+}
+
 extern "C" int ia_layer_bwd2(const ia_layer_cfg* c, const ia_layer_weights* w, const ia_layer_grads* g, const void* x,
                              const uint8_t* key_mask, const void* y, const void* stash, const void* dy, const void* dy2, void* dx, void* dx2,
                              void* scratch, size_t scratch_bytes, ia_stream_t st);

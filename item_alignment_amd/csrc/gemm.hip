@@ -30,7 +30,8 @@ namespace {
 constexpr int BK = 64;
 constexpr uint32_t OOB = 0xFFFFFFF0u;
 
-enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_ADD = 3, EPI_DGELU = 4, EPI_BIAS_ADD = 5, EPI_DGELU_CS = 6 };
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_ADD = 3, EPI_DGELU = 4, EPI_BIAS_ADD = 5, EPI_DGELU_CS = 6, EPI_BIAS_GELU_ACT = 7 };
+// EPI_BIAS_GELU_ACT: the forward-only form of EPI_BIAS_GELU (activation only: no derivative is evaluated or stored)
 
 struct GemmArgs {
   const bf16* A; const bf16* B; void* C; bf16* C2; const float* bias; const bf16* aux;
@@ -74,7 +75,7 @@ IA_DEV __amdgpu_buffer_rsrc_t rsrc_at(const bf16* base, uint64_t total_bytes, ui
 // v = 4 consecutive output columns n..n+3 of row m
 template <int EPI, bool OUTF32>
 IA_DEV void epi_store4(const GemmArgs& p, int m, int n, f32x4 v) {
-  if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_ADD) {
+  if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_ACT || EPI == EPI_BIAS_ADD) {
     const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
     v += b;
   }
@@ -90,6 +91,13 @@ IA_DEV void epi_store4(const GemmArgs& p, int m, int n, f32x4 v) {
       der[r] = f2bf(d[0]); der[r + 1] = f2bf(d[1]);
     }
     *reinterpret_cast<bf16x4*>(p.C2 + (size_t)m * p.ldc + n) = der;
+  }
+  if (EPI == EPI_BIAS_GELU_ACT) {
+#pragma unroll
+    for (int r = 0; r < 4; r += 2) {
+      const f32x2_t a = gelu_act_pair(f32x2_t{v[r], v[r + 1]});
+      v[r] = a[0]; v[r + 1] = a[1];
+    }
   }
   if (EPI == EPI_ADD || EPI == EPI_BIAS_ADD) {
     const bf16x4 a = *reinterpret_cast<const bf16x4*>(p.aux + (size_t)m * p.ldaux + n);
@@ -137,7 +145,7 @@ constexpr int epi_extra_stores() { return EPI == EPI_DGELU_CS ? 2 : 0; }     // 
 template <int EPI, bool OUTF32, bool PRE>
 IA_DEV void epi_store8(const GemmArgs& p, int m, int n, f32x4 lo, f32x4 hi, f32x4 pb0, f32x4 pb1, bf16x8 ax, float (&cs)[8]) {
   float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_ADD) {
+  if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_ACT || EPI == EPI_BIAS_ADD) {
     const f32x4 b0 = PRE ? pb0 : *reinterpret_cast<const f32x4*>(p.bias + n), b1 = PRE ? pb1 : *reinterpret_cast<const f32x4*>(p.bias + n + 4);
 #pragma unroll
     for (int r = 0; r < 4; ++r) { v[r] += b0[r]; v[4 + r] += b1[r]; }
@@ -153,6 +161,13 @@ IA_DEV void epi_store8(const GemmArgs& p, int m, int n, f32x4 lo, f32x4 hi, f32x
       der[r] = f2bf(d[0]); der[r + 1] = f2bf(d[1]);
     }
     gstore16(((p.dbg & 1024) ? reinterpret_cast<bf16*>(p.C) : p.C2) + (size_t)m * p.ldc + n, der);
+  }
+  if (EPI == EPI_BIAS_GELU_ACT) {
+#pragma unroll
+    for (int r = 0; r < 8; r += 2) {
+      const f32x2_t a = gelu_act_pair(f32x2_t{v[r], v[r + 1]});
+      v[r] = a[0]; v[r + 1] = a[1];
+    }
   }
   if (EPI == EPI_ADD || EPI == EPI_BIAS_ADD || EPI == EPI_DGELU || EPI == EPI_DGELU_CS) {
     const bf16x8 a = PRE ? ax : *reinterpret_cast<const bf16x8*>(p.aux + (size_t)m * p.ldaux + n);
@@ -623,7 +638,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs p) {
     const int wrow = li & 15, rrow = lane_e >> 3, c8 = lane_e & 7;
     // this wave's 128 x 64 part lies entirely inside C: no row / column guards, the store count of the tile is exact
     const bool full = m0 + 128 <= p.M && n0 + 64 <= p.N;
-    constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_ADD;
+    constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_ACT || EPI == EPI_BIAS_ADD;
     constexpr bool HAS_AUX = EPI == EPI_ADD || EPI == EPI_BIAS_ADD || EPI == EPI_DGELU || EPI == EPI_DGELU_CS;
     // Slice c (c = 0..15) = rows (c>>2)*32 + ((c>>1)&1)*16 + (c&1)*8 + rrow of this wave's part, the lane's 8 columns n0 + c8*8.
     // PRE (full parts): the bias - the same 8 columns for all slices - is read once per tile, and the aux operand runs AHEAD slices
@@ -1001,7 +1016,7 @@ IA_DEV void drain_half(const GemmArgs& p, f32x16 (&acc)[4][4], int m0, int n0, c
                        f32x4 bias_hi) {
   const int hh = lane_e >> 5, li = lane_e & 31;
   const int rrow = lane_e >> 3, c8 = lane_e & 7;
-  constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_ADD;
+  constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_ACT || EPI == EPI_BIAS_ADD;
   constexpr bool HAS_AUX = EPI == EPI_ADD || EPI == EPI_BIAS_ADD || EPI == EPI_DGELU || EPI == EPI_DGELU_CS;
   constexpr int AHEAD = 4;
   auto drain = [&](auto PREFETCHED) {
@@ -1135,7 +1150,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   int tile = first_tile;
   run(tile, true, acc, false);
   bool stores_in_flight = false;
-  constexpr bool HAS_BIAS_K = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_ADD;
+  constexpr bool HAS_BIAS_K = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_ACT || EPI == EPI_BIAS_ADD;
   while (true) {
     int bm, bn;
     coords(tile, bm, bn);
@@ -1318,7 +1333,7 @@ int launch(GemmArgs a, bool big, hipStream_t st) {
   // IA_GEMM_WIDE=0 / 1 forces one of them for A/B runs.
   static int wide = -1;
   if (wide < 0) { const char* e = getenv("IA_GEMM_WIDE"); wide = e ? atoi(e) : 2; }
-  constexpr bool heavy_epi = EPI == EPI_BIAS_GELU || EPI == EPI_DGELU || EPI == EPI_DGELU_CS;
+  constexpr bool heavy_epi = EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_ACT || EPI == EPI_DGELU || EPI == EPI_DGELU_CS;
   if (big && (wide == 1 || (wide == 2 && !heavy_epi))) {
     a.tiles_m = (a.M + t256::BM - 1) / t256::BM; a.tiles_n = (a.N + t256::BN - 1) / t256::BN;
     static bool attr_set_w = false;
@@ -1461,7 +1476,7 @@ static int gemm_core(const void* A, int a_kstrided, int lda, const void* B, int 
     const uint64_t wb = (b_kstrided ? slab : tile) * (uint64_t)ldb * 2 + (b_kstrided ? 0 : (uint64_t)K * 2);
     if (wa >= 0x7FFFFFF0ull || wb >= 0x7FFFFFF0ull) return IA_ERR_ARG;
   }
-  const bool needs_bias = epilogue == EPI_BIAS || epilogue == EPI_BIAS_GELU || epilogue == EPI_BIAS_ADD;
+  const bool needs_bias = epilogue == EPI_BIAS || epilogue == EPI_BIAS_GELU || epilogue == EPI_BIAS_GELU_ACT || epilogue == EPI_BIAS_ADD;
   const bool needs_aux = epilogue == EPI_ADD || epilogue == EPI_DGELU || epilogue == EPI_BIAS_ADD || epilogue == EPI_DGELU_CS;
   if (needs_bias && !bias) return IA_ERR_ARG;
   if (needs_aux && (!aux || (ldaux & 3))) return IA_ERR_ARG;
@@ -1472,6 +1487,7 @@ static int gemm_core(const void* A, int a_kstrided, int lda, const void* B, int 
       case EPI_NONE: return launch<false, false, EPI_NONE, false>(g, big, stream);
       case EPI_BIAS: return launch<false, false, EPI_BIAS, false>(g, big, stream);
       case EPI_BIAS_GELU: return launch<false, false, EPI_BIAS_GELU, false>(g, big, stream);
+      case EPI_BIAS_GELU_ACT: return launch<false, false, EPI_BIAS_GELU_ACT, false>(g, big, stream);
       case EPI_BIAS_ADD: return launch<false, false, EPI_BIAS_ADD, false>(g, big, stream);
       case EPI_ADD: return launch<false, false, EPI_ADD, false>(g, big, stream);
     }

@@ -134,19 +134,32 @@ class EncoderStackFn(torch.autograd.Function):
             for c in cfgs:
                 c.cu_seqlens, c.total_tokens = cu_seqlens.data_ptr(), x.shape[0]
         ctx.cu_seqlens = cu_seqlens
-        stash_bytes = lib.ia_layer_stash_bytes(C.byref(cfgs[0]))
-        stash = torch.empty((n if keep else 1) * stash_bytes, device=x.device, dtype=torch.uint8)
         outs, cur = [], x.contiguous()
         inputs = [cur]
         mp = ptr(key_mask)
-        for i in range(n):
-            y = torch.empty_like(cur)
-            sp = stash.data_ptr() + (i * stash_bytes if keep else 0)
-            check(lib.ia_layer_fwd(C.byref(cfgs[i]), C.byref(stack.weights(i)), cur.data_ptr(), mp, y.data_ptr(), sp, stream_ptr()),
-                  f"ia_layer_fwd[{i}]")
-            outs.append(y)
-            cur = y
-            inputs.append(cur)
+        if keep:
+            stash_bytes = lib.ia_layer_stash_bytes(C.byref(cfgs[0]))
+            stash = torch.empty(n * stash_bytes, device=x.device, dtype=torch.uint8)
+            for i in range(n):
+                y = torch.empty_like(cur)
+                check(lib.ia_layer_fwd(C.byref(cfgs[i]), C.byref(stack.weights(i)), cur.data_ptr(), mp, y.data_ptr(),
+                                       stash.data_ptr() + i * stash_bytes, stream_ptr()), f"ia_layer_fwd[{i}]")
+                outs.append(y)
+                cur = y
+                inputs.append(cur)
+        else:
+            # evaluation / prediction (no_grad: reference finetune_multimodal.py:470-563): forward-only layers -- nothing is written for
+            # a backward pass (no gelu' stream, no pre-LayerNorm sums) and one transient scratch serves the whole stack
+            stash_bytes, stash = 0, None
+            sbytes = lib.ia_layer_infer_scratch_bytes(C.byref(cfgs[0]))
+            scratch = torch.empty(sbytes, device=x.device, dtype=torch.uint8)
+            for i in range(n):
+                y = torch.empty_like(cur)
+                check(lib.ia_layer_fwd_infer(C.byref(cfgs[i]), C.byref(stack.weights(i)), cur.data_ptr(), mp, y.data_ptr(), scratch.data_ptr(),
+                                             sbytes, stream_ptr()), f"ia_layer_fwd_infer[{i}]")
+                outs.append(y)
+                cur = y
+            inputs = None
         ctx.stack, ctx.cfgs, ctx.stash, ctx.stash_bytes = stack, cfgs, stash, stash_bytes
         ctx.inputs, ctx.key_mask = inputs, key_mask
         if keep:

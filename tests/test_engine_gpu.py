@@ -82,6 +82,14 @@ def test_layer_fwd_bwd(gpu, B, L, nh, pre_ln, masked):
     _lib.check(lib.ia_layer_fwd(C.byref(cfg), C.byref(w), x.data_ptr(), _lib.ptr(mask), y.data_ptr(), stash.data_ptr(), st), "fwd")
     valid = mask.bool().view(-1) if mask is not None else torch.ones(M, dtype=torch.bool, device=gpu)
     assert rel(y[valid], yr.detach().view(M, H)[valid]) < 2e-2
+    # the forward-only layer (evaluation / prediction): the same output bit for bit, from a transient scratch
+    y_inf = torch.empty_like(y)
+    isz = lib.ia_layer_infer_scratch_bytes(C.byref(cfg))
+    assert 0 < isz < stash.numel()
+    iscr = torch.empty(isz, device=gpu, dtype=torch.uint8)
+    _lib.check(lib.ia_layer_fwd_infer(C.byref(cfg), C.byref(w), x.data_ptr(), _lib.ptr(mask), y_inf.data_ptr(), iscr.data_ptr(), isz, st), "fwd_infer")
+    assert torch.equal(y_inf[valid], y[valid])
+    assert lib.ia_layer_fwd_infer(C.byref(cfg), C.byref(w), x.data_ptr(), _lib.ptr(mask), y_inf.data_ptr(), iscr.data_ptr(), isz - 1, st) == -3
     scratch = torch.empty(lib.ia_layer_bwd_scratch_bytes(C.byref(cfg)), device=gpu, dtype=torch.uint8)
     dx = dy.clone().view(M, H)
     _lib.check(lib.ia_layer_bwd(C.byref(cfg), C.byref(w), C.byref(g), x.data_ptr(), _lib.ptr(mask), y.data_ptr(), stash.data_ptr(), dx.data_ptr(),
