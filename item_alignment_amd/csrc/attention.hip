@@ -1464,34 +1464,53 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_dkv_kernel(AttnArgs p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { kf[kb][j] = f2bf(-bf2f(kr[j])); vf[kb][j] = f2bf(-bf2f(vr[j])); }
   }
+  if (PRESCALE) {                                         // query tile 0 (stage 0) is pre-scaled here, see prescale() below
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      bf16x8* const qp = reinterpret_cast<bf16x8*>(smem + i * 4096 + wave * 1024 + lane * 16);
+      bf16x8 v = *qp;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) * p.sc);
+      *qp = v;
+    }
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                           // the K / V row slots (stages 1-2) are free for query tiles
   if (nqt > 1) stage_tile(S1{}, 1);
   f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
 
+  // Q <- bf16(Q * scale * log2 e) in place, each wave on the two 1-KiB pieces of a query tile it fetched itself: exactly the operand
+  // the forward and the dQ kernel multiply with K, so the P recomputed here is the P the saved log-sum-exp and delta belong to
+  // (round 3 scaled the K fragments instead: a different rounding of every score, P rows that no longer sum to one).  Tile 0 in the
+  // prologue; tile qt+1 between the two sub tiles of tile qt, where the matrix pipe is busy (between the wait and the barrier at the
+  // top of a tile the same work cost the ViT launch 130 us).
+  auto prescale = [&](int stage_base) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      bf16x8* const qp = reinterpret_cast<bf16x8*>(smem + stage_base + i * 4096 + wave * 1024 + lane * 16);
+      bf16x8 v = *qp;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) * sc);
+      *qp = v;
+    }
+  };
   auto tile_step = [&](auto SLOT_T, int qt) {
     constexpr int SB = decltype(SLOT_T)::value * KV_STAGE;
     using NEXT2 = std::integral_constant<int, (decltype(SLOT_T)::value + 2) % 3>;
     // query tile qt has landed for this wave (tile qt+1, issued behind it: 5 pieces, may still be in flight), then for everybody
     if (qt + 1 >= nqt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    if (PRESCALE) {
-      // Q <- bf16(Q * scale * log2 e) in place, each wave on the two 1-KiB pieces it fetched: exactly the operand the forward and
-      // the dQ kernel multiply with K, so the P recomputed here is the P the saved log-sum-exp and delta belong to (round 3 scaled
-      // the K fragments instead: a different rounding of every score, P rows that no longer sum to one)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        bf16x8* const qp = reinterpret_cast<bf16x8*>(smem + SB + i * 4096 + wave * 1024 + lane * 16);
-        bf16x8 v = *qp;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) * sc);
-        *qp = v;
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's pre-scaling writes into tile qt (below) are done
     __builtin_amdgcn_s_barrier();
     if (qt + 2 < nqt) stage_tile(NEXT2{}, qt + 2);
-    if (!active) return;
+    if (!active) {                                        // a wave without keys still owns DMA pieces of every query tile: pre-scale them
+      if (PRESCALE && qt + 1 < nqt) {
+        if (qt + 2 < nqt) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        prescale(((decltype(SLOT_T)::value + 1) % 3) * KV_STAGE);
+      }
+      return;
+    }
     if (DROPOUT) {      // row keys of this tile's 64 queries, one per lane (the wave's LDS operations complete in order: no barrier)
       s_rk[lane] = ia_rng_row(seed, stream_id, (uint32_t)(qt * 64 + lane));
       __builtin_amdgcn_wave_barrier();
@@ -1563,6 +1582,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_dkv_kernel(AttnArgs p) {
       dk0 = mfma(a1.a0(), sf[1], dk0); dk1 = mfma(a1.a1(), sf[1], dk1);
     };
     sub_tile(std::integral_constant<int, 0>{});
+    if (PRESCALE && qt + 1 < nqt) {
+      // tile qt+1 (issued a whole step ago) has landed for this wave: only the 5 pieces of tile qt+2, just issued, may be in flight
+      if (qt + 2 < nqt) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      prescale(((decltype(SLOT_T)::value + 1) % 3) * KV_STAGE);
+    }
     if (qt * 64 + 32 < Lq) sub_tile(std::integral_constant<int, 1>{});
   };
   {
