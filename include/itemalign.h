@@ -386,6 +386,23 @@ int ia_layer_bwd2(const ia_layer_cfg* cfg, const ia_layer_weights* w, const ia_l
                   const void* y, const void* stash, const void* dy, const void* dy2, void* dx, void* dx2, void* scratch,
                   size_t scratch_bytes, ia_stream_t stream);
 
+/* ---- data-parallel gradient exchange (pure data parallelism, one process per GPU; reference loop being sharded:
+ * finetune_multimodal.py:371-468).  RCCL over xGMI behind four calls, for hosts that bind only this header (the Python host of this
+ * repository uses torch.distributed, i.e. the same RCCL).  Rank 0 obtains an id and hands its IA_COMM_ID_BYTES bytes to the other
+ * ranks by any out-of-band means; every rank then calls ia_comm_init (collective).  ia_comm_allreduce_bucket sums `count` elements in
+ * place across the ranks, asynchronously on `stream` -- the caller launches it per gradient bucket as soon as the bucket's last
+ * gradient kernel has been enqueued on that stream (or on a side stream ordered behind it) and divides by the world size in its
+ * optimiser step (ia_adamw_flat's grad_scale).  RCCL is bound with dlopen at the first call (a copy already mapped into the process
+ * is reused); IA_ERR_UNSUPPORTED = no librccl, ia_comm_last_error() has the text.  (ABI 5) */
+#define IA_COMM_ID_BYTES 128
+#define IA_COMM_F32 0
+#define IA_COMM_BF16 1
+int ia_comm_unique_id(void* id_out);
+int ia_comm_init(const void* id, int rank, int world_size, void** comm_out);
+int ia_comm_allreduce_bucket(void* comm, void* buf, size_t count, int dtype, ia_stream_t stream);
+int ia_comm_finalize(void* comm);
+const char* ia_comm_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -122,6 +122,11 @@ SIGNATURES = {
     "ia_layer_stash_bytes": (sz, [C.POINTER(LayerCfg)]),
     "ia_layer_bwd_scratch_bytes": (sz, [C.POINTER(LayerCfg)]),
     "ia_layer_fwd": (i32, [C.POINTER(LayerCfg), C.POINTER(LayerWeights), vp, vp, vp, vp, vp]),
+    "ia_comm_unique_id": (i32, [vp]),
+    "ia_comm_init": (i32, [vp, i32, i32, C.POINTER(vp)]),
+    "ia_comm_allreduce_bucket": (i32, [vp, vp, sz, i32, vp]),
+    "ia_comm_finalize": (i32, [vp]),
+    "ia_comm_last_error": (C.c_char_p, []),
     "ia_layer_infer_scratch_bytes": (sz, [C.POINTER(LayerCfg)]),
     "ia_layer_fwd_infer": (i32, [C.POINTER(LayerCfg), C.POINTER(LayerWeights), vp, vp, vp, vp, sz, vp]),
     "ia_layer_bwd": (i32, [C.POINTER(LayerCfg), C.POINTER(LayerWeights), C.POINTER(LayerGrads), vp, vp, vp, vp, vp, vp, vp, sz, vp]),

@@ -116,3 +116,32 @@ def test_two_ranks_equal_one_rank_on_the_global_batch(gpu, kind, bf16):
     # (a direct parameter comparison would be ill-conditioned: Adam turns a sign flip of a near-zero gradient into a full step)
     got = (l0 + l1) / 2
     assert np.allclose(got, ref_losses.numpy(), rtol=5e-3, atol=5e-4), (got, ref_losses)
+
+
+def test_comm_cabi_world_size_one(gpu):
+    """ia_comm_* (RCCL behind the C ABI): id, init, in-place bucket all-reduce on a stream, finalize.  A one-GPU
+    box allows world size 1 only (RCCL refuses two ranks on one device): the sum over one rank is the identity, for fp32 and bf16
+    buckets, and the call is stream-ordered behind the kernel that produced the bucket."""
+    import ctypes as C
+    from item_alignment_amd import _lib
+    lib = _lib.load()
+    ident = (C.c_char * 128)()
+    rc = lib.ia_comm_unique_id(ident)
+    assert rc == 0, lib.ia_comm_last_error()
+    comm = C.c_void_p()
+    assert lib.ia_comm_init(ident, 0, 1, C.byref(comm)) == 0, lib.ia_comm_last_error()
+    assert comm.value
+    st = torch.cuda.current_stream().cuda_stream
+    g32 = torch.randn(1 << 20, device=gpu)
+    want32 = g32.clone()
+    assert lib.ia_comm_allreduce_bucket(comm, g32.data_ptr(), g32.numel(), 0, st) == 0, lib.ia_comm_last_error()
+    g16 = torch.randn(4096 + 8, device=gpu).to(torch.bfloat16)
+    want16 = g16.clone()
+    assert lib.ia_comm_allreduce_bucket(comm, g16.data_ptr(), g16.numel(), 1, st) == 0, lib.ia_comm_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(g32, want32) and torch.equal(g16, want16)
+    # argument errors are reported, not passed to RCCL
+    assert lib.ia_comm_allreduce_bucket(comm, g32.data_ptr(), 0, 0, st) == -1
+    assert lib.ia_comm_allreduce_bucket(comm, g32.data_ptr(), 16, 7, st) == -1
+    assert lib.ia_comm_init(ident, 1, 1, C.byref(C.c_void_p())) == -1
+    assert lib.ia_comm_finalize(comm) == 0
