@@ -55,12 +55,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[i][j] += bf2f(rv[j]);
       }
-      if (z_out) {
+      {
+        // statistics are taken on the bf16-rounded z so fwd and bwd see the same x-hat -- also when z is not stored (forward-only
+        // layers, ia_layer_fwd_infer): evaluation then reproduces the training forward bit for bit
         bf16x8 zv;
 #pragma unroll
         for (int j = 0; j < 8; ++j) zv[j] = f2bf(v[i][j]);
-        *reinterpret_cast<bf16x8*>(z_out + (size_t)row * H + col) = zv;
-        // statistics are taken on the stored (bf16-rounded) z so fwd and bwd see the same x-hat
+        if (z_out) *reinterpret_cast<bf16x8*>(z_out + (size_t)row * H + col) = zv;
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[i][j] = bf2f(zv[j]);
       }
