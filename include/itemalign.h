@@ -360,6 +360,12 @@ typedef struct {
    * key_mask argument is ignored (every token of a sequence is attendable).  NULL / 0: padded [B, L] rows. */
   const int* cu_seqlens;
   int total_tokens;
+  /* pre-LN (ViT) stacks, backward only (ABI 5): the b_fc2 gradient of a block is the column sum of its incoming gradient dy, i.e. of
+   * the input gradient dx the block ABOVE has just produced.  dx_colsum_out != NULL: this block's last LayerNorm backward also adds
+   * the column sums of its dx into that fp32 [H] vector (pass the b_fc2 gradient slot of the block below); dy_colsum_done != 0: the
+   * block above did that for this block's dy, so the separate column-sum pass over dy is skipped.  Zero / NULL = round-3 behaviour. */
+  float* dx_colsum_out;
+  int dy_colsum_done;
 } ia_layer_cfg;
 
 /* per-layer activation stash (saved by forward, read by backward) and shared backward scratch */

@@ -25,7 +25,8 @@ class LayerGrads(C.Structure):
 
 class LayerCfg(C.Structure):
     _fields_ = [("B", i32), ("L", i32), ("H", i32), ("I", i32), ("nh", i32), ("pre_ln", i32), ("eps", f32),
-                ("hidden_drop", f32), ("attn_drop", f32), ("seed", u32), ("layer_id", u32), ("cu_seqlens", vp), ("total_tokens", i32)]
+                ("hidden_drop", f32), ("attn_drop", f32), ("seed", u32), ("layer_id", u32), ("cu_seqlens", vp), ("total_tokens", i32),
+                ("dx_colsum_out", vp), ("dy_colsum_done", i32)]
 
 
 # name -> (restype, argtypes); must list every symbol include/itemalign.h declares

@@ -247,7 +247,7 @@ extern "C" int ia_layer_bwd2(const ia_layer_cfg* c, const ia_layer_weights* w, c
     else
       IA_TRY(ia_gemm_bf16(k.gqkv, 0, 3 * H, w->w_qkv, 1, H, dx, 0, H, M, H, 3 * H, IA_EPI_ADD, nullptr, dz1buf, H, nullptr, 0, nullptr, 0, st));
   } else {
-    IA_TRY(ia_colsum(dy, H, M, H, g->b_fc2, 1, k.ws, k.ws_bytes, st));
+    if (!c->dy_colsum_done) IA_TRY(ia_colsum(dy, H, M, H, g->b_fc2, 1, k.ws, k.ws_bytes, st));
     IA_TRY(ia_gemm_bf16(dy, 1, H, s.hact, 1, I, g->w_fc2, 1, I, H, I, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
     IA_TRY(ia_gemm_bf16(dy, 0, H, w->w_fc2, 1, I, k.gI, 0, I, M, I, H, IA_EPI_DGELU_COLSUM, nullptr, s.hpre, I, g->b_fc1, 0, k.ws, k.ws_bytes, st));
     IA_TRY(ia_gemm_bf16(k.gI, 1, I, s.t2, 1, H, g->w_fc1, 1, H, I, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
@@ -260,7 +260,9 @@ extern "C" int ia_layer_bwd2(const ia_layer_cfg* c, const ia_layer_weights* w, c
     IA_TRY(attn_bwd(c, s.qkv, key_mask, s.ctx, k.g2, s.lse, k.delta, k.gqkv, g->b_qkv, k.ws, k.ws_bytes, scale, 0.f, 0, st));
     IA_TRY(ia_gemm_bf16(k.gqkv, 1, 3 * H, s.t0, 1, H, g->w_qkv, 1, H, 3 * H, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
     IA_TRY(ia_gemm_bf16(k.gqkv, 0, 3 * H, w->w_qkv, 1, H, k.g0, 0, H, M, H, 3 * H, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
-    IA_TRY(ia_ln_bwd(k.g0, k.g1, x, s.mean1, s.rstd1, w->ln1_g, dx, nullptr, g->ln1_g, g->ln1_b, nullptr, M, H, 0.f, 0, 0, k.ws,
+    // dx = LN1'(g0) + g1 is the incoming gradient of the block below: its column sums (that block's fc2 bias gradient) come out of
+    // this kernel's partial sums instead of a separate pass over [M, H] there (cfg->dx_colsum_out)
+    IA_TRY(ia_ln_bwd(k.g0, k.g1, x, s.mean1, s.rstd1, w->ln1_g, dx, nullptr, g->ln1_g, g->ln1_b, c->dx_colsum_out, M, H, 0.f, 0, 0, k.ws,
                      k.ws_bytes, 1, st));
   }
   return IA_OK;

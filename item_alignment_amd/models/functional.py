@@ -174,6 +174,7 @@ class EncoderStackFn(torch.autograd.Function):
         scratch = torch.empty(scratch_bytes, device=ctx.stash.device, dtype=torch.uint8)
         mp = ptr(ctx.key_mask)
         dy, dy2buf, have_dy2 = None, None, False
+        colsum_done = False
         left = _pending_uses.get(id(stack), 1) - 1
         _pending_uses[id(stack)] = left
         for i in reversed(range(n)):
@@ -189,6 +190,14 @@ class EncoderStackFn(torch.autograd.Function):
             split = not cfgs[i].pre_ln and i > 0
             if split and dy2buf is None:
                 dy2buf = torch.empty_like(dy)
+            if cfgs[i].pre_ln:
+                # the fc2 bias gradient of block i-1 = column sums of this block's dx: taken from this block's last LayerNorm backward
+                # (ia_layer_cfg.dx_colsum_out) unless a tapped hidden state adds another gradient to that tensor in between
+                slot = stack.grads(i - 1).b_fc2 if i > 0 else None
+                below = i > 0 and grads[i - 1] is None and bool(slot)
+                cfgs[i].dx_colsum_out = slot if below else None
+                cfgs[i].dy_colsum_done = int(colsum_done)
+                colsum_done = below
             check(lib.ia_layer_bwd2(C.byref(cfgs[i]), C.byref(stack.weights(i)), C.byref(stack.grads(i)), x.data_ptr(), mp,
                                     ctx.inputs[i + 1].data_ptr(), ctx.stash.data_ptr() + i * ctx.stash_bytes, dy.data_ptr(),
                                     dy2buf.data_ptr() if have_dy2 else None, dy.data_ptr(), dy2buf.data_ptr() if split else None,

@@ -115,6 +115,24 @@ def test_layer_fwd_bwd(gpu, B, L, nh, pre_ln, masked):
         assert rel(both, dx) < 3e-2                            # bf16 rounding of the split (da + db) and of the two-term sums
         for k in P32:
             assert cos(G2[k], Pref[k].grad) > 0.995, (k, cos(G2[k], Pref[k].grad))
+    if pre_ln:
+        # the fc2 bias gradient hand-over of a ViT stack: the block emits the column sums of its dx (= the block below's dy) out of its
+        # last LayerNorm backward, and a block told that its dy was summed that way skips the column-sum pass (b_fc2 untouched)
+        G3 = {k: torch.zeros_like(v) for k, v in P32.items()}
+        g3 = LayerGrads()
+        for k in P32:
+            setattr(g3, k, G3[k].data_ptr())
+        below = torch.full((H,), 0.25, device=gpu, dtype=torch.float32)
+        cfg3 = LayerCfg(B=B, L=L, H=H, I=I, nh=nh, pre_ln=1, eps=eps, hidden_drop=0.0, attn_drop=0.0, seed=1, layer_id=0,
+                        dx_colsum_out=below.data_ptr(), dy_colsum_done=1)
+        dx3 = dy.clone().view(M, H)
+        _lib.check(lib.ia_layer_bwd(C.byref(cfg3), C.byref(w), C.byref(g3), x.data_ptr(), _lib.ptr(mask), y.data_ptr(), stash.data_ptr(),
+                                    dx3.data_ptr(), dx3.data_ptr(), scratch.data_ptr(), scratch.numel(), st), "bwd (column-sum hand-over)")
+        torch.cuda.synchronize()
+        assert torch.equal(dx3, dx)
+        want_cs = 0.25 + dx.float().sum(0)
+        assert (below - want_cs).abs().max().item() <= 2e-3 * (1.0 + want_cs.abs().max().item())
+        assert G3["b_fc2"].abs().max().item() == 0.0 and torch.equal(G3["w_fc2"], G["w_fc2"])
     for k in P32:
         want = Pref[k].grad
         assert torch.isfinite(G[k]).all(), k
