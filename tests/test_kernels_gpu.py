@@ -948,3 +948,34 @@ def test_attention_bench_shapes_with_dropout_stay_finite(gpu, B, L, nh):
         dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, B, L, nh, key_mask=mask, drop_p=0.1, seed=it + 1)
         assert torch.isfinite(ctx).all().item() and torch.isfinite(dqkv).all().item() and torch.isfinite(lse).all().item(), it
         assert dqkv.float().abs().max().item() < 1e4 and ctx.float().abs().max().item() < 1e2, it
+
+
+@pytest.mark.parametrize("B,N,K,act", [(200, 100, 72, 1), (512, 1024, 768, 0), (64, 8, 130, 1), (3, 40, 24, 1)])
+def test_linear_small_tiled_and_per_output_paths(gpu, B, N, K, act):
+    """ia_linear_small_fwd / bwd (fp32 heads; reference base.py:139-157, 530): the tiled kernels that take over from 64 rows up (the
+    image-CLS projection sees one row per image) and the one-output-per-thread kernels below that, against torch fp32 autograd;
+    dW / db accumulate."""
+    from item_alignment_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * 7 + N)
+    x = torch.randn((B, K), generator=g).to(gpu)
+    W = (torch.randn((N, K), generator=g) * 0.1).to(gpu)
+    b = (torch.randn((N,), generator=g) * 0.1).to(gpu)
+    dy = torch.randn((B, N), generator=g).to(gpu)
+    st = torch.cuda.current_stream().cuda_stream
+    y = torch.empty((B, N), device=gpu)
+    _lib.check(lib.ia_linear_small_fwd(x.data_ptr(), K, W.data_ptr(), b.data_ptr(), y.data_ptr(), B, N, K, act, st), "fwd")
+    xr, Wr, br = x.clone().requires_grad_(True), W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    pre = xr @ Wr.t() + br
+    yr = torch.tanh(pre) if act else pre
+    assert rel_err(y, yr.detach()) < 1e-5
+    yr.backward(dy)
+    dx = torch.empty_like(x)
+    dW = torch.full_like(W, 0.5)
+    db = torch.full_like(b, 0.25)
+    _lib.check(lib.ia_linear_small_bwd(dy.data_ptr(), y.data_ptr(), x.data_ptr(), K, W.data_ptr(), dx.data_ptr(), K, dW.data_ptr(), db.data_ptr(),
+                                       B, N, K, act, st), "bwd")
+    torch.cuda.synchronize()
+    assert rel_err(dx, xr.grad) < 1e-4
+    assert rel_err(dW - 0.5, Wr.grad) < 1e-4
+    assert rel_err(db - 0.25, br.grad) < 1e-4
