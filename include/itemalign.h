@@ -37,7 +37,7 @@ const char* ia_strerror(int code);
 /* Bumped whenever an entry point is added or the meaning of an argument / output changes (round 2 changed what IA_EPI_BIAS_GELU
  * stores in C2 and what IA_EPI_DGELU expects in aux): a caller built against another header must not run on this library.
  * item_alignment_amd/_lib.py refuses to load a library whose version differs from the one it was written for. */
-#define IA_ABI_VERSION 5
+#define IA_ABI_VERSION 6
 int ia_abi_version(void);
 
 /* ---- GEMM: torch.nn.Linear forward / dgrad / wgrad (src/models/text.py:1241 -> RobertaLayer dense
@@ -56,6 +56,12 @@ int ia_abi_version(void);
 int ia_gemm_bf16(const void* A, int a_kstrided, int lda, const void* B, int b_kstrided, int ldb, void* C, int c_is_f32, int ldc,
                  int M, int N, int K, int epilogue, const float* bias, const void* aux, int ldaux, void* C2, int accumulate,
                  void* workspace, size_t workspace_bytes, ia_stream_t stream);
+/* IA_EPI_BIAS GEMM with k-contiguous operands and bf16 output whose first scaled_cols columns (a multiple of 128) leave as
+ * (acc + bias) * col_scale: the fused QKV projection of an encoder layer (RobertaSelfAttention.query/key/value, src/models/text.py:1241;
+ * timm Attention.qkv) handing q * softmax scale * log2(e) to the ia_attn_*_ps kernels below -- the division by sqrt(d) of the reference
+ * (attention_scores / math.sqrt(head size)) moved in front of the one bf16 rounding of q (ABI 6) */
+int ia_gemm_bf16_qscale(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias,
+                        int scaled_cols, float col_scale, ia_stream_t stream);
 /* fp32-output (weight-gradient) GEMMs cut K across workgroups when given this much scratch; partial sums are
  * combined in a fixed order (deterministic).  workspace may be NULL (no split).
  * Weight-gradient form (A and B k-strided, fp32 C, IA_EPI_NONE): a non-NULL C2 (fp32 [M]) += sum_k A[k][m], i.e. the bias
@@ -104,6 +110,14 @@ size_t ia_attn_bwd_bias_workspace_bytes(int B, int nh, int L);
 int ia_attn_bwd_bias(const void* q, const void* k, const void* v, int ld_qkv, const uint8_t* key_mask, const void* out, const void* d_out,
                      int ld_o, const float* lse2, float* delta, void* dq, void* dk, void* dv, int ld_dqkv, float* dbias, void* workspace,
                      size_t workspace_bytes, int B, int nh, int L, float scale, float drop_p, uint32_t seed, ia_stream_t stream);
+
+/* The same three on a projection whose q columns were written by ia_gemm_bf16_qscale (q * scale * log2 e, bf16): no kernel scales q again,
+ * dq is still the gradient of the unscaled q (what the projection's dgrad / wgrad consume).  `scale` keeps its meaning. (ABI 6) */
+int ia_attn_fwd_ps(const void* q, const void* k, const void* v, int ld_qkv, const uint8_t* key_mask, void* out, int ld_o, float* lse2,
+                   int B, int nh, int L, float scale, float drop_p, uint32_t seed, ia_stream_t stream);
+int ia_attn_bwd_bias_ps(const void* q, const void* k, const void* v, int ld_qkv, const uint8_t* key_mask, const void* out, const void* d_out,
+                        int ld_o, const float* lse2, float* delta, void* dq, void* dk, void* dv, int ld_dqkv, float* dbias, void* workspace,
+                        size_t workspace_bytes, int B, int nh, int L, float scale, float drop_p, uint32_t seed, ia_stream_t stream);
 
 /* General form (cross-attention and multi-query attention of the CoCa multimodal layers, src/models/multimodal.py:590-616
  * ParallelTransformerBlock and :665-706 CrossAttention): Lq queries attend to Lk keys per (sequence, head).  q / out /
@@ -318,6 +332,12 @@ int ia_attn_fwd_varlen(const void* q, const void* k, const void* v, int ld_qkv, 
 int ia_attn_bwd_varlen(const void* q, const void* k, const void* v, int ld_qkv, const int* cu_seqlens, int total_tokens, const void* out,
                        const void* d_out, int ld_o, const float* lse2, float* delta, void* dq, void* dk, void* dv, int ld_dqkv, int B, int nh,
                        int Lmax, float scale, float drop_p, uint32_t seed, ia_stream_t stream);
+
+int ia_attn_fwd_varlen_ps(const void* q, const void* k, const void* v, int ld_qkv, const int* cu_seqlens, int total_tokens, void* out, int ld_o,
+                          float* lse2, int B, int nh, int Lmax, float scale, float drop_p, uint32_t seed, ia_stream_t stream);
+int ia_attn_bwd_varlen_ps(const void* q, const void* k, const void* v, int ld_qkv, const int* cu_seqlens, int total_tokens, const void* out,
+                          const void* d_out, int ld_o, const float* lse2, float* delta, void* dq, void* dk, void* dv, int ld_dqkv, int B, int nh,
+                          int Lmax, float scale, float drop_p, uint32_t seed, ia_stream_t stream);
 
 /* ---- optimiser (torch.optim.AdamW, finetune_multimodal.py:296-308,460-468) */
 int ia_adamw_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, const void* chunk_table,

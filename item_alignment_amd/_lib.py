@@ -49,6 +49,9 @@ SIGNATURES = {
     "ia_attn_bwd": (i32, [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, u32, vp]),
     "ia_attn_bwd_bias_workspace_bytes": (sz, [i32, i32, i32]),
     "ia_attn_bwd_bias": (i32, [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, sz, i32, i32, i32, f32, f32, u32, vp]),
+    "ia_attn_fwd_ps": (i32, [vp, vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, f32, f32, u32, vp]),
+    "ia_attn_bwd_bias_ps": (i32, [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, sz, i32, i32, i32, f32, f32, u32, vp]),
+    "ia_gemm_bf16_qscale": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, i32, f32, vp]),
     "ia_attn_fwd_x": (i32, [vp, i32, vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, f32, f32, u32, vp]),
     "ia_attn_bwd_x": (i32, [vp, i32, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, f32, f32, u32, vp]),
     "ia_rotary_split_fwd": (i32, [vp, i32, vp, vp, i32, i32, i32, vp]),
@@ -114,6 +117,8 @@ SIGNATURES = {
     "ia_pair_head_ce_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "ia_attn_fwd_varlen": (i32, [vp, vp, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, f32, f32, u32, vp]),
     "ia_attn_bwd_varlen": (i32, [vp, vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, u32, vp]),
+    "ia_attn_fwd_varlen_ps": (i32, [vp, vp, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, f32, f32, u32, vp]),
+    "ia_attn_bwd_varlen_ps": (i32, [vp, vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, u32, vp]),
     "ia_span_mean_fwd": (i32, [vp, i32, vp, vp, i32, i32, vp]),
     "ia_span_mean_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "ia_pair_head_ce_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
@@ -137,7 +142,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 5      # = IA_ABI_VERSION of include/itemalign.h (tests/test_cabi_symbols.py keeps the two in step)
+ABI_VERSION = 6      # = IA_ABI_VERSION of include/itemalign.h (tests/test_cabi_symbols.py keeps the two in step)
 
 
 class ItemAlignError(RuntimeError):

@@ -40,6 +40,8 @@ struct AttnArgs {
   uint32_t q_bytes, kv_bytes, o_bytes;
   float sc;                                       // softmax scale * log2(e)
   float scale;                                    // softmax scale
+  int q_prescaled;                                // q rows already hold q * sc rounded to bf16 (ia_gemm_bf16_qscale): the round-3/4
+                                                  // kernels skip their own pre-scaling; dq stays dL/dq of the UNSCALED q
   uint32_t thr16; float inv_keep; uint32_t seed;
   float* cs_part;                                 // backward, optional: [b*ntile + tile][3*nh*64] fp32 column sums of this workgroup's
                                                   // dq | dk | dv rows (the QKV bias gradient, summed over rows by ia_sum_rows_f32); null = off
@@ -651,7 +653,7 @@ __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void attn_fwd3_kernel(AttnArg
     for (int kb = 0; kb < 4; ++kb) {
       const bf16x8 raw = frag_b128(smem + (qb ? QX_OFF : Q_OFF) + wave * 4096, lq, kb * 2 + hh);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) qf[qb][kb][j] = PRESCALE ? f2bf(bf2f(raw[j]) * p.sc) : raw[j];
+      for (int j = 0; j < 8; ++j) qf[qb][kb][j] = (PRESCALE && !p.q_prescaled) ? f2bf(bf2f(raw[j]) * p.sc) : raw[j];
     }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -1078,7 +1080,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_dq_kernel(AttnArgs p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       dlt += bf2f(ov[j]) * bf2f(gf[kb][j]);
-      qf[kb][j] = PRESCALE ? f2bf(bf2f(raw[j]) * p.sc) : raw[j];
+      qf[kb][j] = (PRESCALE && !p.q_prescaled) ? f2bf(bf2f(raw[j]) * p.sc) : raw[j];
     }
   }
   dlt += swap32(dlt);
@@ -1464,7 +1466,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_dkv_kernel(AttnArgs p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { kf[kb][j] = f2bf(-bf2f(kr[j])); vf[kb][j] = f2bf(-bf2f(vr[j])); }
   }
-  if (PRESCALE) {                                         // query tile 0 (stage 0) is pre-scaled here, see prescale() below
+  const bool scale_q = PRESCALE && !p.q_prescaled;        // q arrives pre-scaled from the QKV projection: nothing to do per tile
+  if (scale_q) {                                          // query tile 0 (stage 0) is pre-scaled here, see prescale() below
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       bf16x8* const qp = reinterpret_cast<bf16x8*>(smem + i * 4096 + wave * 1024 + lane * 16);
@@ -1504,7 +1507,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_dkv_kernel(AttnArgs p) {
     __builtin_amdgcn_s_barrier();
     if (qt + 2 < nqt) stage_tile(NEXT2{}, qt + 2);
     if (!active) {                                        // a wave without keys still owns DMA pieces of every query tile: pre-scale them
-      if (PRESCALE && qt + 1 < nqt) {
+      if (scale_q && qt + 1 < nqt) {
         if (qt + 2 < nqt) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         prescale(((decltype(SLOT_T)::value + 1) % 3) * KV_STAGE);
@@ -1582,7 +1585,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_dkv_kernel(AttnArgs p) {
       dk0 = mfma(a1.a0(), sf[1], dk0); dk1 = mfma(a1.a1(), sf[1], dk1);
     };
     sub_tile(std::integral_constant<int, 0>{});
-    if (PRESCALE && qt + 1 < nqt) {
+    if (scale_q && qt + 1 < nqt) {
       // tile qt+1 (issued a whole step ago) has landed for this wave: only the 5 pieces of tile qt+2, just issued, may be in flight
       if (qt + 2 < nqt) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1767,11 +1770,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnArgs p) {
   auto prep = [&](int it, int j, int slot) {
     char* const sl = smem + RING_OFF + slot * SLOT;
     if (wave < 4) {
-      bf16x8* const qp = reinterpret_cast<bf16x8*>(sl + SL_Q + wave * 1024 + lane * 16);
-      bf16x8 v = *qp;
+      if (!p.q_prescaled) {
+        bf16x8* const qp = reinterpret_cast<bf16x8*>(sl + SL_Q + wave * 1024 + lane * 16);
+        bf16x8 v = *qp;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = f2bf(bf2f(v[i]) * p.sc);
-      *qp = v;
+        for (int i = 0; i < 8; ++i) v[i] = f2bf(bf2f(v[i]) * p.sc);
+        *qp = v;
+      }
       if (DROPOUT && wave == 1 && lane < 32)
         *reinterpret_cast<uint32_t*>(sl + SL_RK + lane * 4) = ia_rng_row(p.seed, (uint32_t)it, (uint32_t)(j * 32 + lane));
     } else {
@@ -2102,11 +2107,11 @@ int bwd_version() {
   return v;
 }
 template <bool D> void launch_dkv(const AttnArgs& a, dim3 grid, hipStream_t st) {
-  if (bwd_version() & 2) hipLaunchKernelGGL(attn_bwd3_dkv_kernel<D>, grid, dim3(256), 0, st, a);
+  if ((bwd_version() & 2) || a.q_prescaled) hipLaunchKernelGGL(attn_bwd3_dkv_kernel<D>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(attn_bwd_dkv_kernel<D>, grid, dim3(256), 0, st, a);
 }
 template <bool D> void launch_dq(const AttnArgs& a, dim3 grid, hipStream_t st) {
-  if (bwd_version() & 1) hipLaunchKernelGGL(attn_bwd3_dq_kernel<D>, grid, dim3(256), 0, st, a);
+  if ((bwd_version() & 1) || a.q_prescaled) hipLaunchKernelGGL(attn_bwd3_dq_kernel<D>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, grid, dim3(256), 0, st, a);
 }
 // The fused backward serves plain self-attention (one length for queries and keys, padded rows) of 33 .. 256 tokens
@@ -2127,7 +2132,7 @@ int fwd_version() {
 void launch_fwd(const AttnArgs& a, dim3 grid, hipStream_t stream) {
   const dim3 blk(256);
   const int v = fwd_version();
-  if (v == 2) {
+  if (v == 2 && !a.q_prescaled) {                        // (the round-2 kernels multiply every score by sc themselves)
     if (a.thr16) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, blk, 0, stream, a);
     else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, blk, 0, stream, a);
   } else if (v == 3 || (v != 4 && ((a.Lq - 1) & 255) < 128)) {
@@ -2148,7 +2153,7 @@ void launch_fwd(const AttnArgs& a, dim3 grid, hipStream_t stream) {
 // ld_o), k / v rows are b*Lk + j (stride ld_kv); head h sits at column h*64 of each.  Multi-query attention (one K/V
 // head shared by all query heads, reference multimodal.py:590-616) is the nh = 1 case with the query heads folded
 // into rows: q viewed as [B, n*heads, 64] (ld_q = 64), Lq = n*heads.  key_mask is [B, Lk].
-extern "C" int ia_attn_fwd_x(const void* q, int ld_q, const void* k, const void* v, int ld_kv, const uint8_t* key_mask, void* out,
+static int attn_fwd_impl(int q_prescaled, const void* q, int ld_q, const void* k, const void* v, int ld_kv, const uint8_t* key_mask, void* out,
                              int ld_o, float* lse2, int B, int nh, int Lq, int Lk, float scale, float drop_p, uint32_t seed,
                              hipStream_t stream) {
   (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
@@ -2156,10 +2161,18 @@ extern "C" int ia_attn_fwd_x(const void* q, int ld_q, const void* k, const void*
   AttnArgs a{};
   int rc = fill_args(a, B, nh, Lq, Lk, ld_q, ld_kv, ld_o, scale, drop_p, seed);
   if (rc) return rc;
+  if (q_prescaled && !fwd3::PRESCALE) return IA_ERR_ARG;
+  a.q_prescaled = q_prescaled;
   a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.out = (bf16*)out; a.mask = key_mask; a.lse2 = lse2;
   dim3 grid(((Lq + 127) / 128) * nh * B), blk(256);
   launch_fwd(a, grid, stream);
   return ia_check_launch();
+}
+
+extern "C" int ia_attn_fwd_x(const void* q, int ld_q, const void* k, const void* v, int ld_kv, const uint8_t* key_mask, void* out,
+                             int ld_o, float* lse2, int B, int nh, int Lq, int Lk, float scale, float drop_p, uint32_t seed,
+                             hipStream_t stream) {
+  return attn_fwd_impl(0, q, ld_q, k, v, ld_kv, key_mask, out, ld_o, lse2, B, nh, Lq, Lk, scale, drop_p, seed, stream);
 }
 
 // delta: caller-provided scratch of B*nh*Lq floats (filled by the dQ kernel, read by the dK/dV kernel).
@@ -2197,6 +2210,13 @@ extern "C" int ia_attn_fwd(const void* q, const void* k, const void* v, int ld_q
   return ia_attn_fwd_x(q, ld_qkv, k, v, ld_qkv, key_mask, out, ld_o, lse2, B, nh, L, L, scale, drop_p, seed, stream);
 }
 
+// ia_attn_fwd on a projection whose q columns already hold q * scale * log2(e) rounded to bf16 (ia_gemm_bf16_qscale): no kernel of the
+// forward / backward pair scales q again, so all of them exponentiate bit-identical products
+extern "C" int ia_attn_fwd_ps(const void* q, const void* k, const void* v, int ld_qkv, const uint8_t* key_mask, void* out, int ld_o,
+                              float* lse2, int B, int nh, int L, float scale, float drop_p, uint32_t seed, hipStream_t stream) {
+  return attn_fwd_impl(1, q, ld_qkv, k, v, ld_qkv, key_mask, out, ld_o, lse2, B, nh, L, L, scale, drop_p, seed, stream);
+}
+
 extern "C" int ia_attn_bwd(const void* q, const void* k, const void* v, int ld_qkv, const uint8_t* key_mask, const void* out,
                            const void* d_out, int ld_o, const float* lse2, float* delta, void* dq, void* dk, void* dv,
                            int ld_dqkv, int B, int nh, int L, float scale, float drop_p, uint32_t seed, hipStream_t stream) {
@@ -2212,10 +2232,10 @@ extern "C" size_t ia_attn_bwd_bias_workspace_bytes(int B, int nh, int L) {
   return (size_t)B * ((L + 127) / 128) * 3 * nh * 64 * sizeof(float);
 }
 
-extern "C" int ia_attn_bwd_bias(const void* q, const void* k, const void* v, int ld_qkv, const uint8_t* key_mask, const void* out,
-                                const void* d_out, int ld_o, const float* lse2, float* delta, void* dq, void* dk, void* dv, int ld_dqkv,
-                                float* dbias, void* workspace, size_t workspace_bytes, int B, int nh, int L, float scale, float drop_p,
-                                uint32_t seed, hipStream_t stream) {
+static int attn_bwd_bias_impl(int q_prescaled, const void* q, const void* k, const void* v, int ld_qkv, const uint8_t* key_mask, const void* out,
+                              const void* d_out, int ld_o, const float* lse2, float* delta, void* dq, void* dk, void* dv, int ld_dqkv,
+                              float* dbias, void* workspace, size_t workspace_bytes, int B, int nh, int L, float scale, float drop_p,
+                              uint32_t seed, hipStream_t stream) {
   (void)hipGetLastError();
   if (!q || !k || !v || !out || !d_out || !lse2 || !delta || !dq || !dk || !dv || !dbias) return IA_ERR_ARG;
   if (!workspace || workspace_bytes < ia_attn_bwd_bias_workspace_bytes(B, nh, L)) return IA_ERR_WORKSPACE;
@@ -2227,6 +2247,8 @@ extern "C" int ia_attn_bwd_bias(const void* q, const void* k, const void* v, int
   a.mask = key_mask; a.lse2 = const_cast<float*>(lse2); a.delta = delta;
   a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.ld_dq = ld_dqkv; a.ld_dkv = ld_dqkv;
   a.cs_part = (float*)workspace;
+  if (q_prescaled && !fwd3::PRESCALE) return IA_ERR_ARG;
+  a.q_prescaled = q_prescaled;
   dim3 grid(((L + 127) / 128) * nh * B), blk(256);
   if (fused_applies(a)) {
     launch_fused(a, stream);
@@ -2242,26 +2264,55 @@ extern "C" int ia_attn_bwd_bias(const void* q, const void* k, const void* v, int
   return ia_sum_rows_f32((const float*)workspace, B * ((L + 127) / 128), 3 * nh * 64, dbias, 1, stream);
 }
 
+extern "C" int ia_attn_bwd_bias(const void* q, const void* k, const void* v, int ld_qkv, const uint8_t* key_mask, const void* out,
+                                const void* d_out, int ld_o, const float* lse2, float* delta, void* dq, void* dk, void* dv, int ld_dqkv,
+                                float* dbias, void* workspace, size_t workspace_bytes, int B, int nh, int L, float scale, float drop_p,
+                                uint32_t seed, hipStream_t stream) {
+  return attn_bwd_bias_impl(0, q, k, v, ld_qkv, key_mask, out, d_out, ld_o, lse2, delta, dq, dk, dv, ld_dqkv, dbias, workspace, workspace_bytes,
+                            B, nh, L, scale, drop_p, seed, stream);
+}
+// backward of ia_attn_fwd_ps: q as the forward saw it (pre-scaled); dq is still dL/d(q before the scale), i.e. what the QKV projection's
+// weight / input gradients consume unchanged
+extern "C" int ia_attn_bwd_bias_ps(const void* q, const void* k, const void* v, int ld_qkv, const uint8_t* key_mask, const void* out,
+                                   const void* d_out, int ld_o, const float* lse2, float* delta, void* dq, void* dk, void* dv, int ld_dqkv,
+                                   float* dbias, void* workspace, size_t workspace_bytes, int B, int nh, int L, float scale, float drop_p,
+                                   uint32_t seed, hipStream_t stream) {
+  return attn_bwd_bias_impl(1, q, k, v, ld_qkv, key_mask, out, d_out, ld_o, lse2, delta, dq, dk, dv, ld_dqkv, dbias, workspace, workspace_bytes,
+                            B, nh, L, scale, drop_p, seed, stream);
+}
+
 // Packed ("unpadded") self-attention: the token rows of all sequences lie back to back, sequence b owning rows
 // cu_seqlens[b] .. cu_seqlens[b+1] (int32 [B+1], device; total_tokens = cu_seqlens[B]); no key mask — every key of a sequence is
 // attendable.  Lmax = longest sequence (sets the grid and the row stride of lse2 / delta, which stay [B, nh, Lmax]).  Same
 // arithmetic as ia_attn_fwd / ia_attn_bwd on the valid tokens of a right-padded batch; padded positions are simply absent.
-extern "C" int ia_attn_fwd_varlen(const void* q, const void* k, const void* v, int ld_qkv, const int* cu_seqlens, int total_tokens, void* out,
-                                  int ld_o, float* lse2, int B, int nh, int Lmax, float scale, float drop_p, uint32_t seed, hipStream_t stream) {
+static int attn_fwd_varlen_impl(int q_prescaled, const void* q, const void* k, const void* v, int ld_qkv, const int* cu_seqlens, int total_tokens,
+                                void* out, int ld_o, float* lse2, int B, int nh, int Lmax, float scale, float drop_p, uint32_t seed,
+                                hipStream_t stream) {
   (void)hipGetLastError();
   if (!q || !k || !v || !out || !cu_seqlens || total_tokens <= 0) return IA_ERR_ARG;
   AttnArgs a{};
   int rc = fill_args(a, B, nh, Lmax, Lmax, ld_qkv, ld_qkv, ld_o, scale, drop_p, seed, total_tokens);
   if (rc) return rc;
   a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.out = (bf16*)out; a.mask = nullptr; a.lse2 = lse2; a.cu = cu_seqlens;
+  if (q_prescaled && !fwd3::PRESCALE) return IA_ERR_ARG;
+  a.q_prescaled = q_prescaled;
   dim3 grid(((Lmax + 127) / 128) * nh * B);
   launch_fwd(a, grid, stream);
   return ia_check_launch();
 }
+extern "C" int ia_attn_fwd_varlen(const void* q, const void* k, const void* v, int ld_qkv, const int* cu_seqlens, int total_tokens, void* out,
+                                  int ld_o, float* lse2, int B, int nh, int Lmax, float scale, float drop_p, uint32_t seed, hipStream_t stream) {
+  return attn_fwd_varlen_impl(0, q, k, v, ld_qkv, cu_seqlens, total_tokens, out, ld_o, lse2, B, nh, Lmax, scale, drop_p, seed, stream);
+}
+extern "C" int ia_attn_fwd_varlen_ps(const void* q, const void* k, const void* v, int ld_qkv, const int* cu_seqlens, int total_tokens, void* out,
+                                     int ld_o, float* lse2, int B, int nh, int Lmax, float scale, float drop_p, uint32_t seed,
+                                     hipStream_t stream) {
+  return attn_fwd_varlen_impl(1, q, k, v, ld_qkv, cu_seqlens, total_tokens, out, ld_o, lse2, B, nh, Lmax, scale, drop_p, seed, stream);
+}
 
-extern "C" int ia_attn_bwd_varlen(const void* q, const void* k, const void* v, int ld_qkv, const int* cu_seqlens, int total_tokens,
-                                  const void* out, const void* d_out, int ld_o, const float* lse2, float* delta, void* dq, void* dk, void* dv,
-                                  int ld_dqkv, int B, int nh, int Lmax, float scale, float drop_p, uint32_t seed, hipStream_t stream) {
+static int attn_bwd_varlen_impl(int q_prescaled, const void* q, const void* k, const void* v, int ld_qkv, const int* cu_seqlens, int total_tokens,
+                                const void* out, const void* d_out, int ld_o, const float* lse2, float* delta, void* dq, void* dk, void* dv,
+                                int ld_dqkv, int B, int nh, int Lmax, float scale, float drop_p, uint32_t seed, hipStream_t stream) {
   (void)hipGetLastError();
   if (!q || !k || !v || !out || !d_out || !lse2 || !delta || !dq || !dk || !dv || !cu_seqlens || total_tokens <= 0) return IA_ERR_ARG;
   AttnArgs a{};
@@ -2271,6 +2322,8 @@ extern "C" int ia_attn_bwd_varlen(const void* q, const void* k, const void* v, i
   a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.o = (const bf16*)out; a.d_o = (const bf16*)d_out;
   a.mask = nullptr; a.lse2 = const_cast<float*>(lse2); a.delta = delta; a.cu = cu_seqlens;
   a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.ld_dq = ld_dqkv; a.ld_dkv = ld_dqkv;
+  if (q_prescaled && !fwd3::PRESCALE) return IA_ERR_ARG;
+  a.q_prescaled = q_prescaled;
   dim3 grid(((Lmax + 127) / 128) * nh * B), blk(256);
   if (a.thr16) {
     launch_dq<true>(a, grid, stream);
@@ -2280,4 +2333,16 @@ extern "C" int ia_attn_bwd_varlen(const void* q, const void* k, const void* v, i
     launch_dkv<false>(a, grid, stream);
   }
   return ia_check_launch();
+}
+extern "C" int ia_attn_bwd_varlen(const void* q, const void* k, const void* v, int ld_qkv, const int* cu_seqlens, int total_tokens,
+                                  const void* out, const void* d_out, int ld_o, const float* lse2, float* delta, void* dq, void* dk, void* dv,
+                                  int ld_dqkv, int B, int nh, int Lmax, float scale, float drop_p, uint32_t seed, hipStream_t stream) {
+  return attn_bwd_varlen_impl(0, q, k, v, ld_qkv, cu_seqlens, total_tokens, out, d_out, ld_o, lse2, delta, dq, dk, dv, ld_dqkv, B, nh, Lmax, scale,
+                              drop_p, seed, stream);
+}
+extern "C" int ia_attn_bwd_varlen_ps(const void* q, const void* k, const void* v, int ld_qkv, const int* cu_seqlens, int total_tokens,
+                                     const void* out, const void* d_out, int ld_o, const float* lse2, float* delta, void* dq, void* dk, void* dv,
+                                     int ld_dqkv, int B, int nh, int Lmax, float scale, float drop_p, uint32_t seed, hipStream_t stream) {
+  return attn_bwd_varlen_impl(1, q, k, v, ld_qkv, cu_seqlens, total_tokens, out, d_out, ld_o, lse2, delta, dq, dk, dv, ld_dqkv, B, nh, Lmax, scale,
+                              drop_p, seed, stream);
 }

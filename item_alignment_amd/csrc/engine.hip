@@ -67,14 +67,28 @@ bool cfg_ok(const ia_layer_cfg* c) {
 
 #define IA_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 
+// The QKV projection of a layer writes q already multiplied by softmax scale * log2(e) (one bf16 rounding, in the GEMM epilogue where
+// the value is still fp32) and the attention kernels are told so: none of forward / dQ / dK-dV / fused backward re-scales its q tiles.
+// Needs the q | k boundary on a 128-column tile boundary of the GEMM; IA_Q_PRESCALE=0 switches it off for A/B runs.
+bool q_prescale(const ia_layer_cfg* c) {
+  static const bool on = [] { const char* e = getenv("IA_Q_PRESCALE"); return !e || atoi(e) != 0; }();
+  return on && (c->H & 127) == 0;
+}
+int qkv_proj(const ia_layer_cfg* c, const void* x, const ia_layer_weights* w, void* qkv, int M, float scale, ia_stream_t st) {
+  const int H = c->H;
+  if (q_prescale(c)) return ia_gemm_bf16_qscale(x, H, w->w_qkv, H, qkv, 3 * H, M, 3 * H, H, w->b_qkv, H, scale * 1.4426950408889634f, st);
+  return ia_gemm_bf16(x, 0, H, w->w_qkv, 0, H, qkv, 0, 3 * H, M, 3 * H, H, IA_EPI_BIAS, w->b_qkv, nullptr, 0, nullptr, 0, nullptr, 0, st);
+}
+
 // self-attention over the packed qkv projection [rows, 3H]: padded [B, L] rows with a key mask, or packed rows (cu_seqlens)
 int attn_fwd(const ia_layer_cfg* c, const char* qkv, const uint8_t* key_mask, char* ctx, float* lse, float scale, float drop, uint32_t seed,
              ia_stream_t st) {
   const int H = c->H;
+  const bool ps = q_prescale(c);
   if (c->cu_seqlens)
-    return ia_attn_fwd_varlen(qkv, qkv + (size_t)H * 2, qkv + (size_t)2 * H * 2, 3 * H, c->cu_seqlens, c->total_tokens, ctx, H, lse, c->B, c->nh,
+    return (ps ? ia_attn_fwd_varlen_ps : ia_attn_fwd_varlen)(qkv, qkv + (size_t)H * 2, qkv + (size_t)2 * H * 2, 3 * H, c->cu_seqlens, c->total_tokens, ctx, H, lse, c->B, c->nh,
                               c->L, scale, drop, seed, st);
-  return ia_attn_fwd(qkv, qkv + (size_t)H * 2, qkv + (size_t)2 * H * 2, 3 * H, key_mask, ctx, H, lse, c->B, c->nh, c->L, scale, drop, seed, st);
+  return (ps ? ia_attn_fwd_ps : ia_attn_fwd)(qkv, qkv + (size_t)H * 2, qkv + (size_t)2 * H * 2, 3 * H, key_mask, ctx, H, lse, c->B, c->nh, c->L, scale, drop, seed, st);
 }
 
 // attention backward + the QKV bias gradient (+= into db_qkv): padded rows take the column sums out of the attention kernels'
@@ -82,12 +96,13 @@ int attn_fwd(const ia_layer_cfg* c, const char* qkv, const uint8_t* key_mask, ch
 int attn_bwd(const ia_layer_cfg* c, const char* qkv, const uint8_t* key_mask, const char* ctx, const char* dctx, const float* lse, float* delta,
              char* gqkv, float* db_qkv, void* ws, size_t ws_bytes, float scale, float drop, uint32_t seed, ia_stream_t st) {
   const int H = c->H;
+  const bool ps = q_prescale(c);
   if (c->cu_seqlens) {
-    int rc = ia_attn_bwd_varlen(qkv, qkv + (size_t)H * 2, qkv + (size_t)2 * H * 2, 3 * H, c->cu_seqlens, c->total_tokens, ctx, dctx, H, lse, delta,
+    int rc = (ps ? ia_attn_bwd_varlen_ps : ia_attn_bwd_varlen)(qkv, qkv + (size_t)H * 2, qkv + (size_t)2 * H * 2, 3 * H, c->cu_seqlens, c->total_tokens, ctx, dctx, H, lse, delta,
                                 gqkv, gqkv + (size_t)H * 2, gqkv + (size_t)2 * H * 2, 3 * H, c->B, c->nh, c->L, scale, drop, seed, st);
     return rc ? rc : ia_colsum(gqkv, 3 * H, (int)rows_of(c), 3 * H, db_qkv, 1, ws, ws_bytes, st);
   }
-  return ia_attn_bwd_bias(qkv, qkv + (size_t)H * 2, qkv + (size_t)2 * H * 2, 3 * H, key_mask, ctx, dctx, H, lse, delta, gqkv,
+  return (ps ? ia_attn_bwd_bias_ps : ia_attn_bwd_bias)(qkv, qkv + (size_t)H * 2, qkv + (size_t)2 * H * 2, 3 * H, key_mask, ctx, dctx, H, lse, delta, gqkv,
                           gqkv + (size_t)H * 2, gqkv + (size_t)2 * H * 2, 3 * H, db_qkv, ws, ws_bytes, c->B, c->nh, c->L, scale, drop, seed, st);
 }
 
@@ -115,7 +130,7 @@ extern "C" int ia_layer_fwd(const ia_layer_cfg* c, const ia_layer_weights* w, co
   const uint32_t attn_seed = c->seed * 2654435761u + c->layer_id * 97u + 17u;
   if (!c->pre_ln) {
     // qkv = x Wqkv^T + b
-    IA_TRY(ia_gemm_bf16(x, 0, H, w->w_qkv, 0, H, s.qkv, 0, 3 * H, M, 3 * H, H, IA_EPI_BIAS, w->b_qkv, nullptr, 0, nullptr, 0, nullptr, 0, st));
+    IA_TRY(qkv_proj(c, x, w, s.qkv, M, scale, st));
     IA_TRY(attn_fwd(c, s.qkv, key_mask, s.ctx, s.lse, scale, c->attn_drop, attn_seed, st));
     // z1 = x + dropout(ctx Wo^T + b_o); y1 = LN1(z1)
     IA_TRY(ia_gemm_bf16(s.ctx, 0, H, w->w_o, 0, H, s.t0, 0, H, M, H, H, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
@@ -130,7 +145,7 @@ extern "C" int ia_layer_fwd(const ia_layer_cfg* c, const ia_layer_weights* w, co
   } else {
     if (c->hidden_drop > 0.f || c->attn_drop > 0.f) return IA_ERR_UNSUPPORTED;  // timm ViT default: no dropout
     IA_TRY(ia_ln_fwd(x, nullptr, nullptr, nullptr, s.t0, s.mean1, s.rstd1, w->ln1_g, w->ln1_b, M, H, c->eps, 0.f, 0, 0, st));
-    IA_TRY(ia_gemm_bf16(s.t0, 0, H, w->w_qkv, 0, H, s.qkv, 0, 3 * H, M, 3 * H, H, IA_EPI_BIAS, w->b_qkv, nullptr, 0, nullptr, 0, nullptr, 0, st));
+    IA_TRY(qkv_proj(c, s.t0, w, s.qkv, M, scale, st));
     IA_TRY(attn_fwd(c, s.qkv, key_mask, s.ctx, s.lse, scale, 0.f, 0, st));
     // x1 = x + ctx Wo^T + b_o and LN2(x1): the bias and the residual are added by the LayerNorm kernel (it streams the rows anyway),
     // so the projection keeps the plain epilogue; t1 receives x1 in place of the raw projection
@@ -175,7 +190,7 @@ extern "C" int ia_layer_fwd_infer(const ia_layer_cfg* c, const ia_layer_weights*
   const Infer s = carve_infer(c, scratch);
   const float scale = 0.125f;
   if (!c->pre_ln) {
-    IA_TRY(ia_gemm_bf16(x, 0, H, w->w_qkv, 0, H, s.qkv, 0, 3 * H, M, 3 * H, H, IA_EPI_BIAS, w->b_qkv, nullptr, 0, nullptr, 0, nullptr, 0, st));
+    IA_TRY(qkv_proj(c, x, w, s.qkv, M, scale, st));
     IA_TRY(attn_fwd(c, s.qkv, key_mask, s.ctx, s.lse, scale, 0.f, 0, st));
     IA_TRY(ia_gemm_bf16(s.ctx, 0, H, w->w_o, 0, H, s.t0, 0, H, M, H, H, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
     IA_TRY(ia_ln_fwd(s.t0, w->b_o, x, nullptr, s.t1, s.mean, s.rstd, w->ln1_g, w->ln1_b, M, H, c->eps, 0.f, 0, 0, st));
@@ -184,7 +199,7 @@ extern "C" int ia_layer_fwd_infer(const ia_layer_cfg* c, const ia_layer_weights*
     IA_TRY(ia_ln_fwd(s.t0, w->b_fc2, s.t1, nullptr, y, s.mean, s.rstd, w->ln2_g, w->ln2_b, M, H, c->eps, 0.f, 0, 0, st));
   } else {
     IA_TRY(ia_ln_fwd(x, nullptr, nullptr, nullptr, s.t0, s.mean, s.rstd, w->ln1_g, w->ln1_b, M, H, c->eps, 0.f, 0, 0, st));
-    IA_TRY(ia_gemm_bf16(s.t0, 0, H, w->w_qkv, 0, H, s.qkv, 0, 3 * H, M, 3 * H, H, IA_EPI_BIAS, w->b_qkv, nullptr, 0, nullptr, 0, nullptr, 0, st));
+    IA_TRY(qkv_proj(c, s.t0, w, s.qkv, M, scale, st));
     IA_TRY(attn_fwd(c, s.qkv, key_mask, s.ctx, s.lse, scale, 0.f, 0, st));
     // x1 = x + ctx Wo^T + b_o is formed by the LayerNorm kernel exactly as in ia_layer_fwd (same roundings: evaluation reproduces the
     // training forward bit for bit when dropout is off); t1 receives x1, the fc2 epilogue's residual

@@ -39,6 +39,10 @@ struct GemmArgs {
   int lda, ldb, ldc, ldaux;
   uint64_t a_bytes, b_bytes;  // bytes addressable from A / B (to the end of the tensor); each workgroup re-bases a < 2 GiB buffer window inside them
   int accumulate;
+  // IA_EPI_BIAS only: columns n < qcols leave as (acc + bias) * qscale -- the fused QKV projection hands the attention kernels
+  // q * (softmax scale * log2 e), rounded to bf16 ONCE, so that forward, dQ, dK/dV and the fused backward exponentiate identical
+  // products without any of them re-scaling q (ia_gemm_bf16_qscale); 0 = off
+  int qcols; float qscale;
   int tiles_m, tiles_n;
   int splits, nk_per_split;   // split-K (fp32 output only): split s owns k-tiles [s*nk_per_split, ...)
   float* csum_part;           // EPI_DGELU_CS: [ceil(M/128)][N] fp32 column sums of each 128-row block of the output (T256 only)
@@ -78,6 +82,7 @@ IA_DEV void epi_store4(const GemmArgs& p, int m, int n, f32x4 v) {
   if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_ACT || EPI == EPI_BIAS_ADD) {
     const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
     v += b;
+    if (EPI == EPI_BIAS && n < p.qcols) v *= p.qscale;
   }
   if (EPI == EPI_BIAS_GELU) {
     // C = gelu(pre), C2 = gelu'(pre): the derivative shares the exp / rcp of the activation (gelu_pair, common.h) and turns the
@@ -149,6 +154,10 @@ IA_DEV void epi_store8(const GemmArgs& p, int m, int n, f32x4 lo, f32x4 hi, f32x
     const f32x4 b0 = PRE ? pb0 : *reinterpret_cast<const f32x4*>(p.bias + n), b1 = PRE ? pb1 : *reinterpret_cast<const f32x4*>(p.bias + n + 4);
 #pragma unroll
     for (int r = 0; r < 4; ++r) { v[r] += b0[r]; v[4 + r] += b1[r]; }
+    if (EPI == EPI_BIAS && n < p.qcols) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] *= p.qscale;
+    }
   }
   if (EPI == EPI_BIAS_GELU) {   // see epi_store4
     bf16x8 der;
@@ -947,7 +956,7 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
 // WITH_BIAS (k-contiguous B only): bct[ni][q] = the bias of the lane's columns ni*32 + hh*16 + 4q .. +3 (accumulator layout, fetched
 // before the main loop), added in fp32 before the rounding.
 template <bool BKS, int NH, bool WITH_BIAS>
-IA_DEV void drain_half_plain(const GemmArgs& p, f32x16 (&acc)[4][4], int m0, int n0, char* stg, int lane_e, const f32x4 (&bct)[4][4]) {
+IA_DEV void drain_half_plain(const GemmArgs& p, f32x16 (&acc)[4][4], int m0, int n0, char* stg, int lane_e, const f32x4 (&bct)[4][4], float ts = 1.f) {
   static_assert(!(WITH_BIAS && BKS), "bias rows are laid out for the k-contiguous B fragment permutation");
   const int hh = lane_e >> 5, li = lane_e & 31, rrow = lane_e >> 3, c8 = lane_e & 7;
   auto stage = [&](int mi) {
@@ -967,7 +976,8 @@ IA_DEV void drain_half_plain(const GemmArgs& p, f32x16 (&acc)[4][4], int m0, int
             asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t0[j]) : "a"(a[h8 * 8 + j]));
             asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t1[j]) : "a"(a[h8 * 8 + 4 + j]));
           }
-          if (WITH_BIAS) { t0 += bct[NH * 2 + ni][h8 * 2]; t1 += bct[NH * 2 + ni][h8 * 2 + 1]; }
+          // bct arrives multiplied by ts already (ts = the tile's column scale, 1 outside the q columns: a * 1 + b rounds like a + b)
+          if (WITH_BIAS) { t0 = t0 * ts + bct[NH * 2 + ni][h8 * 2]; t1 = t1 * ts + bct[NH * 2 + ni][h8 * 2 + 1]; }
           const bf16x8 v = {f2bf(t0[0]), f2bf(t0[1]), f2bf(t0[2]), f2bf(t0[3]), f2bf(t1[0]), f2bf(t1[1]), f2bf(t1[2]), f2bf(t1[3])};
           const int chunk = (ni * 32 + hh * 16 + h8 * 8) >> 3;
           *reinterpret_cast<bf16x8*>(sl + li * 128 + ((chunk ^ (li & 7)) << 4)) = v;
@@ -1179,10 +1189,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
       pbv[2] = *reinterpret_cast<const f32x4*>(bp + 64); pbv[3] = *reinterpret_cast<const f32x4*>(bp + 68);
     }
     run(tile, false, acc, stores_in_flight);
+    float ts = 1.f;
     if (bias_pre && BIAS_CT) {
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(bct[ni][0]), "+v"(bct[ni][1]), "+v"(bct[ni][2]), "+v"(bct[ni][3]));
+      if (n0_pre < p.qcols) {                  // wave-uniform: the 128 columns of this wave lie inside the scaled (q) columns
+        ts = p.qscale;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bct[ni][q] *= ts;
+      }
     } else if (bias_pre) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pbv[0]), "+v"(pbv[1]), "+v"(pbv[2]), "+v"(pbv[3]));
     const int next = ordered ? total_tiles : tile + gridDim.x;
     if (next < total_tiles) run(next, true, acc, false);      // the next tile's first two k-tiles travel under this epilogue
@@ -1199,8 +1217,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         drain_half_plain<BKS, 0, false>(p, acc, m0, n0, stg, lane_e, bct);
         drain_half_plain<BKS, 1, false>(p, acc, m0, n0 + 64, stg, lane_e, bct);
       } else if (BIAS_CT && bias_pre) {
-        drain_half_plain<false, 0, BIAS_CT>(p, acc, m0, n0, stg, lane_e, bct);
-        drain_half_plain<false, 1, BIAS_CT>(p, acc, m0, n0 + 64, stg, lane_e, bct);
+        drain_half_plain<false, 0, BIAS_CT>(p, acc, m0, n0, stg, lane_e, bct, ts);
+        drain_half_plain<false, 1, BIAS_CT>(p, acc, m0, n0 + 64, stg, lane_e, bct, ts);
       } else {
         drain_half<EPI, OUTF32, BKS, 0>(p, acc, m0, n0, stg, lane_e, full || (m0 + 128 <= p.M && n0 + 64 <= p.N), bias_pre, pbv[0], pbv[1]);
         drain_half<EPI, OUTF32, BKS, 1>(p, acc, m0, n0 + 64, stg, lane_e, full, bias_pre, pbv[2], pbv[3]);
@@ -1393,7 +1411,7 @@ extern "C" size_t ia_gemm_workspace_bytes(int M, int N, int K, int c_is_f32) {
 
 static int gemm_core(const void* A, int a_kstrided, int lda, const void* B, int b_kstrided, int ldb, void* C, int c_is_f32, int ldc, int M,
                      int N, int K, int epilogue, const float* bias, const void* aux, int ldaux, void* C2, int accumulate, void* workspace,
-                     size_t workspace_bytes, const IaViewGemm* view, hipStream_t stream);
+                     size_t workspace_bytes, const IaViewGemm* view, hipStream_t stream, int qcols = 0, float qscale = 1.f);
 
 // workspace of an IA_EPI_DGELU_COLSUM GEMM: one fp32 row of N partial sums per 128-row block of the output (and never less than
 // the stand-alone column-sum kernel needs, which small shapes fall back to)
@@ -1409,6 +1427,14 @@ extern "C" int ia_gemm_bf16(const void* A, int a_kstrided, int lda, const void* 
                             size_t workspace_bytes, hipStream_t stream) {
   return gemm_core(A, a_kstrided, lda, B, b_kstrided, ldb, C, c_is_f32, ldc, M, N, K, epilogue, bias, aux, ldaux, C2, accumulate, workspace,
                    workspace_bytes, nullptr, stream);
+}
+
+// IA_EPI_BIAS GEMM (k-contiguous operands, bf16 output) whose first scaled_cols columns (a multiple of 128) are multiplied by col_scale
+// after the bias: the fused QKV projection of the encoder layers, q leaving as q * softmax scale * log2 e (GemmArgs::qcols)
+extern "C" int ia_gemm_bf16_qscale(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias,
+                                   int scaled_cols, float col_scale, hipStream_t stream) {
+  return gemm_core(A, 0, lda, B, 0, ldb, C, 0, ldc, M, N, K, EPI_BIAS, bias, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, stream, scaled_cols,
+                   col_scale);
 }
 
 // GEMM with shifted operand views and channel groups batched into one launch (see GemmArgs): the building block of the
@@ -1429,7 +1455,7 @@ size_t ia_gemm_view_workspace_bytes(int M, int N, int K, int groups) {
 
 static int gemm_core(const void* A, int a_kstrided, int lda, const void* B, int b_kstrided, int ldb, void* C, int c_is_f32, int ldc, int M,
                      int N, int K, int epilogue, const float* bias, const void* aux, int ldaux, void* C2, int accumulate, void* workspace,
-                     size_t workspace_bytes, const IaViewGemm* view, hipStream_t stream) {
+                     size_t workspace_bytes, const IaViewGemm* view, hipStream_t stream, int qcols, float qscale) {
   const uint64_t a_window = view ? view->a_window : 0, b_window = view ? view->b_window : 0;
   const int groups = view ? view->groups : 1;
   (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
@@ -1439,6 +1465,8 @@ static int gemm_core(const void* A, int a_kstrided, int lda, const void* B, int 
   GemmArgs g;
   g.A = (const bf16*)A; g.B = (const bf16*)B; g.C = C; g.C2 = (bf16*)C2; g.bias = bias; g.aux = (const bf16*)aux;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux; g.accumulate = accumulate;
+  if (qcols < 0 || qcols > N || (qcols & 127) || (qcols && (epilogue != EPI_BIAS || c_is_f32 || a_kstrided || b_kstrided))) return IA_ERR_ARG;
+  g.qcols = qcols; g.qscale = qscale;
   const uint64_t ab = a_window ? a_window : (a_kstrided ? ((uint64_t)(K - 1) * lda + M) * 2 : ((uint64_t)(M - 1) * lda + K) * 2);
   const uint64_t bb = b_window ? b_window : (b_kstrided ? ((uint64_t)(K - 1) * ldb + N) * 2 : ((uint64_t)(N - 1) * ldb + K) * 2);
   g.csum_part = nullptr; g.split_id = 0;

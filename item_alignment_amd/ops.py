@@ -97,20 +97,35 @@ def colsum(x, out, accumulate=True):
     return out
 
 
-def attn_fwd(qkv, B, L, nh, *, key_mask=None, scale=0.125, drop_p=0.0, seed=0):
-    """qkv: packed [B*L, 3*nh*64] bf16.  Returns (ctx [B*L, nh*64], lse2 [B, nh, L])."""
+def gemm_qscale(a, b, bias, scaled_cols, col_scale):
+    """bf16 [M, N] = (a [M, K] @ b [N, K]^T + bias), columns < scaled_cols multiplied by col_scale before the bf16 rounding (the QKV
+    projection that hands pre-scaled q to attn_fwd / attn_bwd with q_prescaled=True)"""
+    lib = _lib.load()
+    _need(a, BF16, "a"); _need(b, BF16, "b"); _need(bias, F32, "bias")
+    M, K = a.shape
+    N = b.shape[0]
+    out = torch.empty((M, N), device=a.device, dtype=BF16)
+    check(lib.ia_gemm_bf16_qscale(a.data_ptr(), K, b.data_ptr(), K, out.data_ptr(), N, M, N, K, bias.data_ptr(), scaled_cols, col_scale,
+                                  stream_ptr()), "ia_gemm_bf16_qscale")
+    return out
+
+
+def attn_fwd(qkv, B, L, nh, *, key_mask=None, scale=0.125, drop_p=0.0, seed=0, q_prescaled=False):
+    """qkv: packed [B*L, 3*nh*64] bf16.  Returns (ctx [B*L, nh*64], lse2 [B, nh, L]).
+    q_prescaled: the q columns already hold q * scale * log2(e) (gemm_qscale)"""
     lib = _lib.load()
     _need(qkv, BF16, "qkv"); _need(key_mask, torch.uint8, "key_mask")
     H = nh * 64
     out = torch.empty((B * L, H), device=qkv.device, dtype=BF16)
     lse = torch.empty((B, nh, L), device=qkv.device, dtype=F32)
     base = qkv.data_ptr()
-    check(lib.ia_attn_fwd(base, base + 2 * H, base + 4 * H, 3 * H, ptr(key_mask), out.data_ptr(), H, lse.data_ptr(), B, nh, L, scale,
-                          drop_p, seed, stream_ptr()), "ia_attn_fwd")
+    fn = lib.ia_attn_fwd_ps if q_prescaled else lib.ia_attn_fwd
+    check(fn(base, base + 2 * H, base + 4 * H, 3 * H, ptr(key_mask), out.data_ptr(), H, lse.data_ptr(), B, nh, L, scale, drop_p, seed,
+             stream_ptr()), "ia_attn_fwd")
     return out, lse
 
 
-def attn_bwd(qkv, ctx, d_ctx, lse, B, L, nh, *, key_mask=None, scale=0.125, drop_p=0.0, seed=0, dbias=None):
+def attn_bwd(qkv, ctx, d_ctx, lse, B, L, nh, *, key_mask=None, scale=0.125, drop_p=0.0, seed=0, dbias=None, q_prescaled=False):
     """dbias (fp32 [3H], optional): += column sums of dqkv, i.e. the bias gradient of the fused QKV projection, out of the same launches"""
     lib = _lib.load()
     _need(qkv, BF16, "qkv"); _need(ctx, BF16, "ctx"); _need(d_ctx, BF16, "d_ctx"); _need(lse, F32, "lse")
@@ -118,10 +133,13 @@ def attn_bwd(qkv, ctx, d_ctx, lse, B, L, nh, *, key_mask=None, scale=0.125, drop
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, nh, L), device=qkv.device, dtype=F32)
     base, dbase = qkv.data_ptr(), dqkv.data_ptr()
+    if q_prescaled and dbias is None:
+        dbias = torch.zeros(3 * H, device=qkv.device, dtype=F32)
     if dbias is not None:
         _need(dbias, F32, "dbias")
         ws = torch.empty(lib.ia_attn_bwd_bias_workspace_bytes(B, nh, L), device=qkv.device, dtype=torch.uint8)
-        check(lib.ia_attn_bwd_bias(base, base + 2 * H, base + 4 * H, 3 * H, ptr(key_mask), ctx.data_ptr(), d_ctx.data_ptr(), H, lse.data_ptr(),
+        fn = lib.ia_attn_bwd_bias_ps if q_prescaled else lib.ia_attn_bwd_bias
+        check(fn(base, base + 2 * H, base + 4 * H, 3 * H, ptr(key_mask), ctx.data_ptr(), d_ctx.data_ptr(), H, lse.data_ptr(),
                                    delta.data_ptr(), dbase, dbase + 2 * H, dbase + 4 * H, 3 * H, dbias.data_ptr(), ws.data_ptr(), ws.numel(),
                                    B, nh, L, scale, drop_p, seed, stream_ptr()), "ia_attn_bwd_bias")
         return dqkv

@@ -739,6 +739,88 @@ def test_attention_packed_sequences_match_padded(gpu, nh, lens, drop):
     assert rel_err(dp, dqkv.index_select(0, idx)) < 1e-2
 
 
+SC = 0.125 * 1.4426950408889634        # softmax scale * log2(e); * 0.125 is exact, so fp32(SC) is the kernels' p.sc
+
+
+def _prescaled(qkv, H):
+    """the q columns as the kernels pre-scale them internally: bf16(fp32(q) * fp32(sc))"""
+    out = qkv.clone()
+    out[:, :H] = (qkv[:, :H].float() * torch.tensor(SC, dtype=torch.float32, device=qkv.device)).to(torch.bfloat16)
+    return out
+
+
+@pytest.mark.parametrize("B,L,nh,masked,drop", [(2, 20, 1, True, 0.0), (3, 64, 2, False, 0.0), (2, 255, 4, True, 0.1), (2, 510, 4, True, 0.0),
+                                                (2, 577, 3, False, 0.0), (9, 193, 2, True, 0.0), (2, 385, 2, False, 0.1)])
+def test_attention_prescaled_q_entry_points_are_bit_identical(gpu, B, L, nh, masked, drop):
+    """ia_attn_fwd_ps / ia_attn_bwd_bias_ps given q' = bf16(q * scale * log2 e) compute exactly what ia_attn_fwd / ia_attn_bwd_bias
+    compute from q (they form the same q' per tile): context, lse, dq, dk, dv and the bias gradient bit for bit, over the forward,
+    the dQ + dK/dV pair and the fused backward (33 <= L <= 256)."""
+    from item_alignment_amd import ops
+    H = nh * 64
+    qkv = rnd((B * L, 3 * H), gpu, 1.0, 61)
+    dctx = rnd((B * L, H), gpu, 1.0, 62)
+    mask = None
+    if masked:
+        lens = torch.tensor([max(1, L - 5 * (i + 1)) for i in range(B)])
+        mask = (torch.arange(L)[None, :] < lens[:, None]).to(torch.uint8).to(gpu)
+    qs = _prescaled(qkv, H)
+    ctx, lse = ops.attn_fwd(qkv, B, L, nh, key_mask=mask, drop_p=drop, seed=3)
+    ctx2, lse2 = ops.attn_fwd(qs, B, L, nh, key_mask=mask, drop_p=drop, seed=3, q_prescaled=True)
+    assert torch.equal(ctx, ctx2) and torch.equal(lse, lse2)
+    db1 = torch.zeros(3 * H, device=gpu)
+    db2 = torch.zeros(3 * H, device=gpu)
+    g1 = ops.attn_bwd(qkv, ctx, dctx, lse, B, L, nh, key_mask=mask, drop_p=drop, seed=3, dbias=db1)
+    g2 = ops.attn_bwd(qs, ctx, dctx, lse, B, L, nh, key_mask=mask, drop_p=drop, seed=3, dbias=db2, q_prescaled=True)
+    assert torch.equal(g1, g2) and torch.equal(db1, db2)
+
+
+def test_attention_prescaled_q_packed_rows_are_bit_identical(gpu):
+    from item_alignment_amd import _lib
+    from item_alignment_amd.ops import check, stream_ptr
+    lib = _lib.load()
+    nh, lens = 2, [255, 17, 129, 200, 64, 65]
+    B, L, H, T = len(lens), max(lens), nh * 64, sum(lens)
+    pq = rnd((T, 3 * H), gpu, 1.0, 63)
+    pd = rnd((T, H), gpu, 1.0, 64)
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=gpu)
+    res = []
+    for ps, src in ((0, pq), (1, _prescaled(pq, H))):
+        out = torch.empty((T, H), device=gpu, dtype=torch.bfloat16)
+        lse = torch.zeros((B, nh, L), device=gpu)
+        dp = torch.empty_like(pq)
+        delta = torch.empty((B, nh, L), device=gpu)
+        base, db = src.data_ptr(), dp.data_ptr()
+        fwd = lib.ia_attn_fwd_varlen_ps if ps else lib.ia_attn_fwd_varlen
+        bwd = lib.ia_attn_bwd_varlen_ps if ps else lib.ia_attn_bwd_varlen
+        check(fwd(base, base + 2 * H, base + 4 * H, 3 * H, cu.data_ptr(), T, out.data_ptr(), H, lse.data_ptr(), B, nh, L, 0.125, 0.1, 7,
+                  stream_ptr()), "fwd_varlen")
+        check(bwd(base, base + 2 * H, base + 4 * H, 3 * H, cu.data_ptr(), T, out.data_ptr(), pd.data_ptr(), H, lse.data_ptr(), delta.data_ptr(),
+                  db, db + 2 * H, db + 4 * H, 3 * H, B, nh, L, 0.125, 0.1, 7, stream_ptr()), "bwd_varlen")
+        res.append((out, lse, dp))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M,H,K", [(510, 128, 128), (1000, 256, 192), (32640, 1024, 1024), (4616, 768, 768), (77, 128, 64)])
+def test_gemm_qscale_scales_the_q_columns_only(gpu, M, H, K):
+    """ia_gemm_bf16_qscale: columns [0, H) = bf16((x W^T + b) * s), columns [H, 3H) = the plain bias GEMM's, bit for bit"""
+    from item_alignment_amd import _lib, ops
+    x = rnd((M, K), gpu, 1.0, 71)
+    w = rnd((3 * H, K), gpu, K ** -0.5, 72)
+    b = rnd((3 * H,), gpu, 1.0, 73).float()
+    plain = ops.gemm(x, w, epilogue=ops.EPI_BIAS, bias=b)
+    got = ops.gemm_qscale(x, w, b, H, SC)
+    assert torch.equal(got[:, H:], plain[:, H:])
+    want = (x.float() @ w[:H].float().t() + b[:H]) * SC
+    assert rel_err(got[:, :H], want) < 6e-3
+    # at most one bf16 ulp from rounding the exact product (fp32 accumulation order differs from torch's)
+    assert ((got[:, :H].float() - want).abs() <= want.abs() * 2 ** -7 + 1e-3).all()
+    lib = _lib.load()
+    for cols in (64, -128, 3 * H + 128):
+        rc = lib.ia_gemm_bf16_qscale(x.data_ptr(), K, w.data_ptr(), K, got.data_ptr(), 3 * H, M, 3 * H, K, b.data_ptr(), cols, SC, ops.stream_ptr())
+        assert rc == -1, cols
+
+
 def test_conv3x3_padded_full_size_against_miopen(gpu):
     """The eca_nfnet_l0 stage-1 shape at full resolution (200x200, 64 channels, 4 images) and a stage-3 one (50x50, 6 groups of 64):
     forward and both gradients against torch.conv2d in fp32 on the GPU."""

@@ -26,18 +26,22 @@ REL_EXCEPTIONS = {
     ("resnet_two_tower", "img_encoder.stem.conv.weight"): 0.191,
     ("resnet_two_tower", "img_encoder.stages.3.blocks.0.conv3.weight"): 0.072,
     # 3-sample fixtures, bias / head gradients that are sums over a handful of tokens with cancellation
-    ("roberta_two_tower_ce", "roberta.embeddings.LayerNorm.bias"): 0.229,
+    ("roberta_two_tower_ce", "roberta.embeddings.LayerNorm.bias"): 0.286,
     ("roberta_two_tower_cosine", "roberta.embeddings.LayerNorm.bias"): 0.091,
     ("roberta_two_tower_euclidean", "roberta.embeddings.LayerNorm.bias"): 0.088,
     ("roberta_two_tower_euclidean", "classifier.out_proj.weight"): 0.121,
     ("roberta_two_tower_euclidean", "roberta.encoder.layer.1.attention.self.value.weight"): 0.088,
     ("roberta_two_tower_cosine", "roberta.encoder.layer.1.attention.self.value.weight"): 0.052,
-    ("roberta_two_tower_ce", "classifier.out_proj.weight"): 0.060,
+    ("roberta_two_tower_ce", "classifier.out_proj.weight"): 0.073,
     ("roberta_one_tower_cls_ce", "classifier.dense.weight"): 0.083,
     ("roberta_one_tower_cls_ce", "classifier.out_proj.weight"): 0.054,
     ("roberta_one_tower_cls_ce", "roberta.embeddings.position_embeddings.weight"): 0.054,
     ("roberta_one_tower_cls_ce", "roberta.embeddings.word_embeddings.weight"): 0.054,
-    ("roberta_image_two_tower_begin", "classifier.out_proj.weight"): 0.055,
+    ("roberta_image_two_tower_begin", "classifier.out_proj.weight"): 0.067,
+    # values above are the larger of two measurements, q scaled inside the attention kernels / in the QKV projection's epilogue
+    # (IA_Q_PRESCALE=0 / 1: 86 gradient tensors, 31 moved down by > 5 %, 26 up, mean 0.0270 -> 0.0261 -- a different sample of the
+    # same rounding noise, profiles/r04_parity_q_prescale.txt); this one crossed the bar in the second sample (0.038 -> 0.051)
+    ("roberta_one_tower_cls12_avg", "classifier.dense.weight"): 0.051,
 }
 EXCEPTION_HEADROOM = 1.25
 MEASURED = []            # (case, kind, key, value) of everything check() compared: printed by tools/parity_report.py
