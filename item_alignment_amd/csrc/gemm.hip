@@ -750,6 +750,12 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs p) {
 //   k-step 1: MFMAs on set 1 | reads of set 3;  lgkmcnt(0), barrier B1: every wave holds all of k-tile u -> its buffer is free
 //   k-step 2: MFMAs on set 2 | DMA pieces 0..7 of k-tile u+2
 //   k-step 3: vmcnt(8), barrier B2: k-tile u+1 has landed;  MFMAs on set 3 | reads of set 0 of k-tile u+1, DMA pieces 8..15
+#ifndef IA_T256W_ROUND
+#define IA_T256W_ROUND 1       // which GEMM forms run the ROUND k-loop schedule: 0 none, 1 k-contiguous A and B (forward GEMMs), 2 all but the weight-gradient form
+#endif
+#ifndef IA_T256W_MFMA16
+#define IA_T256W_MFMA16 0
+#endif
 namespace t256w {
 using t256::BM;
 using t256::BN;
@@ -833,6 +839,7 @@ template <bool AKS, bool BKS, int PEND>
 IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB, int xa, int xb,
                       int kt0, int ktaA0, int ktaB0, int n_tiles, int nk_all, int wm, int wn, int wave, int lane, bool prologue_only,
                       bool stores_in_flight) {
+  constexpr bool ROUND = IA_T256W_ROUND == 2 ? !(AKS && BKS) : IA_T256W_ROUND == 1 ? !AKS && !BKS : false;      // the k loop's schedule (below)
   const int li = lane & 31;
   const int gt = wave * 64 + lane;                  // thread index inside the workgroup (0..255)
   // ---- DMA: 8 pieces per operand and k-tile, one lane offset per operand (see t256::main_loop)
@@ -868,7 +875,7 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
 #pragma unroll
     for (int i = 0; i < 16; ++i) dma_piece(0, i);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) dma_piece(1, i);      // (zero-filled when it does not exist)
+    for (int i = 0; i < (ROUND ? 12 : 16); ++i) dma_piece(1, i);      // (zero-filled when it does not exist; ROUND: see the loop)
     return;
   }
   // the prologue DMA of this tile.  After a full-tile epilogue exactly PEND store instructions were issued behind it and
@@ -902,7 +909,17 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
+#if IA_T256W_MFMA16      // timing experiment only (results are garbage): two 16x16x32 MFMAs in place of one 32x32x16, same operand registers
+        {
+          f32x16& c = acc[mi][ni];
+          f32x4 c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
+          c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb[ni], va[mi], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb[ni], va[mi], c1, 0, 0, 0);
+          c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; c[3] = c0[3]; c[4] = c1[0]; c[5] = c1[1]; c[6] = c1[2]; c[7] = c1[3];
+        }
+#else
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb[ni], va[mi], acc[mi][ni], 0, 0, 0);
+#endif
         filler(mi * 4 + ni);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -910,6 +927,50 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
 
   uint32_t bo = 0;
   int u = 0;
+  // Two schedules.  ROUND (both operands k-contiguous: the forward GEMMs): every fragment of k-tile u is requested under k-step 0 (24 / 36
+  // LDS reads behind 12 MFMAs), the buffer is handed back after a QUARTER of the k-tile, and the 16 DMA pieces of a k-tile go out one
+  // per FOUR MFMAs all the way round: k-tile u+2's pieces 0 .. 11 under k-steps 1 .. 3, 12 .. 15 under k-step 0 of the next trip (the
+  // tile prologue issues 16 + 12 pieces to match).  The VMEM port takes 60-180 cycles per piece and two MFMAs are 64: one piece per two
+  // MFMAs queued up behind it (K = 4096 forward shapes +4.7 %, profiles/r04_gemm_loop_schedules.txt).  The forms with a k-strided operand
+  // (transpose reads: 36 / 48 per k-tile) lose 3 % under it (data gradient 1148 -> 1184, weight gradient frac 0.522 -> 0.537 back
+  // on the round-2 order below).
+  if constexpr (ROUND) {
+  do {
+    const uint32_t bn = bo ^ (uint32_t)(2 * TILE_BYTES);
+    tie<0>(a0); tie<0>(b0);
+    step(a0, b0, [&](int i) {      // (no reads behind the last four MFMAs: they cover the latency of the last reads)
+      if (i < 4) { read_frag<1>(a1, i, baseA, bo); read_frag<1>(b1, i, baseB, bo); }
+      else if (i < 8) { read_frag<2>(a2, i - 4, baseA, bo); read_frag<2>(b2, i - 4, baseB, bo); }
+      else if (i < 12) { read_frag<3>(a3, i - 8, baseA, bo); read_frag<3>(b3, i - 8, baseB, bo); }
+      if (i % 4 == 3) dma_piece(u + 1, 12 + i / 4);      // the last four pieces of k-tile u+1 (into the other buffer)
+    });
+    tie<0>(a1); tie<0>(b1); tie<0>(a2); tie<0>(b2); tie<0>(a3); tie<0>(b3);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(p.dbg & 16)) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    step(a1, b1, [&](int i) {
+      if (i % 4 == 1) dma_piece(u + 2, i / 4);
+    });
+    step(a2, b2, [&](int i) {
+      if (i % 4 == 1) dma_piece(u + 2, 4 + i / 4);
+    });
+    // k-tile u+1 has landed (its last four pieces went out under k-step 0): only the 8 pieces just issued may be outstanding
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(p.dbg & 16)) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    step(a3, b3, [&](int i) {      // set 0 of k-tile u+1 in the first half: the second half covers the reads' latency
+      if (i < 4) read_frag<0>(a0, i, baseA, bn);
+      else if (i < 8) read_frag<0>(b0, i - 4, baseB, bn);
+      if (i % 4 == 3) dma_piece(u + 2, 8 + i / 4);
+    });
+    bo = bn;
+    ++u;
+  } while (u < n_tiles);
+  // the reads of "set 0 of the k-tile after the last" are dead, but in flight: their destinations must not be handed out before they land
+  tie<0>(a0); tie<0>(b0);
+  return;
+  }
   do {
     const uint32_t bn = bo ^ (uint32_t)(2 * TILE_BYTES);
     // k-step 0: sets 1 and 2 requested, one fragment behind each MFMA
