@@ -756,6 +756,9 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs p) {
 #ifndef IA_T256W_MFMA16
 #define IA_T256W_MFMA16 0
 #endif
+#ifndef IA_T256W_NOREADS
+#define IA_T256W_NOREADS 0
+#endif
 namespace t256w {
 using t256::BM;
 using t256::BN;
@@ -823,6 +826,9 @@ template <int N> IA_DEV void tie(Op<true>& o) {
 // fragment j (0..3: A, 4..7: B) of k-step S of the k-tile at bufoff
 template <int S, bool KS>
 IA_DEV void read_frag(Op<KS>& f, int j, const uint32_t (&base)[4], uint32_t bufoff) {
+#if IA_T256W_NOREADS      // timing experiment only: the MFMAs run on whatever the registers hold
+  return;
+#endif
   if constexpr (!KS) {
     const uint32_t a = base[S] + bufoff;
     if (j == 0) f.v[0] = rd128<0>(a);

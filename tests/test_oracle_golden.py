@@ -6,7 +6,8 @@ import torch
 
 from golden_util import case_names, load_case, run_oracle, weights
 
-SPECIAL = ("roberta_large_one_layer", "roberta_large_24_layers", "vit_hf_crosscheck")
+# fixtures with their own tests and formats (nfnet_reference_assembly: tests/test_convnet_oracle_pins.py)
+SPECIAL = ("roberta_large_one_layer", "roberta_large_24_layers", "vit_hf_crosscheck", "nfnet_reference_assembly")
 CASES = [c for c in case_names() if c not in SPECIAL]
 
 
