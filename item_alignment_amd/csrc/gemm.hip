@@ -759,6 +759,9 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs p) {
 #ifndef IA_T256W_NOREADS
 #define IA_T256W_NOREADS 0
 #endif
+#ifndef IA_GEMM_DBG_HOOKS
+#define IA_GEMM_DBG_HOOKS 0    // 1: the T256W k loop honours the IA_GEMM_DBG timing ablations (tools/abl builds)
+#endif
 namespace t256w {
 using t256::BM;
 using t256::BN;
@@ -818,8 +821,23 @@ IA_DEV void frag_bases(uint32_t (&base)[4], uint32_t tile_addr, int x0, int lane
 template <int N> IA_DEV void tie(Op<false>& o) {
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(o.v[0]), "+v"(o.v[1]), "+v"(o.v[2]), "+v"(o.v[3]) : "n"(N));
 }
+// several fragment sets behind ONE wait (k-contiguous sets: 4 registers each; six sets are 24 of the 30 operands an asm may have)
+template <int N> IA_DEV void tie2(Op<false>& a, Op<false>& b) {
+  asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(a.v[3]), "+v"(b.v[0]), "+v"(b.v[1]), "+v"(b.v[2]), "+v"(b.v[3]) : "n"(N));
+}
+template <int N> IA_DEV void tie6(Op<false>& a, Op<false>& b, Op<false>& c, Op<false>& d, Op<false>& e, Op<false>& f) {
+  asm volatile("s_waitcnt lgkmcnt(%24)"
+               : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(a.v[3]), "+v"(b.v[0]), "+v"(b.v[1]), "+v"(b.v[2]), "+v"(b.v[3]),
+                 "+v"(c.v[0]), "+v"(c.v[1]), "+v"(c.v[2]), "+v"(c.v[3]), "+v"(d.v[0]), "+v"(d.v[1]), "+v"(d.v[2]), "+v"(d.v[3]),
+                 "+v"(e.v[0]), "+v"(e.v[1]), "+v"(e.v[2]), "+v"(e.v[3]), "+v"(f.v[0]), "+v"(f.v[1]), "+v"(f.v[2]), "+v"(f.v[3])
+               : "n"(N));
+}
 template <int N> IA_DEV void tie(Op<true>& o) {
   asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(o.lo[0]), "+v"(o.lo[1]), "+v"(o.lo[2]), "+v"(o.lo[3]), "+v"(o.hi[0]), "+v"(o.hi[1]), "+v"(o.hi[2]), "+v"(o.hi[3]) : "n"(N));
+}
+template <int N> IA_DEV void tie2(Op<true>& a, Op<true>& b) { tie<N>(a); tie<N>(b); }
+template <int N> IA_DEV void tie6(Op<true>& a, Op<true>& b, Op<true>& c, Op<true>& d, Op<true>& e, Op<true>& f) {
+  tie<N>(a); tie<N>(b); tie<N>(c); tie<N>(d); tie<N>(e); tie<N>(f);
 }
 
 
@@ -859,7 +877,8 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
   const int klA = AKS ? (gt >> 5) : ((gt & 7) ^ (((gt >> 3) >> 1) & 7)) * 8;
   const int klB = BKS ? (gt >> 5) : ((gt & 7) ^ (((gt >> 3) >> 1) & 7)) * 8;
   char* const my_part = smem + wave * 1024;
-  const bool dma_on = !(p.dbg & 2);
+  const int dbg = IA_GEMM_DBG_HOOKS ? p.dbg : 0;       // the timing ablations (IA_GEMM_DBG bits 2 / 4 / 16) exist in tools builds only
+  const bool dma_on = !(dbg & 2);
 
   // piece i (0..7: A, 8..15: B) of k-tile u -> buffer u & 1.  Branch-free (a branch next to the accumulator updates makes hipcc copy
   // all 256 of them): lim = number of valid k in this k-tile (0 for a k-tile past the end: the whole piece goes out of range and
@@ -868,11 +887,34 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
     const bool isB = i >= 8;
     const int j = i & 7;
     char* dst = my_part + (isB ? TILE_BYTES : 0) + (u & 1) * 2 * TILE_BYTES + j * 4096;
-    const int kt = kt0 + u, kta = (p.dbg & 4) ? 0 : (isB ? ktaB0 : ktaA0) + u;      // dbg 4: every k-tile re-fetches k-tile 0 (cache-resident)
-    const int lim = (u < n_tiles && dma_on) ? p.K - kt * BK : 0;
+    const int kt = kt0 + u, kta = (dbg & 4) ? 0 : (isB ? ktaB0 : ktaA0) + u;      // dbg 4: every k-tile re-fetches k-tile 0 (cache-resident)
     const bool ks = isB ? BKS : AKS;
-    const int kl = (isB ? klB : klA) + (ks ? j * 8 : 0);
-    const uint32_t off = kl < lim ? (isB ? voffB : voffA) : OOB;
+    const uint32_t soff = (uint32_t)kta * (isB ? kstepB : kstepA) + (uint32_t)j * (isB ? stepB : stepA);
+    if (ks) {
+      // k-strided operand: k is the ROW of the tensor, so a piece past K (the tail of the last k-tile, the look-ahead k-tiles behind it)
+      // lies behind the end of the buffer window -- provided its whole address sits in the LANE offset (the hardware's range check does
+      // not see the scalar offset): one v_add per piece instead of add + compare + select.  (A split-K slab's look-ahead reads the next
+      // slab's first rows instead of zeros: nobody consumes that buffer.)
+      const uint32_t off = dma_on ? (isB ? voffB : voffA) + soff : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(isB ? rsB : rsA, IA_LDS(dst), 16, off, 0, 0, 0);
+    } else {
+      const int lim = (u < n_tiles && dma_on) ? p.K - kt * BK : 0;
+      const uint32_t off = (isB ? klB : klA) < lim ? (isB ? voffB : voffA) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(isB ? rsB : rsA, IA_LDS(dst), 16, off, (int)soff, 0, 0);
+    }
+  };
+
+  // ROUND schedule (k-contiguous operands): the lane offset of a k-tile's pieces is the same for all eight pieces of an operand -- whole
+  // k-tile, K tail, or out of range past the last k-tile -- and is formed where the schedule has room, not at the first piece
+  auto off_of = [&](int u, bool isB) -> uint32_t {
+    const int lim = (u < n_tiles && dma_on) ? p.K - (kt0 + u) * BK : 0;
+    return (isB ? klB : klA) < lim ? (isB ? voffB : voffA) : OOB;
+  };
+  auto dma_c = [&](int u, int i, uint32_t off) {
+    const bool isB = i >= 8;
+    const int j = i & 7;
+    char* dst = my_part + (isB ? TILE_BYTES : 0) + (u & 1) * 2 * TILE_BYTES + j * 4096;
+    const int kta = (dbg & 4) ? 0 : (isB ? ktaB0 : ktaA0) + u;
     const uint32_t soff = (uint32_t)kta * (isB ? kstepB : kstepA) + (uint32_t)j * (isB ? stepB : stepA);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(isB ? rsB : rsA, IA_LDS(dst), 16, off, (int)soff, 0, 0);
   };
@@ -941,40 +983,43 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
   // (transpose reads: 36 / 48 per k-tile) lose 3 % under it (data gradient 1148 -> 1184, weight gradient frac 0.522 -> 0.537 back
   // on the round-2 order below).
   if constexpr (ROUND) {
+  uint32_t offA = OOB, offB = off_of(1, true);
   do {
     const uint32_t bn = bo ^ (uint32_t)(2 * TILE_BYTES);
-    tie<0>(a0); tie<0>(b0);
+    tie2<0>(a0, b0);
     step(a0, b0, [&](int i) {      // (no reads behind the last four MFMAs: they cover the latency of the last reads)
       if (i < 4) { read_frag<1>(a1, i, baseA, bo); read_frag<1>(b1, i, baseB, bo); }
       else if (i < 8) { read_frag<2>(a2, i - 4, baseA, bo); read_frag<2>(b2, i - 4, baseB, bo); }
       else if (i < 12) { read_frag<3>(a3, i - 8, baseA, bo); read_frag<3>(b3, i - 8, baseB, bo); }
-      if (i % 4 == 3) dma_piece(u + 1, 12 + i / 4);      // the last four pieces of k-tile u+1 (into the other buffer)
+      if (i % 4 == 3) dma_c(u + 1, 12 + i / 4, offB);      // the last four pieces of k-tile u+1 (into the other buffer)
+      if (i == 12) offA = off_of(u + 2, false);
     });
-    tie<0>(a1); tie<0>(b1); tie<0>(a2); tie<0>(b2); tie<0>(a3); tie<0>(b3);
+    tie6<0>(a1, b1, a2, b2, a3, b3);
     __builtin_amdgcn_sched_barrier(0);
-    if (!(p.dbg & 16)) __builtin_amdgcn_s_barrier();
+    if (!(dbg & 16)) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     step(a1, b1, [&](int i) {
-      if (i % 4 == 1) dma_piece(u + 2, i / 4);
+      if (i % 4 == 1) dma_c(u + 2, i / 4, offA);
     });
     step(a2, b2, [&](int i) {
-      if (i % 4 == 1) dma_piece(u + 2, 4 + i / 4);
+      if (i % 4 == 1) dma_c(u + 2, 4 + i / 4, offA);
+      if (i == 14) offB = off_of(u + 2, true);
     });
     // k-tile u+1 has landed (its last four pieces went out under k-step 0): only the 8 pieces just issued may be outstanding
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    if (!(p.dbg & 16)) __builtin_amdgcn_s_barrier();
+    if (!(dbg & 16)) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     step(a3, b3, [&](int i) {      // set 0 of k-tile u+1 in the first half: the second half covers the reads' latency
       if (i < 4) read_frag<0>(a0, i, baseA, bn);
       else if (i < 8) read_frag<0>(b0, i - 4, baseB, bn);
-      if (i % 4 == 3) dma_piece(u + 2, 8 + i / 4);
+      if (i % 4 == 3) dma_c(u + 2, 8 + i / 4, offB);
     });
     bo = bn;
     ++u;
   } while (u < n_tiles);
   // the reads of "set 0 of the k-tile after the last" are dead, but in flight: their destinations must not be handed out before they land
-  tie<0>(a0); tie<0>(b0);
+  tie2<0>(a0, b0);
   return;
   }
   do {
@@ -996,7 +1041,7 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
     // every fragment of k-tile u is in registers: once all waves are here its buffer is free for k-tile u+2
     tie<0>(a2); tie<0>(b2); tie<0>(a3); tie<0>(b3);
     __builtin_amdgcn_sched_barrier(0);
-    if (!(p.dbg & 16)) __builtin_amdgcn_s_barrier();
+    if (!(dbg & 16)) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     // k-step 2: the A half of k-tile u+2, one piece per two MFMAs
     step(a2, b2, [&](int i) {
@@ -1005,7 +1050,7 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
     // k-step 3: k-tile u+1 has landed (this wave's share: all but the 8 pieces just issued; everybody's: the barrier)
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    if (!(p.dbg & 16)) __builtin_amdgcn_s_barrier();
+    if (!(dbg & 16)) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     step(a3, b3, [&](int i) {
       if (i & 1) dma_piece(u + 2, 8 + (i >> 1));
