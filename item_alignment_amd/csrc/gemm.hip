@@ -1458,13 +1458,14 @@ int launch(GemmArgs a, bool big, hipStream_t st) {
   constexpr int vid = AKS * 1000 + BKS * 100 + EPI * 10 + (OUTF32 ? 1 : 0);
   const bool rec = g_prof.on && g_prof.variant == vid && g_prof.n < g_prof.cap;
   if (rec) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
-  // Two 256 x 256 kernels: t256w (one wave per SIMD, 128 x 128 wave tiles) has the faster k loop (+5-10 %), t256 (two waves per
-  // SIMD) the faster epilogue when that is VALU-heavy (GELU forward, x GELU' data gradient: 8 waves hide the math, 4 do not).
-  // IA_GEMM_WIDE=0 / 1 forces one of them for A/B runs.
+  // Two 256 x 256 kernels: t256w (one wave per SIMD, 128 x 128 wave tiles) has the faster k loop, t256 (two waves per SIMD) had the
+  // faster epilogue when that is VALU-heavy (GELU forward, x GELU' data gradient) -- until round 4's k loop: since then t256w wins
+  // those too (bias + GELU 412 -> 405 us, x GELU' + column sums 317 -> 313 us at 32640 x 4096 x 1024, step +0.65 % same box).
+  // IA_GEMM_WIDE=0 runs everything on t256, 3 the round-3 split (heavy epilogues on t256) for A/B runs.
   static int wide = -1;
-  if (wide < 0) { const char* e = getenv("IA_GEMM_WIDE"); wide = e ? atoi(e) : 2; }
+  if (wide < 0) { const char* e = getenv("IA_GEMM_WIDE"); wide = e ? atoi(e) : 1; }
   constexpr bool heavy_epi = EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_ACT || EPI == EPI_DGELU || EPI == EPI_DGELU_CS;
-  if (big && (wide == 1 || (wide == 2 && !heavy_epi))) {
+  if (big && (wide == 1 || wide == 2 || (wide == 3 && !heavy_epi))) {
     a.tiles_m = (a.M + t256::BM - 1) / t256::BM; a.tiles_n = (a.N + t256::BN - 1) / t256::BN;
     static bool attr_set_w = false;
     auto kern = t256w::gemm_kernel<AKS, BKS, EPI, OUTF32>;

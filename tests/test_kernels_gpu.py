@@ -2,6 +2,7 @@
 reference of the same op on identical bf16-rounded inputs.  Tolerances (written per test):
 bf16 outputs 2e-2 relative to the tensor's max magnitude (north_star: 5e-2 bf16), fp32 outputs 2e-3."""
 import math
+import os
 
 import pytest
 import torch
@@ -509,6 +510,18 @@ def test_gemm_one_wave_per_simd_kernel_edges(gpu, M, N, K):
     wt, at = w.t().contiguous(), a.t().contiguous()
     assert rel_err(ops.gemm(a, wt, b_kstrided=True), ref) < 2e-2
     assert rel_err(ops.gemm(at, wt, a_kstrided=True, b_kstrided=True, out_f32=True), ref) < 2e-3
+
+
+def test_gemm_two_waves_per_simd_kernel_still_agrees(gpu):
+    """Since round 4 every large GEMM runs on the one-wave-per-SIMD kernel; the two-waves-per-SIMD kernel (IA_GEMM_WIDE=0, read once
+    per process) stays in the library for A/B runs and is held to the same GEMM tests in a child process."""
+    import subprocess, sys
+    env = dict(os.environ, IA_GEMM_WIDE="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                        "gemm_nt_epilogues or gemm_gelu_epilogue_accuracy or gemm_nn_dgrad or gemm_tn_wgrad or gemm_dgelu_with_fused_column_sums "
+                        "or gemm_persistent_rounds"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-1000:]
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(8200, 2056, 256, "none"), (8200, 2056, 320, "bias_gelu"), (16500, 1032, 192, "add")])
