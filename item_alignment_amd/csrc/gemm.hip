@@ -1110,24 +1110,33 @@ IA_DEV void drain_half_plain(const GemmArgs& p, f32x16 (&acc)[4][4], int m0, int
       __builtin_amdgcn_sched_barrier(0);             // one block at a time: hoisting every accumulator read ran the kernel into scratch
     }
   };
+  // Stores through a buffer window over rows m0 .. M-1 of C: a row past M lies behind the window's end and a lane past N starts 2 GiB
+  // out, so the hardware drops both -- no execution-mask branches, one 32-bit add per store instead of a 64-bit multiply-add chain
+  // (the global_store form of rounds 1-3 spent ~400 scalar / branch / address instructions per wave and tile on clipping that a full
+  // tile never needs).  The row advance sits in the LANE offset: the range check does not see a scalar offset.
+  const int rows_left = p.M - m0;
+  const uint64_t wbytes = rows_left > 0 ? (uint64_t)rows_left * p.ldc * 2 : 0;
+  const __amdgpu_buffer_rsrc_t rsC = ia_rsrc(reinterpret_cast<bf16*>(p.C) + (size_t)m0 * p.ldc, (uint32_t)(wbytes < 0x7FFFFFF0ull ? wbytes : 0x7FFFFFF0ull));
+  const int ncol = n0 + c8 * 8;
+  const uint32_t voffC = ncol < p.N ? (uint32_t)((rrow * p.ldc + ncol) * 2) : 0x80000000u;
   stage(0);
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
     __builtin_amdgcn_wave_barrier();
     const char* const sl = stg + (mi & 1) * 4096;
-    bf16x8 v[4];
+    u32x4 v[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int row = it * 8 + rrow;
-      v[it] = *reinterpret_cast<const bf16x8*>(sl + row * 128 + ((c8 ^ (row & 7)) << 4));
+      v[it] = *reinterpret_cast<const u32x4*>(sl + row * 128 + ((c8 ^ (row & 7)) << 4));
     }
     __builtin_amdgcn_wave_barrier();
     if (mi < 3) stage(mi + 1);        // the other slot: no wait for the reads above (LDS operations of a wave complete in order)
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      const int m = m0 + mi * 32 + it * 8 + rrow, n = n0 + c8 * 8;
-      if (m < p.M && n < p.N && !(p.dbg & 64)) gstore16(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n, v[it]);
-      if (p.dbg & 64) asm volatile("" : : "v"(v[it]));
+      const uint32_t off = voffC + (uint32_t)((mi * 32 + it * 8) * p.ldc * 2);
+      if (!IA_GEMM_DBG_HOOKS || !(p.dbg & 64)) __builtin_amdgcn_raw_buffer_store_b128(v[it], rsC, (int)off, 0, 0);
+      else asm volatile("" : : "v"(v[it]));
     }
   }
 }
