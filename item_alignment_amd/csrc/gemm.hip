@@ -759,6 +759,9 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs p) {
 #ifndef IA_T256W_NOREADS
 #define IA_T256W_NOREADS 0
 #endif
+#ifndef IA_T256W_KS_LANEOFF
+#define IA_T256W_KS_LANEOFF 1  // k-strided operands: whole DMA address in the lane offset (hardware range check) instead of compare + select per piece
+#endif
 #ifndef IA_GEMM_DBG_HOOKS
 #define IA_GEMM_DBG_HOOKS 0    // 1: the T256W k loop honours the IA_GEMM_DBG timing ablations (tools/abl builds)
 #endif
@@ -890,16 +893,18 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
     const int kt = kt0 + u, kta = (dbg & 4) ? 0 : (isB ? ktaB0 : ktaA0) + u;      // dbg 4: every k-tile re-fetches k-tile 0 (cache-resident)
     const bool ks = isB ? BKS : AKS;
     const uint32_t soff = (uint32_t)kta * (isB ? kstepB : kstepA) + (uint32_t)j * (isB ? stepB : stepA);
-    if (ks) {
+    if (ks && IA_T256W_KS_LANEOFF) {
       // k-strided operand: k is the ROW of the tensor, so a piece past K (the tail of the last k-tile, the look-ahead k-tiles behind it)
       // lies behind the end of the buffer window -- provided its whole address sits in the LANE offset (the hardware's range check does
       // not see the scalar offset): one v_add per piece instead of add + compare + select.  (A split-K slab's look-ahead reads the next
-      // slab's first rows instead of zeros: nobody consumes that buffer.)
+      // slab's first rows instead of zeros: nobody consumes that buffer.)  Data gradient +4 %, weight gradient +0.7 %; the memory-side
+      // fetches of both went UP 4-8 % with it (FETCH_SIZE 0.996 -> 1.076 GB per weight-gradient launch, same box, IA_T256W_KS_LANEOFF=0
+      // against 1): far more than the two look-ahead k-tiles -- the workgroups that share a panel out of one L2 drift further apart.
       const uint32_t off = dma_on ? (isB ? voffB : voffA) + soff : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(isB ? rsB : rsA, IA_LDS(dst), 16, off, 0, 0, 0);
     } else {
       const int lim = (u < n_tiles && dma_on) ? p.K - kt * BK : 0;
-      const uint32_t off = (isB ? klB : klA) < lim ? (isB ? voffB : voffA) : OOB;
+      const uint32_t off = (isB ? klB : klA) + (ks ? j * 8 : 0) < lim ? (isB ? voffB : voffA) : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(isB ? rsB : rsA, IA_LDS(dst), 16, off, (int)soff, 0, 0);
     }
   };
