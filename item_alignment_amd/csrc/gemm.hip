@@ -25,6 +25,14 @@
 #include <cstdlib>
 #include <type_traits>
 
+// The IA_GEMM_DBG timing ablations (switching the DMA, the barriers, the epilogue, its stores or its math off) exist in tools builds
+// only (-DIA_GEMM_DBG_HOOKS=1): left in as run-time tests they put a branch around every GELU pair of the FFN1 epilogue (334 branches
+// and 1882 s_nops in that kernel: each pair in its own basic block, the four independent chains of a call never interleaved).
+#ifndef IA_GEMM_DBG_HOOKS
+#define IA_GEMM_DBG_HOOKS 0
+#endif
+#define IA_DBG(p) (IA_GEMM_DBG_HOOKS ? (p).dbg : 0)
+
 namespace {
 
 constexpr int BK = 64;
@@ -161,15 +169,34 @@ IA_DEV void epi_store8(const GemmArgs& p, int m, int n, f32x4 lo, f32x4 hi, f32x
   }
   if (EPI == EPI_BIAS_GELU) {   // see epi_store4
     bf16x8 der;
+    {
+      // the four pairs of the call stage by stage (gelu_pair's arithmetic, common.h): four independent chains side by side, so the
+      // transcendental / packed-op latencies of one hide behind the others (one pair at a time left ~1.8 s_nops per exp2 / rcp)
+      constexpr float L2E = 1.4426950408889634f;
+      constexpr float C0 = 1.5949398799788077f, C1 = 0.07403000634661838f, C2 = -0.0007007124749191571f;
+      constexpr float U_MAX = C1 / (2.f * 0.0007007124749191571f);
+      f32x2_t x[4], u[4], t[4], e[4], sg[4], act[4], q[4], d[4];
 #pragma unroll
-    for (int r = 0; r < 8; r += 2) {
-      f32x2_t a, d;
-      if (p.dbg & 512) { a = f32x2_t{v[r], v[r + 1]}; d = a; } else
-      gelu_pair(f32x2_t{v[r], v[r + 1]}, a, d);
-      v[r] = a[0]; v[r + 1] = a[1];
-      der[r] = f2bf(d[0]); der[r + 1] = f2bf(d[1]);
+      for (int i = 0; i < 4; ++i) { x[i] = f32x2_t{v[2 * i], v[2 * i + 1]}; u[i] = x[i] * x[i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { u[i][0] = __builtin_fminf(u[i][0], U_MAX); u[i][1] = __builtin_fminf(u[i][1], U_MAX); }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) t[i] = x[i] * ((u[i] * (-C2 * L2E) + (-C1 * L2E)) * u[i] + (-C0 * L2E));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) e[i] = f32x2_t{__builtin_amdgcn_exp2f(t[i][0]), __builtin_amdgcn_exp2f(t[i][1])};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { e[i] = e[i] + 1.0f; q[i] = (u[i] * (5.f * C2) + (3.f * C1)) * u[i] + C0; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sg[i] = f32x2_t{__builtin_amdgcn_rcpf(e[i][0]), __builtin_amdgcn_rcpf(e[i][1])};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { act[i] = x[i] * sg[i]; d[i] = (act[i] * (1.0f - sg[i])) * q[i] + sg[i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[2 * i] = act[i][0]; v[2 * i + 1] = act[i][1];
+        der[2 * i] = f2bf(d[i][0]); der[2 * i + 1] = f2bf(d[i][1]);
+      }
     }
-    gstore16(((p.dbg & 1024) ? reinterpret_cast<bf16*>(p.C) : p.C2) + (size_t)m * p.ldc + n, der);
+    gstore16(((IA_DBG(p) & 1024) ? reinterpret_cast<bf16*>(p.C) : p.C2) + (size_t)m * p.ldc + n, der);
   }
   if (EPI == EPI_BIAS_GELU_ACT) {
 #pragma unroll
@@ -502,7 +529,7 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][2], __amdg
 
   // B fragment row i <-> n so that a lane ends up with 16 consecutive output columns (k-contiguous B only)
   const int nperm = ((li >> 2) & 1) * 16 + (li >> 3) * 4 + (li & 3);
-  const bool dma_on = !(p.dbg & 2);
+  const bool dma_on = !(IA_DBG(p) & 2);
 
   for (int u = 0; u < n_tiles; ++u) {
     const char* sA = smem + (u & 1) * 2 * TILE_BYTES;
@@ -513,7 +540,7 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][2], __amdg
       for (int i = 0; i < 8; ++i) dma_piece(u + 1, i);
     }
     bf16x8 af[4][4], bfr[4][2];
-    if (!(p.dbg & 8) || u == 0)
+    if (!(IA_DBG(p) & 8) || u == 0)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
@@ -531,7 +558,7 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][2], __amdg
     if (GRP == 1 && u >= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    if (!(p.dbg & 16)) __builtin_amdgcn_s_barrier();
+    if (!(IA_DBG(p) & 16)) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     // ------------------------------------------------------------------ COMPUTE phase
     // G1 streams its 8 DMA pieces of k-tile u+2 in the shadow of its own MFMAs: one piece per 4 MFMAs
@@ -549,7 +576,7 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][2], __amdg
     __builtin_amdgcn_s_setprio(0);
     if (GRP == 0 && u >= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // G0's DMA issued in this iteration's LOAD (u >= 1)
     __builtin_amdgcn_sched_barrier(0);
-    if (!(p.dbg & 16)) __builtin_amdgcn_s_barrier();
+    if (!(IA_DBG(p) & 16)) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   }
   if (GRP == 0) __builtin_amdgcn_s_barrier();      // matches G1's last phase
@@ -609,9 +636,9 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs p) {
                                                kt0, BKS ? 0 : kt0, n_tiles, nk_all, wn, lane, prologue_only, stores_in_flight);
   };
 
-  if ((p.dbg & 2048) && ((blockIdx.x >> 3) & 1)) {     // ablation: every other CU of an XCD starts (dbg >> 16) us late
+  if ((IA_DBG(p) & 2048) && ((blockIdx.x >> 3) & 1)) {     // ablation: every other CU of an XCD starts (dbg >> 16) us late
     const unsigned long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < (unsigned long long)(p.dbg >> 16) * 100ull) __builtin_amdgcn_s_sleep(8);
+    while (wall_clock64() - t0 < (unsigned long long)(IA_DBG(p) >> 16) * 100ull) __builtin_amdgcn_s_sleep(8);
   }
   f32x16 acc[4][2];
   int tile = first_tile;
@@ -699,11 +726,11 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs p) {
                 ax[(c + AHEAD) % (AHEAD + 1)] = aux_of(c + AHEAD);
                 asm volatile("" ::: "memory");      // the load stays in front of this slice's store (hipcc would sink it behind)
               }
-              if (!(p.dbg & 64)) epi_store8<EPI, OUTF32, true>(p, m, n, lo, hi, pb0, pb1, ax[c % (AHEAD + 1)], cs);
+              if (!(IA_DBG(p) & 64)) epi_store8<EPI, OUTF32, true>(p, m, n, lo, hi, pb0, pb1, ax[c % (AHEAD + 1)], cs);
             } else {
-              if (m < p.M && n < p.N && !(p.dbg & 64)) epi_store8<EPI, OUTF32, false>(p, m, n, lo, hi, pb0, pb1, ax[0], cs);
+              if (m < p.M && n < p.N && !(IA_DBG(p) & 64)) epi_store8<EPI, OUTF32, false>(p, m, n, lo, hi, pb0, pb1, ax[0], cs);
             }
-            if (p.dbg & 64) asm volatile("" : : "v"(lo), "v"(hi));
+            if (IA_DBG(p) & 64) asm volatile("" : : "v"(lo), "v"(hi));
           }
           __builtin_amdgcn_wave_barrier();
         }
@@ -725,12 +752,12 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs p) {
         }
       }
     };
-    if (!(p.dbg & 32)) {
-      if (full && (HAS_BIAS || HAS_AUX) && !(p.dbg & 256)) drain_tile(std::true_type{}); else drain_tile(std::false_type{});
+    if (!(IA_DBG(p) & 32)) {
+      if (full && (HAS_BIAS || HAS_AUX) && !(IA_DBG(p) & 256)) drain_tile(std::true_type{}); else drain_tile(std::false_type{});
     }
     if (next >= total_tiles) break;
     // a wave whose 128 x 64 part of the tile was clipped by M or N issued fewer stores than PEND: drain instead of counting
-    stores_in_flight = !(p.dbg & 96) && full;
+    stores_in_flight = !(IA_DBG(p) & 96) && full;
     if (!stores_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     tile = next;
   }
@@ -762,9 +789,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs p) {
 #ifndef IA_T256W_KS_LANEOFF
 #define IA_T256W_KS_LANEOFF 1  // k-strided operands: whole DMA address in the lane offset (hardware range check) instead of compare + select per piece
 #endif
-#ifndef IA_GEMM_DBG_HOOKS
-#define IA_GEMM_DBG_HOOKS 0    // 1: the T256W k loop honours the IA_GEMM_DBG timing ablations (tools/abl builds)
-#endif
+
 namespace t256w {
 using t256::BM;
 using t256::BN;
@@ -1065,6 +1090,7 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
     bo = bn;
     ++u;
   } while (u < n_tiles);
+  tie<0>(a0); tie<0>(b0);      // dead, but in flight (see the ROUND loop's exit)
 }
 
 // Plain bf16 output (no bias / aux operand): the accumulators are rounded to bf16 BEFORE the trip through LDS, so one pass stages
@@ -1218,11 +1244,11 @@ IA_DEV void drain_half(const GemmArgs& p, f32x16 (&acc)[4][4], int m0, int n0, c
             ax[(c + AHEAD) % (AHEAD + 1)] = aux_of(c + AHEAD);
             asm volatile("" ::: "memory");
           }
-          if (!(p.dbg & 64)) epi_store8<EPI, OUTF32, true>(p, m, n, lo[it], hi[it], pb0, pb1, ax[c % (AHEAD + 1)], cs);
+          if (!(IA_DBG(p) & 64)) epi_store8<EPI, OUTF32, true>(p, m, n, lo[it], hi[it], pb0, pb1, ax[c % (AHEAD + 1)], cs);
         } else {
-          if (m < p.M && n < p.N && !(p.dbg & 64)) epi_store8<EPI, OUTF32, false>(p, m, n, lo[it], hi[it], pb0, pb1, ax[0], cs);
+          if (m < p.M && n < p.N && !(IA_DBG(p) & 64)) epi_store8<EPI, OUTF32, false>(p, m, n, lo[it], hi[it], pb0, pb1, ax[0], cs);
         }
-        if (p.dbg & 64) asm volatile("" : : "v"(lo[it]), "v"(hi[it]));
+        if (IA_DBG(p) & 64) asm volatile("" : : "v"(lo[it]), "v"(hi[it]));
       }
     }
     if (EPI == EPI_DGELU_CS) {
@@ -1240,7 +1266,7 @@ IA_DEV void drain_half(const GemmArgs& p, f32x16 (&acc)[4][4], int m0, int n0, c
       }
     }
   };
-  if (full && (HAS_BIAS || HAS_AUX) && !(p.dbg & 256)) drain(std::true_type{}); else drain(std::false_type{});
+  if (full && (HAS_BIAS || HAS_AUX) && !(IA_DBG(p) & 256)) drain(std::true_type{}); else drain(std::false_type{});
 }
 
 template <bool AKS, bool BKS, int EPI, bool OUTF32>
@@ -1338,7 +1364,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     int m0 = m0_pre, n0 = n0_pre;
     asm volatile("" : "+s"(m0), "+s"(n0));
     char* stg = smem + 2 * 2 * TILE_BYTES + wave * 2 * STAGE_BYTES;      // 8 KiB per wave (t256's eight 4-KiB slots, two per wave)
-    if (!(p.dbg & 32)) {
+    if (!(IA_DBG(p) & 32)) {
       if constexpr (EPI == EPI_NONE && !OUTF32) {
         drain_half_plain<BKS, 0, false>(p, acc, m0, n0, stg, lane_e, bct);
         drain_half_plain<BKS, 1, false>(p, acc, m0, n0 + 64, stg, lane_e, bct);
@@ -1351,7 +1377,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
       }
     }
     if (next >= total_tiles) break;
-    stores_in_flight = !(p.dbg & 96) && full;
+    stores_in_flight = !(IA_DBG(p) & 96) && full;
     if (!stores_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     tile = next;
   }
