@@ -198,12 +198,26 @@ IA_DEV void epi_store8(const GemmArgs& p, int m, int n, f32x4 lo, f32x4 hi, f32x
     }
     gstore16(((IA_DBG(p) & 1024) ? reinterpret_cast<bf16*>(p.C) : p.C2) + (size_t)m * p.ldc + n, der);
   }
-  if (EPI == EPI_BIAS_GELU_ACT) {
+  if (EPI == EPI_BIAS_GELU_ACT) {      // gelu_act_pair's arithmetic, the four pairs stage by stage (see above)
+    constexpr float L2E = 1.4426950408889634f;
+    constexpr float C0 = 1.5949398799788077f, C1 = 0.07403000634661838f, C2 = -0.0007007124749191571f;
+    constexpr float U_MAX = C1 / (2.f * 0.0007007124749191571f);
+    f32x2_t x[4], u[4], t[4], e[4];
 #pragma unroll
-    for (int r = 0; r < 8; r += 2) {
-      const f32x2_t a = gelu_act_pair(f32x2_t{v[r], v[r + 1]});
-      v[r] = a[0]; v[r + 1] = a[1];
-    }
+    for (int i = 0; i < 4; ++i) { x[i] = f32x2_t{v[2 * i], v[2 * i + 1]}; u[i] = x[i] * x[i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { u[i][0] = __builtin_fminf(u[i][0], U_MAX); u[i][1] = __builtin_fminf(u[i][1], U_MAX); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = x[i] * ((u[i] * (-C2 * L2E) + (-C1 * L2E)) * u[i] + (-C0 * L2E));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = f32x2_t{__builtin_amdgcn_exp2f(t[i][0]), __builtin_amdgcn_exp2f(t[i][1])} + 1.0f;
+    f32x2_t sg[4], act[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sg[i] = f32x2_t{__builtin_amdgcn_rcpf(e[i][0]), __builtin_amdgcn_rcpf(e[i][1])};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) act[i] = x[i] * sg[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = act[i][0]; v[2 * i + 1] = act[i][1]; }
   }
   if (EPI == EPI_ADD || EPI == EPI_BIAS_ADD || EPI == EPI_DGELU || EPI == EPI_DGELU_CS) {
     const bf16x8 a = PRE ? ax : *reinterpret_cast<const bf16x8*>(p.aux + (size_t)m * p.ldaux + n);
