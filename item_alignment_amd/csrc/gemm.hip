@@ -963,6 +963,17 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
     __builtin_amdgcn_raw_ptr_buffer_load_lds(isB ? rsB : rsA, IA_LDS(dst), 16, off, (int)soff, 0, 0);
   };
 
+  // second schedule (a k-strided operand): in-loop pieces of k-tile u+2; the k-strided operand's k-tile advance lives in a running lane offset
+  uint32_t runA = voffA + (uint32_t)((dbg & 4) ? 0 : ktaA0 + 2) * kstepA, runB = voffB + (uint32_t)((dbg & 4) ? 0 : ktaB0 + 2) * kstepB;
+  auto dma_run = [&](int u, int i) {
+    const bool isB = i >= 8;
+    if (!(isB ? BKS : AKS) || !IA_T256W_KS_LANEOFF || (dbg & 4)) { dma_piece(u, i); return; }
+    const int j = i & 7;
+    char* dst = my_part + (isB ? TILE_BYTES : 0) + (u & 1) * 2 * TILE_BYTES + j * 4096;
+    const uint32_t off = (isB ? runB : runA) + (uint32_t)j * (isB ? stepB : stepA);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(isB ? rsB : rsA, IA_LDS(dst), 16, dma_on ? off : OOB, 0, 0, 0);
+  };
+
   if (prologue_only) {       // called ahead of time (before the previous tile's epilogue): just start the first two k-tiles
 #pragma unroll
     for (int i = 0; i < 16; ++i) dma_piece(0, i);
@@ -1089,7 +1100,7 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
     __builtin_amdgcn_sched_barrier(0);
     // k-step 2: the A half of k-tile u+2, one piece per two MFMAs
     step(a2, b2, [&](int i) {
-      if (i & 1) dma_piece(u + 2, i >> 1);
+      if (i & 1) dma_run(u + 2, i >> 1);
     });
     // k-step 3: k-tile u+1 has landed (this wave's share: all but the 8 pieces just issued; everybody's: the barrier)
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -1097,12 +1108,16 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
     if (!(dbg & 16)) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     step(a3, b3, [&](int i) {
-      if (i & 1) dma_piece(u + 2, 8 + (i >> 1));
+      if (i & 1) dma_run(u + 2, 8 + (i >> 1));
       else if (i < 8) read_frag<0>(a0, i >> 1, baseA, bn);
       else read_frag<0>(b0, (i - 8) >> 1, baseB, bn);
     });
     bo = bn;
     ++u;
+    // one running lane offset per k-strided operand, opaque to the loop optimiser: left alone it keeps SIXTEEN induction variables
+    // (one per piece) and bumps them all in the last MFMA gap of the trip
+    if (AKS) { runA += kstepA; asm volatile("" : "+v"(runA)); }
+    if (BKS) { runB += kstepB; asm volatile("" : "+v"(runB)); }
   } while (u < n_tiles);
   tie<0>(a0); tie<0>(b0);      // dead, but in flight (see the ROUND loop's exit)
 }
