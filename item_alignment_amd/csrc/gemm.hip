@@ -155,8 +155,11 @@ constexpr int epi_extra_stores() { return EPI == EPI_DGELU_CS ? 2 : 0; }     // 
 
 // v = 8 consecutive output columns n..n+7 of row m (row-coalesced epilogue of the T256 kernel).  PRE: bias (pb0 | pb1) and aux (ax)
 // were fetched ahead by the caller; else they are loaded here.
-template <int EPI, bool OUTF32, bool PRE>
-IA_DEV void epi_store8(const GemmArgs& p, int m, int n, f32x4 lo, f32x4 hi, f32x4 pb0, f32x4 pb1, bf16x8 ax, float (&cs)[8]) {
+// BUF (full tiles of the one-wave-per-SIMD kernel, bf16 outputs): the output streams are addressed through buffer windows over the
+// wave's rows with one 32-bit lane offset (io.off) instead of 64-bit pointer arithmetic per access (3 VALU instructions each)
+struct BufIO { __amdgpu_buffer_rsrc_t rsC, rsC2; uint32_t off; };
+template <int EPI, bool OUTF32, bool PRE, bool BUF = false>
+IA_DEV void epi_store8(const GemmArgs& p, int m, int n, f32x4 lo, f32x4 hi, f32x4 pb0, f32x4 pb1, bf16x8 ax, float (&cs)[8], const BufIO* io = nullptr) {
   float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_ACT || EPI == EPI_BIAS_ADD) {
     const f32x4 b0 = PRE ? pb0 : *reinterpret_cast<const f32x4*>(p.bias + n), b1 = PRE ? pb1 : *reinterpret_cast<const f32x4*>(p.bias + n + 4);
@@ -196,7 +199,8 @@ IA_DEV void epi_store8(const GemmArgs& p, int m, int n, f32x4 lo, f32x4 hi, f32x
         der[2 * i] = f2bf(d[i][0]); der[2 * i + 1] = f2bf(d[i][1]);
       }
     }
-    gstore16(((IA_DBG(p) & 1024) ? reinterpret_cast<bf16*>(p.C) : p.C2) + (size_t)m * p.ldc + n, der);
+    if (BUF) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, der), io->rsC2, (int)io->off, 0, 0);
+    else gstore16(((IA_DBG(p) & 1024) ? reinterpret_cast<bf16*>(p.C) : p.C2) + (size_t)m * p.ldc + n, der);
   }
   if (EPI == EPI_BIAS_GELU_ACT) {      // gelu_act_pair's arithmetic, the four pairs stage by stage (see above)
     constexpr float L2E = 1.4426950408889634f;
@@ -238,7 +242,8 @@ IA_DEV void epi_store8(const GemmArgs& p, int m, int n, f32x4 lo, f32x4 hi, f32x
     bf16x8 o;
 #pragma unroll
     for (int r = 0; r < 8; ++r) o[r] = f2bf(v[r]);
-    gstore16(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n, o);
+    if (BUF) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), io->rsC, (int)io->off, 0, 0);
+    else gstore16(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n, o);
   }
 }
 
@@ -1219,9 +1224,25 @@ IA_DEV void drain_half(const GemmArgs& p, f32x16 (&acc)[4][4], int m0, int n0, c
       for (int j = 0; j < 8; ++j) asm volatile("v_mov_b32 %0, 0" : "=v"(cs[j]));
     }
     bf16x8 ax[AHEAD + 1];
+    // full tiles with bf16 outputs: buffer windows over the wave's rows (from row m0 to the end of the tensor), one lane offset each
+    constexpr bool BUF = PRE && !OUTF32;
+    const auto window = [&](const void* base, int ld) {
+      const uint64_t bytes = (uint64_t)(p.M - m0) * ld * 2;
+      return ia_rsrc(reinterpret_cast<const bf16*>(base) + (size_t)m0 * ld, (uint32_t)(bytes < 0x7FFFFFF0ull ? bytes : 0x7FFFFFF0ull));
+    };
+    BufIO io{ia_rsrc(nullptr, 0), ia_rsrc(nullptr, 0), 0u};
+    __amdgpu_buffer_rsrc_t rsAux = ia_rsrc(nullptr, 0);
+    uint32_t voffC = 0, voffAux = 0;
+    if (BUF) {
+      io.rsC = window(p.C, p.ldc);
+      if (EPI == EPI_BIAS_GELU) io.rsC2 = window(p.C2, p.ldc);
+      voffC = (uint32_t)((rrow * p.ldc + n0 + c8 * 8) * 2);
+      if (HAS_AUX) { rsAux = window(p.aux, p.ldaux); voffAux = (uint32_t)((rrow * p.ldaux + n0 + c8 * 8) * 2); }
+    }
     auto aux_of = [&](int c) {
-      const int row = m0 + (c >> 2) * 32 + ((c >> 1) & 1) * 16 + (c & 1) * 8 + rrow;
-      return *reinterpret_cast<const bf16x8*>(p.aux + (size_t)row * p.ldaux + n0 + c8 * 8);
+      const int row_in = (c >> 2) * 32 + ((c >> 1) & 1) * 16 + (c & 1) * 8;
+      if (BUF) return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsAux, (int)(voffAux + (uint32_t)(row_in * p.ldaux * 2)), 0, 0));
+      return *reinterpret_cast<const bf16x8*>(p.aux + (size_t)(m0 + row_in + rrow) * p.ldaux + n0 + c8 * 8);
     };
     if (PRE && HAS_BIAS) {      // normally fetched before the main loop (a load issued here queues behind the previous stores)
       if (bias_ready) { pb0 = bias_lo; pb1 = bias_hi; }
@@ -1273,7 +1294,8 @@ IA_DEV void drain_half(const GemmArgs& p, f32x16 (&acc)[4][4], int m0, int n0, c
             ax[(c + AHEAD) % (AHEAD + 1)] = aux_of(c + AHEAD);
             asm volatile("" ::: "memory");
           }
-          if (!(IA_DBG(p) & 64)) epi_store8<EPI, OUTF32, true>(p, m, n, lo[it], hi[it], pb0, pb1, ax[c % (AHEAD + 1)], cs);
+          io.off = voffC + (uint32_t)((mi * 32 + it * 8) * p.ldc * 2);
+          if (!(IA_DBG(p) & 64)) epi_store8<EPI, OUTF32, true, BUF>(p, m, n, lo[it], hi[it], pb0, pb1, ax[c % (AHEAD + 1)], cs, &io);
         } else {
           if (m < p.M && n < p.N && !(IA_DBG(p) & 64)) epi_store8<EPI, OUTF32, false>(p, m, n, lo[it], hi[it], pb0, pb1, ax[0], cs);
         }
