@@ -78,6 +78,52 @@ void run(const char* name, const char* src, float* out, unsigned long long* cyc,
          (double)nwg * 4 * iters * 64 * 32768.0 / (ms * 1e-3) * 1e-12);
 }
 
+
+// VALU stream (an epilogue's arithmetic: 512 independent v_fma_f32 per trip) with 16 LDS-DMA pieces either in one burst in front of it or
+// one per 32 fmas: does spreading a tile prologue's pieces over the epilogue hide their issue cost?
+template <int MODE>
+__global__ __launch_bounds__(256) void kv(const char* src, float* out, unsigned long long* cyc, int iters) {
+  extern __shared__ __attribute__((aligned(128))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float x[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = (float)(lane + i);
+  const float c = 1.0001f, d = 0.5f;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(src), 0, 1u << 22, 0x00020000);
+  lds_char* const ldst = (lds_char*)smem + wave * 16384;
+  const uint32_t voff = (uint32_t)(blockIdx.x & 63) * 65536u + lane * 16;
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+    if (MODE == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, ldst + r * 1024, 16, voff, r * 4096 + (it & 7) * 128, 0, 0);
+    }
+#pragma unroll
+    for (int m = 0; m < 512; ++m) {
+      asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[m & 15]) : "v"(c), "v"(d));
+      if (MODE == 2 && (m & 31) == 31) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, ldst + (m >> 5) * 1024, 16, voff, (m >> 5) * 4096 + (it & 7) * 128, 0, 0);
+    }
+    if (MODE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += x[i];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+template <int MODE>
+void runv(const char* name, const char* src, float* out, unsigned long long* cyc) {
+  const int iters = 2000, nwg = 256;
+  hipFuncSetAttribute((const void*)kv<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL((kv<MODE>), dim3(nwg), dim3(256), 64 * 1024, 0, src, out, cyc, iters); hipDeviceSynchronize(); }
+  std::vector<unsigned long long> h(nwg);
+  hipMemcpy(h.data(), cyc, nwg * 8, hipMemcpyDeviceToHost);
+  double avg = 0; for (auto v : h) avg += (double)v; avg /= nwg;
+  printf("%-44s %8.1f cycles per trip (512 fma%s)\n", name, avg / iters, MODE ? " + 16 pieces" : "");
+}
+
 int main() {
   char* src; float* out; unsigned long long* cyc;
   hipMalloc(&src, 1 << 23); hipMemset(src, 1, 1 << 23);
@@ -93,5 +139,8 @@ int main() {
   run<0, 32, 16, 0>("+ reads + DMA", src, out, cyc, 256);
   run<0, 0, 8, 0>("+ 8 LDS-DMA pieces / 64", src, out, cyc, 256);
   run<0, 0, 0, 0>("bare, one workgroup only", src, out, cyc, 1);
+  runv<0>("VALU stream alone", src, out, cyc);
+  runv<1>("VALU stream, 16 pieces in a burst in front", src, out, cyc);
+  runv<2>("VALU stream, one piece per 32 fmas", src, out, cyc);
   return 0;
 }
