@@ -805,6 +805,10 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs p) {
 #ifndef IA_T256W_NOREADS
 #define IA_T256W_NOREADS 0
 #endif
+#ifndef IA_T256W_SPREAD3
+#define IA_T256W_SPREAD3 0     // second k-loop schedule (a k-strided operand): DMA pieces one per three MFMAs over k-steps 2, 3 and the next k-step 0
+                               // -- measured: data gradient +-0, weight gradient -0.9 % (what helps the forward forms does not help these)
+#endif
 #ifndef IA_T256W_KS_LANEOFF
 #define IA_T256W_KS_LANEOFF 1  // k-strided operands: whole DMA address in the lane offset (hardware range check) instead of compare + select per piece
 #endif
@@ -979,11 +983,20 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
     __builtin_amdgcn_raw_ptr_buffer_load_lds(isB ? rsB : rsA, IA_LDS(dst), 16, dma_on ? off : OOB, 0, 0, 0);
   };
 
+  // pieces 10 .. 15 (B pieces 2 .. 7) of the k-tile BEFORE the running one (the spread form of the second schedule issues them a trip late)
+  auto dma_prev = [&](int u, int i) {
+    if (!BKS || !IA_T256W_KS_LANEOFF || (dbg & 4)) { dma_piece(u, i); return; }
+    const int j = i & 7;
+    char* dst = my_part + TILE_BYTES + (u & 1) * 2 * TILE_BYTES + j * 4096;
+    const uint32_t off = runB - kstepB + (uint32_t)j * stepB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, IA_LDS(dst), 16, dma_on ? off : OOB, 0, 0, 0);
+  };
+
   if (prologue_only) {       // called ahead of time (before the previous tile's epilogue): just start the first two k-tiles
 #pragma unroll
     for (int i = 0; i < 16; ++i) dma_piece(0, i);
 #pragma unroll
-    for (int i = 0; i < (ROUND ? 12 : 16); ++i) dma_piece(1, i);      // (zero-filled when it does not exist; ROUND: see the loop)
+    for (int i = 0; i < (ROUND ? 12 : IA_T256W_SPREAD3 ? 10 : 16); ++i) dma_piece(1, i);      // (zero-filled when it does not exist; the rest: see the loops)
     return;
   }
   // the prologue DMA of this tile.  After a full-tile epilogue exactly PEND store instructions were issued behind it and
@@ -1091,6 +1104,9 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
       else if (i < 8) read_frag<1>(b1, i - 4, baseB, bo);
       else if (i < 12) read_frag<2>(a2, i - 8, baseA, bo);
       else read_frag<2>(b2, i - 12, baseB, bo);
+      // spread form: the DMA pieces of a k-tile one per THREE MFMAs over k-steps 2, 3 and the next trip's k-step 0 (5 + 5 + 6; the
+      // tile prologue issues 16 + 10): at one per two the VMEM port queues up (see the ROUND schedule)
+      if (IA_T256W_SPREAD3 && i % 3 == 0) dma_prev(u + 1, 10 + i / 3);
     });
     // k-step 1: set 3 requested in the first half
     tie<NR15>(a1); tie<NR15>(b1);
@@ -1105,17 +1121,22 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
     __builtin_amdgcn_sched_barrier(0);
     // k-step 2: the A half of k-tile u+2, one piece per two MFMAs
     step(a2, b2, [&](int i) {
-      if (i & 1) dma_run(u + 2, i >> 1);
+      if (IA_T256W_SPREAD3) { if (i % 3 == 1) dma_run(u + 2, i / 3); }
+      else if (i & 1) dma_run(u + 2, i >> 1);
     });
-    // k-step 3: k-tile u+1 has landed (this wave's share: all but the 8 pieces just issued; everybody's: the barrier)
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    // k-step 3: k-tile u+1 has landed (this wave's share: all but the 8 / 5 pieces just issued; everybody's: the barrier)
+    if (IA_T256W_SPREAD3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     if (!(dbg & 16)) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     step(a3, b3, [&](int i) {
-      if (i & 1) dma_run(u + 2, 8 + (i >> 1));
-      else if (i < 8) read_frag<0>(a0, i >> 1, baseA, bn);
-      else read_frag<0>(b0, (i - 8) >> 1, baseB, bn);
+      if (IA_T256W_SPREAD3) { if (i % 3 == 2) dma_run(u + 2, 5 + i / 3); }
+      else if (i & 1) dma_run(u + 2, 8 + (i >> 1));
+      if (!(i & 1)) {
+        if (i < 8) read_frag<0>(a0, i >> 1, baseA, bn);
+        else read_frag<0>(b0, (i - 8) >> 1, baseB, bn);
+      }
     });
     bo = bn;
     ++u;
