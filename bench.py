@@ -177,12 +177,22 @@ def self_launch(n):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
+    import signal
     child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    # the launcher and its N GPU ranks live in their own session (one killpg reaches all of them): if THIS process is told to stop
+    # (driver timeout, Ctrl-C, hang-up) nothing else would -- take the group down first, then leave with the conventional code
+    def on_term(signum, frame):
+        kill_group(child)
+        raise SystemExit(128 + signum)
+    old = {sg: signal.signal(sg, on_term) for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP)}
     try:
         return child.wait()
     except BaseException:
         kill_group(child)
         raise
+    finally:
+        for sg, h in old.items():
+            signal.signal(sg, h)
 
 
 def kill_group(child):

@@ -97,7 +97,10 @@ int ia_colsum(const void* x, int ld, int M, int N, float* out, int accumulate, v
 /* ---- fused self-attention, head dim 64 (transformers RobertaSelfAttention eager path: QK^T/sqrt(d)
  * + additive key mask -> softmax -> dropout -> PV; timm Attention without mask).  q/k/v point at the
  * first column of head 0 of each operand and share row stride ld_qkv (elements); key_mask is [B,L]
- * uint8 (1 = attend) or NULL; lse2 is [B,nh,L] fp32 (log2-domain log-sum-exp, saved for backward). */
+ * uint8 (1 = attend) or NULL; lse2 is [B,nh,L] fp32 (log2-domain log-sum-exp, saved for backward).
+ * `delta` of every backward entry point is caller-provided SCRATCH of B*nh*L (general form: B*nh*Lq) floats whose contents after
+ * the call are unspecified: the two-kernel path leaves rowsum(dO o O) there, the single-kernel path (32 < L <= 256, Lq == Lk) keeps
+ * its attendable-key bit map in it.  Hosts must not read it. */
 int ia_attn_fwd(const void* q, const void* k, const void* v, int ld_qkv, const uint8_t* key_mask, void* out, int ld_o, float* lse2,
                 int B, int nh, int L, float scale, float drop_p, uint32_t seed, ia_stream_t stream);
 int ia_attn_bwd(const void* q, const void* k, const void* v, int ld_qkv, const uint8_t* key_mask, const void* out, const void* d_out,
@@ -123,7 +126,8 @@ int ia_attn_bwd_bias_ps(const void* q, const void* k, const void* v, int ld_qkv,
  * ParallelTransformerBlock and :665-706 CrossAttention): Lq queries attend to Lk keys per (sequence, head).  q / out /
  * d_out rows are b*Lq + i (strides ld_q, ld_o), k / v rows are b*Lk + j (stride ld_kv), head h at column h*64.  One
  * K/V head shared by all query heads = the nh = 1 case with the query heads folded into rows (q viewed as
- * [B, n*heads, 64], ld_q = 64, Lq = n*heads).  key_mask is [B, Lk] or NULL; lse2 / delta are [B, nh, Lq]. */
+ * [B, n*heads, 64], ld_q = 64, Lq = n*heads).  key_mask is [B, Lk] or NULL; lse2 is [B, nh, Lq], delta scratch of the same size
+ * (contents unspecified on return, see above). */
 int ia_attn_fwd_x(const void* q, int ld_q, const void* k, const void* v, int ld_kv, const uint8_t* key_mask, void* out, int ld_o,
                   float* lse2, int B, int nh, int Lq, int Lk, float scale, float drop_p, uint32_t seed, ia_stream_t stream);
 int ia_attn_bwd_x(const void* q, int ld_q, const void* k, const void* v, int ld_kv, const uint8_t* key_mask, const void* out,
@@ -419,7 +423,9 @@ int ia_layer_bwd2(const ia_layer_cfg* cfg, const ia_layer_weights* w, const ia_l
  * place across the ranks, asynchronously on `stream` -- the caller launches it per gradient bucket as soon as the bucket's last
  * gradient kernel has been enqueued on that stream (or on a side stream ordered behind it) and divides by the world size in its
  * optimiser step (ia_adamw_flat's grad_scale).  RCCL is bound with dlopen at the first call (a copy already mapped into the process
- * is reused); IA_ERR_UNSUPPORTED = no librccl, ia_comm_last_error() has the text.  (ABI 5) */
+ * is reused, whatever file name it was loaded under); IA_ERR_UNSUPPORTED = no librccl, a symbol missing, or not the 2.x API --
+ * ia_comm_last_error() has the text (per calling thread).  PRECONDITION of ia_comm_init and ia_comm_allreduce_bucket: the calling
+ * thread's current HIP device (hipSetDevice) is the GPU this rank owns -- RCCL binds the communicator to it.  (ABI 5) */
 #define IA_COMM_ID_BYTES 128
 #define IA_COMM_F32 0
 #define IA_COMM_BF16 1

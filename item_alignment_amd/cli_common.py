@@ -67,10 +67,18 @@ def load_tokenizer(args):
     # transformers 4.20 (the reference's pin) with do_basic_tokenize=False keeps every whitespace-separated word whole, so the
     # image placeholder "[unused99]" (data.py:9-10, id 99) and the BOS marker reach the vocabulary lookup intact; the 5.x tokenizer
     # backend splits bracketed words at the punctuation unless they are registered as special tokens -- same ids either way
-    try:
-        tk.add_special_tokens({"additional_special_tokens": ["[unused99]", BOS_TOKEN]})
-    except Exception as e:      # an older transformers without this keyword set: the whitespace path above already covers it
-        logger.warning(f"could not register the image / BOS placeholders as special tokens: {e!r}")
+    # Only words the checkpoint's vocabulary already holds are registered: a word it lacks would be APPENDED with an id >= vocab_size,
+    # beyond the embedding table the gather kernel indexes; the reference only sets tokenizer.bos_token (finetune_text.py:189), so such a
+    # word resolves to [UNK] there -- and here.
+    known = [w for w in ("[unused99]", BOS_TOKEN) if w in tk.vocab]
+    if known:
+        size = len(tk)
+        try:
+            tk.add_special_tokens({"additional_special_tokens": known})
+        except TypeError as e:      # an older transformers without this keyword set: the whitespace path above already covers it
+            logger.warning(f"could not register the image / BOS placeholders as special tokens: {e!r}")
+        if len(tk) != size:
+            raise RuntimeError(f"registering {known} grew the tokenizer from {size} to {len(tk)} entries")
     tk.bos_token = BOS_TOKEN
     logger.info(f"vocab size: {tk.vocab_size}")
     return tk

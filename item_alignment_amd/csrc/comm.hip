@@ -6,8 +6,10 @@
 #include "common.h"
 #include "../../include/itemalign.h"
 #include <dlfcn.h>
+#include <link.h>
 #include <cstring>
 #include <mutex>
+#include <string>
 
 namespace {
 // the few RCCL declarations used (rccl.h 2.x: ncclUniqueId = 128 opaque bytes, ncclSum = 0, ncclFloat32 = 7, ncclBfloat16 = 9)
@@ -17,28 +19,54 @@ typedef int (*CommInitRankFn)(void**, int, UniqueId, int);
 typedef int (*AllReduceFn)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef int (*CommDestroyFn)(void*);
 typedef const char* (*GetErrorStringFn)(int);
+typedef int (*GetVersionFn)(int*);
 struct Rccl {
   void* handle = nullptr;
   GetUniqueIdFn get_unique_id = nullptr; CommInitRankFn comm_init_rank = nullptr; AllReduceFn all_reduce = nullptr;
-  CommDestroyFn comm_destroy = nullptr; GetErrorStringFn get_error_string = nullptr;
+  CommDestroyFn comm_destroy = nullptr; GetErrorStringFn get_error_string = nullptr; GetVersionFn get_version = nullptr;
+  bool usable = false;
+  char why[256] = "";             // written once under g_once, read-only afterwards
 };
 Rccl g_rccl;
 std::once_flag g_once;
-char g_comm_error[256] = "";
+// the text behind ia_comm_last_error(): per thread, so two host threads driving two communicators never write one buffer
+thread_local char g_comm_error[256] = "";
+
+// A copy of RCCL the process has already mapped under ANY file name (torch bundles its own librccl next to libtorch_hip.so, which a
+// soname lookup with RTLD_NOLOAD can miss): walk the loaded objects and re-open that very file, so no second instance comes in.
+int find_loaded_rccl(struct dl_phdr_info* info, size_t, void* out) {
+  if (info->dlpi_name && std::strstr(info->dlpi_name, "librccl")) { *static_cast<std::string*>(out) = info->dlpi_name; return 1; }
+  return 0;
+}
 
 bool bind_rccl() {
   std::call_once(g_once, [] {
+    std::string loaded;
+    dl_iterate_phdr(find_loaded_rccl, &loaded);
+    if (!loaded.empty()) g_rccl.handle = dlopen(loaded.c_str(), RTLD_NOW | RTLD_NOLOAD);
     const char* names[] = {"librccl.so.1", "librccl.so"};
-    for (const char* n : names) if (!g_rccl.handle) g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);     // already in the process?
+    for (const char* n : names) if (!g_rccl.handle) g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
     for (const char* n : names) if (!g_rccl.handle) g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-    if (!g_rccl.handle) { snprintf(g_comm_error, sizeof g_comm_error, "librccl not found: %s", dlerror()); return; }
-    g_rccl.get_unique_id = (GetUniqueIdFn)dlsym(g_rccl.handle, "ncclGetUniqueId");
-    g_rccl.comm_init_rank = (CommInitRankFn)dlsym(g_rccl.handle, "ncclCommInitRank");
-    g_rccl.all_reduce = (AllReduceFn)dlsym(g_rccl.handle, "ncclAllReduce");
-    g_rccl.comm_destroy = (CommDestroyFn)dlsym(g_rccl.handle, "ncclCommDestroy");
-    g_rccl.get_error_string = (GetErrorStringFn)dlsym(g_rccl.handle, "ncclGetErrorString");
+    if (!g_rccl.handle) { snprintf(g_rccl.why, sizeof g_rccl.why, "librccl not found: %s", dlerror()); return; }
+    const char* missing = nullptr;
+    auto sym = [&](const char* name) { void* p = dlsym(g_rccl.handle, name); if (!p && !missing) missing = name; return p; };
+    g_rccl.get_unique_id = (GetUniqueIdFn)sym("ncclGetUniqueId");
+    g_rccl.comm_init_rank = (CommInitRankFn)sym("ncclCommInitRank");
+    g_rccl.all_reduce = (AllReduceFn)sym("ncclAllReduce");
+    g_rccl.comm_destroy = (CommDestroyFn)sym("ncclCommDestroy");
+    g_rccl.get_version = (GetVersionFn)sym("ncclGetVersion");
+    g_rccl.get_error_string = (GetErrorStringFn)dlsym(g_rccl.handle, "ncclGetErrorString");      // optional
+    if (missing) { snprintf(g_rccl.why, sizeof g_rccl.why, "librccl lacks %s", missing); return; }
+    // the enum values used below (ncclSum 0, ncclFloat32 7, ncclBfloat16 9) and the 128-byte id are those of the 2.x API
+    int version = 0;
+    if (g_rccl.get_version(&version) != 0 || version / 10000 != 2) {
+      snprintf(g_rccl.why, sizeof g_rccl.why, "unsupported RCCL version code %d (the 2.x API is bound by value)", version);
+      return;
+    }
+    g_rccl.usable = true;
   });
-  return g_rccl.get_unique_id && g_rccl.comm_init_rank && g_rccl.all_reduce && g_rccl.comm_destroy;
+  if (!g_rccl.usable) snprintf(g_comm_error, sizeof g_comm_error, "%s", g_rccl.why);
+  return g_rccl.usable;
 }
 int fail(int rc) {
   if (rc != 0) snprintf(g_comm_error, sizeof g_comm_error, "RCCL: %s", g_rccl.get_error_string ? g_rccl.get_error_string(rc) : "error");

@@ -344,3 +344,81 @@ def test_bench_self_launch_builds_a_child_launcher_command(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert e.value.code == 5
+
+
+def test_bench_self_launch_takes_the_child_group_down_on_sigterm(tmp_path):
+    """The launcher child of `bench.py --gpus N` lives in its own session, so a SIGTERM to the parent (a driver timeout) must reach it
+    explicitly: the parent kills the child's process group and leaves with 128 + SIGTERM.  A sleeping stand-in plays the launcher."""
+    import os
+    import signal
+    import subprocess
+    import sys
+    import textwrap
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pidfile = tmp_path / "child.pid"
+    prog = textwrap.dedent(f"""
+        import importlib.util, os, subprocess, sys
+        spec = importlib.util.spec_from_file_location("bench_under_test", {os.path.join(root, "bench.py")!r})
+        bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+        real = subprocess.Popen
+        def fake(cmd, env=None, start_new_session=False, **kw):
+            c = real([sys.executable, "-c", "import time; time.sleep(600)"], start_new_session=start_new_session)
+            open({str(pidfile)!r}, "w").write(str(c.pid))
+            return c
+        bench.subprocess.Popen = fake
+        sys.argv = ["bench.py", "--gpus", "2"]
+        raise SystemExit(bench.self_launch(2))
+    """)
+    parent = subprocess.Popen([sys.executable, "-c", prog])
+    try:
+        for _ in range(600):
+            if pidfile.exists() and pidfile.read_text():
+                break
+            time.sleep(0.1)
+        child_pid = int(pidfile.read_text())
+        time.sleep(0.3)                                   # let the parent reach child.wait() with its handlers installed
+        parent.send_signal(signal.SIGTERM)
+        assert parent.wait(timeout=30) == 128 + signal.SIGTERM
+        for _ in range(100):
+            try:
+                os.kill(child_pid, 0)
+            except ProcessLookupError:
+                break
+            # a killed child of the (now dead) parent may linger as a zombie of init for a moment
+            try:
+                if open(f"/proc/{child_pid}/stat").read().split(")")[1].split()[0] == "Z":
+                    break
+            except FileNotFoundError:
+                break
+            time.sleep(0.1)
+        else:
+            raise AssertionError("the launcher child survived the parent's SIGTERM")
+    finally:
+        if parent.poll() is None:
+            parent.kill()
+        try:
+            os.kill(int(pidfile.read_text()), signal.SIGKILL)
+        except Exception:
+            pass
+
+
+def test_load_tokenizer_never_grows_the_vocabulary(tmp_path):
+    """cli_common.load_tokenizer registers the image / BOS placeholders as special tokens only when the checkpoint's vocabulary already
+    holds them: a vocabulary without '<S>' must keep its size (an appended id would index past the embedding table) and resolve the
+    word to [UNK], as the reference's `tokenizer.bos_token = BOS_TOKEN` does (finetune_text.py:186-189)."""
+    from types import SimpleNamespace
+    import pytest
+    pytest.importorskip("transformers")
+    from item_alignment_amd.cli_common import load_tokenizer
+    base = ["[PAD]"] + [f"[unused{i}]" for i in range(1, 100)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]", "手", "机"]
+    for extra, has_bos in ((["<S>"], True), ([], False)):
+        d = tmp_path / f"vocab_{int(has_bos)}"
+        d.mkdir()
+        (d / "vocab.txt").write_text("\n".join(base + extra) + "\n", encoding="utf-8")
+        tk = load_tokenizer(SimpleNamespace(pretrained_model_path=str(d), do_lower_case=True))
+        assert len(tk) == tk.vocab_size == len(base) + len(extra)
+        ids = tk.convert_tokens_to_ids(tk.tokenize("[unused99] <S> 手"))
+        assert max(ids) < tk.vocab_size
+        assert ids[0] == 99
+        assert (tk.vocab["<S>"] in ids) if has_bos else (tk.unk_token_id in ids)

@@ -287,7 +287,10 @@ def test_attention_dropout_statistics(gpu):
 
 
 # ------------------------------------------------------------------ CoCa multimodal-layer kernels
-@pytest.mark.parametrize("B,nh,Lq,Lk", [(2, 3, 100, 177), (3, 1, 20 * 2, 17), (2, 1, 255 * 4, 577), (1, 2, 130, 64)])
+@pytest.mark.parametrize("B,nh,Lq,Lk", [(2, 3, 100, 177), (3, 1, 20 * 2, 17), (2, 1, 255 * 4, 577), (1, 2, 130, 64),
+                                        # Lq == Lk in (32, 256] with ld_q != ld_kv: the general entry point takes the single-kernel
+                                        # backward here too (q rows of stride H, k / v rows of stride 2H, separate dq / dkv strides)
+                                        (2, 3, 130, 130), (3, 1, 200, 200), (2, 2, 256, 256), (5, 4, 33, 33)])
 def test_attention_x_fwd_bwd(gpu, B, nh, Lq, Lk):
     """ia_attn_fwd_x / ia_attn_bwd_x (cross attention; nh = 1 with folded query heads = multi-query attention)
     against fp32 softmax(q k^T / 8) v on the same bf16 inputs (reference multimodal.py:605-620, :686-696)."""
