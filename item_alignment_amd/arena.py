@@ -64,6 +64,7 @@ class ParamArena:
             view.copy_(p.data.to(self.device, torch.float32))
             p.data = view
             p.grad = self.grad[o:o + n].view(p.shape)
+            p._ia_arena = self              # item_alignment_amd.optim.AdamW finds the arena from the parameters it is handed
             self._shadow_of[id(p)] = self.shadow[o:o + n].view(p.shape)
             if p.requires_grad:
                 decay = 0 if any(nd in name for nd in NO_DECAY) else 1
@@ -72,6 +73,8 @@ class ParamArena:
         self.n_chunks = len(chunks)
         self.chunk_table = torch.from_numpy(np.asarray(chunks, dtype=np.uint32).reshape(-1, 4)).to(self.device)
         self.step_count = 0
+        self.stale_refreshes = 0
+        self.optimizer_bound = False
         self.refresh_shadow()
 
     # ------------------------------------------------------------------ views
@@ -101,7 +104,36 @@ class ParamArena:
     # ------------------------------------------------------------------ maintenance
     def refresh_shadow(self):
         lib = _lib.load()
+        self.join_side_streams()
         check(lib.ia_cast_f32_to_bf16(self.master.data_ptr(), self.shadow.data_ptr(), self.numel, stream_ptr()), "ia_cast_f32_to_bf16")
+        self._versions = self._param_versions()
+
+    def _param_versions(self):
+        return sum(p._version for p in self.params)
+
+    def sync_shadow(self):
+        """Staleness guard, called at the top of every model forward.  The GEMMs read the bf16 shadow, which the fused optimiser rewrites
+        together with the fp32 masters; anything ELSE that writes a parameter through torch (a foreign `torch.optim.AdamW(model.parameters())`
+        kept from the reference loop, `p.mul_()`, `copy_`, an initialiser) bumps that parameter's version counter -- the shadow is then
+        re-cast from the masters (one 6 B / parameter pass) instead of silently serving the old weights.  Writes through `p.data` bypass
+        the counter, as they bypass autograd's own checks: call refresh_shadow() after those."""
+        dropped = [i for i, p in enumerate(self.params) if p.grad is None]
+        if dropped:
+            # `optimizer.zero_grad()` of a torch optimizer (set_to_none=True is its default) dropped the p.grad views: to torch that MEANS
+            # "the gradients are zero".  The kernels accumulate into the gradient arena whatever p.grad says, so clear what was dropped
+            # and re-point the views -- otherwise the old gradients would be added to, and torch's step() would skip every parameter.
+            if len(dropped) == len(self.params):
+                self.zero_grad()
+            else:
+                for i in dropped:
+                    o = self.offsets[i]
+                    self.grad[o:o + self.params[i].numel()].zero_()
+            self.reattach()
+        if self._param_versions() != self._versions:
+            self.refresh_shadow()
+            self.stale_refreshes += 1
+            return True
+        return False
 
     def join_side_streams(self):
         """Models that run independent towers on extra HIP streams register them in `side_streams`: everything that reads or

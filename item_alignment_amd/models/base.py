@@ -83,6 +83,8 @@ class HipModule(nn.Module):
                 self.__dict__["_anchor"] = torch.zeros(1, device=p.device, requires_grad=True)
             for m in self.modules():
                 m.__dict__["anchor"] = self.__dict__["_anchor"]
+        else:
+            arena.sync_shadow()
         return arena
 
     @property

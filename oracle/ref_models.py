@@ -29,20 +29,47 @@ import torch.nn.functional as F
 # on the GPU.  The casts are differentiable (the gradient passes through, itself rounded), so the gradients of this mode carry the
 # noise bf16 storage puts on an fp32 computation: the yardstick the GPU gradient tolerances are justified against
 # (tests/test_models_gpu.py).  It does not reproduce the engine's roundings bit for bit (accumulation orders differ).
+# `flash_delta=True` additionally differentiates the attention core the way a flash-style backward does: dS = P o (dP - delta) with
+# delta = rowsum(dO o O) taken from the ROUNDED context the forward stored, instead of autograd's exact rowsum(P o dP) -- the one place
+# where bf16 storage changes the backward's FORMULA and not just its operands (tools/c5_delta_probe.py measures what it
+# does to the last layer's query projection).
 _ROUND = None
+_FLASH_DELTA = False
 
 
 class rounding:
-    def __init__(self, dtype):
+    def __init__(self, dtype, flash_delta=False):
         self.dtype = dtype
+        self.flash_delta = flash_delta
 
     def __enter__(self):
-        global _ROUND
-        self.prev, _ROUND = _ROUND, self.dtype
+        global _ROUND, _FLASH_DELTA
+        self.prev, _ROUND = (_ROUND, _FLASH_DELTA), self.dtype
+        _FLASH_DELTA = self.flash_delta
 
     def __exit__(self, *exc):
-        global _ROUND
-        _ROUND = self.prev
+        global _ROUND, _FLASH_DELTA
+        _ROUND, _FLASH_DELTA = self.prev
+
+
+class _FlashStyleCore(torch.autograd.Function):
+    """softmax(s) v with the probabilities and the context rounded for storage; backward from the stored (rounded) context."""
+
+    @staticmethod
+    def forward(ctx, s, v, dtype):
+        p = torch.softmax(s, dim=-1)
+        pr = p.to(dtype).to(s.dtype)
+        o = torch.matmul(pr, v).to(dtype).to(s.dtype)
+        ctx.save_for_backward(p, pr, v, o)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        p, pr, v, o = ctx.saved_tensors
+        dv = torch.matmul(pr.transpose(-1, -2), do)
+        dp = torch.matmul(do, v.transpose(-1, -2))
+        delta = (do * o).sum(-1, keepdim=True)               # from the rounded o: the flash-style identity
+        return p * (dp - delta), dv, None
 
 
 def _r(x):
@@ -93,8 +120,11 @@ def bert_self_attention(x, sd, p, cfg, ext_mask, training):
     s = torch.matmul(q, k.transpose(-1, -2)) * (dh ** -0.5)
     if ext_mask is not None:
         s = s + ext_mask
-    a = _r(dropout(torch.softmax(s, dim=-1), cfg.attention_probs_dropout_prob, training))
-    ctx = _r(torch.matmul(a, v).transpose(1, 2).reshape(B, L, H))
+    if _FLASH_DELTA and _ROUND is not None and not (training and cfg.attention_probs_dropout_prob > 0):
+        ctx = _FlashStyleCore.apply(s, v, _ROUND).transpose(1, 2).reshape(B, L, H)
+    else:
+        a = _r(dropout(torch.softmax(s, dim=-1), cfg.attention_probs_dropout_prob, training))
+        ctx = _r(torch.matmul(a, v).transpose(1, 2).reshape(B, L, H))
     # RobertaSelfOutput: dense -> dropout -> LayerNorm(h + input)
     h = dropout(linear(ctx, sd, p + ".output.dense"), cfg.hidden_dropout_prob, training)
     return layer_norm(h + x, sd, p + ".output.LayerNorm", cfg.layer_norm_eps)

@@ -219,3 +219,61 @@ def test_c5_full_width_coca_pair(gpu):
     for k, v in params.items():
         if v.grad is not None:
             assert torch.isfinite(v.grad).all(), k
+
+
+def test_c2_full_width_one_tower(gpu):
+    """C2: RobertaOneTower, roberta_large (24 layers, H = 1024, 16 heads), both items in ONE sequence of L = 2 x (50 + 205) = 510 tokens,
+    cls / ce, B = 2 (reference src/models/text.py:1417-1492).  L = 510 is beyond the single-kernel attention backward (L <= 256): this
+    is the configuration that runs the dQ / dK-dV kernel pair in every layer -- the shape class where round 3's rare NaN-dQ fault
+    lived.  Loss, logits and the backward pass against the fp32 oracle, same six-point check as the C5 pair: the head, the first,
+    a middle and the last layer's projections, and the embedding LayerNorm (the bottom of the backward chain)."""
+    import item_alignment_amd.models as M
+    from bench import roberta_large_config
+    from oracle import ref_models as O
+    L, B = 510, 2
+    cfg = roberta_large_config(interaction_type="one_tower", hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    rs = np.random.RandomState(21)
+    ids = np.zeros((B, L), dtype=np.int64); mask = np.zeros((B, L), dtype=np.int64); tt = np.zeros((B, L), dtype=np.int64)
+    for i, (n1, n2) in enumerate([(255, 255), (171, 98)]):            # one full-length pair, one ragged (241 padded positions)
+        ids[i, 0] = 101
+        ids[i, 1:n1 - 1] = rs.randint(1000, 21128, size=n1 - 2); ids[i, n1 - 1] = 102
+        ids[i, n1:n1 + n2 - 1] = rs.randint(1000, 21128, size=n2 - 1); ids[i, n1 + n2 - 1] = 102
+        mask[i, :n1 + n2] = 1
+        tt[i, n1:n1 + n2] = 1
+    labels = torch.tensor([1, 0])
+    torch.manual_seed(77)
+    model = M.RobertaOneTower(cfg)
+    sd = state_of(model, head_gain=20.0)
+    model = model.cuda().eval()
+    t = [torch.from_numpy(a) for a in (ids, mask, tt)]
+    model.param_arena.zero_grad()
+    out = model(input_ids=t[0].cuda(), attention_mask=t[1].cuda(), token_type_ids=t[2].cuda(), position_ids=None, labels=labels.cuda())
+    out.loss.backward()
+    torch.cuda.synchronize()
+
+    def key(*parts):
+        hits = [k for k in sd if all(p_ in k for p_ in parts)]
+        assert len(hits) == 1, (parts, hits)
+        return hits[0]
+    keys = [key("classifier", "out_proj.weight"), key("layer.0.", "self.query.weight"), key("layer.11.", "self.key.weight"),
+            key("layer.23.", "self.value.weight"), key("layer.23.", "intermediate.dense.weight"), key("embeddings.LayerNorm.weight")]
+    rsd = {k: (v.requires_grad_(True) if k in keys else v) for k, v in sd.items()}
+    ref = O.roberta_one_tower(rsd, cfg, *t, None, labels, False)
+    ref.loss.backward()
+    assert abs(out.loss.item() - ref.loss.item()) < TOL * max(1.0, abs(ref.loss.item())), (out.loss.item(), ref.loss.item())
+    assert rel(out.logits.detach(), ref.logits.detach()) < TOL, (out.logits, ref.logits)
+    assert (out.probs.detach().float().cpu() - ref.probs.detach()).abs().max().item() < TOL
+    params = dict(model.named_parameters())
+    report = {k: (cosine(params[k].grad, rsd[k].grad), rel(params[k].grad, rsd[k].grad)) for k in keys}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "c2_full_width_gradients.txt"), "w") as f:
+        for k, (c, r) in report.items():
+            f.write(f"{k}: cosine {c:.4f} rel {r:.4f}\n")
+    print("C2 full-width gradients (cosine, rel):", report)
+    for k, (c, r) in report.items():
+        assert c >= 0.99, (k, c, r)
+        assert r <= 0.10, (k, c, r)
+    for k, v in params.items():
+        if v.grad is not None:
+            assert torch.isfinite(v.grad).all(), k

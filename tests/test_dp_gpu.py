@@ -32,7 +32,7 @@ def _build(kind):
     cfg.attention_probs_dropout_prob = 0.0           # train mode without dropout: deterministic, rank-independent
     model = (M.RobertaTwoTower if kind == "roberta_two_tower" else M.PKGMOneTower)(cfg)
     model.load_state_dict(weights(case), strict=False)
-    # six pairs: the fixture's three twice, with the second copy's labels flipped so the shards differ in content
+    # the fixture's pairs twice (2 x 8 two-tower, 2 x 3 PKGM), with the second copy's labels flipped so the shards differ in content
     i = case.inputs
     rep = {k: torch.cat([v, v]) for k, v in i.items()}
     rep["labels"] = torch.cat([i["labels"], 1 - i["labels"]])

@@ -989,7 +989,8 @@ def _sampled_attention_reference(qkv, dctx, B, L, nh, mask, pairs):
     return o.detach(), sel.grad                                 # [P, L, 64], [P, L, 3, 64]
 
 
-@pytest.mark.parametrize("B,L,nh,masked", [(512, 577, 12, False), (512, 255, 16, True), (128, 385, 12, False), (128, 193, 12, True)])
+@pytest.mark.parametrize("B,L,nh,masked", [(512, 577, 12, False), (512, 255, 16, True), (128, 385, 12, False), (128, 193, 12, True),
+                                           (128, 510, 16, True)])        # the last: a C2 batch (roberta_large one_tower, L = 2 x 255)
 def test_attention_bench_shapes_whole_output_scan(gpu, B, L, nh, masked):
     """The attention kernels AT THE BENCH SHAPES (512 images x 577 tokens x 12 heads, 512 sequences x 255 x 16 heads with the padding
     mask) and at the two shapes whose ragged last key tile once faulted (385, 193): 20 launches on fresh random data, every element

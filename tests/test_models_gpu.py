@@ -12,8 +12,9 @@ from golden_util import load_case, weights, vit_cfg
 pytestmark = pytest.mark.gpu
 TOL = 5e-2
 COS_MIN = 0.99           # gradient direction; see check().  Measured (tools/parity_report.py, profiles/r02_parity_report.txt): median 1.0000
-# tensors measured below 0.99: a bias gradient that is a sum over the few tokens of a 3-sample batch (cancellation), bf16 ReLU gates
-COS_EXCEPTIONS = {("roberta_two_tower_ce", "roberta.embeddings.LayerNorm.bias"): 0.97}
+# tensors measured below 0.99: none since the two-tower fixtures hold eight samples (round 5; with three, roberta_two_tower_ce's
+# embedding LayerNorm.bias -- a sum over a handful of tokens with cancellation -- sat at 0.97)
+COS_EXCEPTIONS = {}
 # gradient magnitude: |got - want|_max / |want|_max <= 5e-2 (north_star's bf16 bar), against the reference's fp32 gradients (the fixture)
 # or -- when the fixture's 3-sample batch makes the tensor a small difference of large sums -- against the gradients the CPU oracle
 # produces when it rounds to bf16 where the engine stores bf16 (oracle.ref_models.rounding: weights, linear / LayerNorm / GELU outputs,
@@ -25,14 +26,8 @@ REL_EXCEPTIONS = {
     # conv towers: the rounding mode does not cover convolutions; BatchNorm batch statistics over 3 images / ReLU gates in bf16
     ("resnet_two_tower", "img_encoder.stem.conv.weight"): 0.191,
     ("resnet_two_tower", "img_encoder.stages.3.blocks.0.conv3.weight"): 0.072,
-    # 3-sample fixtures, bias / head gradients that are sums over a handful of tokens with cancellation
-    ("roberta_two_tower_ce", "roberta.embeddings.LayerNorm.bias"): 0.286,
-    ("roberta_two_tower_cosine", "roberta.embeddings.LayerNorm.bias"): 0.091,
-    ("roberta_two_tower_euclidean", "roberta.embeddings.LayerNorm.bias"): 0.088,
-    ("roberta_two_tower_euclidean", "classifier.out_proj.weight"): 0.121,
-    ("roberta_two_tower_euclidean", "roberta.encoder.layer.1.attention.self.value.weight"): 0.088,
-    ("roberta_two_tower_cosine", "roberta.encoder.layer.1.attention.self.value.weight"): 0.052,
-    ("roberta_two_tower_ce", "classifier.out_proj.weight"): 0.073,
+    # 3-sample fixtures, bias / head gradients that are sums over a handful of tokens with cancellation (the roberta_two_tower_* fixtures
+    # were regenerated with eight samples in round 5 and carry no exception any more)
     ("roberta_one_tower_cls_ce", "classifier.dense.weight"): 0.083,
     ("roberta_one_tower_cls_ce", "classifier.out_proj.weight"): 0.054,
     ("roberta_one_tower_cls_ce", "roberta.embeddings.position_embeddings.weight"): 0.054,
