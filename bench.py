@@ -10,9 +10,13 @@ One JSON line on rank 0.  `value` = pairs processed by ALL ranks / max-over-rank
 steps (inputs resident in HBM, weak scaling: per-GPU batch fixed).  The batches are drawn without replacement from the
 50 000-pair synthetic set of SURVEY §8(d) (16 resident global batches; longer runs walk them again).  Extra objects:
   roofline     the dominant kernel (by summed time: the wgrad GEMM instantiation), timed per launch with HIP
-               events on its launch stream inside the timed region: achieved = algorithmic FLOPs / time; `traffic` = HBM
-               bytes per launch from two rocprofv3 --pmc child passes of this same command (FETCH_SIZE x 2 on gfx950 +
-               WRITE_SIZE, MI355X_MICROARCH.md HBM section), N = 1 only, null when rocprofv3 is unavailable.
+               events on its launch stream: achieved = algorithmic FLOPs / time.  The headline region runs the image tower on a
+               second HIP stream (round 5 default, +1.5-2 % pairs/s), where a kernel's event interval also contains whatever the
+               other stream's kernels took from it -- so the event-timed leg is taken in a SEPARATE short single-stream pass of
+               the same step right after the timed region (`roofline.measured_in` says so; `frac_in_timed_region` is the
+               two-stream figure for comparison; --single-stream runs everything on one stream as in rounds 1-4).  `traffic` = HBM
+               bytes per launch from two rocprofv3 --pmc child passes of this same command, single-stream (FETCH_SIZE x 2 on
+               gfx950 + WRITE_SIZE, MI355X_MICROARCH.md HBM section), N = 1 only, null when rocprofv3 is unavailable.
   variants     the same step with every sequence at the full 255 tokens, and with the unpadded text towers (--unpad,
                DESIGN.md 4.8), a few steps each after the headline measurement (not part of `value`).
   cpu_baseline the CPU oracle (oracle/ref_models.py, a pure-torch port pinned to the reference by golden
@@ -55,7 +59,7 @@ def pmc_traffic(args):
         # the same workload as the parent (--unpad / --full-length are forwarded), 1 + 1 steps, two resident batches only
         cmd = [rocprof, "--pmc", counter, "-d", out, "-o", "p", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
                "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-pmc", "--no-variants", "--pairs-per-gpu", str(args.pairs_per_gpu),
-               "--image-model", args.image_model, "--seed", str(args.seed), "--resident-batches", "2"]
+               "--image-model", args.image_model, "--seed", str(args.seed), "--resident-batches", "2", "--single-stream"]
         cmd += (["--unpad"] if args.unpad else []) + (["--full-length"] if args.full_length else [])
         try:
             # a plain single-process child even when this run was started by a launcher (no inherited rendezvous)
@@ -220,7 +224,10 @@ def main():
     ap.add_argument("--seed", type=int, default=2345)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=2)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-oracle steps (BASELINE.md 3: 3 timed + 1 warm-up)")
+    ap.add_argument("--single-stream", action="store_true", help="both towers on one HIP stream (the round 1-4 headline); default: the "
+                    "image tower on a second stream, the roofline leg in a separate single-stream pass")
+    ap.add_argument("--roofline-steps", type=int, default=3, help="steps of the separate single-stream pass behind `roofline`")
     ap.add_argument("--full-length", action="store_true", help="all sequences at the full 255 tokens (mask all ones)")
     ap.add_argument("--unpad", action="store_true", help="text towers on the valid tokens only (IA_UNPAD=1, DESIGN.md 4.8); off by "
                     "default: the reference computes densely on the padding and the headline number keeps that workload")
@@ -247,6 +254,7 @@ def main():
     from item_alignment_amd import dist as iadist
     from item_alignment_amd.data.synthetic import SyntheticCocaPairs
     from item_alignment_amd.models import functional as Fn
+    from item_alignment_amd.models import multimodal as _mm
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
@@ -301,6 +309,8 @@ def main():
         if world > 1 or iadist.FORCE:
             torch.distributed.barrier()
 
+    two_streams = not args.single_stream
+    _mm.TOWER_STREAMS = two_streams
     for i in range(args.warmup):
         loss = step(i)
     torch.cuda.synchronize()
@@ -317,11 +327,29 @@ def main():
     ms, fl, nl = C.c_double(), C.c_double(), C.c_int()
     _lib.check(lib.ia_prof_end(C.byref(ms), C.byref(fl), C.byref(nl)), "ia_prof_end")
     alg_bytes = lib.ia_prof_bytes()
+    in_region = (ms.value, fl.value, nl.value)
+    final_loss_region = float(loss.detach())
+    if two_streams:
+        # the roofline leg: the same step, both towers on ONE stream, so that an event interval around a launch holds that kernel alone
+        _mm.TOWER_STREAMS = False
+        try:
+            step(n_steps)                                  # one untimed step: the allocator settles into the single-stream pattern
+            torch.cuda.synchronize()
+            _lib.check(lib.ia_prof_begin(WGRAD_VARIANT, 400 * args.roofline_steps), "ia_prof_begin")
+            for i in range(args.roofline_steps):
+                step(n_steps + 1 + i)
+            torch.cuda.synchronize()
+            _lib.check(lib.ia_prof_end(C.byref(ms), C.byref(fl), C.byref(nl)), "ia_prof_end")
+            alg_bytes = lib.ia_prof_bytes()
+        finally:
+            _mm.TOWER_STREAMS = True
+    n_steps_done = n_steps + (1 + args.roofline_steps if two_streams else 0)
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1 or iadist.FORCE:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = tmax.item()
-    final_loss = float(loss.detach())
+    final_loss = final_loss_region
+    n_steps = n_steps_done                                 # the side measurements continue the step counter (seeds, schedule)
 
     def timed(pool, k, first, pairs_per_rank=None):
         """k more steps on `pool` (2 untimed first), max over ranks, like the headline region"""
@@ -380,15 +408,13 @@ def main():
             return {"value": B * world * k / tm.item(), "unit": "item-pairs/sec", "ms_per_step": tm.item() / k * 1e3, "steps": k, "pairs_per_gpu": B,
                     "what": "forward + loss only (model.eval(), no_grad)"}
         variants["eval_forward_only"] = eval_pass(args.variant_steps)
-        # the image tower on a second HIP stream (IA_TOWER_STREAMS=1): the same arithmetic, the two towers' kernels
-        # overlap.  Not the headline because per-kernel roofline figures stop describing the kernels when two of them share the chip.
-        from item_alignment_amd.models import multimodal as _mm
-        if hasattr(_mm, "TOWER_STREAMS"):
-            _mm.TOWER_STREAMS = True
-            try:
-                variants["image_tower_on_second_stream"] = timed(batches, args.variant_steps, n_steps + 4 + 2 * args.variant_steps)
-            finally:
-                _mm.TOWER_STREAMS = False
+        # the other stream arrangement than the headline's (one stream: the round 1-4 headline; two: this round's), same steps
+        _mm.TOWER_STREAMS = not two_streams
+        try:
+            variants["single_stream" if two_streams else "image_tower_on_second_stream"] = timed(
+                batches, args.variant_steps, n_steps + 4 + 2 * args.variant_steps)
+        finally:
+            _mm.TOWER_STREAMS = two_streams
 
     if rank == 0:
         pairs = B * world * args.steps
@@ -409,6 +435,12 @@ def main():
             # dense FLOP count of the padded workload; with --unpad the padded rows are not computed, so it does not apply
             "model_tflops_per_gpu": None if args.unpad else pairs / dt * TRAIN_FLOPS_PER_PAIR / 1e12 / world,
             "mfma_fraction_whole_step": None if args.unpad else pairs / dt * TRAIN_FLOPS_PER_PAIR / 1e12 / world / 2500.0,
+            # the strictly dense figure: the same FLOP count over the run in which every sequence holds 255 tokens, so that no attention
+            # kernel skips a padded key tile (the default batch's ragged lengths let them skip ~3 % of the attention work)
+            "mfma_fraction_dense": (variants["full_length_sequences"]["value"] * TRAIN_FLOPS_PER_PAIR / 1e12 / world / 2500.0
+                                    if variants and "full_length_sequences" in variants else
+                                    (pairs / dt * TRAIN_FLOPS_PER_PAIR / 1e12 / world / 2500.0 if args.full_length else None)),
+            "tower_streams": 2 if two_streams else 1,
             "final_loss": final_loss,
             "roofline": ({"bound": "mfma", "kernel": WGRAD_KERNEL, "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s",
                           "frac": achieved / 2500.0} if bound == "mfma" else
@@ -417,7 +449,11 @@ def main():
             "variants": variants,
         }
         res["roofline"].update({"traffic": None, "launches": nl.value, "avg_launch_us": ms.value * 1e3 / max(1, nl.value),
-                                "flop_per_byte": intensity, "algorithmic_bytes_per_launch": alg_bytes / max(1, nl.value)})
+                                "flop_per_byte": intensity, "algorithmic_bytes_per_launch": alg_bytes / max(1, nl.value),
+                                "measured_in": (f"separate single-stream pass of {args.roofline_steps} steps right after the timed region (HIP "
+                                                "events on the launch stream; the timed region overlaps the towers on two streams)"
+                                                if two_streams else "the timed region (HIP events on the launch stream)"),
+                                "frac_in_timed_region": (in_region[1] / (in_region[0] * 1e-3) / 1e12 / 2500.0 if in_region[0] > 0 else None)})
         res["config"]["dataset_pairs"] = DATASET_PAIRS
         res["config"]["resident_batches"] = n_batches
         res["peak_hbm_gib"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)      # this rank, incl. the resident batches

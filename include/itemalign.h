@@ -37,7 +37,7 @@ const char* ia_strerror(int code);
 /* Bumped whenever an entry point is added or the meaning of an argument / output changes (round 2 changed what IA_EPI_BIAS_GELU
  * stores in C2 and what IA_EPI_DGELU expects in aux): a caller built against another header must not run on this library.
  * item_alignment_amd/_lib.py refuses to load a library whose version differs from the one it was written for. */
-#define IA_ABI_VERSION 6
+#define IA_ABI_VERSION 7
 int ia_abi_version(void);
 
 /* ---- GEMM: torch.nn.Linear forward / dgrad / wgrad (src/models/text.py:1241 -> RobertaLayer dense
@@ -74,6 +74,12 @@ size_t ia_gemm_colsum_workspace_bytes(int M, int N);
 int ia_prof_begin(int variant, int max_launches);
 int ia_prof_end(double* total_ms, double* total_flops, int* launches);
 double ia_prof_bytes(void); /* algorithmic bytes of the recorded launches: A and B read once, C written once */
+/* Diagnostics (ABI 7): occupy `workgroups` whole CUs (one 256-thread workgroup holding all 160 KiB of LDS each, so nothing else can
+ * co-reside) for `milliseconds` on `stream` -- a stand-in for a communication kernel that holds CUs next to the persistent GEMMs
+ * (tools/cu_contention.py: how much a GEMM on another stream slows down with 0 / 8 / 16 / 32 CUs taken, SURVEY 8(e) overlap of the
+ * gradient all-reduce with backward).  The large persistent GEMM launches claim their tiles dynamically (one counter per XCD), so
+ * a workgroup that starts late finds no work instead of holding a 1/256 share back; IA_GEMM_DYNAMIC=0 restores the static order. */
+int ia_debug_cu_hog(int workgroups, float milliseconds, ia_stream_t stream);
 
 /* ---- LayerNorm tails (RobertaSelfOutput / RobertaOutput: dense -> dropout -> +residual -> LayerNorm;
  * timm Block norm1/norm2).  z = residual + dropout(x + bias); y = LN(z).  z_out may alias x. */

@@ -39,6 +39,7 @@ SIGNATURES = {
     "ia_prof_begin": (i32, [i32, i32]),
     "ia_prof_end": (i32, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i32)]),
     "ia_prof_bytes": (C.c_double, []),
+    "ia_debug_cu_hog": (i32, [i32, C.c_float, vp]),
     "ia_ln_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, u32, u32, vp]),
     "ia_ln_bwd_workspace_bytes": (sz, [i32, i32]),
     "ia_ln_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, u32, u32, vp, sz, i32, vp]),
@@ -142,7 +143,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 6      # = IA_ABI_VERSION of include/itemalign.h (tests/test_cabi_symbols.py keeps the two in step)
+ABI_VERSION = 7      # = IA_ABI_VERSION of include/itemalign.h (tests/test_cabi_symbols.py keeps the two in step)
 
 
 class ItemAlignError(RuntimeError):

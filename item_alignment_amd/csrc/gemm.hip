@@ -71,7 +71,14 @@ struct GemmArgs {
   // channel groups: operands advance by ga / gb / gc / gbias elements per group (all groups in one launch)
   int groups;
   long ga, gb, gc, gbias;
+  // Dynamic tile claim (t256w, persistent launches): 8 per-XCD claim counters + 1 exit counter of this launch's slot (zero on entry,
+  // zeroed again by the last workgroup to leave); NULL = the static order (tile + gridDim.x).
+  uint32_t* tile_ctr;
 };
+
+// One slot per launch in flight (launches of different streams may overlap; a slot comes round again after CTR_SLOTS launches).
+constexpr int CTR_SLOTS = 1024, CTR_WORDS = 16;
+__device__ uint32_t g_tile_ctr[CTR_SLOTS * CTR_WORDS];
 
 IA_DEV int tap_delta(int t, int pw) { return (t / 3 - 1) * pw + (t % 3 - 1); }
 
@@ -1374,6 +1381,68 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
                               AKS ? 0 : kt0, BKS ? 0 : kt0, n_tiles, nk_all, wm, wn, wave, lane, prologue_only, stores_in_flight);
   };
 
+  // ---- Dynamic tile claim (persistent launches).  With the static order every workgroup owns the tiles bid, bid + gridDim.x, ...: a
+  // workgroup that cannot start -- its CU is held by another stream's kernel (an RCCL all-reduce next to the backward GEMMs: this
+  // kernel takes all 160 KiB of LDS, nothing co-resides) -- keeps its 1/256 share hostage until a sibling has finished ALL of its
+  // own tiles, i.e. the launch takes two rounds.  Claimed tiles instead: every XCD's contiguous run of the work order (the same runs
+  // as before, so the panels still share that XCD's L2) is handed out position by position through one counter per XCD; a workgroup
+  // whose own run is exhausted takes from the other XCDs' runs; one that starts late finds nothing left and exits.  The claim for the
+  // NEXT tile is issued in front of the main loop (wave 0, one lane; it is older than every DMA piece of the loop, so the loop's
+  // counted vmcnt waits only get stricter by it) and read behind it.
+  const bool dyn = p.tile_ctr != nullptr && !ordered;
+  const int xcd = blockIdx.x & 7, q8 = total_tiles >> 3, r8 = total_tiles & 7;
+  auto run_start = [&](int x) { return x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8; };
+  auto run_len = [&](int x) { return q8 + (x < r8 ? 1 : 0); };
+  int* const mailbox = reinterpret_cast<int*>(smem + 2 * 2 * TILE_BYTES);     // wave 0's staging slot, idle outside the epilogue
+  uint32_t claimed = 0;
+  // (inline asm: handed the builtin, LLVM's atomic optimizer folds the active lanes into one add and consumes the result -- with an
+  // s_waitcnt vmcnt(0) -- on the spot, i.e. in front of the main loop, where the previous tile's stores are still draining.  The
+  // returned value stays in `claimed` across the main loop; tools/lint_asm_waits.py checks the ISA for any use of that register
+  // ahead of the vmcnt(0) in claim_resolve.)
+  auto claim_issue = [&]() {
+    if (wave == 0 && lane0 == 0)
+      asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(claimed) : "v"(0u), "v"(1u), "s"(p.tile_ctr + xcd) : "memory");
+  };
+  // -> position in the work order (tile_of_order), or -1: nothing left.  Workgroup-uniform (LDS mailbox between two barriers).
+  auto claim_resolve = [&]() -> int {
+    // (every wave waits, not only the claimer: behind the main loop nothing but its past-the-end dummy pieces is in flight, and the
+    // ISA lint can then see the wait on every path from the atomic)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(claimed));
+    if (wave == 0) {
+      int pos = (int)__builtin_amdgcn_readfirstlane(claimed), w = -1;
+      if (pos < run_len(xcd)) w = run_start(xcd) + pos;
+      else {
+        for (int d = 1; d < 8 && w < 0; ++d) {                       // own run exhausted (the launch's tail): take from the others
+          const int x = (xcd + d) & 7;
+          uint32_t got = 0;
+          if (lane0 == 0) got = __hip_atomic_fetch_add(p.tile_ctr + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          pos = (int)__builtin_amdgcn_readfirstlane(got);
+          if (pos < run_len(x)) w = run_start(x) + pos;
+        }
+      }
+      if (lane0 == 0) *reinterpret_cast<volatile int*>(mailbox) = w;
+    }
+    __syncthreads();
+    const int w = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(mailbox));
+    __syncthreads();                                                  // wave 0's epilogue writes its staging slot next
+    return w;
+  };
+  auto leave = [&]() {                                                // the last workgroup out re-arms the slot for its next launch
+    if (dyn && wave == 0 && lane0 == 0) {
+      const uint32_t d = __hip_atomic_fetch_add(p.tile_ctr + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (d == gridDim.x - 1) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) __hip_atomic_store(p.tile_ctr + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
+  if (dyn) {
+    ordered = true;                                                   // `tile` below is a position of the work order
+    claim_issue();
+    first_tile = claim_resolve();
+    if (first_tile < 0) { leave(); return; }
+  }
+
   f32x16 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -1412,6 +1481,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
       pbv[0] = *reinterpret_cast<const f32x4*>(bp); pbv[1] = *reinterpret_cast<const f32x4*>(bp + 4);
       pbv[2] = *reinterpret_cast<const f32x4*>(bp + 64); pbv[3] = *reinterpret_cast<const f32x4*>(bp + 68);
     }
+    if (dyn) claim_issue();
     run(tile, false, acc, stores_in_flight);
     float ts = 1.f;
     if (bias_pre && BIAS_CT) {
@@ -1426,7 +1496,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
           for (int q = 0; q < 4; ++q) bct[ni][q] *= ts;
       }
     } else if (bias_pre) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pbv[0]), "+v"(pbv[1]), "+v"(pbv[2]), "+v"(pbv[3]));
-    const int next = ordered ? total_tiles : tile + gridDim.x;
+    int next = ordered ? total_tiles : tile + gridDim.x;
+    if (dyn) { next = claim_resolve(); if (next < 0) next = total_tiles; }
     if (next < total_tiles) run(next, true, acc, false);      // the next tile's first two k-tiles travel under this epilogue
 
     int lane_e = lane0;
@@ -1453,6 +1524,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     if (!stores_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     tile = next;
   }
+  leave();
 }
 }  // namespace t256w
 
@@ -1587,6 +1659,16 @@ int launch(GemmArgs a, bool big, hipStream_t st) {
     }
     const int ntile = a.tiles_m * a.tiles_n;
     const int gx = a.splits > 1 ? ntile * a.splits : (ntile < 256 ? ntile : 256);
+    // persistent launches with more than one tile per workgroup claim their tiles dynamically (IA_GEMM_DYNAMIC=0: the static order)
+    static int dynamic = -1;
+    static uint32_t* ctr_base = nullptr;
+    static unsigned launch_seq = 0;
+    if (dynamic < 0) {
+      const char* e = getenv("IA_GEMM_DYNAMIC");
+      dynamic = e ? atoi(e) : 1;
+      if (dynamic && hipGetSymbolAddress((void**)&ctr_base, HIP_SYMBOL(g_tile_ctr)) != hipSuccess) return IA_ERR_LAUNCH;
+    }
+    a.tile_ctr = (dynamic && a.splits == 1 && ntile > gx) ? ctr_base + (size_t)(launch_seq++ % CTR_SLOTS) * CTR_WORDS : nullptr;
     hipLaunchKernelGGL(kern, dim3(gx), dim3(256), t256::LDS_BYTES, st, a);
   } else if (big) {
     a.tiles_m = (a.M + t256::BM - 1) / t256::BM; a.tiles_n = (a.N + t256::BN - 1) / t256::BN;
@@ -1694,7 +1776,7 @@ static int gemm_core(const void* A, int a_kstrided, int lda, const void* B, int 
   g.qcols = qcols; g.qscale = qscale;
   const uint64_t ab = a_window ? a_window : (a_kstrided ? ((uint64_t)(K - 1) * lda + M) * 2 : ((uint64_t)(M - 1) * lda + K) * 2);
   const uint64_t bb = b_window ? b_window : (b_kstrided ? ((uint64_t)(K - 1) * ldb + N) * 2 : ((uint64_t)(N - 1) * ldb + K) * 2);
-  g.csum_part = nullptr; g.split_id = 0;
+  g.csum_part = nullptr; g.split_id = 0; g.tile_ctr = nullptr;
   g.a_view = g.b_view = g.pw = 0; g.lca = g.lcbk = g.lcbn = 6;
   g.groups = 1; g.ga = g.gb = g.gc = g.gbias = 0;
   if (view) {
@@ -1807,6 +1889,27 @@ extern "C" int ia_prof_end(double* total_ms, double* total_flops, int* launches)
   if (total_flops) *total_flops = g_prof.flops;
   if (launches) *launches = g_prof.n;
   return IA_OK;
+}
+
+// Diagnostics: `workgroups` workgroups that each take a whole CU's LDS and spin for `milliseconds` (100 MHz wall clock)
+namespace {
+__global__ __launch_bounds__(256) void cu_hog_kernel(unsigned long long ticks) {
+  extern __shared__ __attribute__((aligned(16))) char hog_smem[];
+  if (threadIdx.x == 0) *reinterpret_cast<volatile int*>(hog_smem) = 1;      // the allocation is real
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+}  // namespace
+extern "C" int ia_debug_cu_hog(int workgroups, float milliseconds, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (workgroups <= 0 || workgroups > 256 || !(milliseconds > 0.f) || milliseconds > 1000.f) return IA_ERR_ARG;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)cu_hog_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES) != hipSuccess) return IA_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(cu_hog_kernel, dim3(workgroups), dim3(256), t256::LDS_BYTES, stream, (unsigned long long)(milliseconds * 1e5f));
+  return ia_check_launch();
 }
 
 // algorithmic bytes (each operand read once, the output written once) of the launches recorded between ia_prof_begin / ia_prof_end

@@ -127,25 +127,36 @@ class GradBucketReducer:
         s, e = self.buckets[i]
         self.launched[i] = True
         if self.world > 1 or (FORCE and dist.is_initialized()):
-            # gradients of one bucket may have been produced on several HIP streams (models that run independent towers
-            # concurrently): the stream the collective is ordered after must have seen all of them
-            cur = torch.cuda.current_stream() if self.flat.is_cuda else None
-            for st in self.streams():
-                if cur is not None and st != cur:
-                    cur.wait_stream(st)
-            if self.bf16:
-                # one pass fp32 -> bf16 into a staging slice (ia_cast_f32_to_bf16; torch's .to() only on CPU tensors, i.e. in the gloo tests)
-                if self.stage[i] is None:
-                    self.stage[i] = torch.empty(e - s, dtype=torch.bfloat16, device=self.flat.device)
-                stage = self.stage[i]
-                if self.flat.is_cuda:
-                    from . import ops
-                    ops.cast_to_bf16(self.flat[s:e], stage)
+            # Gradients of one bucket may have been produced on several HIP streams (models that run independent towers concurrently), so
+            # the collective must be ordered behind all of them -- without making any of THEM wait for the others: the collective (and
+            # its bf16 staging cast) is issued on a stream of its own that waits for the compute streams, and RCCL orders itself
+            # behind that stream.  (Rounds 2-4 made the launching compute stream wait for the others: with the image tower on a second
+            # stream the rest of that tower's backward then queued behind the whole text backward.)
+            import contextlib
+            ctx = contextlib.nullcontext()
+            if self.flat.is_cuda:
+                if getattr(self, "comm_stream", None) is None:
+                    self.comm_stream = torch.cuda.Stream(device=self.flat.device)
+                cur = torch.cuda.current_stream()
+                self.comm_stream.wait_stream(cur)
+                for st in self.streams():
+                    if st != cur:
+                        self.comm_stream.wait_stream(st)
+                ctx = torch.cuda.stream(self.comm_stream)
+            with ctx:
+                if self.bf16:
+                    # one pass fp32 -> bf16 into a staging slice (ia_cast_f32_to_bf16; torch's .to() only on CPU tensors, i.e. in the gloo tests)
+                    if self.stage[i] is None:
+                        self.stage[i] = torch.empty(e - s, dtype=torch.bfloat16, device=self.flat.device)
+                    stage = self.stage[i]
+                    if self.flat.is_cuda:
+                        from . import ops
+                        ops.cast_to_bf16(self.flat[s:e], stage)
+                    else:
+                        stage.copy_(self.flat[s:e])
+                    self.works.append((dist.all_reduce(stage, op=dist.ReduceOp.SUM, group=self.group, async_op=True), stage, s, e))
                 else:
-                    stage.copy_(self.flat[s:e])
-                self.works.append((dist.all_reduce(stage, op=dist.ReduceOp.SUM, group=self.group, async_op=True), stage, s, e))
-            else:
-                self.works.append((dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, s, e))
+                    self.works.append((dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, s, e))
 
     def grads_ready(self, params, final=False):
         """Hook target: these parameters' gradient kernels have been enqueued on the current stream.  Only a FINAL report
@@ -172,7 +183,9 @@ class GradBucketReducer:
             if not self.launched[i]:
                 self._launch(i)
         for w, stage, s, e in self.works:
-            w.wait()
+            w.wait()                                     # the current (optimiser) stream waits for the collective
+            if getattr(self, "comm_stream", None) is not None:
+                torch.cuda.current_stream().wait_stream(self.comm_stream)      # (gloo on device tensors completes on the issuing stream)
             if stage is not None:
                 if self.flat.is_cuda:
                     from . import ops

@@ -1100,3 +1100,53 @@ def test_linear_small_tiled_and_per_output_paths(gpu, B, N, K, act):
     assert rel_err(dx, xr.grad) < 1e-4
     assert rel_err(dW - 0.5, Wr.grad) < 1e-4
     assert rel_err(db - 0.25, br.grad) < 1e-4
+
+
+def test_gemm_dynamic_tile_claim_under_cu_contention(gpu):
+    """The large persistent GEMM launches hand their tiles out through per-XCD claim counters (gemm.hip, t256w::gemm_kernel): whatever
+    the claim order -- alone, next to a kernel that holds 24 whole CUs on another stream (ia_debug_cu_hog: workgroups that start late find
+    no work left), from two streams at once, and after the counter slots have come round (> 1024 launches) -- every tile is computed exactly
+    once: outputs bit-identical to the undisturbed launch, and equal to the fp32 reference within the bf16 bar."""
+    import time
+    from item_alignment_amd import _lib, ops
+    lib = _lib.load()
+    M, N, K = 5000, 4096, 512                       # 20 x 16 = 320 tiles (one clipped row of tiles): more than one per workgroup
+    a, b = rnd((M, K), gpu, 1.0, 71), rnd((N, K), gpu, 0.05, 72)
+    bias = torch.linspace(-1, 1, N, device=gpu)
+    ref = a.float() @ b.float().t() + bias
+    base = ops.gemm(a, b, epilogue=ops.EPI_BIAS, bias=bias).clone()
+    assert rel_err(base, ref) < 2e-2
+    side = torch.cuda.Stream()
+    for hog in (8, 24):
+        torch.cuda.synchronize()
+        _lib.check(lib.ia_debug_cu_hog(hog, 20.0, side.cuda_stream), "ia_debug_cu_hog")
+        time.sleep(0.003)
+        outs = [ops.gemm(a, b, epilogue=ops.EPI_BIAS, bias=bias) for _ in range(6)]
+        torch.cuda.synchronize()
+        for o in outs:
+            assert torch.equal(o, base), hog
+    # two streams launching the same shape concurrently (each launch has its own counter slot)
+    outs = []
+    for i in range(8):
+        with torch.cuda.stream(side if i & 1 else torch.cuda.current_stream()):
+            outs.append(ops.gemm(a, b, epilogue=ops.EPI_BIAS, bias=bias))
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, base)
+    # slot reuse: more launches than counter slots, the last ones still exact (a slot left non-zero would skip tiles)
+    a2, b2 = rnd((4352, 64), gpu, 1.0, 73), rnd((4096, 64), gpu, 0.1, 74)       # 17 x 16 = 272 tiles, one k-tile each
+    first = ops.gemm(a2, b2).clone()
+    out2 = torch.empty_like(first)
+    for _ in range(1100):
+        ops.gemm(a2, b2, out=out2)
+    torch.cuda.synchronize()
+    assert torch.equal(out2, first)
+    assert rel_err(first, a2.float() @ b2.float().t()) < 2e-2
+    # the data-gradient and GELU forms go through the same loop
+    w = rnd((K, N), gpu, 0.05, 75)
+    d0 = ops.gemm(a, w, b_kstrided=True).clone()
+    _lib.check(lib.ia_debug_cu_hog(16, 10.0, side.cuda_stream), "ia_debug_cu_hog")
+    time.sleep(0.003)
+    d1 = ops.gemm(a, w, b_kstrided=True)
+    torch.cuda.synchronize()
+    assert torch.equal(d0, d1) and rel_err(d0, a.float() @ w.float()) < 2e-2

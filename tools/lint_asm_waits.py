@@ -12,6 +12,10 @@ For every inline-asm LDS read this walks all paths of the function's control-flo
 `s_waitcnt lgkmcnt(N)` retires it (LDS operations complete in order: the read is complete once N <= number of LGKM operations
 issued after it) and reports any instruction on the way that mentions one of its destination registers.
 
+The same walk covers the one asynchronous VMEM result the GEMM kernels keep in a register across their main loop: the tile-claim
+`global_atomic_add ... sc0` issued through inline asm in front of the loop and consumed behind it (gemm.hip, claim_issue /
+claim_resolve).  It is retired by an `s_waitcnt vmcnt(0)`; a counted vmcnt(N > 0) on the way is ignored (stricter than needed).
+
 usage: lint_asm_waits.py file.s [--kernel substr]      (file.s from `hipcc -S --cuda-device-only`)
 exit status 1 when a violation is found.
 """
@@ -22,6 +26,7 @@ REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 LGKM_OP = re.compile(r"^\s*(ds_|s_load_|s_buffer_load_|s_sendmsg|s_memtime|s_memrealtime)")
 WAIT = re.compile(r"s_waitcnt\b(.*)")
 LGKM_N = re.compile(r"lgkmcnt\((\d+)\)")
+VM_N = re.compile(r"vmcnt\((\d+)\)")
 NEAR = 48
 BRANCH = re.compile(r"^\s*(s_branch|s_cbranch_\w+)\s+(\S+)")
 LABEL = re.compile(r"^(\.LBB\d+_\d+):")
@@ -37,6 +42,8 @@ def split_operands(text):
     if len(parts) < 2:
         return set(), set()
     ops = parts[1].split(",")
+    if parts[0].startswith(("global_atomic", "buffer_atomic")) and "sc0" in text.split():
+        return regs_of(ops[0]), regs_of(",".join(ops[1:]))        # returning form: the first operand receives the old value
     if ALL_SOURCES.match(parts[0]):
         return set(), regs_of(parts[1])
     return regs_of(ops[0]), regs_of(",".join(ops[1:]))
@@ -104,21 +111,26 @@ def lint_function(name, items):
         return [i + 1] if i + 1 < len(items) else []
 
     for i, (kind, text, in_asm) in enumerate(items):
-        if kind != "ins" or not in_asm or not text.startswith("ds_read"):
+        if kind != "ins" or not in_asm or not (text.startswith("ds_read") or text.startswith("global_atomic")):
             continue
+        vmem = text.startswith("global_atomic")
+        if vmem and "sc0" not in text.split():
+            continue                                  # no returned value, nothing to wait for
         dest = regs_of(text.split(",")[0])
         seen, stack = set(), [(j, 0, 1) for j in successors(i)]
         while stack:
             j, k, steps = stack.pop()
-            if (j, k) in seen or k > 40 or steps > 2000:
+            if vmem:
+                k = 0                                 # retired by vmcnt(0) only: the path state is the position alone
+            if (j, k) in seen or k > 40 or steps > (200000 if vmem else 2000):
                 continue
             seen.add((j, k))
             kind2, t2, asm2 = items[j]
             if kind2 == "ins":
                 w = WAIT.match(t2)
                 if w:
-                    n = LGKM_N.search(t2)
-                    # a wait without an lgkmcnt field leaves LGKM alone (vmcnt / expcnt only)
+                    n = (VM_N if vmem else LGKM_N).search(t2)
+                    # a wait without the counter's field leaves it alone
                     if n is not None and int(n.group(1)) <= k:
                         continue                      # retired on this path
                 else:
@@ -154,12 +166,12 @@ def main():
         for name, items in parse_functions(path).items():
             if flt and flt not in name:
                 continue
-            n_reads = sum(1 for k, t, a in items if k == "ins" and a and t.startswith("ds_read"))
+            n_reads = sum(1 for k, t, a in items if k == "ins" and a and (t.startswith("ds_read") or t.startswith("global_atomic")))
             if not n_reads:
                 continue
             bad = lint_function(name, items)
             uniq = sorted({(b[2], b[3], b[4]) for b in bad})
-            print(f"{name}: {n_reads} asm LDS reads, {len(uniq)} premature uses")
+            print(f"{name}: {n_reads} asm LDS reads / returning atomics, {len(uniq)} premature uses")
             for rd, use, how in uniq[:20]:
                 print(f"    {rd}\n        before its wait, {how} it: {use}")
             total += len(uniq)
