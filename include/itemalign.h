@@ -80,6 +80,7 @@ double ia_prof_bytes(void); /* algorithmic bytes of the recorded launches: A and
  * gradient all-reduce with backward).  The large persistent GEMM launches claim their tiles dynamically (one counter per XCD), so
  * a workgroup that starts late finds no work instead of holding a 1/256 share back; IA_GEMM_DYNAMIC=0 restores the static order. */
 int ia_debug_cu_hog(int workgroups, float milliseconds, ia_stream_t stream);
+int ia_debug_gemm_dynamic(int on); /* run-time switch of the dynamic tile claim (tests, A/B runs); returns the previous setting */
 
 /* ---- LayerNorm tails (RobertaSelfOutput / RobertaOutput: dense -> dropout -> +residual -> LayerNorm;
  * timm Block norm1/norm2).  z = residual + dropout(x + bias); y = LN(z).  z_out may alias x. */

@@ -40,6 +40,7 @@ SIGNATURES = {
     "ia_prof_end": (i32, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i32)]),
     "ia_prof_bytes": (C.c_double, []),
     "ia_debug_cu_hog": (i32, [i32, C.c_float, vp]),
+    "ia_debug_gemm_dynamic": (i32, [i32]),
     "ia_ln_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, u32, u32, vp]),
     "ia_ln_bwd_workspace_bytes": (sz, [i32, i32]),
     "ia_ln_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, u32, u32, vp, sz, i32, vp]),

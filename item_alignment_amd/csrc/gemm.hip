@@ -1401,7 +1401,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   // ahead of the vmcnt(0) in claim_resolve.)
   auto claim_issue = [&]() {
     if (wave == 0 && lane0 == 0)
-      asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(claimed) : "v"(0u), "v"(1u), "s"(p.tile_ctr + xcd) : "memory");
+      // s_nop 4: the counter address may just have been rebuilt by VALU instructions (v_readlane of a spilled SGPR pair) -- a VALU
+      // write of an SGPR needs 5 wait states before a VMEM instruction reads it, and the compiler's hazard recogniser does not look
+      // inside inline asm (found the hard way: without it the first build's atomic went to a wild address)
+      asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=v"(claimed) : "v"(0u), "v"(1u), "s"(p.tile_ctr + xcd) : "memory");
   };
   // -> position in the work order (tile_of_order), or -1: nothing left.  Workgroup-uniform (LDS mailbox between two barriers).
   auto claim_resolve = [&]() -> int {
@@ -1637,6 +1640,21 @@ Plan make_plan(int M, int N, int K, bool f32_out, int groups = 1) {
   return pl;
 }
 
+// Counter slot of the next dynamic-claim launch (nullptr: static order).  File-scope state: `launch` is a template, its function-local
+// statics would exist once per instantiation -- and two instantiations running on two streams would share slot 0.
+int g_dynamic = -1;
+uint32_t* g_ctr_base = nullptr;
+unsigned g_launch_seq = 0;
+uint32_t* next_ctr_slot() {
+  if (g_dynamic < 0) {
+    const char* e = getenv("IA_GEMM_DYNAMIC");
+    g_dynamic = e ? atoi(e) : 1;
+  }
+  if (!g_dynamic) return nullptr;
+  if (!g_ctr_base && hipGetSymbolAddress((void**)&g_ctr_base, HIP_SYMBOL(g_tile_ctr)) != hipSuccess) { g_ctr_base = nullptr; return nullptr; }
+  return g_ctr_base + (size_t)(g_launch_seq++ % CTR_SLOTS) * CTR_WORDS;
+}
+
 template <bool AKS, bool BKS, int EPI, bool OUTF32>
 int launch(GemmArgs a, bool big, hipStream_t st) {
   constexpr int vid = AKS * 1000 + BKS * 100 + EPI * 10 + (OUTF32 ? 1 : 0);
@@ -1660,15 +1678,7 @@ int launch(GemmArgs a, bool big, hipStream_t st) {
     const int ntile = a.tiles_m * a.tiles_n;
     const int gx = a.splits > 1 ? ntile * a.splits : (ntile < 256 ? ntile : 256);
     // persistent launches with more than one tile per workgroup claim their tiles dynamically (IA_GEMM_DYNAMIC=0: the static order)
-    static int dynamic = -1;
-    static uint32_t* ctr_base = nullptr;
-    static unsigned launch_seq = 0;
-    if (dynamic < 0) {
-      const char* e = getenv("IA_GEMM_DYNAMIC");
-      dynamic = e ? atoi(e) : 1;
-      if (dynamic && hipGetSymbolAddress((void**)&ctr_base, HIP_SYMBOL(g_tile_ctr)) != hipSuccess) return IA_ERR_LAUNCH;
-    }
-    a.tile_ctr = (dynamic && a.splits == 1 && ntile > gx) ? ctr_base + (size_t)(launch_seq++ % CTR_SLOTS) * CTR_WORDS : nullptr;
+    a.tile_ctr = (a.splits == 1 && ntile > gx) ? next_ctr_slot() : nullptr;
     hipLaunchKernelGGL(kern, dim3(gx), dim3(256), t256::LDS_BYTES, st, a);
   } else if (big) {
     a.tiles_m = (a.M + t256::BM - 1) / t256::BM; a.tiles_n = (a.N + t256::BN - 1) / t256::BN;
@@ -1900,6 +1910,14 @@ __global__ __launch_bounds__(256) void cu_hog_kernel(unsigned long long ticks) {
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 }  // namespace
+// Diagnostics: switch the dynamic tile claim of the persistent GEMM launches on / off at run time (the IA_GEMM_DYNAMIC default otherwise);
+// returns the previous setting.
+extern "C" int ia_debug_gemm_dynamic(int on) {
+  if (g_dynamic < 0) (void)next_ctr_slot();
+  const int prev = g_dynamic;
+  g_dynamic = on ? 1 : 0;
+  return prev;
+}
 extern "C" int ia_debug_cu_hog(int workgroups, float milliseconds, hipStream_t stream) {
   (void)hipGetLastError();
   if (workgroups <= 0 || workgroups > 256 || !(milliseconds > 0.f) || milliseconds > 1000.f) return IA_ERR_ARG;

@@ -243,7 +243,8 @@ def test_c2_full_width_one_tower(gpu):
     labels = torch.tensor([1, 0])
     torch.manual_seed(77)
     model = M.RobertaOneTower(cfg)
-    sd = state_of(model, head_gain=20.0)
+    sd = state_of(model, head_gain=5.0)                   # dense and out_proj both: O(0.5) logits (x 20 gave |logits| ~ 10: the loss then
+                                                          # amplifies the encoder's bf16 error by the head's gain)
     model = model.cuda().eval()
     t = [torch.from_numpy(a) for a in (ids, mask, tt)]
     model.param_arena.zero_grad()

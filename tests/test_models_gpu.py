@@ -343,17 +343,17 @@ def test_train_step_decreases_loss_and_matches_adamw(gpu):
     p = dict(model.named_parameters())["classifier.out_proj.weight"]
     ref_p = p.detach().clone().requires_grad_(True)
     ref_p.grad = p.grad.detach().clone()
-    opt = torch.optim.AdamW([ref_p], lr=1e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=1e-5)
+    opt = torch.optim.AdamW([ref_p], lr=1e-4, betas=(0.9, 0.98), eps=1e-8, weight_decay=1e-5)
     opt.step()
-    arena.adamw_step(1e-3)
+    arena.adamw_step(1e-4)
     torch.cuda.synchronize()
-    assert torch.allclose(p.detach(), ref_p.detach(), atol=1e-6, rtol=1e-5)
+    assert torch.allclose(p.detach(), ref_p.detach(), atol=1e-7, rtol=1e-5)
     losses = [loss0.item()]
-    for _ in range(5):
+    for _ in range(6):                      # (1e-3 makes the eight-sample fixture's loss jump about; the reference trains at 1e-5)
         arena.zero_grad()
         l = model(**args).loss
         l.backward()
-        arena.adamw_step(1e-3)
+        arena.adamw_step(1e-4)
         losses.append(l.item())
     assert losses[-1] < losses[0], losses
 
@@ -665,10 +665,18 @@ def test_train_step_with_dropout_on(gpu):
     # (both samples are seeded, so the outcome is fixed for a given build; 3 standard errors leave room for another torch's CPU stream)
     assert abs(hl.mean().item() - ol.mean().item()) <= 3 * se + bias, (hl.mean().item(), ol.mean().item(), se)
     hg, og = torch.stack(hg).double(), torch.stack(og).double()
+    # the deterministic part of the difference: bf16 against fp32 with dropout off (the same weights, the same inputs) -- with eight samples
+    # per batch the sampling error of a 64-seed mean is small enough for that bias to show in the z scores, so it is taken out first
+    model.eval()
+    _, ge = hip_step(0)
+    model.train()
+    sd0 = weights(case, requires_grad=True)
+    run_oracle(case, sd0, training=False).loss.backward()
+    bias_g = (ge[key].double() - sd0[key].grad.double()).abs()
     # per element of the pair head's weight gradient (2 x 256): z = |difference of the two sample means| / its standard error.
     # Two samplers of the same distribution give |N(0, 1)| scores: mean 0.80, 95 % below 2, the largest of 512 around 3.1
     # (measured with 128 seeds: 0.85 / 0.953 / 3.08); a wrong keep probability or a missing 1 / (1 - p) shifts every one of them.
-    z = (hg.mean(0) - og.mean(0)).abs() / (hg.var(0) / n + og.var(0) / n).sqrt()
+    z = ((hg.mean(0) - og.mean(0)).abs() - bias_g).clamp_min(0) / (hg.var(0) / n + og.var(0) / n).sqrt()
     assert z.mean().item() < 1.05, z.mean().item()
     assert (z < 2).double().mean().item() > 0.90, (z < 2).double().mean().item()
     assert z.max().item() < 5.0, z.max().item()
