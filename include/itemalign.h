@@ -80,7 +80,10 @@ double ia_prof_bytes(void); /* algorithmic bytes of the recorded launches: A and
  * gradient all-reduce with backward).  The large persistent GEMM launches claim their tiles dynamically (one counter per XCD), so
  * a workgroup that starts late finds no work instead of holding a 1/256 share back; IA_GEMM_DYNAMIC=0 restores the static order. */
 int ia_debug_cu_hog(int workgroups, float milliseconds, ia_stream_t stream);
-int ia_debug_gemm_dynamic(int on); /* run-time switch of the dynamic tile claim (tests, A/B runs); returns the previous setting */
+/* Run-time switch of the dynamic tile claim; returns the previous setting (on < 0: query only).  Default off (static order) unless
+ * IA_GEMM_DYNAMIC=1: a host that overlaps a communication stream with the GEMMs (world size > 1) switches it on -- 0-1.5 % per large
+ * GEMM for not paying ~1.3-1.5 x when CUs are taken (profiles/r05_cu_contention.txt). */
+int ia_debug_gemm_dynamic(int on);
 
 /* ---- LayerNorm tails (RobertaSelfOutput / RobertaOutput: dense -> dropout -> +residual -> LayerNorm;
  * timm Block norm1/norm2).  z = residual + dropout(x + bias); y = LN(z).  z_out may alias x. */
@@ -351,6 +354,9 @@ int ia_attn_bwd_varlen_ps(const void* q, const void* k, const void* v, int ld_qk
                           int Lmax, float scale, float drop_p, uint32_t seed, ia_stream_t stream);
 
 /* ---- optimiser (torch.optim.AdamW, finetune_multimodal.py:296-308,460-468) */
+/* dst[offset + c*rows + r] = src[offset + r*cols + c] for each of the n table entries {offset_lo, offset_hi, rows, cols} (uint32 x 4,
+ * device memory; element offsets, the same in src and dst): the transposed weight shadows of ia_layer_weights::wt_*.  (ABI 7) */
+int ia_transpose_bf16_batched(const void* src, void* dst, const void* table, int n, int max_tiles, ia_stream_t stream);
 int ia_adamw_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, const void* chunk_table,
                   int n_chunks, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                   ia_stream_t stream);
@@ -372,6 +378,13 @@ typedef struct {
   const float* b_fc2;
   const float* ln2_g;  /* output.LayerNorm / norm2 */
   const float* ln2_b;
+  /* (ABI 7) optional transposed bf16 copies, [H, 3H] / [H, H] / [H, I] / [I, H] (ia_transpose_bf16_batched keeps them in step with the
+   * shadows above): the backward's data-gradient GEMMs dx = dy W then read W^T k-contiguously -- 2-16 % faster per launch than the
+   * k-strided form (transpose reads out of LDS), 5.7 ms of a 434 ms step.  NULL = not provided (k-strided form). */
+  const void* wt_qkv;
+  const void* wt_o;
+  const void* wt_fc1;
+  const void* wt_fc2;
 } ia_layer_weights;
 
 typedef struct { /* fp32 gradient arena slots, same shapes as above; all accumulate (+=) */

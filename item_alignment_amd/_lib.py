@@ -15,7 +15,7 @@ vp, i32, u32, f32, sz = C.c_void_p, C.c_int, C.c_uint32, C.c_float, C.c_size_t
 
 class LayerWeights(C.Structure):
     _fields_ = [(n, vp) for n in ("w_qkv", "b_qkv", "w_o", "b_o", "ln1_g", "ln1_b", "w_fc1", "b_fc1", "w_fc2", "b_fc2",
-                                  "ln2_g", "ln2_b")]
+                                  "ln2_g", "ln2_b", "wt_qkv", "wt_o", "wt_fc1", "wt_fc2")]
 
 
 class LayerGrads(C.Structure):
@@ -124,6 +124,7 @@ SIGNATURES = {
     "ia_span_mean_fwd": (i32, [vp, i32, vp, vp, i32, i32, vp]),
     "ia_span_mean_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "ia_pair_head_ce_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "ia_transpose_bf16_batched": (i32, [vp, vp, vp, i32, i32, vp]),
     "ia_adamw_flat": (i32, [vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, i32, f32, vp]),
     "ia_cast_f32_to_bf16": (i32, [vp, vp, sz, vp]),
     "ia_cast_bf16_to_f32": (i32, [vp, vp, sz, vp]),

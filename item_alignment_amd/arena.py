@@ -72,6 +72,10 @@ class ParamArena:
                     chunks.append(((o + c) & 0xFFFFFFFF, (o + c) >> 32, min(CHUNK, n - c), decay))
         self.n_chunks = len(chunks)
         self.chunk_table = torch.from_numpy(np.asarray(chunks, dtype=np.uint32).reshape(-1, 4)).to(self.device)
+        # transposed bf16 copies of registered 2-D weights (register_transposed): the data-gradient GEMMs read W^T k-contiguously
+        self.shadow_t = None
+        self._transposed = {}              # element offset -> (rows, cols)
+        self._transposed_table = None
         self.step_count = 0
         self.stale_refreshes = 0
         self.optimizer_bound = False
@@ -107,6 +111,38 @@ class ParamArena:
         self.join_side_streams()
         check(lib.ia_cast_f32_to_bf16(self.master.data_ptr(), self.shadow.data_ptr(), self.numel, stream_ptr()), "ia_cast_f32_to_bf16")
         self._versions = self._param_versions()
+        self.refresh_transposed()
+
+    def register_transposed(self, params):
+        """bf16 W^T [cols, rows] of a 2-D weight -- or of several stacked ones laid out back to back (q | k | v = one [3H, H] matrix) --
+        kept in `shadow_t` at the weight's own element offset and rewritten after every optimiser step / shadow refresh (one batched
+        launch, ~4 B per parameter).  Returns the bf16 view."""
+        params = list(params) if isinstance(params, (tuple, list)) else [params]
+        first = self._shadow_of[id(params[0])]
+        off, cols = first.storage_offset(), params[0].shape[1]
+        rows, exp = 0, off
+        for p in params:
+            if p.dim() != 2 or p.shape[1] != cols or self._shadow_of[id(p)].storage_offset() != exp:
+                raise RuntimeError("register_transposed: 2-D weights of one width, contiguous in the arena")
+            rows += p.shape[0]
+            exp += p.numel()
+        if self.shadow_t is None:
+            self.shadow_t = torch.zeros_like(self.shadow)
+        if self._transposed.get(off) != (rows, cols):
+            self._transposed[off] = (rows, cols)
+            self._transposed_table = None
+        return self.shadow_t[off:off + rows * cols].view(cols, rows)
+
+    def refresh_transposed(self):
+        if not self._transposed:
+            return
+        lib = _lib.load()
+        if self._transposed_table is None:
+            ent = [((o & 0xFFFFFFFF), o >> 32, r, c) for o, (r, c) in sorted(self._transposed.items())]
+            self._transposed_table = torch.from_numpy(np.asarray(ent, dtype=np.uint32).reshape(-1, 4)).to(self.device)
+            self._transposed_tiles = max(((r + 63) // 64) * ((c + 63) // 64) for _, _, r, c in ent)
+        check(lib.ia_transpose_bf16_batched(self.shadow.data_ptr(), self.shadow_t.data_ptr(), self._transposed_table.data_ptr(),
+                                            self._transposed_table.shape[0], self._transposed_tiles, stream_ptr()), "ia_transpose_bf16_batched")
 
     def _param_versions(self):
         return sum(p._version for p in self.params)
@@ -161,6 +197,7 @@ class ParamArena:
         check(lib.ia_adamw_flat(self.master.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                                 self.shadow.data_ptr(), self.chunk_table.data_ptr(), self.n_chunks, lr, betas[0], betas[1], eps,
                                 weight_decay, self.step_count, grad_scale, stream_ptr()), "ia_adamw_flat")
+        self.refresh_transposed()
 
     def grad_buckets(self, bucket_bytes=64 << 20):
         """Contiguous slices of the gradient arena, last-to-first (backward produces the last layers'

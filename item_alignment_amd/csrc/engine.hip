@@ -67,6 +67,19 @@ bool cfg_ok(const ia_layer_cfg* c) {
 
 #define IA_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 
+// Data gradient dx[M, n_in] = dy[M, k_out] W[k_out, n_in] (+ epilogue): through the transposed shadow wt[n_in, k_out] when the caller
+// provides one (both operands k-contiguous: the faster form, ia_layer_weights::wt_*), else W read k-strided.  IA_DGRAD_NT=0: A/B switch.
+bool dgrad_nt() {
+  static const bool on = [] { const char* e = getenv("IA_DGRAD_NT"); return !e || atoi(e) != 0; }();
+  return on;
+}
+int dgrad(const void* dy, int k_out, const void* w, const void* wt, int n_in, void* dx, int M, int epilogue, const void* aux, int ldaux, void* c2,
+          void* ws, size_t ws_bytes, ia_stream_t st) {
+  if (wt && dgrad_nt())
+    return ia_gemm_bf16(dy, 0, k_out, wt, 0, k_out, dx, 0, n_in, M, n_in, k_out, epilogue, nullptr, aux, ldaux, c2, 0, ws, ws_bytes, st);
+  return ia_gemm_bf16(dy, 0, k_out, w, 1, n_in, dx, 0, n_in, M, n_in, k_out, epilogue, nullptr, aux, ldaux, c2, 0, ws, ws_bytes, st);
+}
+
 // The QKV projection of a layer writes q already multiplied by softmax scale * log2(e) (one bf16 rounding, in the GEMM epilogue where
 // the value is still fp32) and the attention kernels are told so: none of forward / dQ / dK-dV / fused backward re-scales its q tiles.
 // Needs the q | k boundary on a 128-column tile boundary of the GEMM; IA_Q_PRESCALE=0 switches it off for A/B runs.
@@ -244,9 +257,9 @@ extern "C" int ia_layer_bwd2(const ia_layer_cfg* c, const ia_layer_weights* w, c
     const char* d_ffn = drop ? k.g1 : k.g0;
     IA_TRY(ia_gemm_bf16(d_ffn, 1, H, s.hact, 1, I, g->w_fc2, 1, I, H, I, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
     // d(pre-activation) = (d_ffn W2) * gelu'(pre), and its column sums (the fc1 bias gradient) out of the same epilogue
-    IA_TRY(ia_gemm_bf16(d_ffn, 0, H, w->w_fc2, 1, I, k.gI, 0, I, M, I, H, IA_EPI_DGELU_COLSUM, nullptr, s.hpre, I, g->b_fc1, 0, k.ws, k.ws_bytes, st));
+    IA_TRY(dgrad(d_ffn, H, w->w_fc2, w->wt_fc2, I, k.gI, M, IA_EPI_DGELU_COLSUM, s.hpre, I, g->b_fc1, k.ws, k.ws_bytes, st));
     IA_TRY(ia_gemm_bf16(k.gI, 1, I, s.t1, 1, H, g->w_fc1, 1, H, I, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
-    IA_TRY(ia_gemm_bf16(k.gI, 0, I, w->w_fc1, 1, H, k.g2, 0, H, M, H, I, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
+    IA_TRY(dgrad(k.gI, I, w->w_fc1, w->wt_fc1, H, k.g2, M, IA_EPI_NONE, nullptr, 0, nullptr, nullptr, 0, st));
     // LN1 backward: d(y1) = g2 (through fc1) + g0 (residual into LN2) -> dz1 (the layer input's residual-path gradient) in
     // dz1buf: the caller's dx2 when the split form is wanted, else g0 (in place over the term just consumed)
     char* dz1buf = dx2 ? (char*)dx2 : k.g0;
@@ -254,27 +267,27 @@ extern "C" int ia_layer_bwd2(const ia_layer_cfg* c, const ia_layer_weights* w, c
                       c->hidden_drop, c->seed, c->layer_id * 4u + 0u, k.ws, k.ws_bytes, 1, st));
     const char* d_att = drop ? k.g1 : dz1buf;
     IA_TRY(ia_gemm_bf16(d_att, 1, H, s.ctx, 1, H, g->w_o, 1, H, H, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
-    IA_TRY(ia_gemm_bf16(d_att, 0, H, w->w_o, 1, H, k.g2, 0, H, M, H, H, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
+    IA_TRY(dgrad(d_att, H, w->w_o, w->wt_o, H, k.g2, M, IA_EPI_NONE, nullptr, 0, nullptr, nullptr, 0, st));
     IA_TRY(attn_bwd(c, s.qkv, key_mask, s.ctx, k.g2, s.lse, k.delta, k.gqkv, g->b_qkv, k.ws, k.ws_bytes, scale, c->attn_drop, attn_seed, st));
     IA_TRY(ia_gemm_bf16(k.gqkv, 1, 3 * H, x, 1, H, g->w_qkv, 1, H, 3 * H, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
     if (dx2)   // split form: dx = the attention sub-block's data gradient, dx2 = dz1 (already written)
-      IA_TRY(ia_gemm_bf16(k.gqkv, 0, 3 * H, w->w_qkv, 1, H, dx, 0, H, M, H, 3 * H, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
+      IA_TRY(dgrad(k.gqkv, 3 * H, w->w_qkv, w->wt_qkv, H, dx, M, IA_EPI_NONE, nullptr, 0, nullptr, nullptr, 0, st));
     else
-      IA_TRY(ia_gemm_bf16(k.gqkv, 0, 3 * H, w->w_qkv, 1, H, dx, 0, H, M, H, 3 * H, IA_EPI_ADD, nullptr, dz1buf, H, nullptr, 0, nullptr, 0, st));
+      IA_TRY(dgrad(k.gqkv, 3 * H, w->w_qkv, w->wt_qkv, H, dx, M, IA_EPI_ADD, dz1buf, H, nullptr, nullptr, 0, st));
   } else {
     if (!c->dy_colsum_done) IA_TRY(ia_colsum(dy, H, M, H, g->b_fc2, 1, k.ws, k.ws_bytes, st));
     IA_TRY(ia_gemm_bf16(dy, 1, H, s.hact, 1, I, g->w_fc2, 1, I, H, I, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
-    IA_TRY(ia_gemm_bf16(dy, 0, H, w->w_fc2, 1, I, k.gI, 0, I, M, I, H, IA_EPI_DGELU_COLSUM, nullptr, s.hpre, I, g->b_fc1, 0, k.ws, k.ws_bytes, st));
+    IA_TRY(dgrad(dy, H, w->w_fc2, w->wt_fc2, I, k.gI, M, IA_EPI_DGELU_COLSUM, s.hpre, I, g->b_fc1, k.ws, k.ws_bytes, st));
     IA_TRY(ia_gemm_bf16(k.gI, 1, I, s.t2, 1, H, g->w_fc1, 1, H, I, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
-    IA_TRY(ia_gemm_bf16(k.gI, 0, I, w->w_fc1, 1, H, k.g0, 0, H, M, H, I, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
+    IA_TRY(dgrad(k.gI, I, w->w_fc1, w->wt_fc1, H, k.g0, M, IA_EPI_NONE, nullptr, 0, nullptr, nullptr, 0, st));
     // LN2 backward (+ residual path dy) -> g1 = d x2 ; its column sum is the proj-bias gradient
     IA_TRY(ia_ln_bwd(k.g0, dy, s.t1, s.mean2, s.rstd2, w->ln2_g, k.g1, nullptr, g->ln2_g, g->ln2_b, g->b_o, M, H, 0.f, 0, 0, k.ws,
                      k.ws_bytes, 1, st));
     IA_TRY(ia_gemm_bf16(k.g1, 1, H, s.ctx, 1, H, g->w_o, 1, H, H, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
-    IA_TRY(ia_gemm_bf16(k.g1, 0, H, w->w_o, 1, H, k.g2, 0, H, M, H, H, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
+    IA_TRY(dgrad(k.g1, H, w->w_o, w->wt_o, H, k.g2, M, IA_EPI_NONE, nullptr, 0, nullptr, nullptr, 0, st));
     IA_TRY(attn_bwd(c, s.qkv, key_mask, s.ctx, k.g2, s.lse, k.delta, k.gqkv, g->b_qkv, k.ws, k.ws_bytes, scale, 0.f, 0, st));
     IA_TRY(ia_gemm_bf16(k.gqkv, 1, 3 * H, s.t0, 1, H, g->w_qkv, 1, H, 3 * H, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
-    IA_TRY(ia_gemm_bf16(k.gqkv, 0, 3 * H, w->w_qkv, 1, H, k.g0, 0, H, M, H, 3 * H, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, st));
+    IA_TRY(dgrad(k.gqkv, 3 * H, w->w_qkv, w->wt_qkv, H, k.g0, M, IA_EPI_NONE, nullptr, 0, nullptr, nullptr, 0, st));
     // dx = LN1'(g0) + g1 is the incoming gradient of the block below: its column sums (that block's fc2 bias gradient) come out of
     // this kernel's partial sums instead of a separate pass over [M, H] there (cfg->dx_colsum_out)
     IA_TRY(ia_ln_bwd(k.g0, k.g1, x, s.mean1, s.rstd1, w->ln1_g, dx, nullptr, g->ln1_g, g->ln1_b, c->dx_colsum_out, M, H, 0.f, 0, 0, k.ws,

@@ -1386,9 +1386,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   // kernel takes all 160 KiB of LDS, nothing co-resides) -- keeps its 1/256 share hostage until a sibling has finished ALL of its
   // own tiles, i.e. the launch takes two rounds.  Claimed tiles instead: every XCD's contiguous run of the work order (the same runs
   // as before, so the panels still share that XCD's L2) is handed out position by position through one counter per XCD; a workgroup
-  // whose own run is exhausted takes from the other XCDs' runs; one that starts late finds nothing left and exits.  The claim for the
-  // NEXT tile is issued in front of the main loop (wave 0, one lane; it is older than every DMA piece of the loop, so the loop's
-  // counted vmcnt waits only get stricter by it) and read behind it.
+  // whose own run is exhausted takes from the other XCDs' runs; one that starts late finds nothing left and exits.  Claims run two
+  // tiles ahead: issued (wave 0, one lane) in front of a tile's epilogue, read behind the NEXT tile's main loop; an outstanding claim
+  // is older than every DMA piece the loops wait for, so their counted vmcnt waits only get stricter by it.
   const bool dyn = p.tile_ctr != nullptr && !ordered;
   const int xcd = blockIdx.x & 7, q8 = total_tiles >> 3, r8 = total_tiles & 7;
   auto run_start = [&](int x) { return x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8; };
@@ -1404,7 +1404,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
       // s_nop 4: the counter address may just have been rebuilt by VALU instructions (v_readlane of a spilled SGPR pair) -- a VALU
       // write of an SGPR needs 5 wait states before a VMEM instruction reads it, and the compiler's hazard recogniser does not look
       // inside inline asm (found the hard way: without it the first build's atomic went to a wild address)
-      asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=v"(claimed) : "v"(0u), "v"(1u), "s"(p.tile_ctr + xcd) : "memory");
+      // (the address through readfirstlane: where the compiler keeps the uniform pointer in a VGPR it cannot hand it to an "s" operand)
+      {
+        const uint64_t a64 = (uint64_t)(p.tile_ctr + xcd);
+        const uint32_t alo = __builtin_amdgcn_readfirstlane((uint32_t)a64), ahi = __builtin_amdgcn_readfirstlane((uint32_t)(a64 >> 32));
+        const uint64_t addr = ((uint64_t)ahi << 32) | alo;
+        asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=v"(claimed) : "v"(0u), "v"(1u), "s"(addr) : "memory");
+      }
   };
   // -> position in the work order (tile_of_order), or -1: nothing left.  Workgroup-uniform (LDS mailbox between two barriers).
   auto claim_resolve = [&]() -> int {
@@ -1415,8 +1421,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
       int pos = (int)__builtin_amdgcn_readfirstlane(claimed), w = -1;
       if (pos < run_len(xcd)) w = run_start(xcd) + pos;
       else {
-        for (int d = 1; d < 8 && w < 0; ++d) {                       // own run exhausted (the launch's tail): take from the others
+        // Own run exhausted (the launch's tail): take from the other XCDs' runs.  One snapshot of the eight counters (lanes 0-7, one
+        // load each) tells which runs are used up, so the tail -- where all runs end within a tile time of each other -- costs one load
+        // round trip instead of seven returning atomics in a row in front of the last tile's epilogue (+19 % on a 113-us launch).
+        uint32_t seen = 0xFFFFFFFFu;
+        if (lane0 < 8) seen = __hip_atomic_load(p.tile_ctr + lane0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t mask = (uint32_t)__ballot((int)seen >= q8 + (lane0 < r8 ? 1 : 0)) | (1u << xcd);
+        for (int d = 1; d < 8 && w < 0; ++d) {
           const int x = (xcd + d) & 7;
+          if ((mask >> x) & 1u) continue;
           uint32_t got = 0;
           if (lane0 == 0) got = __hip_atomic_fetch_add(p.tile_ctr + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           pos = (int)__builtin_amdgcn_readfirstlane(got);
@@ -1431,6 +1444,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     return w;
   };
   auto leave = [&]() {                                                // the last workgroup out re-arms the slot for its next launch
+    // every claim of this workgroup has been PERFORMED before it counts itself out (the last one's value may be unused)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(claimed) : : "memory");
     if (dyn && wave == 0 && lane0 == 0) {
       const uint32_t d = __hip_atomic_fetch_add(p.tile_ctr + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (d == gridDim.x - 1) {
@@ -1444,6 +1459,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     claim_issue();
     first_tile = claim_resolve();
     if (first_tile < 0) { leave(); return; }
+    claim_issue();                                                    // the second tile's claim travels under the first main loop
   }
 
   f32x16 acc[4][4];
@@ -1484,7 +1500,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
       pbv[0] = *reinterpret_cast<const f32x4*>(bp); pbv[1] = *reinterpret_cast<const f32x4*>(bp + 4);
       pbv[2] = *reinterpret_cast<const f32x4*>(bp + 64); pbv[3] = *reinterpret_cast<const f32x4*>(bp + 68);
     }
-    if (dyn) claim_issue();
     run(tile, false, acc, stores_in_flight);
     float ts = 1.f;
     if (bias_pre && BIAS_CT) {
@@ -1500,7 +1515,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
       }
     } else if (bias_pre) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pbv[0]), "+v"(pbv[1]), "+v"(pbv[2]), "+v"(pbv[3]));
     int next = ordered ? total_tiles : tile + gridDim.x;
-    if (dyn) { next = claim_resolve(); if (next < 0) next = total_tiles; }
+    if (dyn) {
+      next = claim_resolve();
+      // the claim for the tile AFTER next goes out here, in front of next's prologue DMA and this tile's epilogue: VMEM retires in
+      // order, so a claim issued right in front of a main loop holds that loop's first counted wait up for the atomic's round trip
+      // (1-3 us under load: +14 % on 25-us tiles at K = 1024, N = 1024); here it has the whole epilogue to come back
+      // (issued also when nothing is left -- written as `else claim_issue()` the backend fails with "illegal VGPR to SGPR copy";
+      // the stray claim only overshoots a counter, and leave() waits for it before it reports this workgroup done)
+      claim_issue();
+      if (next < 0) next = total_tiles;
+    }
     if (next < total_tiles) run(next, true, acc, false);      // the next tile's first two k-tiles travel under this epilogue
 
     int lane_e = lane0;
@@ -1646,9 +1670,12 @@ int g_dynamic = -1;
 uint32_t* g_ctr_base = nullptr;
 unsigned g_launch_seq = 0;
 uint32_t* next_ctr_slot() {
+  // Default: the static order.  The claims cost the 256-wide GEMMs 0-1.5 % (two workgroup barriers per tile; 14 % on a 113-us launch of
+  // four 25-us tiles per workgroup) and buy nothing while no other stream holds CUs; the data-parallel host switches them on when it
+  // creates a communicator (dist.init_from_env at world size > 1 -> ia_debug_gemm_dynamic(1)), IA_GEMM_DYNAMIC=0/1 forces either.
   if (g_dynamic < 0) {
     const char* e = getenv("IA_GEMM_DYNAMIC");
-    g_dynamic = e ? atoi(e) : 1;
+    g_dynamic = e ? atoi(e) : 0;
   }
   if (!g_dynamic) return nullptr;
   if (!g_ctr_base && hipGetSymbolAddress((void**)&g_ctr_base, HIP_SYMBOL(g_tile_ctr)) != hipSuccess) { g_ctr_base = nullptr; return nullptr; }
@@ -1835,6 +1862,18 @@ static int gemm_core(const void* A, int a_kstrided, int lda, const void* B, int 
       case EPI_BIAS_GELU_ACT: return launch<false, false, EPI_BIAS_GELU_ACT, false>(g, big, stream);
       case EPI_BIAS_ADD: return launch<false, false, EPI_BIAS_ADD, false>(g, big, stream);
       case EPI_ADD: return launch<false, false, EPI_ADD, false>(g, big, stream);
+      // (the data-gradient epilogues on a k-contiguous B: the transposed weight shadows of ia_layer_weights::wt_*)
+      case EPI_DGELU: return launch<false, false, EPI_DGELU, false>(g, big, stream);
+      case EPI_DGELU_CS: {
+        if (!C2 || !workspace || workspace_bytes < ia_gemm_colsum_workspace_bytes(M, N) || ldc != N) return IA_ERR_WORKSPACE;
+        if (!big) {
+          int rc = launch<false, false, EPI_DGELU, false>(g, false, stream);
+          return rc ? rc : ia_colsum(C, ldc, M, N, (float*)C2, 1, workspace, workspace_bytes, stream);
+        }
+        g.csum_part = (float*)workspace;
+        int rc = launch<false, false, EPI_DGELU_CS, false>(g, true, stream);
+        return rc ? rc : ia_sum_rows_f32((const float*)workspace, ((M + 255) / 256) * 2, N, (float*)C2, 1, stream);
+      }
     }
   } else if (!a_kstrided && b_kstrided && !c_is_f32) {
     switch (epilogue) {
@@ -1915,7 +1954,7 @@ __global__ __launch_bounds__(256) void cu_hog_kernel(unsigned long long ticks) {
 extern "C" int ia_debug_gemm_dynamic(int on) {
   if (g_dynamic < 0) (void)next_ctr_slot();
   const int prev = g_dynamic;
-  g_dynamic = on ? 1 : 0;
+  if (on >= 0) g_dynamic = on ? 1 : 0;        // (negative: query only)
   return prev;
 }
 extern "C" int ia_debug_cu_hog(int workgroups, float milliseconds, hipStream_t stream) {

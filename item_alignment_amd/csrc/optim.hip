@@ -74,7 +74,44 @@ __global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16* __restri
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = bf2f(src[i]);
 }
 
+// dst[c][r] = src[r][c] for every matrix of the table: 64 x 64 tiles through LDS (both sides move 128-byte rows), one workgroup per tile
+struct TransposeEntry { uint32_t offset_lo; uint32_t offset_hi; uint32_t rows; uint32_t cols; };
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst,
+                                                                const TransposeEntry* __restrict__ table) {
+  __shared__ bf16 tile[64][66];
+  const TransposeEntry e = table[blockIdx.y];
+  const uint32_t tiles_c = (e.cols + 63) / 64, tiles_r = (e.rows + 63) / 64;
+  if (blockIdx.x >= tiles_c * tiles_r) return;
+  const size_t base = ((size_t)e.offset_hi << 32) | e.offset_lo;
+  const uint32_t r0 = (blockIdx.x / tiles_c) * 64, c0 = (blockIdx.x % tiles_c) * 64;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;              // 32 lanes x 2 columns, 8 row groups
+  for (int i = ty; i < 64; i += 8) {
+    const uint32_t r = r0 + i, c = c0 + 2 * tx;
+    bf16 a = f2bf(0.f), b = f2bf(0.f);
+    if (r < e.rows && c < e.cols) a = src[base + (size_t)r * e.cols + c];
+    if (r < e.rows && c + 1 < e.cols) b = src[base + (size_t)r * e.cols + c + 1];
+    tile[i][2 * tx] = a; tile[i][2 * tx + 1] = b;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 8) {
+    const uint32_t c = c0 + i, r = r0 + 2 * tx;                          // output row = source column
+    if (c < e.cols && r < e.rows) dst[base + (size_t)c * e.rows + r] = tile[2 * tx][i];
+    if (c < e.cols && r + 1 < e.rows) dst[base + (size_t)c * e.rows + r + 1] = tile[2 * tx + 1][i];
+  }
+}
+
 }  // namespace
+
+// Transposed bf16 copies of 2-D weights (the data-gradient GEMMs dx = dy W read W^T k-contiguously: the faster operand form).
+// table: device array of n {offset_lo, offset_hi, rows, cols} (element offsets into src / dst, the same on both sides);
+// dst[offset .. offset + rows*cols) receives the [cols, rows] transpose of src's [rows, cols] matrix.  max_tiles = the largest
+// ceil(rows/64) * ceil(cols/64) of the table.
+extern "C" int ia_transpose_bf16_batched(const void* src, void* dst, const void* table, int n, int max_tiles, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!src || !dst || !table || n <= 0 || max_tiles <= 0 || n > 65535) return IA_ERR_ARG;
+  hipLaunchKernelGGL(transpose_batched_kernel, dim3(max_tiles, n), dim3(256), 0, stream, (const bf16*)src, (bf16*)dst, (const TransposeEntry*)table);
+  return ia_check_launch();
+}
 
 // table: device array of n_chunks {offset_lo, offset_hi, count (<= 4096, offsets 4-element aligned), decay}.
 extern "C" int ia_adamw_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,

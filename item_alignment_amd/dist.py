@@ -51,6 +51,11 @@ def init_from_env(device_type="cuda"):
         # enough that a dead rank surfaces; IA_DP_TIMEOUT_MIN overrides it
         minutes = float(os.environ.get("IA_DP_TIMEOUT_MIN", "30"))
         dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=minutes))
+        if device_type == "cuda" and os.environ.get("IA_GEMM_DYNAMIC") is None:
+            # a communication stream will hold CUs next to the backward GEMMs from now on: the persistent GEMM launches hand their tiles
+            # out dynamically (a workgroup that cannot start keeps no share of the work hostage; profiles/r05_cu_contention.txt)
+            from . import _lib
+            _lib.load().ia_debug_gemm_dynamic(1)
     return rank, world, local
 
 

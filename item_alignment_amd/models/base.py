@@ -17,6 +17,10 @@ from .._lib import LayerCfg, LayerGrads, LayerWeights
 from . import functional as Fn
 
 ACT_NONE, ACT_TANH = 0, 1
+# transposed bf16 shadows of the encoder layers' 2-D weights (+2 B / parameter of HBM, one batched transpose per optimiser step): the
+# backward's data-gradient GEMMs run in the k-contiguous form; IA_TRANSPOSED_SHADOWS=0 keeps the k-strided form (no extra copy)
+import os as _os
+TRANSPOSED_SHADOWS = _os.environ.get("IA_TRANSPOSED_SHADOWS", "1") != "0"
 
 
 class SequenceClassifierOutput(OrderedDict):
@@ -329,11 +333,16 @@ class _EngineStack:
             for name in ("w_o", "w_fc1", "w_fc2"):
                 setattr(w, name, A.shadow_of(d[name]).data_ptr())
                 setattr(g, name, d[name].grad.data_ptr())
+            if TRANSPOSED_SHADOWS:          # W^T copies for the data-gradient GEMMs (arena.register_transposed)
+                w.wt_qkv = A.register_transposed(qkv_w).data_ptr()
+                for name in ("w_o", "w_fc1", "w_fc2"):
+                    setattr(w, "wt" + name[1:], A.register_transposed(d[name]).data_ptr())
             for name in ("b_o", "ln1_g", "ln1_b", "b_fc1", "b_fc2", "ln2_g", "ln2_b"):
                 setattr(w, name, d[name].data_ptr())
                 setattr(g, name, d[name].grad.data_ptr())
             ws.append(w); gs.append(g)
         self.__dict__["_w"], self.__dict__["_g"] = ws, gs
+        A.refresh_transposed()
 
     def weights(self, i):
         self._build()

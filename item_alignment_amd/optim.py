@@ -100,6 +100,7 @@ class AdamW(torch.optim.Optimizer):
                 if st is not None:
                     st["step"] = torch.tensor(float(group["step_count"]))
         arena.step_count += 1
+        arena.refresh_transposed()
         return loss
 
     def zero_grad(self, set_to_none=True):

@@ -1110,12 +1110,20 @@ def test_gemm_dynamic_tile_claim_under_cu_contention(gpu):
     import time
     from item_alignment_amd import _lib, ops
     lib = _lib.load()
+    prev = lib.ia_debug_gemm_dynamic(0)             # the undisturbed static order first
     M, N, K = 5000, 4096, 512                       # 20 x 16 = 320 tiles (one clipped row of tiles): more than one per workgroup
     a, b = rnd((M, K), gpu, 1.0, 71), rnd((N, K), gpu, 0.05, 72)
     bias = torch.linspace(-1, 1, N, device=gpu)
     ref = a.float() @ b.float().t() + bias
     base = ops.gemm(a, b, epilogue=ops.EPI_BIAS, bias=bias).clone()
     assert rel_err(base, ref) < 2e-2
+    a2, b2 = rnd((4352, 64), gpu, 1.0, 73), rnd((4096, 64), gpu, 0.1, 74)       # 17 x 16 = 272 tiles, one k-tile each
+    first = ops.gemm(a2, b2).clone()
+    w = rnd((K, N), gpu, 0.05, 75)
+    d0 = ops.gemm(a, w, b_kstrided=True).clone()
+    torch.cuda.synchronize()
+    lib.ia_debug_gemm_dynamic(1)
+    assert torch.equal(ops.gemm(a, b, epilogue=ops.EPI_BIAS, bias=bias), base)
     side = torch.cuda.Stream()
     for hog in (8, 24):
         torch.cuda.synchronize()
@@ -1134,8 +1142,6 @@ def test_gemm_dynamic_tile_claim_under_cu_contention(gpu):
     for o in outs:
         assert torch.equal(o, base)
     # slot reuse: more launches than counter slots, the last ones still exact (a slot left non-zero would skip tiles)
-    a2, b2 = rnd((4352, 64), gpu, 1.0, 73), rnd((4096, 64), gpu, 0.1, 74)       # 17 x 16 = 272 tiles, one k-tile each
-    first = ops.gemm(a2, b2).clone()
     out2 = torch.empty_like(first)
     for _ in range(1100):
         ops.gemm(a2, b2, out=out2)
@@ -1143,10 +1149,9 @@ def test_gemm_dynamic_tile_claim_under_cu_contention(gpu):
     assert torch.equal(out2, first)
     assert rel_err(first, a2.float() @ b2.float().t()) < 2e-2
     # the data-gradient and GELU forms go through the same loop
-    w = rnd((K, N), gpu, 0.05, 75)
-    d0 = ops.gemm(a, w, b_kstrided=True).clone()
     _lib.check(lib.ia_debug_cu_hog(16, 10.0, side.cuda_stream), "ia_debug_cu_hog")
     time.sleep(0.003)
     d1 = ops.gemm(a, w, b_kstrided=True)
     torch.cuda.synchronize()
+    lib.ia_debug_gemm_dynamic(prev)
     assert torch.equal(d0, d1) and rel_err(d0, a.float() @ w.float()) < 2e-2

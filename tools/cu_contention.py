@@ -6,8 +6,11 @@ nothing co-resides on their CUs -- is started on a side stream; once it is resid
 and timed with events.  The fair price of k missing CUs is 256 / (256 - k); the static tile order (IA_GEMM_DYNAMIC=0) pays ~2 x for any
 k > 0 (the workgroups that cannot start keep their tiles until a sibling has finished all of its own).
 
-    IA_GEMM_DYNAMIC=0 python tools/cu_contention.py > gpurun_out/cu_contention_static.txt
-    IA_GEMM_DYNAMIC=1 python tools/cu_contention.py > gpurun_out/cu_contention_dynamic.txt
+Both tile orders are measured in ONE process on one box (ia_debug_gemm_dynamic), k = 0 / 8 / 16 / 32 hogged CUs each.  Note on the
+k > 0 columns: the hog sleeps, so the chip's power budget is shared by fewer busy CUs and the GEMM's clock RISES -- a dynamic launch
+beside 8-32 sleeping CUs can come out faster than alone; the comparison that matters is static against dynamic at the same k.
+
+    python tools/cu_contention.py > profiles/r05_cu_contention.txt
 """
 import os
 import sys
@@ -29,8 +32,8 @@ def main():
               ("dgrad   NN x gelu'   ", M, 4096, 1024, 0, 1, ops.EPI_DGELU), ("wgrad   TN split-K   ", 4096, 1024, M, 1, 1, ops.EPI_NONE),
               ("small M NT (16 pairs)", 8160, 4096, 1024, 0, 0, ops.EPI_BIAS)]
     reps = 4
-    print(f"IA_GEMM_DYNAMIC={os.environ.get('IA_GEMM_DYNAMIC', '1 (default)')}; times in us per launch, {reps} launches under one hog")
-    print(f"{'gemm':22s} {'M':>6s} {'N':>5s} {'K':>6s} | " + " | ".join(f"k={k:<3d} (fair x{256 / (256 - k):.3f})" for k in (0, 8, 16, 32)))
+    print(f"times in us per launch ({reps} launches under one 30-ms hog, median of 3); x = against the same order's k = 0; fair price of k CUs = 256 / (256 - k)")
+    print(f"{'gemm':22s} {'M':>6s} {'N':>5s} {'K':>6s} {'order':8s}| " + " | ".join(f"k={k:<3d} (fair x{256 / (256 - k):.3f})" for k in (0, 8, 16, 32)))
     for name, m, n, k_, aks, bks, epi in shapes:
         a = torch.randn((k_, m) if aks else (m, k_), device=dev).to(torch.bfloat16)
         b = (torch.randn((k_, n) if bks else (n, k_), device=dev) * 0.05).to(torch.bfloat16)
@@ -49,26 +52,28 @@ def main():
         for _ in range(5):
             run()
         torch.cuda.synchronize()
-        row = []
-        base = None
-        for hog in (0, 8, 16, 32):
-            best = []
-            for trial in range(3):
-                torch.cuda.synchronize()
-                if hog:
-                    _lib.check(lib.ia_debug_cu_hog(hog, 30.0, side.cuda_stream), "ia_debug_cu_hog")
-                    time.sleep(0.003)                       # the hog is resident before the first GEMM workgroup is dispatched
-                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                s.record()
-                for _ in range(reps):
-                    run()
-                e.record()
-                torch.cuda.synchronize()
-                best.append(s.elapsed_time(e) / reps * 1e3)
-            t = sorted(best)[1]
-            base = t if hog == 0 else base
-            row.append(f"{t:8.1f} (x{t / base:5.3f})   ")
-        print(f"{name:22s} {m:6d} {n:5d} {k_:6d} | " + " | ".join(row))
+        for mode in (0, 1):
+            lib.ia_debug_gemm_dynamic(mode)
+            row = []
+            base = None
+            for hog in (0, 8, 16, 32):
+                best = []
+                for trial in range(3):
+                    torch.cuda.synchronize()
+                    if hog:
+                        _lib.check(lib.ia_debug_cu_hog(hog, 30.0, side.cuda_stream), "ia_debug_cu_hog")
+                        time.sleep(0.003)                       # the hog is resident before the first GEMM workgroup is dispatched
+                    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s.record()
+                    for _ in range(reps):
+                        run()
+                    e.record()
+                    torch.cuda.synchronize()
+                    best.append(s.elapsed_time(e) / reps * 1e3)
+                t = sorted(best)[1]
+                base = t if hog == 0 else base
+                row.append(f"{t:8.1f} (x{t / base:5.3f})   ")
+            print(f"{name:22s} {m:6d} {n:5d} {k_:6d} {'dynamic' if mode else 'static':8s}| " + " | ".join(row))
 
 
 if __name__ == "__main__":
