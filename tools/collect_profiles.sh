@@ -7,13 +7,14 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profiles
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/kt -o b --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pmc --no-variants > $OUT/${TAG}_bench_under_rocprof.json 2> /dev/null
+# (--single-stream: per-kernel times of kernels that run alone; the headline runs the towers on two streams, where concurrent kernels stretch each other)
+rocprofv3 --kernel-trace --stats -d $OUT/kt -o b --output-format csv -- python3 $R/bench.py --single-stream --steps 5 --warmup 2 --no-cpu-baseline --no-pmc --no-variants > $OUT/${TAG}_bench_under_rocprof.json 2> /dev/null
 cp $OUT/kt/b_kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv
 python3 $R/tools/prof_summary.py $OUT/kt/b_kernel_stats.csv 7 40 > $OUT/${TAG}_bench_kernel_stats_summary.txt
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA"; do
   i=$((i+1))
-  rocprofv3 --pmc $set -d $OUT/pmc$i -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pmc --no-variants > /dev/null 2>&1
+  rocprofv3 --pmc $set -d $OUT/pmc$i -o p --output-format csv -- python3 $R/bench.py --single-stream --steps 2 --warmup 1 --no-cpu-baseline --no-pmc --no-variants > /dev/null 2>&1
   python3 $R/tools/pmc_summary.py $(ls $OUT/pmc$i/*counter_collection.csv | head -1) > $OUT/${TAG}_pmc_$i.csv
 done
 mv $OUT/${TAG}_pmc_1.csv $OUT/${TAG}_pmc_fetch_size.csv
@@ -29,7 +30,7 @@ for cfg in c3 c3r; do
   tail -1 $OUT/${TAG}_${cfg}_log.txt | grep -v rocprofv3 >> $OUT/${TAG}_${cfg}_kernel_stats_summary.txt
   rm -rf $OUT/kt_$cfg $OUT/${TAG}_${cfg}_log.txt
 done
-rocprofv3 --kernel-trace --stats -d $OUT/kt_u -o b --output-format csv -- python3 $R/bench.py --unpad --steps 5 --warmup 2 --no-cpu-baseline --no-pmc --no-variants > $OUT/${TAG}_bench_unpad_under_rocprof.json 2> /dev/null
+rocprofv3 --kernel-trace --stats -d $OUT/kt_u -o b --output-format csv -- python3 $R/bench.py --single-stream --unpad --steps 5 --warmup 2 --no-cpu-baseline --no-pmc --no-variants > $OUT/${TAG}_bench_unpad_under_rocprof.json 2> /dev/null
 python3 $R/tools/prof_summary.py $OUT/kt_u/b_kernel_stats.csv 7 30 > $OUT/${TAG}_bench_unpad_kernel_stats_summary.txt
 rm -rf $OUT/kt_u
 ls -la $OUT

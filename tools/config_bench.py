@@ -173,5 +173,6 @@ if __name__ == "__main__":
         PMC = True
         argv.remove("--pmc")
     which = argv or ["c2", "c3", "c4", "c5x"]
+    pairs = os.environ.get("IA_CB_PAIRS")              # pairs per step override (batch-size sweeps: IA_CB_PAIRS=32 ... c3)
     for w in which:
-        globals()[w]()
+        globals()[w](int(pairs)) if pairs else globals()[w]()
