@@ -230,6 +230,16 @@ int ia_conv3x3_padded_fwd(const void* xp, const void* what, const float* bias, v
                           ia_stream_t stream);
 int ia_conv3x3_padded_bwd_data(const void* dyp, const void* what, void* dxp, int B, int H, int W, int Cin, int Cout, int groups,
                                ia_stream_t stream);
+/* (ABI 7) Direct form for groups of 64 -> 64 channels (every 3x3 convolution of the NF-Net stages) and the stem's 16 -> 32 / 32 -> 64:
+ * ia_conv3x3_padded_fwd takes it by itself -- persistent workgroups keep the group's filter bank in LDS and stream 8 x 30-pixel tiles
+ * (input with halo staged once by LDS-DMA, the nine taps as LDS row offsets) instead of nine shifted reads per tile through the
+ * L2 -> LDS path.  The data gradient is the same kernel on dy with the tap-flipped, transposed bank: ia_conv3x3_flip_weights(what ->
+ * what_t [Cin][9 * Cout / groups], the same number of elements), then ia_conv3x3_padded_bwd_data_t.  ia_conv3x3_direct_supported:
+ * 1 when forward AND data gradient of the shape take that path (IA_CONV_DIRECT=0 switches it off). */
+int ia_conv3x3_direct_supported(int Cin, int Cout, int groups);
+int ia_conv3x3_flip_weights(const void* what, void* what_t, int Cin, int Cout, int groups, ia_stream_t stream);
+int ia_conv3x3_padded_bwd_data_t(const void* dyp, const void* what_t, void* dxp, int B, int H, int W, int Cin, int Cout, int groups,
+                                 ia_stream_t stream);
 size_t ia_conv3x3_padded_workspace_bytes(int B, int H, int W, int Cin, int Cout, int groups);
 int ia_conv3x3_padded_bwd_weight(const void* xp, const void* dyp, float* dwhat, float* dbias, int B, int H, int W, int Cin, int Cout,
                                  int groups, void* workspace, size_t workspace_bytes, ia_stream_t stream);

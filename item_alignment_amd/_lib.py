@@ -86,6 +86,9 @@ SIGNATURES = {
     "ia_eca_bwd": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, sz, vp]),
     "ia_conv3x3_padded_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "ia_conv3x3_padded_bwd_data": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "ia_conv3x3_direct_supported": (i32, [i32, i32, i32]),
+    "ia_conv3x3_flip_weights": (i32, [vp, vp, i32, i32, i32, vp]),
+    "ia_conv3x3_padded_bwd_data_t": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "ia_conv3x3_padded_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
     "ia_conv3x3_padded_bwd_weight": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "ia_pad_rows": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),

@@ -643,6 +643,264 @@ extern "C" int ia_eca_bwd(const void* dout, const void* x, const float* conv_w, 
 // k axis of the GEMMs is (tap, channel): tap t reads the tensor itself shifted by (t/3-1)(W+2) + (t%3-1) rows (ia_gemm_view), so
 // the activations are read in place (9 shifted reads served by L2) instead of through a 9x larger gathered matrix, and all
 // channel groups run in one launch.
+
+// ====================================================================================== direct 3x3 convolution (few channels per group)
+// Round 5.  The shifted-view GEMM above fetches every activation row nine times through the L2 -> LDS path and synchronises once per
+// tap; on the 64-channel groups of the NF-Net stages (288 FLOP per HBM byte: not an HBM-bound shape) it ran latency-bound at one DMA
+// round trip per tap and workgroup (0.19 ms for 32 x 200 x 200 x 64 -> 64, 500 TFLOP/s), and on the stem's 16 -> 32 / 32 -> 64
+// convolutions (HBM-bound shapes) at 1.1-1.7 TB/s.  This kernel is the layout-native form for CI -> CO channels per group, CI and CO
+// in {16, 32, 64}:
+//   * persistent workgroups, each bound to ONE channel group: the group's whole filter bank (<= 72 KiB) is fetched into LDS once;
+//   * the work list is (image, 8 x 30 output tile); a tile's input -- 10 x 32 pixels, halo included -- arrives by LDS-DMA as one-KiB
+//     pieces (16-byte chunks XOR-swizzled so that the 16 pixels of an MFMA fragment read conflict-free) into one of two buffers, the
+//     NEXT tile's while the current one is computed: 1.33 x the activation bytes through the DMA path instead of 9 x, one wait + one
+//     barrier per tile instead of nine;
+//   * the nine taps are nine LDS row offsets of the same image: wave w owns output pixels 64 w .. 64 w + 63 of the tile (4 blocks of
+//     16 pixels x CO output channels, MFMA 16x16x32; one k-step = 32 input channels of a tap -- two taps at CI = 16), fragments read
+//     through inline asm one k-step ahead (a plain LDS load behind an LDS-DMA makes hipcc drain vmcnt(0): the DMA would be
+//     serialised with the arithmetic -- measured, the parts added up);
+//   * outputs leave straight from the accumulators: a lane holds CO / 4 consecutive channels of one pixel, the four lanes of a pixel
+//     its whole row; the stores of tile t drain under tile t + 1.
+// The data gradient is the same kernel (<CO, CI>) run on dy with the tap-flipped, transposed filter bank (ia_conv3x3_flip_weights).
+namespace dconv {
+constexpr int TH = 8, TW = 30, TWP = 32, IN_PX = (TH + 2) * TWP, TILE_PX = TH * TW;      // 240 output pixels per tile
+
+struct Args {
+  const bf16* xp; const bf16* w; const float* bias; bf16* yp;
+  int B, H, W, Cin, Cout, groups;
+  int tiles_x, tiles_y;
+  int dbg;                     // IA_CONV_DBG (timing ablations, results wrong): 1 = no stores, 4 = no input DMA after the first tile
+};
+
+template <int CI> IA_DEV int akey(int P) { return CI == 64 ? (P & 7) : CI == 32 ? ((P >> 1) & 3) : 0; }     // swizzle key of input pixel P
+template <int CO> IA_DEV int bkey(int row) { return (row >> (CO == 64 ? 3 : CO == 32 ? 2 : 1)) & 3; }      // of filter row n (64-byte rows)
+// Fragment reads through inline asm, destinations tied to counted lgkmcnt waits (tools/lint_asm_waits.py checks the ISA for uses ahead of them)
+IA_DEV void lds_read128(bf16x8& dst, uint32_t addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr)); }
+template <int N, int NI>
+IA_DEV void wait_frags(bf16x8 (&a)[4], bf16x8 (&b)[NI]) {
+  if constexpr (NI == 4) asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
+  else if constexpr (NI == 2) asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]) : "n"(N));
+  else asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]) : "n"(N));
+}
+
+template <int CI, int CO>
+struct Geo {
+  static constexpr int PB = CI * 2, NC = CI / 8, PPP = 64 / NC;            // bytes / 16-byte chunks per pixel, pixels per DMA piece
+  static constexpr int NS = CI == 64 ? 18 : CI == 32 ? 9 : 5, NI = CO / 16;  // k-steps of 32, output-channel blocks of 16
+  static constexpr int IN_BYTES = IN_PX * PB, W_BYTES = NS * CO * 64, LDS_BYTES = W_BYTES + 2 * IN_BYTES;
+  static constexpr int IN_PIECES = IN_BYTES / 1024, W_PIECES = W_BYTES / 1024;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+template <int CI, int CO>
+__global__ __launch_bounds__(256) void conv3x3_direct_kernel(Args p) {
+  using G = Geo<CI, CO>;
+  constexpr int PB = G::PB, NC = G::NC, PPP = G::PPP, NS = G::NS, NI = G::NI, IN_BYTES = G::IN_BYTES, W_BYTES = G::W_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int grp = blockIdx.x % p.groups, slot = blockIdx.x / p.groups, nslots = gridDim.x / p.groups;
+  const int ntiles = p.B * p.tiles_y * p.tiles_x;
+  if (slot >= ntiles) return;
+  const int PW = p.W + 2, PH = p.H + 2;
+  typedef __attribute__((address_space(3))) char lds_char;
+  lds_char* const lsm = (lds_char*)IA_LDS(smem);
+  const uint32_t sbase = ia_lds_addr(smem);
+
+  // ---- the filter bank of this group: NS k-step tiles [CO n][32 k] with 64-byte rows, chunk position XOR bkey(n).  k-step s holds
+  // tap s / 2, channels 32 (s & 1) .. (CI = 64); tap s (CI = 32); taps 2 s and 2 s + 1 (CI = 16; the tenth tap does not exist: zeros)
+  {
+    const bf16* wg = p.w + (size_t)grp * CO * 9 * CI;
+    const __amdgpu_buffer_rsrc_t rsW = ia_rsrc(wg, (uint32_t)(CO * 9 * CI * 2));
+#pragma unroll 1
+    for (int pc = wave; pc < G::W_PIECES; pc += 4) {          // piece = 16 rows of one k-step tile
+      const int s = pc / (CO / 16), r16 = pc - s * (CO / 16);
+      const int row = r16 * 16 + (lane >> 2);
+      const int chunk = (lane & 3) ^ bkey<CO>(row);
+      int k;
+      bool ok = true;
+      if (CI == 64) k = (s >> 1) * 64 + (s & 1) * 32 + chunk * 8;
+      else if (CI == 32) k = s * 32 + chunk * 8;
+      else { const int tap = 2 * s + (chunk >> 1); k = tap * 16 + (chunk & 1) * 8; ok = tap < 9; }
+      const uint32_t off = ok ? (uint32_t)((row * 9 * CI + k) * 2) : 0xFFFFFFF0u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, lsm + pc * 1024, 16, off, 0, 0, 0);
+    }
+  }
+  // ---- lane constants
+  // A fragments: pixel q = 64 wave + 16 mi + li of the tile (clamped: the last 16 of the 256 fragment rows have no pixel) at
+  // (y, x) = (q / 30, q % 30); LDS pixel of tap (dy, dx): P = (y + dy) * 32 + x + dx, byte P * PB + ((chunk ^ akey(P)) << 4)
+  int a_p0[4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    int q = wave * 64 + mi * 16 + li;
+    q = q < TILE_PX ? q : TILE_PX - 1;
+    const int y = q / TW, x = q - y * TW;
+    a_p0[mi] = y * TWP + x;
+  }
+  // B fragments: row n = (li >> 2) * (CO / 4) + ni * 4 + (li & 3) (lane group g then holds CO / 4 consecutive n over its ni), chunk g
+  int b_off[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int row = (li >> 2) * (CO / 4) + ni * 4 + (li & 3);
+    b_off[ni] = row * 64 + ((g ^ bkey<CO>(row)) << 4);
+  }
+  f32x4 bv[NI];                                            // this lane's bias values, fetched once (a load in the epilogue would drain the stores)
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+    bv[ni] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + grp * CO + g * (CO / 4) + ni * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  // DMA piece of the input: pixel lane / NC of the piece, chunk position lane % NC holds chunk (lane % NC) ^ akey(pixel)
+  const uint32_t lane_in = (uint32_t)(((lane / NC) * p.Cin + (((lane % NC) ^ akey<CI>(lane / NC)) * 8)) * 2);
+  const size_t total_in = (size_t)p.B * PH * PW * p.Cin;       // elements
+
+  auto tile_of = [&](int t, int& b, int& y0, int& x0) {
+    const int tx = t % p.tiles_x, r = t / p.tiles_x;
+    const int ty = r % p.tiles_y;
+    b = r / p.tiles_y; y0 = 1 + ty * TH; x0 = 1 + tx * TW;      // first OUTPUT pixel of the tile, bordered coordinates
+  };
+  // input of tile t -> buffer: rows y0 - 1 .. y0 + 8, pixels x0 - 1 .. x0 + 30 of image b, channels of this group.  The buffer window
+  // starts at the tile's first pixel and ends with the tensor: pieces past the last image read zeros; pixels past a row's end are the
+  // next row's first ones (they only feed output pixels that are never stored).
+  auto stage = [&](int t, int buf) {
+    int b, y0, x0;
+    tile_of(t, b, y0, x0);
+    const size_t org = (((size_t)b * PH + (y0 - 1)) * PW + (x0 - 1)) * p.Cin + (size_t)grp * CI;
+    const size_t rem = (total_in - org) * 2;
+    const __amdgpu_buffer_rsrc_t rs = ia_rsrc(p.xp + org, (uint32_t)(rem < 0x7FFFFFF0ull ? rem : 0x7FFFFFF0ull));
+#pragma unroll
+    for (int i = 0; i < (G::IN_PIECES + 3) / 4; ++i) {
+      const int pc = wave + 4 * i;
+      if (pc < G::IN_PIECES) {
+        const int r = pc / (TWP / PPP), c = pc - r * (TWP / PPP);      // piece c of tile row r
+        const uint32_t soff = (uint32_t)((r * PW + c * PPP) * p.Cin * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lsm + W_BYTES + buf * IN_BYTES + pc * 1024, 16, lane_in, soff, 0, 0);
+      }
+    }
+  };
+
+  stage(slot, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int buf = 0;
+#pragma unroll 1
+  for (int t = slot; t < ntiles; t += nslots, buf ^= 1) {
+    if (t + nslots < ntiles && !(p.dbg & 4)) stage(t + nslots, buf ^ 1);
+    const uint32_t in = sbase + W_BYTES + buf * IN_BYTES;
+    f32x4 acc[4][NI];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // NS k-steps, the fragments of step s + 1 requested before the MFMAs of step s (nothing else covers the LDS latency); LDS returns
+    // in order, so "at most 4 + NI reads outstanding" = step s has arrived
+    bf16x8 af[2][4], bfr[2][NI];
+    auto load = [&](int s, int slot2) {
+      int off, chunk;
+      if (CI == 64) { const int tap = s >> 1; off = (tap / 3) * TWP + tap % 3; chunk = (s & 1) * 4 + g; }
+      else if (CI == 32) { off = (s / 3) * TWP + s % 3; chunk = g; }
+      else {                                                   // two taps per k-step: lane groups 0, 1 the first, 2, 3 the second
+        const int t0 = 2 * s, t1 = 2 * s + 1 < 9 ? 2 * s + 1 : 8;      // (the tenth tap's weights are zeros: any finite data will do)
+        const int o0 = (t0 / 3) * TWP + t0 % 3, o1 = (t1 / 3) * TWP + t1 % 3;
+        off = o0 + (g >> 1) * (o1 - o0); chunk = g & 1;
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int P = a_p0[mi] + off;
+        lds_read128(af[slot2][mi], in + (uint32_t)(P * PB + ((chunk ^ akey<CI>(P)) << 4)));
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) lds_read128(bfr[slot2][ni], sbase + (uint32_t)(s * (CO * 64) + b_off[ni]));
+    };
+    load(0, 0);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      // (no branch may sit between a read and its wait: a merge point makes hipcc copy the fragment registers -- before the data is there)
+      if (s + 1 < NS) { load(s + 1, (s + 1) & 1); wait_frags<4 + NI, NI>(af[s & 1], bfr[s & 1]); }
+      else wait_frags<0, NI>(af[s & 1], bfr[s & 1]);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[s & 1][ni], af[s & 1][mi], acc[mi][ni], 0, 0, 0);
+    }
+    // the next tile's input has landed (and this workgroup's previous stores, issued before it, are done); everybody is through with `in`
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // ---- stores: pixel q -> bordered (y0 + y, x0 + x); a lane's CO / 4 channels g * CO / 4 .. = acc[mi][0 .. NI - 1]
+    int b, y0, x0;
+    tile_of(t, b, y0, x0);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int q = wave * 64 + mi * 16 + li;
+      const int y = q / TW, x = q - y * TW;
+      if (q >= TILE_PX || y0 + y > p.H || x0 + x > p.W || (p.dbg & 1)) continue;
+      bf16* const dst = p.yp + (((size_t)b * PH + (y0 + y)) * PW + (x0 + x)) * p.Cout + (size_t)grp * CO + g * (CO / 4);
+      if constexpr (NI == 1) {
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = f2bf(acc[mi][0][j] + bv[0][j]);
+        *reinterpret_cast<bf16x4*>(dst) = o;
+      } else {
+#pragma unroll
+        for (int h = 0; h < NI / 2; ++h) {
+          bf16x8 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { o[j] = f2bf(acc[mi][2 * h][j] + bv[2 * h][j]); o[4 + j] = f2bf(acc[mi][2 * h + 1][j] + bv[2 * h + 1][j]); }
+          *reinterpret_cast<bf16x8*>(dst + 8 * h) = o;
+        }
+      }
+    }
+  }
+}
+
+// wt[g][ci][(8 - tap) * CO + co] = w[g][co][tap * CI + ci]: the filter bank of the data gradient (a correlation with the flipped taps)
+__global__ __launch_bounds__(256) void flip_weights_kernel(const bf16* __restrict__ w, bf16* __restrict__ wt, int CI, int CO, int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int ci = idx % CI, tap = (idx / CI) % 9, co = (idx / (9 * CI)) % CO, grp = idx / (9 * CI * CO);
+  wt[((size_t)grp * CI + ci) * (9 * CO) + (8 - tap) * CO + co] = w[idx];
+}
+
+static bool enabled() {
+  static const bool on = [] { const char* e = getenv("IA_CONV_DIRECT"); return !e || atoi(e) != 0; }();
+  return on;
+}
+static bool pair_ok(int ci, int co) {
+  return (ci == 64 && co == 64) || (ci == 16 && co == 32) || (ci == 32 && co == 64) || (ci == 64 && co == 32) || (ci == 32 && co == 16);
+}
+template <int CI, int CO>
+static int launch_t(Args a, hipStream_t stream) {
+  using G = Geo<CI, CO>;
+  auto kern = conv3x3_direct_kernel<CI, CO>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) return IA_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const long ntiles = (long)a.B * a.tiles_x * a.tiles_y;
+  const int per_cu = (160 * 1024) / G::LDS_BYTES >= 2 ? 2 : 1;      // (the kernel's ~220 registers allow two workgroups per CU)
+  long per_group = (256L * per_cu) / a.groups;
+  if (per_group > ntiles) per_group = ntiles;
+  if (per_group < 1) per_group = 1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(per_group * a.groups)), dim3(256), G::LDS_BYTES, stream, a);
+  return ia_check_launch();
+}
+// y (bordered) = conv3x3(x bordered) + bias for `groups` groups of ci -> co channels
+static int launch(const void* xp, const void* w, const float* bias, void* yp, int B, int H, int W, int ci, int co, int groups, hipStream_t stream) {
+  Args a;
+  a.xp = (const bf16*)xp; a.w = (const bf16*)w; a.bias = bias; a.yp = (bf16*)yp;
+  a.B = B; a.H = H; a.W = W; a.Cin = groups * ci; a.Cout = groups * co; a.groups = groups;
+  a.tiles_x = (W + TW - 1) / TW; a.tiles_y = (H + TH - 1) / TH;
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("IA_CONV_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
+  if (ci == 64 && co == 64) return launch_t<64, 64>(a, stream);
+  if (ci == 16 && co == 32) return launch_t<16, 32>(a, stream);
+  if (ci == 32 && co == 64) return launch_t<32, 64>(a, stream);
+  if (ci == 64 && co == 32) return launch_t<64, 32>(a, stream);
+  if (ci == 32 && co == 16) return launch_t<32, 16>(a, stream);
+  return IA_ERR_UNSUPPORTED;
+}
+}  // namespace dconv
+
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static int padded_ok(int B, int H, int W, int Cin, int Cout, int groups) {
   if (B <= 0 || H <= 0 || W <= 0 || groups <= 0 || Cin <= 0 || Cout <= 0 || Cin % groups || Cout % groups) return IA_ERR_ARG;
@@ -660,6 +918,7 @@ extern "C" int ia_conv3x3_padded_fwd(const void* xp, const void* what, const flo
   if (!xp || !what || !yp) return IA_ERR_ARG;
   const size_t Mp = (size_t)B * (H + 2) * (W + 2);
   const int ci = Cin / groups, co = Cout / groups;
+  if (dconv::pair_ok(ci, co) && groups <= 64 && dconv::enabled()) return dconv::launch(xp, what, bias, yp, B, H, W, ci, co, groups, stream);
   IaViewGemm v{};
   v.A = xp; v.lda = Cin; v.B = what; v.ldb = 9 * ci; v.C = yp; v.ldc = Cout;
   v.M = (int)Mp; v.N = co; v.K = 9 * ci; v.bias = bias;
@@ -684,6 +943,30 @@ extern "C" int ia_conv3x3_padded_bwd_data(const void* dyp, const void* what, voi
   v.a_window = Mp * Cout * 2; v.b_window = (size_t)Cout * 9 * ci * 2;
   v.groups = groups; v.ga = co; v.gb = (long)co * 9 * ci; v.gc = ci;
   return ia_gemm_view(v, stream);
+}
+
+// Data gradient through the direct kernel (16 -> 32, 32 -> 64 or 64 -> 64 channels per group): what_t [groups * ci][9 * co] = the
+// tap-flipped, transposed filter bank written by ia_conv3x3_flip_weights.  Other shapes: IA_ERR_UNSUPPORTED (ia_conv3x3_padded_bwd_data).
+extern "C" int ia_conv3x3_direct_supported(int Cin, int Cout, int groups) {
+  return groups > 0 && groups <= 64 && Cin % groups == 0 && Cout % groups == 0 && dconv::pair_ok(Cin / groups, Cout / groups) &&
+         dconv::pair_ok(Cout / groups, Cin / groups) && dconv::enabled();
+}
+extern "C" int ia_conv3x3_flip_weights(const void* what, void* what_t, int Cin, int Cout, int groups, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!what || !what_t) return IA_ERR_ARG;
+  if (!ia_conv3x3_direct_supported(Cin, Cout, groups)) return IA_ERR_UNSUPPORTED;
+  const int ci = Cin / groups, co = Cout / groups, total = groups * co * 9 * ci;
+  hipLaunchKernelGGL(dconv::flip_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, (const bf16*)what, (bf16*)what_t, ci, co, total);
+  return ia_check_launch();
+}
+extern "C" int ia_conv3x3_padded_bwd_data_t(const void* dyp, const void* what_t, void* dxp, int B, int H, int W, int Cin, int Cout, int groups,
+                                            hipStream_t stream) {
+  (void)hipGetLastError();
+  const int rc = padded_ok(B, H, W, Cin, Cout, groups);
+  if (rc) return rc;
+  if (!dyp || !what_t || !dxp) return IA_ERR_ARG;
+  if (!ia_conv3x3_direct_supported(Cin, Cout, groups)) return IA_ERR_UNSUPPORTED;
+  return dconv::launch(dyp, what_t, nullptr, dxp, B, H, W, Cout / groups, Cin / groups, groups, stream);
 }
 
 extern "C" size_t ia_conv3x3_padded_workspace_bytes(int B, int H, int W, int Cin, int Cout, int groups) {

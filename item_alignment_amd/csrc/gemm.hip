@@ -275,6 +275,9 @@ IA_DEV void tile_of_index(const GemmArgs& p, int bid, int nwg, int& bm, int& bn)
 // ============================================================================== T128 (4 waves, 16x16x32)
 namespace t128 {
 constexpr int BM = 128, BN = 128, TILE_BYTES = 16384;
+// "row3" form of a shifted-view convolution GEMM (below): two 136-row A images + two B tiles; else two (A, B) k-tile pairs
+constexpr int A3_ROWS = 136, A3_BYTES = A3_ROWS * 128, SMEM_BYTES = 2 * A3_BYTES + 2 * TILE_BYTES;
+static_assert(SMEM_BYTES >= 4 * TILE_BYTES && 2 * SMEM_BYTES <= 160 * 1024, "two workgroups per CU");
 
 // 32-byte-slot swizzle of a k-strided tile row (row = k index within the 64-row tile, 256 B rows)
 IA_DEV int ks_swz(int k) { return ((k & 3) | (((k >> 3) & 1) << 2)) << 1; }
@@ -322,7 +325,7 @@ IA_DEV bf16x8 frag_ks(const char* s, int k, int col) {
 
 template <bool AKS, bool BKS, int EPI, bool OUTF32>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+  __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -367,22 +370,98 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   const __amdgpu_buffer_rsrc_t rsA = rsrc_at(p.A, p.a_bytes, (uint64_t)a_org * p.lda);
   const __amdgpu_buffer_rsrc_t rsB = rsrc_at(p.B, p.b_bytes, (uint64_t)b_org * p.ldb);
   const int xa = AKS ? m0 : m0 - a_org, xb = BKS ? n0 : 0;
-  stage_tile<AKS>(rsA, smem, kt0, xa, p.lda, p.K, tid, wave, a_org, p.a_view, p.pw, p.lca, 0);
-  stage_tile<BKS>(rsB, smem + TILE_BYTES, kt0, xb, p.ldb, p.K, tid, wave, b_org, p.b_view, p.pw, p.lcbk, p.lcbn);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  // ---- "row3": a 3x3 shifted-view convolution whose taps are whole k-tiles (64 channels per group: k-tile t = tap t) reads the SAME
+  // 128 rows nine times, shifted by (dy, dx) rows.  The L2 -> LDS path is what bounds this kernel on those shapes (9 x the activation
+  // bytes at the ~6.4 TB/s the chip's LDS-DMA engines sustain: 0.19 ms for 32 images x 200 x 200 x 64, measured), so the three taps of
+  // one dy share ONE image of rows m0-1 .. m0+128 (136 rows fetched) and differ only in the LDS row their fragments start at: 3.2 x
+  // the bytes instead of 9 x.  Forward and data gradient (a_view = +-1, k-contiguous A, N <= 64); the weight tiles stay per tap.
+  const bool row3 = !AKS && p.a_view != 0 && p.lca == 6 && p.K == 9 * BK && p.splits == 1 && p.N <= 64;
+  if (!row3) {
+    stage_tile<AKS>(rsA, smem, kt0, xa, p.lda, p.K, tid, wave, a_org, p.a_view, p.pw, p.lca, 0);
+    stage_tile<BKS>(rsB, smem + TILE_BYTES, kt0, xb, p.ldb, p.K, tid, wave, b_org, p.b_view, p.pw, p.lcbk, p.lcbn);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
 
   const int g = lane >> 4, li = lane & 15;
-  // a wave whose 64 x 64 quadrant lies entirely outside C (M or N <= 64: conv groups, heads) only helps with the staging
-  const bool quadrant_live = m0 + wm * 64 < p.M && n0 + wn * 64 < p.N;
+  // A wave whose 64 x 64 quadrant lies entirely outside C (M or N <= 64: the 64-channel groups of the convolutions -- forward and data
+  // gradient have N = 64, the weight gradient M = 64 --, attention heads) would only help with the staging.  Round 5: such a wave
+  // JOINS the live quadrant beside it and takes the second k-step of every k-tile (the quadrant's owner keeps the first); the pair adds
+  // its accumulators up through LDS behind the loop.  The 64-wide shapes are MFMA-bound in this kernel (a 3x3 convolution over 64
+  // channels has 288 FLOP per HBM byte), so halving each live wave's MFMA chain is worth up to 2 x there.
+  const bool m_narrow = p.M - m0 <= 64, n_narrow = p.N - n0 <= 64;           // uniform per workgroup
+  const bool ksplit = m_narrow || n_narrow;
+  int qm = wm, qn = wn, my_ks = 0;
+  bool helper_idle = false;
+  if (n_narrow && !m_narrow) { qn = 0; my_ks = wn; }
+  else if (m_narrow && !n_narrow) { qm = 0; my_ks = wm; }
+  else if (m_narrow && n_narrow) { qm = 0; qn = 0; my_ks = wave & 1; helper_idle = wave >= 2; }
+  const bool quadrant_live = !helper_idle && m0 + qm * 64 < p.M && n0 + qn * 64 < p.N;
   constexpr bool WGRAD = AKS && BKS && OUTF32 && EPI == EPI_NONE;
-  const bool row_sums = WGRAD && p.rsum_out != nullptr && bn == 0 && wn == 0;      // uniform per wave
+  const bool row_sums = WGRAD && p.rsum_out != nullptr && bn == 0 && qn == 0;      // uniform per wave
   f32x4 racc[4];
   bf16x8 ones;
 #pragma unroll
   for (int i = 0; i < 4; ++i) racc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < 8; ++i) ones[i] = f2bf(1.0f);
+  if (row3) {
+    char* const A3 = smem;
+    char* const B2 = smem + 2 * A3_BYTES;
+    // LDS row j of image gy <- tensor row m0 + j - 1 + a_view (gy - 1) pw (rows before the tensor wrap out of range: zeros), chunk
+    // position XOR (j & 7) as frag_kc reads it; 4 issues of 32 rows by all waves + 8 rows by wave 0
+    auto stage_a3 = [&](int gy, int b3) {
+      char* const s3 = A3 + b3 * A3_BYTES;
+      const int shift = p.a_view * (gy - 1) * p.pw - 1;
+#pragma unroll
+      for (int issue = 0; issue < 4; ++issue) {
+        const int j = issue * 32 + (tid >> 3);
+        const uint32_t off = (uint32_t)(((xa + j + shift) * p.lda + (((tid & 7) ^ (j & 7)) * 8)) * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, IA_LDS(s3 + issue * 4096 + wave * 1024), 16, off, 0, 0, 0);
+      }
+      if (wave == 0) {
+        const int j = 128 + (lane >> 3);
+        const uint32_t off = (uint32_t)(((xa + j + shift) * p.lda + (((lane & 7) ^ (j & 7)) * 8)) * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, IA_LDS(s3 + 16384), 16, off, 0, 0, 0);
+      }
+    };
+    stage_a3(0, 0);
+    stage_tile<BKS>(rsB, B2, 0, xb, p.ldb, p.K, tid, wave, b_org, p.b_view, p.pw, p.lcbk, p.lcbn);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < 9; ++kt) {
+      const int gy = kt / 3, dxi = kt - 3 * gy, bb = kt & 1;
+      if (kt + 1 < 9) stage_tile<BKS>(rsB, B2 + (bb ^ 1) * TILE_BYTES, kt + 1, xb, p.ldb, p.K, tid, wave, b_org, p.b_view, p.pw, p.lcbk, p.lcbn);
+      if (dxi == 0 && gy < 2) stage_a3(gy + 1, (gy + 1) & 1);
+      const char* sA = A3 + (gy & 1) * A3_BYTES;
+      const char* sB = B2 + bb * TILE_BYTES;
+      const int rowoff = 1 + p.a_view * (dxi - 1);
+      if (quadrant_live)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if (ksplit && ks != my_ks) continue;
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) af[mi] = frag_kc(sA, qm * 64 + mi * 16 + li + rowoff, ks * 4 + g);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          if (!BKS) bfr[ni] = frag_kc(sB, qn * 64 + (li >> 2) * 16 + ni * 4 + (li & 3), ks * 4 + g);
+          else      bfr[ni] = frag_ks(sB, ks * 32 + g * 8 + (li >> 2), qn * 64 + ni * 16 + (li & 3) * 4);
+        }
+        if (BKS) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else
   for (int kt = kt0; kt < nk; ++kt) {
     const int buf = (kt - kt0) & 1;
     if (kt + 1 < nk) {
@@ -395,18 +474,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     if (quadrant_live)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
+      if (ksplit && ks != my_ks) continue;
       bf16x8 af[4], bfr[4];
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
-        if (!AKS) af[mi] = frag_kc(sA, wm * 64 + mi * 16 + li, ks * 4 + g);
-        else      af[mi] = frag_ks(sA, ks * 32 + g * 8 + (li >> 2), wm * 64 + mi * 16 + (li & 3) * 4);
+        if (!AKS) af[mi] = frag_kc(sA, qm * 64 + mi * 16 + li, ks * 4 + g);
+        else      af[mi] = frag_ks(sA, ks * 32 + g * 8 + (li >> 2), qm * 64 + mi * 16 + (li & 3) * 4);
       }
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
         // k-contiguous B: fragment row i <-> n = (i>>2)*16 + ni*4 + (i&3), so lane group g ends up
         // holding 16 consecutive n; k-strided B: plain n = ni*16 + i (conflict-free transpose read).
-        if (!BKS) bfr[ni] = frag_kc(sB, wn * 64 + (li >> 2) * 16 + ni * 4 + (li & 3), ks * 4 + g);
-        else      bfr[ni] = frag_ks(sB, ks * 32 + g * 8 + (li >> 2), wn * 64 + ni * 16 + (li & 3) * 4);
+        if (!BKS) bfr[ni] = frag_kc(sB, qn * 64 + (li >> 2) * 16 + ni * 4 + (li & 3), ks * 4 + g);
+        else      bfr[ni] = frag_ks(sB, ks * 32 + g * 8 + (li >> 2), qn * 64 + ni * 16 + (li & 3) * 4);
       }
       if (AKS || BKS) {   // the transpose reads are asm (common.h): order the MFMAs behind their data
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -425,13 +505,35 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     __syncthreads();
   }
 
+  if (ksplit) {
+    // the helper (k-step 1) hands its sums to the quadrant's owner: 20 x 16-byte columns per lane, lane-major inside a column so
+    // that both sides move whole 1-KiB lines; the k-tile buffers are free behind the loop's last barrier
+    float* const xch = reinterpret_cast<float*>(smem) + (size_t)(qm * 2 + qn) * (20 * 64 * 4);
+    if (quadrant_live && my_ks == 1) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) *reinterpret_cast<f32x4*>(xch + ((mi * 4 + ni) * 64 + lane) * 4) = acc[mi][ni];
+        *reinterpret_cast<f32x4*>(xch + ((16 + mi) * 64 + lane) * 4) = racc[mi];
+      }
+    }
+    __syncthreads();
+    if (!quadrant_live || my_ks == 1) return;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] += *reinterpret_cast<const f32x4*>(xch + ((mi * 4 + ni) * 64 + lane) * 4);
+      racc[mi] += *reinterpret_cast<const f32x4*>(xch + ((16 + mi) * 64 + lane) * 4);
+    }
+  }
+
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
-    const int m = m0 + wm * 64 + mi * 16 + li;
+    const int m = m0 + qm * 64 + mi * 16 + li;
     if (m >= p.M) continue;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
-      const int n = n0 + wn * 64 + (BKS ? ni * 16 + g * 4 : g * 16 + ni * 4);
+      const int n = n0 + qn * 64 + (BKS ? ni * 16 + g * 4 : g * 16 + ni * 4);
       if (n >= p.N) continue;
       epi_store4<EPI, OUTF32>(p, m, n, acc[mi][ni]);
     }
@@ -439,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   if (WGRAD && row_sums && g == 0) {
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
-      const int m = m0 + wm * 64 + mi * 16 + li;
+      const int m = m0 + qm * 64 + mi * 16 + li;
       if (m >= p.M) continue;
       if (p.splits > 1) p.rsum_ws[((size_t)grp * p.splits + p.split_id) * p.M + m] = racc[mi][0];
       else p.rsum_out[(size_t)grp * p.M + m] += racc[mi][0];

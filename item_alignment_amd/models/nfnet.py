@@ -141,8 +141,15 @@ class PaddedStdConvFn(torch.autograd.Function):
         dxp = None
         if ctx.need_dx:
             dxp = torch.empty_like(xp)
-            check(lib.ia_conv3x3_padded_bwd_data(dyp.data_ptr(), what.data_ptr(), dxp.data_ptr(), B, H, W, Cin, Cout, g, stream_ptr()),
-                  "ia_conv3x3_padded_bwd_data")
+            if lib.ia_conv3x3_direct_supported(Cin, Cout, g):
+                # the direct kernel on dy with the tap-flipped, transposed filter bank [Cin][9 * Cout / groups] (as many elements as `what`)
+                what_t = torch.empty((Cin, 9 * (Cout // g)), device=dev, dtype=BF16)
+                check(lib.ia_conv3x3_flip_weights(what.data_ptr(), what_t.data_ptr(), Cin, Cout, g, stream_ptr()), "ia_conv3x3_flip_weights")
+                check(lib.ia_conv3x3_padded_bwd_data_t(dyp.data_ptr(), what_t.data_ptr(), dxp.data_ptr(), B, H, W, Cin, Cout, g, stream_ptr()),
+                      "ia_conv3x3_padded_bwd_data_t")
+            else:
+                check(lib.ia_conv3x3_padded_bwd_data(dyp.data_ptr(), what.data_ptr(), dxp.data_ptr(), B, H, W, Cin, Cout, g, stream_ptr()),
+                      "ia_conv3x3_padded_bwd_data")
         if conv.weight.requires_grad:
             dwhat = torch.empty((Cout, 9 * ci), device=dev, dtype=F32)
             bg = conv.bias.grad.data_ptr() if conv.bias is not None and conv.bias.requires_grad else None

@@ -595,6 +595,49 @@ def test_conv3x3_padded_domain(gpu, B, H, W, Cin, Cout, groups):
     assert rel_err(dbias, br.grad) < 2e-3
 
 
+@pytest.mark.parametrize("B,H,W,groups,ci,co", [(3, 37, 41, 1, 64, 64), (2, 25, 25, 6, 64, 64), (1, 8, 30, 2, 64, 64), (2, 9, 31, 1, 64, 64),
+                                                (1, 200, 200, 1, 64, 64), (5, 50, 50, 3, 64, 64), (40, 7, 5, 2, 64, 64),
+                                                (2, 61, 45, 1, 16, 32), (2, 33, 64, 1, 32, 64), (1, 400, 400, 1, 16, 32), (3, 17, 9, 2, 32, 64)])
+def test_conv3x3_direct_few_channel_groups(gpu, B, H, W, groups, ci, co):
+    """The direct 3x3 convolution for groups of 64 -> 64 channels (NF-Net stages) and the stem's 16 -> 32 / 32 -> 64 (conv.hip, dconv:
+    filter bank resident in LDS, 8 x 30-pixel tiles with their halo staged once, taps as LDS row offsets; reference
+    src/models/image.py:253-257 -> timm NormFreeBlock.conv2 / conv2b, create_stem) against torch conv2d in fp32 on the same bf16
+    inputs, forward and data gradient (the same kernel <co, ci> on dy with the flipped, transposed bank); tile edges (H, W not
+    multiples of 8 / 30, fewer tiles than workgroups, more), the output border left untouched, and the shifted-view GEMM it
+    replaces within bf16 of it."""
+    from item_alignment_amd import _lib
+    from item_alignment_amd.ops import check, stream_ptr
+    lib = _lib.load()
+    Cin, Cout = groups * ci, groups * co
+    assert lib.ia_conv3x3_direct_supported(Cin, Cout, groups) == 1
+    assert lib.ia_conv3x3_direct_supported(groups * 128, groups * 128, groups) == 0
+    x = rnd((B, H, W, Cin), gpu, 1.0, 21)
+    w = rnd((Cout, ci, 3, 3), gpu, 0.05, 22)
+    bias = torch.randn(Cout, device=gpu)
+    dy = rnd((B, H, W, Cout), gpu, 1.0, 23)
+    what = w.permute(0, 2, 3, 1).reshape(Cout, 9 * ci).contiguous()
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    ref = torch.nn.functional.conv2d(xr, w.float(), bias, padding=1, groups=groups)
+    ref.backward(dy.float().permute(0, 3, 1, 2))
+    xp, dyp = _pad_nhwc(x), _pad_nhwc(dy)
+    yp = torch.full_like(dyp, float("nan"))
+    check(lib.ia_conv3x3_padded_fwd(xp.data_ptr(), what.data_ptr(), bias.data_ptr(), yp.data_ptr(), B, H, W, Cin, Cout, groups, stream_ptr()), "fwd")
+    got = yp[:, 1:-1, 1:-1]
+    assert torch.isfinite(got).all()
+    assert rel_err(got, ref.permute(0, 2, 3, 1)) < 2e-2
+    assert torch.isnan(yp[:, 0]).all() and torch.isnan(yp[:, :, 0]).all() and torch.isnan(yp[:, -1]).all() and torch.isnan(yp[:, :, -1]).all()   # border untouched
+    what_t = torch.empty((Cin, 9 * co), device=gpu, dtype=torch.bfloat16)
+    check(lib.ia_conv3x3_flip_weights(what.data_ptr(), what_t.data_ptr(), Cin, Cout, groups, stream_ptr()), "flip")
+    want_t = w.view(groups, co, ci, 3, 3).flip(3, 4).permute(0, 2, 3, 4, 1).reshape(Cin, 9 * co)       # [g][ci][tap'][co]
+    assert torch.equal(what_t, want_t.contiguous())
+    dxp = torch.full_like(xp, float("nan"))
+    check(lib.ia_conv3x3_padded_bwd_data_t(dyp.data_ptr(), what_t.data_ptr(), dxp.data_ptr(), B, H, W, Cin, Cout, groups, stream_ptr()), "bwd_data_t")
+    assert rel_err(dxp[:, 1:-1, 1:-1], xr.grad.permute(0, 2, 3, 1)) < 2e-2
+    dx2 = torch.empty_like(xp)
+    check(lib.ia_conv3x3_padded_bwd_data(dyp.data_ptr(), what.data_ptr(), dx2.data_ptr(), B, H, W, Cin, Cout, groups, stream_ptr()), "bwd_data")
+    assert rel_err(dxp[:, 1:-1, 1:-1], dx2[:, 1:-1, 1:-1]) < 1e-2
+
+
 def test_silu_between_padded_and_compact_layouts(gpu):
     from item_alignment_amd import _lib
     from item_alignment_amd.ops import check, stream_ptr
