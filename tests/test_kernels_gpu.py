@@ -636,6 +636,23 @@ def test_conv3x3_direct_few_channel_groups(gpu, B, H, W, groups, ci, co):
     dx2 = torch.empty_like(xp)
     check(lib.ia_conv3x3_padded_bwd_data(dyp.data_ptr(), what.data_ptr(), dx2.data_ptr(), B, H, W, Cin, Cout, groups, stream_ptr()), "bwd_data")
     assert rel_err(dxp[:, 1:-1, 1:-1], dx2[:, 1:-1, 1:-1]) < 1e-2
+    # weight + bias gradient: the direct kernel (dy and x tiles in LDS, transposed fragment reads, per-workgroup fp32 banks folded in
+    # fixed order), twice -- bit-identical -- and against autograd
+    wr = w.float().requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), wr, br, padding=1, groups=groups).backward(dy.float().permute(0, 3, 1, 2))
+    wsb = lib.ia_conv3x3_padded_workspace_bytes(B, H, W, Cin, Cout, groups)
+    ws = torch.empty(max(wsb, 16), device=gpu, dtype=torch.uint8)
+    outs = []
+    for _ in range(2):
+        dwhat = torch.full((Cout, 9 * ci), float("nan"), device=gpu, dtype=torch.float32)
+        dbias = torch.full((Cout,), 0.25, device=gpu)
+        check(lib.ia_conv3x3_padded_bwd_weight(xp.data_ptr(), dyp.data_ptr(), dwhat.data_ptr(), dbias.data_ptr(), B, H, W, Cin, Cout, groups,
+                                               ws.data_ptr(), wsb, stream_ptr()), "bwd_weight")
+        outs.append((dwhat, dbias))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert rel_err(outs[0][0].view(Cout, 3, 3, ci).permute(0, 3, 1, 2), wr.grad) < 2e-3
+    assert rel_err(outs[0][1] - 0.25, br.grad) < 2e-3
 
 
 def test_silu_between_padded_and_compact_layouts(gpu):
