@@ -95,8 +95,10 @@ def pmc_traffic(args):
                 if "gemm_kernel<true, true, 0, true>" in r["Kernel_Name"] and r["Counter_Name"] == counter:
                     tot += float(r["Counter_Value"]); n += 1
             if n == 0:
-                tail = open(os.path.join(out, "child.err"), "rb").read()[-300:].decode("utf-8", "replace").replace("\n", " | ")
-                return None, f"{counter} pass exited with {rc}, kernel not in the trace: {tail}"
+                # the child's own last words sit in front of the profiler's closing lines
+                lines = [ln for ln in open(os.path.join(out, "child.err"), "rb").read().decode("utf-8", "replace").splitlines()
+                         if "rocprofv3" not in ln and "rocprofiler" not in ln and ln.strip()]
+                return None, f"{counter} pass exited with {rc}, kernel not in the trace: " + " | ".join(lines[-6:])[-900:]
             kb[counter] = tot / n
         except Exception as e:
             return None, f"{counter} pass failed: {e!r}"
@@ -462,8 +464,14 @@ def main():
         if world == 1 and not args.no_pmc:
             # free this process's HBM first: the child runs build their own model and batches
             del batches
+            import gc
+            gc.collect()
+            torch.cuda.synchronize()
             torch.cuda.empty_cache()
+            held = torch.cuda.memory_reserved() / 2 ** 30
             traffic, note = pmc_traffic(args)
+            if traffic is None:
+                note += f" (this process still held {held:.1f} GiB of HBM while the pass ran)"
             res["roofline"]["traffic"] = traffic
             res["roofline"]["traffic_source"] = note
             if traffic:

@@ -92,18 +92,25 @@ def test_c4_pkgm_large_full_entity_table(gpu):
         assert want[rows].abs().max().item() < 0.02 * rsd[rel_key].grad.abs().max().item(), want[rows].abs().max().item()
     else:
         assert (got[rows] - want[rows]).abs().max().item() <= TOL * want[rows].abs().max().item() + 1e-6
-    for k in (rel_key, next(k for k in sd if k.endswith("proj_mat.weight"))):
-        g_, w_ = dict(model.named_parameters())[k].grad, rsd[k].grad
+    # 24 bf16 layers between these tables and the loss, a batch of 2.  The bar is set by a measurement that does not involve the engine
+    # (advisor, round 4): the same oracle under bf16 storage rounding (oracle.ref_models.rounding) is one more draw of the rounding noise
+    # this depth carries; the HIP gradient has to stay within 1.6 x of that draw's distance from fp32 (floor: the common 0.10 bar), and
+    # inside the absolute caps that were in force before (0.19 Frobenius / 0.22 max-norm).
+    table_keys = (rel_key, next(k for k in sd if k.endswith("proj_mat.weight")))
+    bsd = {k: (v.detach().clone().requires_grad_(True) if k in table_keys else v.detach()) for k, v in sd.items()}
+    with O.rounding(torch.bfloat16):
+        O.pkgm_one_tower(bsd, cfg, *t, labels=labels, training=False).loss.backward()
+    for k in table_keys:
+        g_, w_, b_ = dict(model.named_parameters())[k].grad, rsd[k].grad, bsd[k].grad
         fro = ((g_.float().cpu() - w_.float()).norm() / w_.float().norm()).item()
+        noise_fro, noise_rel = ((b_.float() - w_.float()).norm() / w_.float().norm()).item(), rel(b_, w_)
         os.makedirs("gpurun_out", exist_ok=True)
         with open("gpurun_out/c4_table_gradients.txt", "a") as f:
-            f.write(f"{k}: cosine {cosine(g_, w_):.5f} max-norm rel {rel(g_, w_):.4f} frobenius rel {fro:.4f}\n")
+            f.write(f"{k}: cosine {cosine(g_, w_):.5f} max-norm rel {rel(g_, w_):.4f} frobenius rel {fro:.4f} | bf16-rounding oracle vs fp32: "
+                    f"max-norm rel {noise_rel:.4f} frobenius rel {noise_fro:.4f}\n")
         assert cosine(g_, w_) > 0.98, (k, cosine(g_, w_))
-        # 24 bf16 layers between these tables and the loss, a batch of 2.  The max-norm figure is one extreme element and moves with
-        # every change of a rounding point upstream (rel_emb: 0.127 with q scaled inside the attention kernels, 0.174 with q scaled in
-        # the QKV epilogue; 0.06 with 2 layers in round 3); the Frobenius figure is the stable one.
-        assert fro < 0.19, (k, fro)                      # measured 0.140 / 0.159 in the same two configurations
-        assert rel(g_, w_) < 0.22, (k, rel(g_, w_))
+        assert fro < min(0.19, max(0.10, 1.6 * noise_fro)), (k, fro, noise_fro)
+        assert rel(g_, w_) < min(0.22, max(0.10, 1.6 * noise_rel)), (k, rel(g_, w_), noise_rel)
 
 
 def test_c3_eca_nfnet_l0_at_800(gpu):
@@ -210,11 +217,22 @@ def test_c5_full_width_coca_pair(gpu):
     # the same effect over its 255 query rows (layer 0: 0.017).  DESIGN.md 5 records it as a deviation of bf16 context storage.
     # Being noise, the figure moves with any change of a rounding point upstream: 0.9740 / 0.274 since the QKV projection rounds
     # q * scale * log2 e once (IA_Q_PRESCALE=1) instead of q and then q * sc inside the kernels (0.9858 / 0.268).
-    loose = {key("layer.23.", "self.query.weight"): (0.96, 0.32)}
+    # Round 5 -- the exception is MEASURED here, not only argued: the same oracle under bf16 storage rounding with delta taken the
+    # flash way (rowsum(dO o O_rounded), oracle.ref_models.rounding(bf16, flash_delta=True)) moves this one tensor by the same order
+    # (tools/c5_delta_probe.py, profiles/r05_c5_delta_probe.txt: fp32 vs bf16 0.029, fp32 vs bf16 + flash delta 0.212, HIP vs fp32
+    # 0.275 -- two draws of one noise).  The HIP gradient has to stay within 1.6 x of what that restatement of the arithmetic does to
+    # the tensor (and inside the absolute bound that has been in force since round 4); every other tensor keeps the common bar.
+    kq = key("layer.23.", "self.query.weight")
+    fsd = {k: (v.detach().clone().requires_grad_(True) if k == kq else v.detach()) for k, v in sd.items()}
+    with O.rounding(torch.bfloat16, flash_delta=True):
+        O.coca_item_alignment(fsd, cfg, vcfg, *bc[:10], labels=bc[10], training=False).loss.backward()
+    flash_rel, flash_cos = rel(fsd[kq].grad, rsd[kq].grad), cosine(fsd[kq].grad, rsd[kq].grad)
+    print("layer-23 query.weight, bf16 oracle with flash-style delta against fp32 (cosine, rel):", flash_cos, flash_rel)
+    loose = {kq: (min(0.99, max(0.96, 1.0 - 3.0 * (1.0 - flash_cos))), max(0.10, min(0.32, 1.6 * flash_rel)))}
     for k, (c, r) in report.items():
         cmin, rmax = loose.get(k, (0.99, 0.10))
-        assert c >= cmin, (k, c, r)
-        assert r <= rmax, (k, c, r)
+        assert c >= cmin, (k, c, r, loose.get(k))
+        assert r <= rmax, (k, c, r, loose.get(k))
     # every parameter of both towers received a finite gradient (a poisoned row anywhere in the backward would be non-finite here)
     for k, v in params.items():
         if v.grad is not None:

@@ -34,8 +34,19 @@ for (H, Cin, Cout, groups, what_) in ((400, 16, 32, 1, "stem conv2"), (400, 32, 
     wsb = lib.ia_conv3x3_padded_workspace_bytes(N, H, W, Cin, Cout, groups)
     ws = torch.empty(max(wsb, 16), device=dev, dtype=torch.uint8)
     s = stream_ptr()
+    direct = bool(lib.ia_conv3x3_direct_supported(Cin, Cout, groups))     # the data gradient = the direct kernel on the flipped bank (co <-> ci)
+    what_t = torch.empty((Cin, 9 * (Cout // groups)), device=dev, dtype=torch.bfloat16)
+    if direct:
+        check(lib.ia_conv3x3_flip_weights(what.data_ptr(), what_t.data_ptr(), Cin, Cout, groups, s), "flip")
+
+    def dgrad():
+        if direct:      # as models/nfnet.py: flip (a few us, part of the timed call) + direct kernel
+            check(lib.ia_conv3x3_flip_weights(what.data_ptr(), what_t.data_ptr(), Cin, Cout, groups, s), "flip")
+            check(lib.ia_conv3x3_padded_bwd_data_t(dyp.data_ptr(), what_t.data_ptr(), dxp.data_ptr(), N, H, W, Cin, Cout, groups, s), "dt")
+        else:
+            check(lib.ia_conv3x3_padded_bwd_data(dyp.data_ptr(), what.data_ptr(), dxp.data_ptr(), N, H, W, Cin, Cout, groups, s), "d")
     t = [timed(lambda: check(lib.ia_conv3x3_padded_fwd(xp.data_ptr(), what.data_ptr(), None, yp.data_ptr(), N, H, W, Cin, Cout, groups, s), "f")),
-         timed(lambda: check(lib.ia_conv3x3_padded_bwd_data(dyp.data_ptr(), what.data_ptr(), dxp.data_ptr(), N, H, W, Cin, Cout, groups, s), "d")),
+         timed(dgrad),
          timed(lambda: check(lib.ia_conv3x3_padded_bwd_weight(xp.data_ptr(), dyp.data_ptr(), dwhat.data_ptr(), None, N, H, W, Cin, Cout, groups, ws.data_ptr(), wsb, s), "w"))]
     gb = Mp * (Cin + Cout) * 2 / 1e9
     flops = 2.0 * N * H * W * Cout * 9 * ci
