@@ -60,9 +60,13 @@ class AdamW(torch.optim.Optimizer):
             raise ValueError("optimizer got an empty parameter list")
         self.arena = arena
         offset_of = {id(p): o for p, o in zip(arena.params, arena.offsets)}
-        tables = []
+        tables, step_tensors = [], []
         for group in self.param_groups:
             chunks = []
+            # torch keeps a `step` tensor per parameter; all parameters of a group step together, so they share ONE tensor per group
+            # that step() updates in place (no per-parameter host work in the loop)
+            step_t = torch.full((), float(group.get("step_count", 0)), dtype=torch.float32)
+            step_tensors.append(step_t)
             for p in group["params"]:
                 if not p.requires_grad:
                     continue
@@ -70,11 +74,11 @@ class AdamW(torch.optim.Optimizer):
                 for c in range(0, n, CHUNK):
                     chunks.append(((o + c) & 0xFFFFFFFF, (o + c) >> 32, min(CHUNK, n - c), 1))
                 # torch's per-parameter state, as views of the arenas (never re-allocated: the kernel writes them in place)
-                self.state[p] = {"step": torch.zeros((), dtype=torch.float32),
+                self.state[p] = {"step": step_t,
                                  "exp_avg": arena.exp_avg[o:o + n].view(p.shape), "exp_avg_sq": arena.exp_avg_sq[o:o + n].view(p.shape)}
             table = torch.from_numpy(np.asarray(chunks, dtype=np.uint32).reshape(-1, 4)).to(arena.device) if chunks else None
             tables.append((table, len(chunks)))
-        self._tables = tables
+        self._tables, self._step_tensors = tables, step_tensors
         arena.optimizer_bound = True
         return True
 
@@ -87,7 +91,7 @@ class AdamW(torch.optim.Optimizer):
         self._bind()
         arena, lib = self.arena, _lib.load()
         arena.join_side_streams()
-        for group, (table, n) in zip(self.param_groups, self._tables):
+        for group, (table, n), step_t in zip(self.param_groups, self._tables, self._step_tensors):
             if n == 0:
                 continue
             group["step_count"] += 1
@@ -95,13 +99,17 @@ class AdamW(torch.optim.Optimizer):
             check(lib.ia_adamw_flat(arena.master.data_ptr(), arena.grad.data_ptr(), arena.exp_avg.data_ptr(), arena.exp_avg_sq.data_ptr(),
                                     arena.shadow.data_ptr(), table.data_ptr(), n, float(group["lr"]), b1, b2, group["eps"],
                                     group["weight_decay"], group["step_count"], float(self.grad_scale), stream_ptr()), "ia_adamw_flat")
-            for p in group["params"]:
-                st = self.state.get(p)
-                if st is not None:
-                    st["step"] = torch.tensor(float(group["step_count"]))
+            step_t.fill_(float(group["step_count"]))
         arena.step_count += 1
         arena.refresh_transposed()
         return loss
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        self.param_groups[-1].setdefault("step_count", 0)
+        if getattr(self, "_tables", None) is not None:          # bound already: rebuild the slice tables (the moments are arena views, nothing is lost)
+            self._tables = None
+            self._bind()
 
     def zero_grad(self, set_to_none=True):
         """One memset of the gradient arena; `p.grad` stays a view of it (the kernels write gradients there whatever `p.grad` says)."""
@@ -117,7 +125,7 @@ class AdamW(torch.optim.Optimizer):
         super().load_state_dict(state_dict)
         arena = self.arena
         offset_of = {id(p): o for p, o in zip(arena.params, arena.offsets)}
-        for group in self.param_groups:
+        for group, step_t in zip(self.param_groups, self._step_tensors):
             steps = []
             for p in group["params"]:
                 st = self.state.get(p)
@@ -130,5 +138,7 @@ class AdamW(torch.optim.Optimizer):
                         view.copy_(st[key].to(view.device, torch.float32))
                         st[key] = view
                 steps.append(int(float(st.get("step", 0))))
+                st["step"] = step_t                       # back to the group's shared tensor (torch's loader made per-parameter copies)
             if steps:
                 group["step_count"] = max(steps)
+            step_t.fill_(float(group["step_count"]))

@@ -181,7 +181,9 @@ def attn_ref(qkv, B, L, nh, mask, dctx=None):
 
 
 @pytest.mark.parametrize("B,L,nh,masked", [(2, 20, 1, True), (3, 64, 2, False), (2, 255, 4, True), (2, 510, 16, True),
-                                           (2, 577, 12, False), (1, 129, 2, True), (2, 220, 16, True), (2, 248, 16, True)])
+                                           (2, 577, 12, False), (1, 129, 2, True), (2, 220, 16, True), (2, 248, 16, True),
+                                           # lengths just past a multiple of 256 (the 128- / 256-query forward forms meet a nearly empty last block)
+                                           (2, 300, 2, True), (1, 513, 3, True), (3, 577, 2, True), (1, 769, 1, False)])
 def test_attention_fwd_bwd(gpu, B, L, nh, masked):
     from item_alignment_amd import ops
     H = nh * 64
