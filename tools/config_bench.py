@@ -57,6 +57,7 @@ def hbm_bytes_per_step(which):
 
 
 def run(name, model, batch_fn, pairs, flops_per_pair, steps=8, warm=3, which=None):
+    steps = int(os.environ.get("IA_CB_STEPS", steps))          # soak runs: IA_CB_STEPS=200 ... c3 (the final loss printed must be finite)
     if CHILD_STEPS:
         warm, steps = (int(v) for v in CHILD_STEPS.split(","))
     model = model.cuda().train()
