@@ -77,8 +77,9 @@ double ia_prof_bytes(void); /* algorithmic bytes of the recorded launches: A and
 /* Diagnostics (ABI 7): occupy `workgroups` whole CUs (one 256-thread workgroup holding all 160 KiB of LDS each, so nothing else can
  * co-reside) for `milliseconds` on `stream` -- a stand-in for a communication kernel that holds CUs next to the persistent GEMMs
  * (tools/cu_contention.py: how much a GEMM on another stream slows down with 0 / 8 / 16 / 32 CUs taken, SURVEY 8(e) overlap of the
- * gradient all-reduce with backward).  The large persistent GEMM launches claim their tiles dynamically (one counter per XCD), so
- * a workgroup that starts late finds no work instead of holding a 1/256 share back; IA_GEMM_DYNAMIC=0 restores the static order. */
+ * gradient all-reduce with backward).  With the dynamic tile claim on (ia_debug_gemm_dynamic below) the large persistent GEMM
+ * launches take their tiles from one counter per XCD, so a workgroup that starts late finds no work instead of holding a 1/256
+ * share back. */
 int ia_debug_cu_hog(int workgroups, float milliseconds, ia_stream_t stream);
 /* Run-time switch of the dynamic tile claim; returns the previous setting (on < 0: query only).  Default off (static order) unless
  * IA_GEMM_DYNAMIC=1: a host that overlaps a communication stream with the GEMMs (world size > 1) switches it on -- 0-1.5 % per large
@@ -235,7 +236,10 @@ int ia_conv3x3_padded_bwd_data(const void* dyp, const void* what, void* dxp, int
  * (input with halo staged once by LDS-DMA, the nine taps as LDS row offsets) instead of nine shifted reads per tile through the
  * L2 -> LDS path.  The data gradient is the same kernel on dy with the tap-flipped, transposed bank: ia_conv3x3_flip_weights(what ->
  * what_t [Cin][9 * Cout / groups], the same number of elements), then ia_conv3x3_padded_bwd_data_t.  ia_conv3x3_direct_supported:
- * 1 when forward AND data gradient of the shape take that path (IA_CONV_DIRECT=0 switches it off). */
+ * 1 when forward AND data gradient of the shape take that path (IA_CONV_DIRECT=0 switches it off).  ia_conv3x3_padded_bwd_weight
+ * takes its direct form by itself for the same channel pairs when the launch covers >= 10^5 pixels (transpose reads of the dy and x
+ * tiles, one fp32 bank per workgroup, fixed-order fold: bit-reproducible; IA_CONV_DIRECT_WGRAD=0 switches it off);
+ * ia_conv3x3_padded_workspace_bytes covers both forms. */
 int ia_conv3x3_direct_supported(int Cin, int Cout, int groups);
 int ia_conv3x3_flip_weights(const void* what, void* what_t, int Cin, int Cout, int groups, ia_stream_t stream);
 int ia_conv3x3_padded_bwd_data_t(const void* dyp, const void* what_t, void* dxp, int B, int H, int W, int Cin, int Cout, int groups,
