@@ -422,3 +422,29 @@ def test_load_tokenizer_never_grows_the_vocabulary(tmp_path):
         assert max(ids) < tk.vocab_size
         assert ids[0] == 99
         assert (tk.vocab["<S>"] in ids) if has_bos else (tk.unk_token_id in ids)
+
+
+def test_direct_convolution_swizzle_keys_are_the_best_of_their_family():
+    """The XOR keys of the direct 3x3 convolution's LDS tiles (csrc/conv.hip: dconv::akey / bkey) under the b128 service-group model of
+    MI355X_MICROARCH.md (tools/abl/swizzle_search.py): the filter bank is conflict-free, the input tile at most 2-way (a fragment that
+    wraps a 30-pixel tile row), and no (shift, mask) candidate of the searched family does better -- what DESIGN.md 4.6 claims."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("swizzle_search", os.path.join(root, "tools", "abl", "swizzle_search.py"))
+    ss = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ss)
+    shipped_a = {64: lambda P: P & 7, 32: lambda P: (P >> 1) & 3, 16: lambda P: 0}
+    for ci, key in shipped_a.items():
+        cost = ss.a_cost(ci, key)
+        assert cost == 2, (ci, cost)
+        best = min(ss.a_cost(ci, lambda P, s=s, m=m: (P >> s) & m) for s in range(5) for m in (0, 1, 3, 7) if m < ci // 8)
+        assert best == cost, (ci, best, cost)
+        assert ss.a_cost(ci, lambda P: 0) >= cost
+    for co, shift in {64: 3, 32: 2, 16: 1}.items():
+        assert ss.b_cost(co, lambda n, s=shift: (n >> s) & 3) == 1, co
+        assert ss.b_cost(co, lambda n: 0) == 2, co
+    # the kernel's own key functions say the same thing as the table above
+    src = open(os.path.join(root, "item_alignment_amd", "csrc", "conv.hip")).read()
+    assert "return CI == 64 ? (P & 7) : CI == 32 ? ((P >> 1) & 3) : 0;" in src
+    assert "return (row >> (CO == 64 ? 3 : CO == 32 ? 2 : 1)) & 3;" in src
