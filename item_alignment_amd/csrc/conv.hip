@@ -19,6 +19,19 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
   out[idx] = f2bf(c < C ? in[(b * C + c) * HW + hw] : 0.f);
 }
 
+// Cp = 8 (the stem's 3 -> 8 padded channels): one thread per pixel -- C plane reads that are contiguous across the wave (256 B per
+// plane) and one 16-byte store, instead of one 2-byte store per thread and plane-strided 4-byte reads (0.84 -> ~0.2 ms for 64 images
+// of 800 x 800)
+__global__ __launch_bounds__(256) void nchw_to_nhwc8_kernel(const float* __restrict__ in, bf16* __restrict__ out, int C, int HW, size_t npix) {
+  const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= npix) return;
+  const size_t b = pix / HW, hw = pix % HW;
+  bf16x8 v;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) v[c] = f2bf(c < C ? in[(b * C + c) * HW + hw] : 0.f);
+  *reinterpret_cast<bf16x8*>(out + pix * 8) = v;
+}
+
 // ------------------------------------------------------------------------------------------- im2col
 // cols[m][g*9*Cg + t*Cg + c] = x[b, oy*s + ky - 1, ox*s + kx - 1, g*Cg + c]   (t = ky*3 + kx, zero outside the image)
 __global__ __launch_bounds__(256) void im2col3_kernel(const bf16* __restrict__ x, bf16* __restrict__ cols, int H, int W, int C, int Cg,
@@ -431,7 +444,12 @@ extern "C" int ia_nchw_to_nhwc_bf16(const float* in, void* out, int B, int C, in
   (void)hipGetLastError();
   if (!in || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0 || Cp < C) return IA_ERR_ARG;
   const size_t total = (size_t)B * H * W * Cp;
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, in, (bf16*)out, C, H * W, Cp, total);
+  if (Cp == 8 && C <= 8) {
+    const size_t npix = (size_t)B * H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc8_kernel, dim3(blocks_of(npix)), dim3(256), 0, stream, in, (bf16*)out, C, H * W, npix);
+  } else {
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, in, (bf16*)out, C, H * W, Cp, total);
+  }
   return ia_check_launch();
 }
 
