@@ -90,12 +90,16 @@ class VisionTransformer(HipModule, _EngineStack):
                     w_fc2=b.mlp.fc2.weight, b_fc2=b.mlp.fc2.bias, ln2_g=b.norm2.weight, ln2_b=b.norm2.bias)
 
     def forward_features(self, x):
+        """x: [B, 3, S, S] images, or a tuple / list of such batches that are to run as ONE batch in that order (the two items of a pair:
+        no concatenated copy of the images is made, Fn.PatchEmbedFn)."""
         (self._root if "_root" in self.__dict__ else self).ensure_arena()
-        B = x.shape[0]
-        if x.shape[-1] != self.img_size or x.shape[-2] != self.img_size:
-            raise ValueError(f"Input image size ({x.shape[-2]}*{x.shape[-1]}) doesn't match model ({self.img_size}*{self.img_size}).")
+        xs = tuple(x) if isinstance(x, (tuple, list)) else (x,)
+        B = sum(t.shape[0] for t in xs)
+        for t in xs:
+            if t.shape[-1] != self.img_size or t.shape[-2] != self.img_size:
+                raise ValueError(f"Input image size ({t.shape[-2]}*{t.shape[-1]}) doesn't match model ({self.img_size}*{self.img_size}).")
         N, H = self.num_patches + 1, self.embed_dim
-        tok = Fn.PatchEmbedFn.apply(x, self.anchor, self)
+        tok = Fn.PatchEmbedFn.apply(xs[0], self.anchor, self, *xs[1:])
         outs = Fn.EncoderStackFn.apply(tok, self.anchor, self, None, B, N, torch.is_grad_enabled(), None)
         y = Fn.LayerNormFn.apply(outs[-1], self.anchor, self.norm, 1e-6)
         return y.view(B, N, H)
@@ -150,7 +154,7 @@ class _ImageTwoTower(HipModule):
     def forward(self, images_1, images_2, labels=None):
         self.ensure_arena()
         B = images_1.shape[0]
-        f = self._embed(torch.cat((images_1, images_2), dim=0))          # both towers share weights: one 2B batch
+        f = self._embed((images_1, images_2))                            # both towers share weights: one 2B batch (no image concat)
         f1, f2 = f[:B], f[B:]
         training = self.training and torch.is_grad_enabled()
         p = self.classifier.drop_p if training else 0.0
@@ -182,6 +186,8 @@ class NFNetTwoTower(_ImageTwoTower):
 
     def _embed(self, images):
         enc = self.img_encoder
+        if isinstance(images, (tuple, list)):          # the conv towers take one tensor (their layout kernel reads it once anyway)
+            images = torch.cat(tuple(images), dim=0)
         n = images.shape[0]
         if self.max_images is None:
             return enc.head.global_pool(enc.forward_features(images))
@@ -198,6 +204,8 @@ class ResNetTwoTower(NFNetTwoTower):
 
     def _embed(self, images):
         enc = self.img_encoder
+        if isinstance(images, (tuple, list)):
+            images = torch.cat(tuple(images), dim=0)
         had = getattr(enc, "bn_segments", None)
         if had is not None:
             enc.bn_segments = 2
