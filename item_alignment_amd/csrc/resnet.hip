@@ -256,6 +256,38 @@ __global__ __launch_bounds__(256) void patches_nchw_kernel(const float* __restri
   *reinterpret_cast<bf16x8*>(cols + m * Kp + kk0) = o;
 }
 
+// The timm stem (7 x 7, stride 2, pad 3, 3 channels, Kp = 152) through LDS: a workgroup owns 64 consecutive output pixels of one output
+// row.  Their 7 input rows x 133 columns x 3 planes are read ONCE, contiguously along x (the gather form above reads every input value
+// ~12 times in 4-byte pieces scattered over 21 row segments per pixel), and the 64 x 152 patch rows leave as one contiguous 19 KB run
+// of 16-byte stores.
+__global__ __launch_bounds__(256) void patches_stem7_kernel(const float* __restrict__ img, bf16* __restrict__ cols, int H, int W, int Ho, int Wo) {
+  constexpr int K = 7, C = 3, PX = 64, IW = 2 * (PX - 1) + K, Kp = 152, NCH = Kp / 8;       // IW = 133 input columns per segment
+  __shared__ bf16 tile[C][K][IW + 3];
+  const int seg = blockIdx.x, oy = blockIdx.y, b = blockIdx.z;
+  const int ox0 = seg * PX, ix0 = 2 * ox0 - 3, iy0 = 2 * oy - 3;
+  for (int i = threadIdx.x; i < C * K * IW; i += 256) {
+    const int x = i % IW, r = i / IW, ky = r % K, c = r / K;
+    const int iy = iy0 + ky, ix = ix0 + x;
+    float v = 0.f;
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = img[(((size_t)b * C + c) * H + iy) * W + ix];
+    tile[c][ky][x] = f2bf(v);
+  }
+  __syncthreads();
+  const int npx = min(PX, Wo - ox0);
+  bf16* const out = cols + (((size_t)b * Ho + oy) * Wo + ox0) * Kp;
+  for (int i = threadIdx.x; i < npx * NCH; i += 256) {
+    const int px = i / NCH, j = i - px * NCH;
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int kk = j * 8 + e;                     // (ky * 7 + kx) * 3 + c; columns 147 .. 151 are padding
+      const int t = kk / C, c = kk - t * C, ky = t / K, kx = t - ky * K;
+      o[e] = kk < K * K * C ? tile[c][ky][2 * px + kx] : f2bf(0.f);
+    }
+    *reinterpret_cast<bf16x8*>(out + (size_t)i * 8) = o;
+  }
+}
+
 // ------------------------------------------------------------------------------------------- MaxPool 3x3 / 2 / pad 1
 // y[b, oy, ox, c] = max over the 3x3 window at (2oy-1, 2ox-1); arg = window position (ky*3+kx) of the FIRST maximum in scan
 // order (the element PyTorch's max_pool2d backward routes the gradient to)
@@ -459,7 +491,9 @@ extern "C" int ia_patches_nchw(const float* images, void* cols, int B, int C, in
   const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
   if (Ho <= 0 || Wo <= 0) return IA_ERR_ARG;
   const size_t total = (size_t)B * Ho * Wo * (Kp >> 3);
-  if (k == 7 && C == 3)
+  if (k == 7 && C == 3 && stride == 2 && pad == 3 && Kp == 152 && Ho <= 65535 && B <= 65535)
+    hipLaunchKernelGGL(patches_stem7_kernel, dim3((Wo + 63) / 64, Ho, B), dim3(256), 0, stream, images, (bf16*)cols, H, W, Ho, Wo);
+  else if (k == 7 && C == 3)
     hipLaunchKernelGGL((patches_nchw_kernel<7, 3>), dim3(blocks_of(total)), dim3(256), 0, stream, images, (bf16*)cols, C, H, W, Ho, Wo, k, stride, pad, Kp, total);
   else
     hipLaunchKernelGGL((patches_nchw_kernel<0, 0>), dim3(blocks_of(total)), dim3(256), 0, stream, images, (bf16*)cols, C, H, W, Ho, Wo, k, stride, pad, Kp, total);

@@ -779,6 +779,16 @@ def test_maxpool_stem_patches_and_subsample(gpu, B, H, W, C):
     want = unf.view(B, 3, 49, Hs * Ws).permute(0, 3, 2, 1).reshape(B * Hs * Ws, 147)      # column (ky*7+kx)*3 + c
     assert torch.equal(cols[:, :147].float(), want.bfloat16().float())
     assert cols[:, 147:].abs().max().item() == 0.0
+    # the LDS-staged stem form walks output rows in 64-pixel segments: several segments, a ragged last one, odd image sizes
+    for (Hi, Wi) in ((262, 302), (129, 131)):
+        img = torch.randn((2, 3, Hi, Wi), generator=g).to(gpu)
+        Hs, Ws = (Hi + 6 - 7) // 2 + 1, (Wi + 6 - 7) // 2 + 1
+        cols = torch.full((2 * Hs * Ws, 152), 7.0, device=gpu, dtype=torch.bfloat16)
+        check(lib.ia_patches_nchw(img.data_ptr(), cols.data_ptr(), 2, 3, Hi, Wi, 7, 2, 3, 152, stream_ptr()), "patches")
+        unf = torch.nn.functional.unfold(img, 7, padding=3, stride=2)
+        want = unf.view(2, 3, 49, Hs * Ws).permute(0, 3, 2, 1).reshape(2 * Hs * Ws, 147)
+        assert torch.equal(cols[:, :147].float(), want.bfloat16().float()), (Hi, Wi)
+        assert cols[:, 147:].abs().max().item() == 0.0
 
 
 @pytest.mark.parametrize("nh,lens,drop", [(2, [5, 64, 1, 130], 0.0), (4, [255, 17, 129, 200, 64, 65], 0.0), (2, [70, 33], 0.1)])
