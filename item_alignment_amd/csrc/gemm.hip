@@ -1019,7 +1019,10 @@ IA_DEV void read_frag(Op<KS>& f, int j, const uint32_t (&base)[4], uint32_t bufo
   }
 }
 
-template <bool AKS, bool BKS, int PEND>
+#ifndef IA_T256W_PEEL
+#define IA_T256W_PEEL 1
+#endif
+template <bool AKS, bool BKS, int PEND, bool PEEL_OK = true>
 IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB, int xa, int xb,
                       int kt0, int ktaA0, int ktaB0, int n_tiles, int nk_all, int wm, int wn, int wave, int lane, bool prologue_only,
                       bool stores_in_flight) {
@@ -1131,7 +1134,9 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
   for (int j = 0; j < 4; ++j) read_frag<0>(b0, j, baseB, 0u);
 
   // the 16 MFMAs of one k-step; filler(i) is issued right behind MFMA i and pinned there
-  auto step = [&](const auto& fa, const auto& fb, auto&& filler) {
+  // FRESH (the first k-step of a tile under IA_T256W_PEEL): the MFMAs take a zero C operand, so nothing has to clear the accumulators
+  auto step = [&](const auto& fa, const auto& fb, auto&& filler, auto FRESH_T) {
+    constexpr bool FRESH = decltype(FRESH_T)::value;
     bf16x8 va[4], vb[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { va[j] = frag_of(fa, j); vb[j] = frag_of(fb, j); }
@@ -1148,12 +1153,16 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
           c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; c[3] = c0[3]; c[4] = c1[0]; c[5] = c1[1]; c[6] = c1[2]; c[7] = c1[3];
         }
 #else
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb[ni], va[mi], acc[mi][ni], 0, 0, 0);
+        if constexpr (FRESH) {
+          const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb[ni], va[mi], z, 0, 0, 0);
+        } else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb[ni], va[mi], acc[mi][ni], 0, 0, 0);
 #endif
         filler(mi * 4 + ni);
         __builtin_amdgcn_sched_barrier(0);
       }
   };
+  using Acc = std::false_type;
 
   uint32_t bo = 0;
   int u = 0;
@@ -1166,7 +1175,10 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
   // on the round-2 order below).
   if constexpr (ROUND) {
   uint32_t offA = OOB, offB = off_of(1, true);
-  do {
+  // one trip = one k-tile.  IA_T256W_PEEL: the first trip of a tile is its own copy of the body whose k-step 0 writes the accumulators
+  // with a zero C operand -- the 256 v_accvgpr_write per tile and wave that cleared them (in the epilogue: an issue-bound stretch) are
+  // gone; the loop behind it runs at least once more (a k-tile past the end reads zeros: K <= 64 pays one empty trip).
+  auto trip = [&](auto FIRST_T) {
     const uint32_t bn = bo ^ (uint32_t)(2 * TILE_BYTES);
     tie2<0>(a0, b0);
     step(a0, b0, [&](int i) {      // (no reads behind the last four MFMAs: they cover the latency of the last reads)
@@ -1175,18 +1187,18 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
       else if (i < 12) { read_frag<3>(a3, i - 8, baseA, bo); read_frag<3>(b3, i - 8, baseB, bo); }
       if (i % 4 == 3) dma_c(u + 1, 12 + i / 4, offB);      // the last four pieces of k-tile u+1 (into the other buffer)
       if (i == 12) offA = off_of(u + 2, false);
-    });
+    }, FIRST_T);
     tie6<0>(a1, b1, a2, b2, a3, b3);
     __builtin_amdgcn_sched_barrier(0);
     if (!(dbg & 16)) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     step(a1, b1, [&](int i) {
       if (i % 4 == 1) dma_c(u + 2, i / 4, offA);
-    });
+    }, Acc{});
     step(a2, b2, [&](int i) {
       if (i % 4 == 1) dma_c(u + 2, 4 + i / 4, offA);
       if (i == 14) offB = off_of(u + 2, true);
-    });
+    }, Acc{});
     // k-tile u+1 has landed (its last four pieces went out under k-step 0): only the 8 pieces just issued may be outstanding
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -1196,10 +1208,16 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
       if (i < 4) read_frag<0>(a0, i, baseA, bn);
       else if (i < 8) read_frag<0>(b0, i - 4, baseB, bn);
       if (i % 4 == 3) dma_c(u + 2, 8 + i / 4, offB);
-    });
+    }, Acc{});
     bo = bn;
     ++u;
-  } while (u < n_tiles);
+    };
+  if constexpr (IA_T256W_PEEL && PEEL_OK) {
+    trip(std::true_type{});
+    do { trip(Acc{}); } while (u < n_tiles);
+  } else {
+    do { trip(Acc{}); } while (u < n_tiles);
+  }
   // the reads of "set 0 of the k-tile after the last" are dead, but in flight: their destinations must not be handed out before they land
   tie2<0>(a0, b0);
   return;
@@ -1216,13 +1234,13 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
       // spread form: the DMA pieces of a k-tile one per THREE MFMAs over k-steps 2, 3 and the next trip's k-step 0 (5 + 5 + 6; the
       // tile prologue issues 16 + 10): at one per two the VMEM port queues up (see the ROUND schedule)
       if (IA_T256W_SPREAD3 && i % 3 == 0) dma_prev(u + 1, 10 + i / 3);
-    });
+    }, Acc{});
     // k-step 1: set 3 requested in the first half
     tie<NR15>(a1); tie<NR15>(b1);
     step(a1, b1, [&](int i) {
       if (i < 4) read_frag<3>(a3, i, baseA, bo);
       else if (i < 8) read_frag<3>(b3, i - 4, baseB, bo);
-    });
+    }, Acc{});
     // every fragment of k-tile u is in registers: once all waves are here its buffer is free for k-tile u+2
     tie<0>(a2); tie<0>(b2); tie<0>(a3); tie<0>(b3);
     __builtin_amdgcn_sched_barrier(0);
@@ -1232,7 +1250,7 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
     step(a2, b2, [&](int i) {
       if (IA_T256W_SPREAD3) { if (i % 3 == 1) dma_run(u + 2, i / 3); }
       else if (i & 1) dma_run(u + 2, i >> 1);
-    });
+    }, Acc{});
     // k-step 3: k-tile u+1 has landed (this wave's share: all but the 8 / 5 pieces just issued; everybody's: the barrier)
     if (IA_T256W_SPREAD3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -1246,7 +1264,7 @@ IA_DEV void main_loop(const GemmArgs& p, char* smem, f32x16 (&acc)[4][4], __amdg
         if (i < 8) read_frag<0>(a0, i >> 1, baseA, bn);
         else read_frag<0>(b0, (i - 8) >> 1, baseB, bn);
       }
-    });
+    }, Acc{});
     bo = bn;
     ++u;
     // one running lane offset per k-strided operand, opaque to the loop optimiser: left alone it keeps SIXTEEN induction variables
@@ -1479,7 +1497,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     int lane = lane0;
     asm volatile("" : "+v"(lane));      // keep per-lane address arithmetic from being hoisted across the tile loop
     const uint64_t oa = (uint64_t)(AKS ? kt0 * BK : bm * BM) * p.lda, ob = (uint64_t)(BKS ? kt0 * BK : bn * BN) * p.ldb;
-    main_loop<AKS, BKS, PEND>(p, smem, acc, rsrc_at(p.A, p.a_bytes, oa), rsrc_at(p.B, p.b_bytes, ob), AKS ? bm * BM : 0, BKS ? bn * BN : 0, kt0,
+    // (the bf16 bias form keeps 64 bias values in registers across the main loop -- 468 of 512: the peeled first trip spilled there)
+    constexpr bool PEEL_OK = !(EPI == EPI_BIAS && !OUTF32 && !BKS);
+    main_loop<AKS, BKS, PEND, PEEL_OK>(p, smem, acc, rsrc_at(p.A, p.a_bytes, oa), rsrc_at(p.B, p.b_bytes, ob), AKS ? bm * BM : 0, BKS ? bn * BN : 0, kt0,
                               AKS ? 0 : kt0, BKS ? 0 : kt0, n_tiles, nk_all, wm, wn, wave, lane, prologue_only, stores_in_flight);
   };
 
