@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Image-only two-tower pair matching (ViT / ECA-NFNet / ResNetV2 through `create_model`): CLI-compatible with
 the reference's finetune_image.py (flags :17-74, dispatch :192-218, loop :310-348).  The ViT family, eca_nfnet_l0/l1/l2
-and resnetv2_50/101/152 (BatchNorm) have HIP encoders; the BiT resnetv2_*_bitm variants raise NotImplementedError."""
+and resnetv2_50/101/152 (BatchNorm) have HIP encoders; any other name (the BiT resnetv2_*_bitm variants among them) is a usage error at
+argparse time that lists the supported towers."""
 import argparse
 import json
 import os
@@ -11,7 +12,7 @@ import torch
 from item_alignment_amd import train
 from item_alignment_amd.cli_common import add_common_flags, freeze_and_resume, load_config, pick_device
 from item_alignment_amd.data.datasets import PairedImageDataset, collate_image
-from item_alignment_amd.models.image import create_model
+from item_alignment_amd.models.image import check_image_encoder_name, create_model
 from item_alignment_amd.utils import logger
 from src.models import NFNetTwoTower, ResNetTwoTower, VitTwoTower
 
@@ -32,7 +33,9 @@ def get_parser():
                        ("group_size", 128, int), ("bottle_ratio", 0.5, float), ("feat_mult", 2.0, float), ("act_layer", "gelu", str),
                        ("attn_layer", "se", str), ("attn_kwargs", None, str)):
         a("--" + name, default=d, type=t, help="NfCfg field: parsed but unused, as in the reference (finetune_image.py:56-72,193-207)")
-    return p.parse_args()
+    args = p.parse_args()
+    check_image_encoder_name(p, args.model_name)
+    return args
 
 
 def load_raw_data(args):

@@ -11,7 +11,7 @@ from item_alignment_amd import train
 from item_alignment_amd.cli_common import add_common_flags, freeze_and_resume, load_config, load_tokenizer, pick_device
 from item_alignment_amd.data.datasets import (PairedMultimodalDataset, RobertaImageOneTowerDataset, RobertaImageTwoTowerDataset,
                                               collate_coca_pair, collate_multimodal, collate_multimodal_two_tower)
-from item_alignment_amd.models.image import create_model
+from item_alignment_amd.models.image import check_image_encoder_name, create_model
 from item_alignment_amd.utils import VIT_WEIGHTS_NAME, logger
 from src.models import CoCaForItemAlignment, RobertaImageOneTower, RobertaImageTwoTower, RobertaModel
 
@@ -39,7 +39,10 @@ def get_parser(extra_flags=None):
     a("--image_model_name", default="vit_base_patch16_384", type=str)
     a("--hflip", default=0.5, type=float)
     a("--color_jitter", default=None, type=float)
-    return p.parse_args()
+    args = p.parse_args()
+    if "coca" in args.model_name:
+        check_image_encoder_name(p, args.image_model_name)
+    return args
 
 
 def load_raw_data(args):

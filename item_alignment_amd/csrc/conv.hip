@@ -791,8 +791,10 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(Args p) {
       const int pc = wave + 4 * i;
       if (pc < IN_PIECES) {
         const int r = pc / (TWP / PPP), c = pc - r * (TWP / PPP);      // piece c of tile row r
-        const uint32_t soff = (uint32_t)((r * PW + c * PPP) * p.Cin * 2);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lsm + W_BYTES + buf * IN_BYTES + pc * 1024, 16, lane_in, soff, 0, 0);
+        // (the row / piece advance sits in the LANE offset: the hardware's range check does not see a scalar offset, and the last
+        // image's bottom / right tiles reach past the end of the tensor whenever H % 8 or W % 30 is not zero -- those lanes must read zeros)
+        const uint32_t adv = (uint32_t)((r * PW + c * PPP) * p.Cin * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lsm + W_BYTES + buf * IN_BYTES + pc * 1024, 16, lane_in + adv, 0, 0, 0);
       }
     }
   };
@@ -887,6 +889,12 @@ static bool enabled() {
 static bool wgrad_enabled() {
   static const bool on = [] { const char* e = getenv("IA_CONV_DIRECT_WGRAD"); return !e || atoi(e) != 0; }();
   return on;
+}
+// smallest B * H * W the direct weight gradient takes (below it the split-K GEMM is faster); IA_CONV_DIRECT_WGRAD_MIN overrides it --
+// read on every call, so that a test can route small ragged maps through the direct kernel
+static size_t wgrad_min_pixels() {
+  const char* e = getenv("IA_CONV_DIRECT_WGRAD_MIN");
+  return e ? (size_t)atol(e) : 100000;
 }
 static bool pair_ok(int ci, int co) {
   return (ci == 64 && co == 64) || (ci == 16 && co == 32) || (ci == 32 && co == 64) || (ci == 64 && co == 32) || (ci == 32 && co == 16);
@@ -999,8 +1007,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WArgs p) {
         const int pc = wave + 4 * i;
         if (pc < X_PIECES) {
           const int r = pc / (TWP / PPP), c = pc - r * (TWP / PPP);
-          const uint32_t soff = (uint32_t)((r * PW + c * PPP) * p.Cin * 2);
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lsm + buf * STAGE + pc * 1024, 16, lane_x, soff, 0, 0);
+          // whole address in the lane offset (range-checked; see the forward kernel): x past the end of the tensor arrives as zeros --
+          // read through the scalar offset it was whatever lies behind the allocation, and 0 (masked dy) x NaN = NaN in dW
+          const uint32_t adv = (uint32_t)((r * PW + c * PPP) * p.Cin * 2);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lsm + buf * STAGE + pc * 1024, 16, lane_x + adv, 0, 0, 0);
         }
       }
     }
@@ -1016,8 +1026,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WArgs p) {
           const int r = pc / (TWP / PPP), c = pc - r * (TWP / PPP);
           const int col = c * PPP + ypix;
           const bool ok = col < TW && x0 + col <= p.W && y0 + r <= p.H;
-          const uint32_t voff = ok ? lane_y : 0xFFFFFFF0u, soff = (uint32_t)((r * PW + c * PPP) * p.Cout * 2);
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lsm + buf * STAGE + X_BYTES + pc * 1024, 16, voff, soff, 0, 0);
+          const uint32_t voff = ok ? lane_y + (uint32_t)((r * PW + c * PPP) * p.Cout * 2) : 0xFFFFFFF0u;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lsm + buf * STAGE + X_BYTES + pc * 1024, 16, voff, 0, 0, 0);
         }
       }
     }
@@ -1239,7 +1249,7 @@ extern "C" int ia_conv3x3_padded_bwd_weight(const void* xp, const void* dyp, flo
   const int ci = Cin / groups, co = Cout / groups;
   // (small maps keep the split-K GEMM: with a handful of tiles per workgroup the per-workgroup banks and their fold cost more than they
   // save -- 25 x 25: 0.049 against 0.036 ms at 32 images)
-  if (dconv::wgrad_ok(ci, co) && groups <= 64 && (size_t)B * H * W >= 100000 && dconv::enabled() && dconv::wgrad_enabled())
+  if (dconv::wgrad_ok(ci, co) && groups <= 64 && (size_t)B * H * W >= dconv::wgrad_min_pixels() && dconv::enabled() && dconv::wgrad_enabled())
     return dconv::wgrad(xp, dyp, dwhat, dbias, B, H, W, ci, co, groups, workspace, stream);
   IaViewGemm v{};
   v.A = dyp; v.a_kstrided = 1; v.lda = Cout; v.B = xp; v.b_kstrided = 1; v.ldb = Cin; v.C = dwhat; v.c_is_f32 = 1; v.ldc = 9 * ci;

@@ -22,6 +22,7 @@
 // tails need no extra code) with the XOR swizzle applied on the source side.  The MFMA is issued with
 // swapped operands (C^T fragments) so each lane ends up with runs of consecutive output columns.
 #include "common.h"
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -1788,9 +1789,14 @@ Plan make_plan(int M, int N, int K, bool f32_out, int groups = 1) {
 
 // Counter slot of the next dynamic-claim launch (nullptr: static order).  File-scope state: `launch` is a template, its function-local
 // statics would exist once per instantiation -- and two instantiations running on two streams would share slot 0.
+// Host threads may launch concurrently (ctypes releases the GIL): the sequence is atomic, so two launches never share a slot, and the
+// counter array's address is kept per device (a __device__ symbol has one instance per device).  A slot comes round again after
+// CTR_SLOTS launches of this process; the kernel's last workgroup re-arms it, so a reuse is only unsafe while >= CTR_SLOTS persistent
+// GEMM launches are in flight at once -- the step has ~400 of them in total, each queue holds far fewer.
 int g_dynamic = -1;
-uint32_t* g_ctr_base = nullptr;
-unsigned g_launch_seq = 0;
+constexpr int MAX_DEVICES = 16;
+uint32_t* g_ctr_base[MAX_DEVICES] = {};
+std::atomic<unsigned> g_launch_seq{0};
 uint32_t* next_ctr_slot() {
   // Default: the static order.  The claims cost the 256-wide GEMMs 0-1.5 % (two workgroup barriers per tile; 14 % on a 113-us launch of
   // four 25-us tiles per workgroup) and buy nothing while no other stream holds CUs; the data-parallel host switches them on when it
@@ -1800,8 +1806,14 @@ uint32_t* next_ctr_slot() {
     g_dynamic = e ? atoi(e) : 0;
   }
   if (!g_dynamic) return nullptr;
-  if (!g_ctr_base && hipGetSymbolAddress((void**)&g_ctr_base, HIP_SYMBOL(g_tile_ctr)) != hipSuccess) { g_ctr_base = nullptr; return nullptr; }
-  return g_ctr_base + (size_t)(g_launch_seq++ % CTR_SLOTS) * CTR_WORDS;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return nullptr;
+  uint32_t* base = __atomic_load_n(&g_ctr_base[dev], __ATOMIC_ACQUIRE);
+  if (!base) {
+    if (hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_tile_ctr)) != hipSuccess || !base) return nullptr;
+    __atomic_store_n(&g_ctr_base[dev], base, __ATOMIC_RELEASE);
+  }
+  return base + (size_t)(g_launch_seq.fetch_add(1u, std::memory_order_relaxed) % CTR_SLOTS) * CTR_WORDS;
 }
 
 template <bool AKS, bool BKS, int EPI, bool OUTF32>

@@ -126,8 +126,27 @@ def create_model(model_name, pretrained=False, **kwargs):
     from .resnetv2 import RESNETV2_CONFIGS, create_resnetv2
     if model_name in RESNETV2_CONFIGS:
         return create_resnetv2(model_name, **kwargs)
-    raise NotImplementedError(f"image encoder {model_name!r}: the ViT family, eca_nfnet_l0/l1/l2 and resnetv2_50/101/152 run on the HIP "
-                              "engine (the BiT resnetv2_*_bitm variants are not built, DESIGN.md)")
+    raise ValueError(unsupported_encoder_message(model_name))
+
+
+def supported_image_encoders():
+    """every name `create_model` builds on the HIP engine (the reference hands any name to timm, finetune_image.py:191)"""
+    from .nfnet import NFNET_CONFIGS
+    from .resnetv2 import RESNETV2_CONFIGS
+    return sorted(VIT_CONFIGS) + sorted(NFNET_CONFIGS) + sorted(RESNETV2_CONFIGS)
+
+
+def unsupported_encoder_message(model_name):
+    extra = (" (the BiT `resnetv2_*_bitm` variants -- GroupNorm + StdConv -- are not built: use the BatchNorm resnetv2_50 / 101 / 152)"
+             if "bit" in model_name else "")
+    return f"image encoder {model_name!r} has no HIP tower{extra}; supported: {', '.join(supported_image_encoders())}"
+
+
+def check_image_encoder_name(parser, model_name):
+    """argparse-time check of --model_name / --image_model_name: an unsupported tower ends the run with a usage error that names the
+    supported set, before any data is read or any model is built"""
+    if model_name not in supported_image_encoders():
+        parser.error(unsupported_encoder_message(model_name))
 
 
 class _ImageTwoTower(HipModule):

@@ -11,6 +11,11 @@ drive the learning rate exactly as they drive torch's -- and each group is ONE `
 arenas (fp32 master, gradient, both moments; the bf16 shadow the GEMMs read is rewritten by the same launch).  The arithmetic is
 torch.optim.AdamW's (decoupled decay first, bias-corrected moments, eps added to sqrt(v) / sqrt(bc2)); `state_dict()` exposes the
 moments as `exp_avg` / `exp_avg_sq` views per parameter plus a `step` tensor, i.e. torch's layout.
+
+One documented difference: a group's launch updates EVERY parameter of the group, also one whose gradient torch would report as
+`None` (a head the forward never used): its gradient slice of the arena is zero, so the moments decay and the decoupled weight decay is
+applied where `torch.optim.AdamW` skips the parameter.  Every model of this package uses all of its parameters in every step; freeze an
+unused head with `requires_grad_(False)` (such parameters are left out of the slice tables) to get torch's behaviour.
 """
 import numpy as np
 import torch
@@ -139,6 +144,9 @@ class AdamW(torch.optim.Optimizer):
                         st[key] = view
                 steps.append(int(float(st.get("step", 0))))
                 st["step"] = step_t                       # back to the group's shared tensor (torch's loader made per-parameter copies)
+            # a torch.optim.AdamW checkpoint (the reference's format) has no `step_count` in its groups, and one saved before the first
+            # step has no per-parameter state either
+            group.setdefault("step_count", 0)
             if steps:
                 group["step_count"] = max(steps)
             step_t.fill_(float(group["step_count"]))

@@ -158,30 +158,46 @@ def two_tower_cases(M):
                               "roberta.encoder.layer.0.intermediate.dense.bias"]))
 
 
-def main():
-    os.makedirs(GOLDEN, exist_ok=True)
-    M = load_reference()
-    if "--only-aux" in sys.argv:          # added after the other fixtures were captured: does not disturb their random draws
-        return aux_case(M)
-    if "--only-two-tower" in sys.argv:
-        return two_tower_cases(M)
-    rs = np.random.RandomState(2345)
-    B = 3
+ONE_TOWER_CASES = [("roberta_one_tower_cls_ce", {}),
+                   ("roberta_one_tower_cls12_cat", dict(cls_layers="1,2")),
+                   ("roberta_one_tower_cls12_avg", dict(cls_layers="1,2", cls_pool="avg")),
+                   ("roberta_one_tower_vecsim_cosine", dict(classification_method="vec_sim", similarity_measure="cosine", loss_type="cosine")),
+                   ("roberta_one_tower_vecsim_l2_bce", dict(classification_method="vec_sim", similarity_measure="l2", loss_type="bce")),
+                   ("roberta_one_tower_vecsim_ip_hinge", dict(classification_method="vec_sim", similarity_measure="inner_product", loss_type="hinge")),
+                   ]
 
-    # ---- RobertaOneTower: cls/ce ; cls layers 1,2 cat ; vec_sim cosine
-    for name, over in [("roberta_one_tower_cls_ce", {}),
-                       ("roberta_one_tower_cls12_cat", dict(cls_layers="1,2")),
-                       ("roberta_one_tower_cls12_avg", dict(cls_layers="1,2", cls_pool="avg")),
-                       ("roberta_one_tower_vecsim_cosine", dict(classification_method="vec_sim", similarity_measure="cosine", loss_type="cosine")),
-                       ("roberta_one_tower_vecsim_l2_bce", dict(classification_method="vec_sim", similarity_measure="l2", loss_type="bce")),
-                       ("roberta_one_tower_vecsim_ip_hinge", dict(classification_method="vec_sim", similarity_measure="inner_product", loss_type="hinge")),
-                       ]:
+
+def text_batch_lens(rs, lens, L, vocab, split_types=True):
+    B = len(lens)
+    ids = rs.randint(3, vocab, size=(B, L)).astype(np.int64)
+    mask = np.zeros((B, L), dtype=np.int64)
+    for b, n in enumerate(lens):
+        ids[b, n:] = 0
+        mask[b, :n] = 1
+    ids[:, 0] = 1
+    tt = np.zeros((B, L), dtype=np.int64)
+    if split_types:
+        tt[:, L // 2:] = 1
+        tt = tt * mask
+    return ids, mask, tt
+
+
+def one_tower_cases(M):
+    """RobertaOneTower (reference text.py:1417-1492), every head / loss variant, B = 8 ragged samples (round 6: the three-sample
+    fixtures left six named gradient exceptions -- head / embedding-table gradients that are sums over a handful of tokens).  Own
+    RandomState: the other fixtures keep their draws."""
+    rs = np.random.RandomState(5151)
+    L = 40
+    lens = [38, 31, 24, 40, 19, 35, 13, 28]
+    for name, over in ONE_TOWER_CASES:
         cfg = reference_config(**TINY, interaction_type="one_tower", max_seq_len=8, max_seq_len_pv=12, **over)
         model = M.RobertaOneTower(cfg).eval()
         seed = 11
         spec = load_weights(model, seed)
-        ids, mask, tt = text_batch(rs, B, 40, cfg.vocab_size)
-        labels = np.array([0, 1, 1], dtype=np.int64)
+        ids, mask, tt = text_batch_lens(rs, lens, L, cfg.vocab_size)
+        labels = np.array([0, 1, 1, 0, 1, 1, 0, 1], dtype=np.int64)
+        if over.get("loss_type") == "hinge":      # (see two_tower_cases: inside the margin a balanced batch is a difference of large sums)
+            labels = np.array([1, 1, 1, 0, 1, 1, 0, 1], dtype=np.int64)
         lab = t(labels).float() if over.get("loss_type") == "bce" else t(labels)
         out = model(input_ids=t(ids), attention_mask=t(mask), token_type_ids=t(tt), position_ids=None, labels=lab,
                     output_hidden_states=True)
@@ -192,6 +208,50 @@ def main():
                               "roberta.encoder.layer.1.output.LayerNorm.weight", "roberta.embeddings.word_embeddings.weight",
                               "roberta.embeddings.position_embeddings.weight", "roberta.encoder.layer.0.intermediate.dense.bias"]),
              extra=dict(hidden0=hs[0], hidden1=hs[1], hidden_last=hs[-1]))
+
+
+def image_two_tower_case(M):
+    """RobertaImageTwoTower, ensemble = begin (reference text.py image two-tower wrapper), B = 8 ragged samples, own RandomState."""
+    rs = np.random.RandomState(6161)
+    IH, L = 48, 20
+    lens = [18, 15, 12, 20, 9, 17, 6, 14]
+    B = len(lens)
+    cfg = reference_config(**TINY, interaction_type="two_tower", max_seq_len=8, max_seq_len_pv=12, ensemble="begin", image_hidden_size=IH)
+    model = M.RobertaImageTwoTower(cfg).eval()
+    seed = 14
+    spec = load_weights(model, seed)
+    labels = np.array([1, 1, 0, 1, 0, 0, 1, 0], dtype=np.int64)
+    ids1, mask1, tt1 = text_batch_lens(rs, lens, L, cfg.vocab_size, split_types=False)
+    ids2, mask2, tt2 = text_batch_lens(rs, lens[::-1], L, cfg.vocab_size, split_types=False)
+    img1 = rs.standard_normal((B, IH)).astype(np.float32); img2 = rs.standard_normal((B, IH)).astype(np.float32)
+    out = model(input_ids_1=t(ids1), attention_mask_1=t(mask1), token_type_ids_1=t(tt1), position_ids_1=None, images_1=t(img1),
+                input_ids_2=t(ids2), attention_mask_2=t(mask2), token_type_ids_2=t(tt2), position_ids_2=None, images_2=t(img2),
+                labels=t(labels))
+    out.loss.backward()
+    save("roberta_image_two_tower_begin", cfg, seed, spec,
+         dict(input_ids_1=ids1, attention_mask_1=mask1, token_type_ids_1=tt1, input_ids_2=ids2, attention_mask_2=mask2,
+              token_type_ids_2=tt2, img1=img1, img2=img2, labels=labels), out,
+         grads_of(model, ["classifier.out_proj.weight", "roberta.embeddings.img2txt.weight"]))
+
+
+def main():
+    os.makedirs(GOLDEN, exist_ok=True)
+    M = load_reference()
+    if "--only-aux" in sys.argv:          # added after the other fixtures were captured: does not disturb their random draws
+        return aux_case(M)
+    if "--only-two-tower" in sys.argv:
+        return two_tower_cases(M)
+    if "--only-one-tower" in sys.argv:
+        one_tower_cases(M)
+        return image_two_tower_case(M)
+    rs = np.random.RandomState(2345)
+    B = 3
+
+    # ---- RobertaOneTower, every head / loss variant: eight samples per fixture since round 6 (one_tower_cases, own RandomState).  The
+    # shared stream below still takes the draws the original three-sample fixtures took, so every later fixture keeps its inputs bit for bit.
+    for _name, _over in ONE_TOWER_CASES:
+        text_batch(rs, B, 40, TINY["vocab_size"])
+    one_tower_cases(M)
 
     # ---- RobertaTwoTower with each loss: eight samples per fixture (two_tower_cases, own RandomState).  The shared stream below still
     # takes the draws the original three-sample fixtures took, so every later fixture keeps its inputs bit for bit.
@@ -258,16 +318,10 @@ def main():
             save(name, cfg, seed, spec, dict(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, img1=img1, img2=img2,
                                              image_indices=image_indices), out, grads_of(model, gnames))
         else:
-            ids1, mask1, tt1 = text_batch(rs, B, 20, cfg.vocab_size); ids2, mask2, tt2 = text_batch(rs, B, 20, cfg.vocab_size)
-            tt1[:] = 0; tt2[:] = 0
-            img1 = rs.standard_normal((B, IH)).astype(np.float32); img2 = rs.standard_normal((B, IH)).astype(np.float32)
-            out = model(input_ids_1=t(ids1), attention_mask_1=t(mask1), token_type_ids_1=t(tt1), position_ids_1=None, images_1=t(img1),
-                        input_ids_2=t(ids2), attention_mask_2=t(mask2), token_type_ids_2=t(tt2), position_ids_2=None, images_2=t(img2),
-                        labels=t(labels))
-            out.loss.backward()
-            save(name, cfg, seed, spec, dict(input_ids_1=ids1, attention_mask_1=mask1, token_type_ids_1=tt1, input_ids_2=ids2,
-                                             attention_mask_2=mask2, token_type_ids_2=tt2, img1=img1, img2=img2, labels=labels), out,
-                 grads_of(model, ["classifier.out_proj.weight", "roberta.embeddings.img2txt.weight"]))
+            # eight samples since round 6 (image_two_tower_case, own RandomState); the shared stream keeps the old fixture's draws
+            text_batch(rs, B, 20, cfg.vocab_size); text_batch(rs, B, 20, cfg.vocab_size)
+            rs.standard_normal((B, IH)); rs.standard_normal((B, IH))
+            image_two_tower_case(M)
 
     # ---- TextCNN two tower (config C1 shapes scaled down)
     cfg = reference_config(**TINY, interaction_type="two_tower", max_seq_len=8, max_seq_len_pv=12, filter_sizes="1,2,3,5", num_filters=6)

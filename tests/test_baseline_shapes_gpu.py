@@ -190,7 +190,7 @@ def test_c5_full_width_coca_pair(gpu):
         assert len(hits) == 1, (parts, hits)
         return hits[0]
     keys = [key("classifier", "out_proj.weight"), key("layer.0.", "self.query.weight"), key("layer.23.", "self.query.weight"),
-            key("layer.23.", "self.value.weight"), key("blocks.0.", "attn.qkv.weight"), key("patch_embed.proj.weight")]
+            key("layer.23.", "self.key.weight"), key("layer.23.", "self.value.weight"), key("blocks.0.", "attn.qkv.weight"), key("patch_embed.proj.weight")]
     rsd = {k: (v.requires_grad_(True) if k in keys else v) for k, v in sd.items()}
     ref = O.coca_item_alignment(rsd, cfg, vcfg, *bc[:10], labels=bc[10], training=False)
     ref.loss.backward()
@@ -222,13 +222,18 @@ def test_c5_full_width_coca_pair(gpu):
     # (tools/c5_delta_probe.py, profiles/r05_c5_delta_probe.txt: fp32 vs bf16 0.029, fp32 vs bf16 + flash delta 0.212, HIP vs fp32
     # 0.275 -- two draws of one noise).  The HIP gradient has to stay within 1.6 x of what that restatement of the arithmetic does to
     # the tensor (and inside the absolute bound that has been in force since round 4); every other tensor keeps the common bar.
-    kq = key("layer.23.", "self.query.weight")
-    fsd = {k: (v.detach().clone().requires_grad_(True) if k == kq else v.detach()) for k, v in sd.items()}
+    # Round 6: the last layer's KEY projection sits in the same place for the same reason (dK of the last layer is the CLS row's dS
+    # column, dS = P (dP - delta): the same delta; round 5 measured 0.249 and left it out of the list) -- it is in `keys` now, under
+    # the same measured bound taken from ITS OWN flash-delta restatement.
+    kq, kk = key("layer.23.", "self.query.weight"), key("layer.23.", "self.key.weight")
+    fsd = {k: (v.detach().clone().requires_grad_(True) if k in (kq, kk) else v.detach()) for k, v in sd.items()}
     with O.rounding(torch.bfloat16, flash_delta=True):
         O.coca_item_alignment(fsd, cfg, vcfg, *bc[:10], labels=bc[10], training=False).loss.backward()
-    flash_rel, flash_cos = rel(fsd[kq].grad, rsd[kq].grad), cosine(fsd[kq].grad, rsd[kq].grad)
-    print("layer-23 query.weight, bf16 oracle with flash-style delta against fp32 (cosine, rel):", flash_cos, flash_rel)
-    loose = {kq: (min(0.99, max(0.96, 1.0 - 3.0 * (1.0 - flash_cos))), max(0.10, min(0.32, 1.6 * flash_rel)))}
+    loose = {}
+    for kx in (kq, kk):
+        flash_rel, flash_cos = rel(fsd[kx].grad, rsd[kx].grad), cosine(fsd[kx].grad, rsd[kx].grad)
+        print(kx, "bf16 oracle with flash-style delta against fp32 (cosine, rel):", flash_cos, flash_rel)
+        loose[kx] = (min(0.99, max(0.96, 1.0 - 3.0 * (1.0 - flash_cos))), max(0.10, min(0.32, 1.6 * flash_rel)))
     for k, (c, r) in report.items():
         cmin, rmax = loose.get(k, (0.99, 0.10))
         assert c >= cmin, (k, c, r, loose.get(k))

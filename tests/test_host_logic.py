@@ -448,3 +448,22 @@ def test_direct_convolution_swizzle_keys_are_the_best_of_their_family():
     src = open(os.path.join(root, "item_alignment_amd", "csrc", "conv.hip")).read()
     assert "return CI == 64 ? (P & 7) : CI == 32 ? ((P >> 1) & 3) : 0;" in src
     assert "return (row >> (CO == 64 ? 3 : CO == 32 ? 2 : 1)) & 3;" in src
+
+
+def test_unsupported_image_tower_is_a_usage_error_at_argparse_time():
+    """`finetune_image.py --model_name resnetv2_50x1_bitm` (a name the reference hands to timm, finetune_image.py:191,215) has no HIP
+    tower: the run ends in argparse with the supported set named, not with a NotImplementedError in the middle of model construction;
+    `create_model` itself raises a ValueError with the same text."""
+    import os
+    import subprocess
+    import sys
+    from item_alignment_amd.models.image import create_model, supported_image_encoders
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = supported_image_encoders()
+    assert "vit_base_patch16_384" in names and "eca_nfnet_l0" in names and "resnetv2_50" in names
+    with pytest.raises(ValueError, match="resnetv2_50x1_bitm.*BiT.*supported: .*eca_nfnet_l0"):
+        create_model("resnetv2_50x1_bitm")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "finetune_image.py"), "--data_dir", "/nonexistent", "--output_dir", "/nonexistent",
+                        "--data_version", "v0", "--model_name", "resnetv2_50x1_bitm"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert "has no HIP tower" in r.stderr and "resnetv2_50" in r.stderr and "usage:" in r.stderr

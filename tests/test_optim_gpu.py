@@ -136,6 +136,24 @@ def test_optimizer_state_dict_round_trip(gpu):
         assert torch.allclose(p.detach(), q.detach(), rtol=0, atol=2e-6), (n, (p.detach() - q.detach()).abs().max().item())
 
 
+def test_optimizer_loads_a_torch_adamw_checkpoint_saved_before_its_first_step(gpu):
+    """The reference's checkpoints hold `torch.optim.AdamW.state_dict()`: groups without `step_count`, and -- saved before the first
+    step -- no per-parameter state at all (round-5 advisor: KeyError).  Loading one and stepping works, from step 0."""
+    from item_alignment_amd.optim import AdamW
+    case = load_case("roberta_two_tower_ce")
+    args = two_tower_args(case)
+    model = fresh(case).cuda().eval()
+    model.ensure_arena()
+    foreign = torch.optim.AdamW(grouped(model, 0.01), lr=1e-4, betas=(0.9, 0.98), eps=1e-8)
+    opt = AdamW(grouped(model, 0.01), lr=3e-4, betas=(0.9, 0.999))
+    opt.load_state_dict(foreign.state_dict())
+    assert all(g["step_count"] == 0 and g["lr"] == 1e-4 and tuple(g["betas"]) == (0.9, 0.98) for g in opt.param_groups)
+    opt.zero_grad()
+    model(**args).loss.backward()
+    opt.step()
+    assert all(g["step_count"] == 1 for g in opt.param_groups)
+
+
 @pytest.mark.parametrize("set_to_none", [False, True])
 def test_foreign_torch_adamw_no_longer_trains_on_a_stale_shadow(gpu, set_to_none):
     """A maintainer who keeps `torch.optim.AdamW(model.parameters())`: torch updates the fp32 masters (views of the arena) in place;
