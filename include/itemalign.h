@@ -37,7 +37,7 @@ const char* ia_strerror(int code);
 /* Bumped whenever an entry point is added or the meaning of an argument / output changes (round 2 changed what IA_EPI_BIAS_GELU
  * stores in C2 and what IA_EPI_DGELU expects in aux): a caller built against another header must not run on this library.
  * item_alignment_amd/_lib.py refuses to load a library whose version differs from the one it was written for. */
-#define IA_ABI_VERSION 7
+#define IA_ABI_VERSION 8
 int ia_abi_version(void);
 
 /* ---- GEMM: torch.nn.Linear forward / dgrad / wgrad (src/models/text.py:1241 -> RobertaLayer dense
@@ -219,6 +219,13 @@ int ia_gap_bwd(const float* dpooled, void* dx, int B, int HW, int C, ia_stream_t
  * [B, C] fp32 are saved for ia_eca_bwd, which returns dx (the shortcut's gradient is dout) and accumulates dconv_w [k] */
 int ia_eca_fwd(const void* x, const float* conv_w, int k, const void* shortcut, void* out, float* pooled, float* gate, int B, int HW, int C,
                float coef, void* workspace, size_t workspace_bytes, ia_stream_t stream);
+/* the same tail with pooled = (mean_HW a) what^T + bias, a [B*HW, Cmid] = the input of the 1x1 convolution (what [C][Cmid] bf16, bias
+ * [C] fp32 or NULL) whose output is x: the mean over pixels commutes with the per-pixel linear map, so the reduction reads the narrow
+ * tensor (reference src/models/image.py:253-257 -> timm NormFreeBlock.conv3 + attn_last; round 6, ABI 8).  Backward: ia_eca_bwd. */
+size_t ia_eca_fwd_linear_workspace_bytes(int B, int HW, int Cmid);
+int ia_eca_fwd_linear(const void* x, const void* a, const void* what, const float* bias, int Cmid, const float* conv_w, int k,
+                      const void* shortcut, void* out, float* pooled, float* gate, int B, int HW, int C, float coef, void* workspace,
+                      size_t workspace_bytes, ia_stream_t stream);
 size_t ia_eca_bwd_workspace_bytes(int B, int HW, int C);
 int ia_eca_bwd(const void* dout, const void* x, const float* conv_w, int k, const float* pooled, const float* gate, void* dx,
                float* dconv_w, int B, int HW, int C, float coef, void* workspace, size_t workspace_bytes, ia_stream_t stream);

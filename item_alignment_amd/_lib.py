@@ -82,6 +82,8 @@ SIGNATURES = {
     "ia_gap_fwd": (i32, [vp, vp, i32, i32, i32, vp, sz, vp]),
     "ia_gap_bwd": (i32, [vp, vp, i32, i32, i32, vp]),
     "ia_eca_fwd": (i32, [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, sz, vp]),
+    "ia_eca_fwd_linear_workspace_bytes": (sz, [i32, i32, i32]),
+    "ia_eca_fwd_linear": (i32, [vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, sz, vp]),
     "ia_eca_bwd_workspace_bytes": (sz, [i32, i32, i32]),
     "ia_eca_bwd": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, sz, vp]),
     "ia_conv3x3_padded_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
@@ -148,7 +150,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 7      # = IA_ABI_VERSION of include/itemalign.h (tests/test_cabi_symbols.py keeps the two in step)
+ABI_VERSION = 8      # = IA_ABI_VERSION of include/itemalign.h (tests/test_cabi_symbols.py keeps the two in step)
 
 
 class ItemAlignError(RuntimeError):

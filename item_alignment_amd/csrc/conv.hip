@@ -331,6 +331,25 @@ __global__ __launch_bounds__(1024) void eca_gate_wgrad_kernel(const float* __res
   }
 }
 
+// pooled[b, c] = sum_k what[c][k] * mean_a[b][k] + bias[c]: the spatial mean of a 1x1 convolution's OUTPUT taken from the spatial mean of
+// its INPUT (the mean over pixels commutes with a per-pixel linear map), one thread per (b, c)
+__global__ __launch_bounds__(256) void eca_pool_linear_kernel(const float* __restrict__ mean_a, const bf16* __restrict__ what,
+                                                              const float* __restrict__ bias, float* __restrict__ pooled, int C, int K, int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int b = idx / C, c = idx % C;
+  const float* m = mean_a + (size_t)b * K;
+  const bf16* w = what + (size_t)c * K;
+  float s0 = 0.f, s1 = 0.f;
+  for (int k = 0; k < K; k += 8) {
+    const bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + k);
+    const f32x4 m0 = *reinterpret_cast<const f32x4*>(m + k), m1 = *reinterpret_cast<const f32x4*>(m + k + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s0 += bf2f(wv[j]) * m0[j]; s1 += bf2f(wv[4 + j]) * m1[j]; }
+  }
+  pooled[idx] = s0 + s1 + (bias ? bias[c] : 0.f);
+}
+
 // out = x * gate[b, c] * coef + shortcut      (attn_gain * ECA(x) * alpha + shortcut, timm NormFreeBlock.forward tail)
 __global__ __launch_bounds__(256) void scale_residual_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ gate,
                                                                  const bf16* __restrict__ shortcut, bf16* __restrict__ out, int HW, int C,
@@ -627,6 +646,32 @@ extern "C" int ia_eca_fwd(const void* x, const float* conv_w, int k, const void*
   if (!x || !conv_w || !shortcut || !out || !pooled || !gate || k <= 0 || k > 16 || !(k & 1)) return IA_ERR_ARG;
   int rc = ia_gap_fwd(x, pooled, B, HW, C, workspace, workspace_bytes, stream);
   if (rc) return rc;
+  hipLaunchKernelGGL(eca_gate_fwd_kernel, dim3((B * C + 255) / 256), dim3(256), 0, stream, (const float*)pooled, conv_w, gate, C, k, B * C);
+  const size_t total = (size_t)B * HW * (C >> 3);
+  hipLaunchKernelGGL(scale_residual_fwd_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)x, (const float*)gate,
+                     (const bf16*)shortcut, (bf16*)out, HW, C, coef, total);
+  return ia_check_launch();
+}
+
+// The same block tail with `pooled` taken from the INPUT of the 1x1 convolution that produced x (x = a what^T + bias per pixel, so
+// mean_HW x = (mean_HW a) what^T + bias exactly): the spatial reduction reads a [B, HW, Cmid] -- a quarter of x's bytes in a
+// NormFreeBlock (conv3: mid -> 4 mid channels) -- and the fp32 mean no longer carries x's per-element bf16 rounding.  what
+// [C][Cmid] bf16 (ia_ws_conv_weight_fwd's output), bias [C] or NULL.  Backward is ia_eca_bwd unchanged (the function is the same).
+extern "C" size_t ia_eca_fwd_linear_workspace_bytes(int B, int HW, int Cmid) {
+  return ia_gap_workspace_bytes(B, HW, Cmid) + (size_t)B * Cmid * sizeof(float);
+}
+extern "C" int ia_eca_fwd_linear(const void* x, const void* a, const void* what, const float* bias, int Cmid, const float* conv_w, int k,
+                                 const void* shortcut, void* out, float* pooled, float* gate, int B, int HW, int C, float coef, void* workspace,
+                                 size_t workspace_bytes, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!x || !a || !what || !conv_w || !shortcut || !out || !pooled || !gate || k <= 0 || k > 16 || !(k & 1) || Cmid <= 0 || (Cmid & 7) || (C & 7))
+    return IA_ERR_ARG;
+  if (!workspace || workspace_bytes < ia_eca_fwd_linear_workspace_bytes(B, HW, Cmid)) return IA_ERR_WORKSPACE;
+  float* mean_a = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ia_gap_workspace_bytes(B, HW, Cmid));
+  int rc = ia_gap_fwd(a, mean_a, B, HW, Cmid, workspace, workspace_bytes, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(eca_pool_linear_kernel, dim3((B * C + 255) / 256), dim3(256), 0, stream, (const float*)mean_a, (const bf16*)what, bias, pooled,
+                     C, Cmid, B * C);
   hipLaunchKernelGGL(eca_gate_fwd_kernel, dim3((B * C + 255) / 256), dim3(256), 0, stream, (const float*)pooled, conv_w, gate, C, k, B * C);
   const size_t total = (size_t)B * HW * (C >> 3);
   hipLaunchKernelGGL(scale_residual_fwd_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)x, (const float*)gate,

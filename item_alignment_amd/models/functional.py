@@ -441,10 +441,15 @@ def _gemm(lib, a, a_ks, lda, b, b_ks, ldb, c, c_f32, ldc, M, N, K, epi=0, aux=No
 
 class LinearBf16Fn(torch.autograd.Function):
     """y = x W^T (+ add) for the bias-free Linears of the CoCa blocks (reference multimodal.py:545-551,646-659):
-    MFMA GEMM on the weight's bf16 shadow; dgrad k-strided; wgrad accumulated in fp32 straight into the arena."""
+    MFMA GEMM on the weight's bf16 shadow; dgrad k-strided; wgrad accumulated in fp32 straight into the arena.
+
+    swiglu_src = (src, column offset, F): x is silu(gate) * x' of the columns [offset, offset + 2F) of `src` (SwiGLUFn / FusedSplitFn
+    produced it from that tensor, which they keep for their own backward anyway).  x is then NOT kept for the weight gradient -- it is
+    recomputed from `src` in backward (one ia_swiglu_fwd pass, ~1 % of the GEMM it feeds).  With ff_mult 12 (coca_large.json) the two
+    SwiGLU outputs of a multimodal layer are 48 KiB per token, a third of the layer's stash."""
 
     @staticmethod
-    def forward(ctx, x, add, weight, owner):
+    def forward(ctx, x, add, weight, owner, swiglu_src=None):
         lib = _lib.load()
         _need_gpu(x, "tokens")
         x = x.contiguous()
@@ -455,7 +460,8 @@ class LinearBf16Fn(torch.autograd.Function):
         if add is not None:
             add = add.contiguous()
         _gemm(lib, x, 0, K, w, 0, K, y, False, N, M, N, K, epi=3 if add is not None else 0, aux=add, ldaux=N if add is not None else 0)
-        ctx.weight, ctx.owner, ctx.x = weight, owner, x
+        ctx.weight, ctx.owner = weight, owner
+        ctx.x, ctx.swiglu_src, ctx.x_shape = (None, swiglu_src, (M, K)) if swiglu_src is not None else (x, None, (M, K))
         ctx.need_dx, ctx.has_add = ctx.needs_input_grad[0], add is not None
         return y
 
@@ -464,7 +470,12 @@ class LinearBf16Fn(torch.autograd.Function):
         lib = _lib.load()
         weight, x = ctx.weight, ctx.x
         dy = dy.contiguous()
-        M, K = x.shape
+        M, K = ctx.x_shape
+        if x is None:                                  # recompute the SwiGLU output this Linear consumed
+            src, off, F_ = ctx.swiglu_src
+            x = torch.empty((M, K), device=dy.device, dtype=BF16)
+            check(lib.ia_swiglu_fwd(src.data_ptr() + 2 * off, src.shape[1], x.data_ptr(), M, F_, stream_ptr()), "ia_swiglu_fwd[recompute]")
+        ctx.x = ctx.swiglu_src = None                  # (the node outlives backward while the caller holds the loss: drop the tensors now)
         N = weight.shape[0]
         dx = None
         if ctx.need_dx:
@@ -474,7 +485,7 @@ class LinearBf16Fn(torch.autograd.Function):
         if weight.requires_grad:
             _gemm(lib, dy, 1, N, x, 1, K, weight.grad, True, K, N, K, M, accumulate=1, what="ia_gemm_bf16[wgrad]")
             _notify([weight])
-        return dx, (dy if ctx.has_add else None), None, None
+        return dx, (dy if ctx.has_add else None), None, None, None
 
 
 class GammaLayerNormFn(torch.autograd.Function):
@@ -510,6 +521,7 @@ class GammaLayerNormFn(torch.autograd.Function):
               "ia_ln_bwd")
         if wg:
             _notify([gamma])
+        ctx.saved = None
         return dz, None, None, None
 
 
@@ -601,6 +613,7 @@ class AttentionXFn(torch.autograd.Function):
         check(lib.ia_attn_bwd_x(q.data_ptr(), H, kv.data_ptr(), kv.data_ptr() + 2 * H, 2 * H, None, out.data_ptr(), dout.data_ptr(), H,
                                 lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), H, dkv.data_ptr(), dkv.data_ptr() + 2 * H, 2 * H, B, nh, Lq,
                                 Lk, scale, 0.0, 0, stream_ptr()), "ia_attn_bwd_x")
+        ctx.saved = None
         return dq, dkv, None, None, None, None, None
 
 

@@ -164,7 +164,8 @@ class ParallelTransformerBlock(nn.Module):
         # multi-query attention: every query head attends to the single k/v head -> fold the heads into query rows
         o = Fn.AttentionXFn.apply(q.view(B * n * h, 64), kv, B, 1, n * h, n, self.scale)
         y = Fn.LinearBf16Fn.apply(o.view(B * n, h * 64), residual, self.attn_out.weight, self)
-        return Fn.LinearBf16Fn.apply(s, y, self.ff_out[1].weight, self)
+        # (s is not kept for ff_out's weight gradient: backward recomputes it from the x | gate columns of `fused`, which FusedSplitFn holds)
+        return Fn.LinearBf16Fn.apply(s, y, self.ff_out[1].weight, self, (fused, h * 64 + 128, self.ff_inner_dim))
 
 
 class CrossAttention(nn.Module):
@@ -200,7 +201,7 @@ class CrossAttention(nn.Module):
         y = Fn.LinearBf16Fn.apply(o.view(B * n, h * 64), residual, self.to_out.weight, self)
         if self.ff is not None:
             f = Fn.LinearBf16Fn.apply(xn, None, self.ff[0].weight, self)
-            y = Fn.LinearBf16Fn.apply(self.ff[1](f), y, self.ff[2].weight, self)
+            y = Fn.LinearBf16Fn.apply(self.ff[1](f), y, self.ff[2].weight, self, (f, 0, f.shape[1] // 2))
         return y
 
 

@@ -23,6 +23,7 @@ NONLIN_GAMMA_SILU = 1.7881293296813965          # timm nfnet.py _nonlin_gamma['s
 # stride-1 grouped 3x3 convolutions run as shifted-view GEMMs over a zero-bordered tensor; IA_CONV_PATCH_MATRIX=1 keeps the
 # gathered patch matrix for them too (A/B measurement switch, tools/config_bench.py)
 PADDED_CONV = os.environ.get("IA_CONV_PATCH_MATRIX", "0") != "1"
+ECA_LINEAR = os.environ.get("IA_ECA_LINEAR", "1") != "0"      # ECA pooling from conv3's input (EcaResidualFn); 0: the reduction over conv3's output
 
 NFNET_CONFIGS = {   # timm nfnet.py model_cfgs (_nfnet_cfg): depths, channels, feat_mult
     "eca_nfnet_l0": ((1, 2, 6, 3), (256, 512, 1536, 1536), 1.5),
@@ -69,6 +70,7 @@ class StdConvFn(torch.autograd.Function):
                                    stream_ptr()), "ia_conv_nhwc_fwd")
         ctx.conv, ctx.saved, ctx.dims = conv, (x, what, mean, rstd), (B, H, W, C, Cout, k, s, g, Cg, Cgp, kk)
         ctx.need_dx = ctx.needs_input_grad[0]
+        conv.__dict__["_last_what"] = what      # the standardised bf16 weight of this call (the block tail takes the ECA pooling from it)
         # keep the 3x3 patch matrix for the weight gradient (9x the input, a few GB per step on 288 GB of HBM) instead of
         # gathering it again in backward
         ctx.cols_ws = ws if (k == 3 and conv.weight.requires_grad and conv.keep_cols) else None
@@ -262,7 +264,10 @@ class EcaResidualFn(torch.autograd.Function):
     """out = x * sigmoid(conv1d(mean_HW x)) * (attn_gain * alpha) + shortcut  (timm EcaModule + NormFreeBlock.forward tail)."""
 
     @staticmethod
-    def forward(ctx, x, shortcut, conv_w, eca, B, HW, coef):
+    def forward(ctx, x, shortcut, conv_w, eca, B, HW, coef, pre=None):
+        # pre = (a, what, bias): x = a what^T + bias is the output of a 1x1 convolution (conv3): the ECA pooling mean_HW(x) is then taken
+        # as (mean_HW a) what^T + bias -- exact, the mean commutes with the per-pixel linear map -- from the 4 x narrower tensor a
+        # (ia_eca_fwd_linear, round 6; IA_ECA_LINEAR=0 keeps the reduction over x for A/B runs).  Backward is the same either way.
         lib = _lib.load()
         x, shortcut = x.contiguous(), shortcut.contiguous()
         C, k = x.shape[1], conv_w.shape[-1]
@@ -270,10 +275,19 @@ class EcaResidualFn(torch.autograd.Function):
         out = torch.empty_like(x)
         pooled = torch.empty((B, C), device=dev, dtype=F32)
         gate = torch.empty((B, C), device=dev, dtype=F32)
-        wsb = lib.ia_gap_workspace_bytes(B, HW, C)
-        ws = _ws(dev, wsb)
-        check(lib.ia_eca_fwd(x.data_ptr(), conv_w.data_ptr(), k, shortcut.data_ptr(), out.data_ptr(), pooled.data_ptr(), gate.data_ptr(), B, HW, C,
-                             coef, ws.data_ptr(), wsb, stream_ptr()), "ia_eca_fwd")
+        if pre is not None and ECA_LINEAR:
+            a, what, bias = pre
+            Cmid = a.shape[1]
+            wsb = lib.ia_eca_fwd_linear_workspace_bytes(B, HW, Cmid)
+            ws = _ws(dev, wsb)
+            check(lib.ia_eca_fwd_linear(x.data_ptr(), a.data_ptr(), what.data_ptr(), ptr(bias), Cmid, conv_w.data_ptr(), k, shortcut.data_ptr(),
+                                        out.data_ptr(), pooled.data_ptr(), gate.data_ptr(), B, HW, C, coef, ws.data_ptr(), wsb, stream_ptr()),
+                  "ia_eca_fwd_linear")
+        else:
+            wsb = lib.ia_gap_workspace_bytes(B, HW, C)
+            ws = _ws(dev, wsb)
+            check(lib.ia_eca_fwd(x.data_ptr(), conv_w.data_ptr(), k, shortcut.data_ptr(), out.data_ptr(), pooled.data_ptr(), gate.data_ptr(), B, HW, C,
+                                 coef, ws.data_ptr(), wsb, stream_ptr()), "ia_eca_fwd")
         ctx.eca, ctx.saved, ctx.dims = eca, (x, pooled, gate), (B, HW, C, k, coef)
         return out
 
@@ -291,7 +305,7 @@ class EcaResidualFn(torch.autograd.Function):
                              w.grad.data_ptr() if w.requires_grad else None, B, HW, C, coef, ws.data_ptr(), wsb, stream_ptr()), "ia_eca_bwd")
         Fn._notify([w])
         ctx.saved = None
-        return dx, dout, None, None, None, None, None
+        return dx, dout, None, None, None, None, None, None
 
 
 class GapFn(torch.autograd.Function):
@@ -431,8 +445,10 @@ class NormFreeBlock(nn.Module):
         else:
             out = self.conv2(act(out))
             out = act(self.conv2b(act(out)))
+        a = out.t                                                 # conv3's input [B*H*W, mid] (contiguous: every producer above allocates it)
         out = self.conv3(out)
-        y = EcaResidualFn.apply(out.t, shortcut, self.attn_last.conv.weight, self.attn_last, out.B, out.H * out.W, self.attn_gain * self.alpha)
+        pre = (a, self.conv3.__dict__.pop("_last_what"), self.conv3.bias) if a.is_contiguous() else None
+        y = EcaResidualFn.apply(out.t, shortcut, self.attn_last.conv.weight, self.attn_last, out.B, out.H * out.W, self.attn_gain * self.alpha, pre)
         return FeatureMap(y, out.B, out.H, out.W)
 
 

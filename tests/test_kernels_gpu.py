@@ -672,6 +672,45 @@ def test_conv3x3_direct_few_channel_groups(gpu, monkeypatch, B, H, W, groups, ci
         assert rel_err(outs[0][1] - 0.25, br.grad) < 2e-3
 
 
+@pytest.mark.parametrize("B,HW,Cmid,C", [(3, 625, 384, 1536), (2, 10000, 128, 512), (5, 49, 64, 256)])
+def test_eca_block_tail_pools_through_the_1x1_convolution(gpu, B, HW, Cmid, C):
+    """ia_eca_fwd_linear: the NormFreeBlock tail out = x * sigmoid(conv1d(mean_HW x)) * coef + shortcut (reference src/models/image.py:253-257
+    -> timm NormFreeBlock.forward: attn_last(conv3(.)) * alpha + shortcut) with the pooling taken from conv3's INPUT a -- mean_HW(a what^T +
+    bias) = (mean_HW a) what^T + bias -- against torch in fp32 on the same bf16 operands, and against ia_eca_fwd (the reduction over the
+    bf16-rounded x itself), whose gate it must match to the rounding of x; ia_eca_bwd runs unchanged on the saved pooled / gate."""
+    from item_alignment_amd import _lib
+    from item_alignment_amd.ops import check, stream_ptr
+    lib = _lib.load()
+    k, coef = 5, 0.4
+    a = rnd((B * HW, Cmid), gpu, 1.0, 31)
+    what = rnd((C, Cmid), gpu, Cmid ** -0.5, 32)
+    bias = torch.randn(C, device=gpu) * 0.3
+    shortcut = rnd((B * HW, C), gpu, 1.0, 33)
+    conv_w = torch.randn(k, device=gpu) * 0.5
+    x32 = a.float() @ what.float().t() + bias                      # what the convolution computes before its output is rounded
+    x = x32.to(torch.bfloat16)
+    pooled_ref = x32.view(B, HW, C).mean(1)
+    gate_ref = torch.sigmoid(torch.nn.functional.conv1d(pooled_ref.view(B, 1, C), conv_w.view(1, 1, k), padding=(k - 1) // 2).view(B, C))
+    out_ref = x.float().view(B, HW, C) * gate_ref[:, None, :] * coef + shortcut.float().view(B, HW, C)
+    out, pooled, gate = torch.empty_like(x), torch.empty((B, C), device=gpu), torch.empty((B, C), device=gpu)
+    wsb = lib.ia_eca_fwd_linear_workspace_bytes(B, HW, Cmid)
+    ws = torch.empty(wsb, device=gpu, dtype=torch.uint8)
+    check(lib.ia_eca_fwd_linear(x.data_ptr(), a.data_ptr(), what.data_ptr(), bias.data_ptr(), Cmid, conv_w.data_ptr(), k, shortcut.data_ptr(),
+                                out.data_ptr(), pooled.data_ptr(), gate.data_ptr(), B, HW, C, coef, ws.data_ptr(), wsb, stream_ptr()), "ia_eca_fwd_linear")
+    assert rel_err(pooled, pooled_ref) < 1e-4
+    assert rel_err(gate, gate_ref) < 1e-4
+    assert rel_err(out.view(B, HW, C), out_ref) < 1e-2
+    assert lib.ia_eca_fwd_linear(x.data_ptr(), a.data_ptr(), what.data_ptr(), bias.data_ptr(), Cmid, conv_w.data_ptr(), k, shortcut.data_ptr(),
+                                 out.data_ptr(), pooled.data_ptr(), gate.data_ptr(), B, HW, C, coef, ws.data_ptr(), wsb - 1, stream_ptr()) != 0
+    out2, pooled2, gate2 = torch.empty_like(x), torch.empty_like(pooled), torch.empty_like(gate)
+    wsb2 = lib.ia_gap_workspace_bytes(B, HW, C)
+    ws2 = torch.empty(wsb2, device=gpu, dtype=torch.uint8)
+    check(lib.ia_eca_fwd(x.data_ptr(), conv_w.data_ptr(), k, shortcut.data_ptr(), out2.data_ptr(), pooled2.data_ptr(), gate2.data_ptr(), B, HW, C, coef,
+                         ws2.data_ptr(), wsb2, stream_ptr()), "ia_eca_fwd")
+    assert rel_err(pooled, pooled2) < 2e-3 and rel_err(gate, gate2) < 2e-3          # the old path sums the ROUNDED x: bf16 noise, averaged over HW
+    assert rel_err(out.view(B, HW, C), out2.view(B, HW, C)) < 1e-2
+
+
 def test_silu_between_padded_and_compact_layouts(gpu):
     from item_alignment_amd import _lib
     from item_alignment_amd.ops import check, stream_ptr

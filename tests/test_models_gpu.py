@@ -4,6 +4,8 @@ tests/golden/*.npz (captured from the reference's own classes) within the bf16 t
 5e-2 relative (here: relative to the tensor's max magnitude), outputs and parameter gradients alike."""
 from types import SimpleNamespace
 
+import os
+
 import pytest
 import torch
 
@@ -598,8 +600,8 @@ def test_train_step_with_dropout_on(gpu):
     """Dropout ON (the bench configuration: hidden 0.1, attention 0.1) through the whole RobertaTwoTower train step.  The engine's masks
     come from a counter-based generator keyed by (step seed, layer, element) -- not torch's stream -- so the reference's masks cannot
     be reproduced bit for bit; what must hold: (a) the same step seed gives the bit-identical loss and gradients (embedding tables: to
-    atomic-add order), a different seed does not; (b) over 64 seeds the mean loss and the mean gradient of the pair head agree with the oracle's (training=True, torch
-    dropout, 64 seeds of its own) within a few standard errors of the difference (loss: plus the bf16 bias measured with dropout off)."""
+    atomic-add order), a different seed does not; (b) over 256 seeds the mean loss and the mean gradient of the pair head agree with the oracle's (training=True, torch
+    dropout, 256 seeds of its own, under bf16 storage rounding) within a few standard errors of the difference (loss: plus the bf16 bias measured with dropout off)."""
     from golden_util import run_oracle
     from item_alignment_amd.models import functional as Fn
     case = load_case("roberta_two_tower_ce")
@@ -637,42 +639,42 @@ def test_train_step_with_dropout_on(gpu):
     assert not torch.equal(le, l0)
     model.train()
 
-    n = 64
+    # 256 seeds per side (round 6; 64 until then).  The 512 z scores below are strongly correlated (the two rows of the head's weight
+    # gradient are each other's negatives, every column shares the per-sample logit gradients), so their mean is itself noisy: measured
+    # on one box against the bf16-rounding oracle: 64 seeds mean 1.144 / 0.859 below 2, 256 seeds 0.974 / 0.914 -- a real mismatch (a wrong
+    # keep probability, a missing 1 / (1 - p)) would GROW with sqrt(n) instead.  IA_DROPOUT_SEEDS overrides n for such diagnostics.
+    n = int(os.environ.get("IA_DROPOUT_SEEDS", 256))
     hl, hg = [], []
     for s in range(n):
         l, gr = hip_step(1000 + 7 * s)
         hl.append(l.item()); hg.append(gr[key])
+    # The oracle's 64 dropout-on steps run under bf16 STORAGE ROUNDING (oracle.ref_models.rounding: the same places the engine stores
+    # bf16), so both samples carry the deterministic bf16-against-fp32 bias and the z scores below need no bias term at all (round 6;
+    # the round-5 form subtracted |eval-mode bias| and clamped at zero, which hid any mismatch smaller than that bias in either direction
+    # -- advisor finding; subtracting the SIGNED eval-mode bias instead was measured too: mean z 1.10, the part of the bias that dropout
+    # itself changes is not in an eval-mode measurement).
+    from oracle import ref_models as O
     ol, og = [], []
     for s in range(n):
         torch.manual_seed(5000 + s)
         sd = weights(case, requires_grad=True)
-        out = run_oracle(case, sd, training=True)
-        out.loss.backward()
+        with O.rounding(torch.bfloat16):
+            out = run_oracle(case, sd, training=True)
+            out.loss.backward()
         ol.append(out.loss.item()); og.append(sd[key].grad.clone())
     hl, ol = torch.tensor(hl, dtype=torch.float64), torch.tensor(ol, dtype=torch.float64)
     assert hl.std() > 1e-3 and ol.std() > 1e-3                              # dropout really is on in both
     se = (hl.var() / n + ol.var() / n).sqrt().item()
-    bias = 5e-3                                                             # |loss - oracle loss| with dropout off is 3e-3 on this fixture
     # (both samples are seeded, so the outcome is fixed for a given build; 3 standard errors leave room for another torch's CPU stream)
-    assert abs(hl.mean().item() - ol.mean().item()) <= 3 * se + bias, (hl.mean().item(), ol.mean().item(), se)
+    assert abs(hl.mean().item() - ol.mean().item()) <= 3 * se + 1e-3, (hl.mean().item(), ol.mean().item(), se)
     hg, og = torch.stack(hg).double(), torch.stack(og).double()
-    # the deterministic part of the difference: bf16 against fp32 with dropout off (the same weights, the same inputs) -- with eight samples
-    # per batch the sampling error of a 64-seed mean is small enough for that bias to show in the z scores, so it is taken out first
-    model.eval()
-    _, ge = hip_step(0)
-    model.train()
-    sd0 = weights(case, requires_grad=True)
-    run_oracle(case, sd0, training=False).loss.backward()
-    bias_g = ge[key].double() - sd0[key].grad.double()                     # SIGNED: HIP minus oracle, dropout off
     # per element of the pair head's weight gradient (2 x 256): z = |difference of the two sample means| / its standard error.
     # Two samplers of the same distribution give |N(0, 1)| scores: mean 0.80, 95 % below 2, the largest of 512 around 3.1
     # (measured with 128 seeds: 0.85 / 0.953 / 3.08); a wrong keep probability or a missing 1 / (1 - p) shifts every one of them.
-    # (the signed bias is subtracted from the signed difference -- round-5 advisor: |difference| - |bias| clamped at zero hid any mismatch
-    # smaller than the bias, in either direction)
-    z = (hg.mean(0) - og.mean(0) - bias_g).abs() / (hg.var(0) / n + og.var(0) / n).sqrt()
+    z = (hg.mean(0) - og.mean(0)).abs() / (hg.var(0) / n + og.var(0) / n).sqrt()
+    print(f"dropout z scores against the bf16-rounding oracle: mean {z.mean().item():.3f}, below 2: {(z < 2).double().mean().item():.3f}, "
+          f"max {z.max().item():.2f}; loss means {hl.mean().item():.4f} / {ol.mean().item():.4f}, se {se:.4f}")
     assert z.mean().item() < 1.05, z.mean().item()
-    # (with the eight-sample fixture of round 5 the standard errors are ~0.6 x those of the three-sample one, and the part of the bf16
-    # bias that dropout itself changes -- the eval-mode bias above is only its bulk -- lifts the tail: measured 0.883 below 2, mean 0.97)
-    assert (z < 2).double().mean().item() > 0.85, (z < 2).double().mean().item()
+    assert (z < 2).double().mean().item() > 0.90, (z < 2).double().mean().item()
     assert z.max().item() < 5.0, z.max().item()
     assert abs(hl.std().item() / ol.std().item() - 1.0) < 0.5              # the spread over masks matches too (0.162 vs 0.158 at 128 seeds)

@@ -60,6 +60,7 @@ def run(name, model, batch_fn, pairs, flops_per_pair, steps=8, warm=3, which=Non
     steps = int(os.environ.get("IA_CB_STEPS", steps))          # soak runs: IA_CB_STEPS=200 ... c3 (the final loss printed must be finite)
     if CHILD_STEPS:
         warm, steps = (int(v) for v in CHILD_STEPS.split(","))
+    torch.cuda.reset_peak_memory_stats()          # (several configurations may run in one process: the peak printed below is this one's)
     model = model.cuda().train()
     arena = model.param_arena
 
@@ -152,7 +153,7 @@ def c4(pairs=256):
         lambda m: m(input_ids=t[0], attention_mask=t[1], token_type_ids=t[2], position_ids=t[3], labels=labels), pairs, 4.129e11, which="c4")
 
 
-def c5x(pairs=16):
+def c5x(pairs=64):      # 64 pairs/step since round 6 (16 until then: profiles/r06_c5x_batch_sweep.txt -- 16 -> 112, 64 -> 184 pairs/s, 131 GiB)
     # coca_large.json: 24 multimodal layers, 16 heads, ff_mult 12 (reference src/config/coca_large.json) + ViT-L/16 @384 (1024-d tokens)
     cfg = roberta_large_config(ensemble="cross_attn", num_hidden_layers_multimodal=24, num_attention_heads_multimodal=16,
                                feedforward_multiplication_multimodal=12)
