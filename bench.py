@@ -458,6 +458,22 @@ def main():
                                                 "events on the launch stream; the timed region overlaps the towers on two streams)"
                                                 if two_streams else "the timed region (HIP events on the launch stream)"),
                                 "frac_in_timed_region": (in_region[1] / (in_region[0] * 1e-3) / 1e12 / 2500.0 if in_region[0] > 0 else None)})
+        # Text attention: the kernels skip key tiles that hold no attendable key (right-padded batches), so a per-kernel MFMA fraction taken
+        # from the DENSE 255 x 255 FLOP count flatters them.  From the attention masks of the timed batches: the share of
+        # the dense key positions each kernel actually visits -- forward (attn_fwd3: 64-key tiles per sequence) and fused backward
+        # (attn_bwd_fused: 32-key blocks per sequence); executed FLOPs per launch = dense FLOPs x this share.
+        try:
+            lens = torch.cat([torch.cat((b[1], b[6])).sum(1) for b in batches]).float()      # attention_mask_1 | attention_mask_2: tokens per sequence
+            L = batches[0][1].shape[1]
+            res["attention_text"] = {
+                "mean_tokens": round(lens.mean().item(), 1), "padded_len": L,
+                "executed_key_share_fwd": round((torch.ceil(lens / 64) * 64).clamp(max=L).mean().item() / L, 4),
+                "executed_key_share_bwd": round((torch.ceil(lens / 32) * 32).clamp(max=L).mean().item() / L, 4),
+                "dense_flops_per_launch_fwd": 4.0 * 2 * B * 16 * L * L * 64, "dense_flops_per_launch_bwd": 10.0 * 2 * B * 16 * L * L * 64,
+                "note": "per-kernel TFLOP/s on EXECUTED work = dense_flops_per_launch x executed_key_share / the kernel's launch time "
+                        "(profiles/*_kernel_stats_summary.txt); the ViT kernels (no padding mask) execute 19 of their 20 32-key blocks"}
+        except Exception as e:      # (a diagnostic: never fail the line over it)
+            res["attention_text"] = {"error": repr(e)}
         res["config"]["dataset_pairs"] = DATASET_PAIRS
         res["config"]["resident_batches"] = n_batches
         res["peak_hbm_gib"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)      # this rank, incl. the resident batches

@@ -221,11 +221,13 @@ int ia_eca_fwd(const void* x, const float* conv_w, int k, const void* shortcut, 
                float coef, void* workspace, size_t workspace_bytes, ia_stream_t stream);
 /* the same tail with pooled = (mean_HW a) what^T + bias, a [B*HW, Cmid] = the input of the 1x1 convolution (what [C][Cmid] bf16, bias
  * [C] fp32 or NULL) whose output is x: the mean over pixels commutes with the per-pixel linear map, so the reduction reads the narrow
- * tensor (reference src/models/image.py:253-257 -> timm NormFreeBlock.conv3 + attn_last; round 6, ABI 8).  Backward: ia_eca_bwd. */
+ * tensor (reference src/models/image.py:253-257 -> timm NormFreeBlock.conv3 + attn_last; round 6, ABI 8).  act_out (bf16, same shape as
+ * out; may be NULL) = silu(out) * act_scale: the activation the next NormFreeBlock opens with (act1(x) * beta), written by the same
+ * pass, bit-identical to ia_silu_fwd(out).  Backward: ia_eca_bwd (+ ia_silu_bwd for the gradient that arrives through act_out). */
 size_t ia_eca_fwd_linear_workspace_bytes(int B, int HW, int Cmid);
 int ia_eca_fwd_linear(const void* x, const void* a, const void* what, const float* bias, int Cmid, const float* conv_w, int k,
-                      const void* shortcut, void* out, float* pooled, float* gate, int B, int HW, int C, float coef, void* workspace,
-                      size_t workspace_bytes, ia_stream_t stream);
+                      const void* shortcut, void* out, void* act_out, float act_scale, float* pooled, float* gate, int B, int HW, int C,
+                      float coef, void* workspace, size_t workspace_bytes, ia_stream_t stream);
 size_t ia_eca_bwd_workspace_bytes(int B, int HW, int C);
 int ia_eca_bwd(const void* dout, const void* x, const float* conv_w, int k, const float* pooled, const float* gate, void* dx,
                float* dconv_w, int B, int HW, int C, float coef, void* workspace, size_t workspace_bytes, ia_stream_t stream);

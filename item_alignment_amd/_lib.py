@@ -83,7 +83,7 @@ SIGNATURES = {
     "ia_gap_bwd": (i32, [vp, vp, i32, i32, i32, vp]),
     "ia_eca_fwd": (i32, [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, sz, vp]),
     "ia_eca_fwd_linear_workspace_bytes": (sz, [i32, i32, i32]),
-    "ia_eca_fwd_linear": (i32, [vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, sz, vp]),
+    "ia_eca_fwd_linear": (i32, [vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, f32, vp, vp, i32, i32, i32, f32, vp, sz, vp]),
     "ia_eca_bwd_workspace_bytes": (sz, [i32, i32, i32]),
     "ia_eca_bwd": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, sz, vp]),
     "ia_conv3x3_padded_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),

@@ -131,7 +131,14 @@ class ParamArena:
         if self._transposed.get(off) != (rows, cols):
             self._transposed[off] = (rows, cols)
             self._transposed_table = None
+            self._transposed_stale = True      # the new image is only written by the next refresh_transposed()
         return self.shadow_t[off:off + rows * cols].view(cols, rows)
+
+    def transposed_ready(self):
+        """bring the transposed images up to date if one was registered since the last refresh (a Linear that registers its weight in
+        its first forward calls this in front of its first data-gradient GEMM)"""
+        if getattr(self, "_transposed_stale", False):
+            self.refresh_transposed()
 
     def refresh_transposed(self):
         if not self._transposed:
@@ -143,6 +150,7 @@ class ParamArena:
             self._transposed_tiles = max(((r + 63) // 64) * ((c + 63) // 64) for _, _, r, c in ent)
         check(lib.ia_transpose_bf16_batched(self.shadow.data_ptr(), self.shadow_t.data_ptr(), self._transposed_table.data_ptr(),
                                             self._transposed_table.shape[0], self._transposed_tiles, stream_ptr()), "ia_transpose_bf16_batched")
+        self._transposed_stale = False
 
     def _param_versions(self):
         return sum(p._version for p in self.params)

@@ -45,6 +45,7 @@ struct AttnArgs {
   uint32_t thr16; float inv_keep; uint32_t seed;
   float* cs_part;                                 // backward, optional: [b*ntile + tile][3*nh*64] fp32 column sums of this workgroup's
                                                   // dq | dk | dv rows (the QKV bias gradient, summed over rows by ia_sum_rows_f32); null = off
+  int exact_delta;                                // backward, IA_ATTN_EXACT_DELTA=1: `delta` already holds sum_k P dP in fp32 (attn_bwd3_delta_kernel)
 };
 
 // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): renumber them so that consecutive
@@ -1084,7 +1085,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_dq_kernel(AttnArgs p) {
     }
   }
   dlt += swap32(dlt);
-  if (active && hh == 0 && q < Lq) p.delta[sidx] = dlt;       // for the dK/dV kernel, which runs behind this one on the stream
+  // IA_ATTN_EXACT_DELTA=1: the pre-pass (attn_bwd3_delta_kernel) has left the exact fp32 sum_k P dP there -- rowsum(dO o O) above is the
+  // flash-style form of the same number taken from the bf16-ROUNDED context, 2^-9 |dO . O| off
+  if (p.exact_delta) dlt = p.delta[sidx];
+  else if (active && hh == 0 && q < Lq) p.delta[sidx] = dlt;       // for the dK/dV kernel, which runs behind this one on the stream
   f32x16 nl, nd;                                              // C operands: -lse, -delta (dropout: the mask sits between dP and delta)
 #pragma unroll
   for (int r = 0; r < 16; ++r) { nl[r] = PRESCALE ? -lse : -lse / p.sc; nd[r] = DROPOUT ? 0.f : -dlt; }
@@ -1211,6 +1215,182 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_dq_kernel(AttnArgs p) {
       p.cs_part[(size_t)(b * ((p.Lq + 127) >> 7) + tile) * (3 * p.nh * 64) + h * 64 + lane] = (c[lane] + c[64 + lane]) + (c[128 + lane] + c[192 + lane]);
     }
   }
+}
+
+// ---------------------------------------------------------------------- backward, round 6: exact softmax-gradient delta (opt-in)
+// IA_ATTN_EXACT_DELTA=1.  A flash-style backward takes delta_q = rowsum(dO o O) from the context the forward STORED, i.e. rounded to
+// bf16: delta is off by ~2^-9 |dO . O| and enters dS = P (dP - delta) as eps * P -- invisible where a layer's 255 query rows average it
+// out, but the one place it shows is a top layer whose gradient arrives through a single row (CoCa ensemble = sum: only the CLS row
+// of the last text layer carries gradient; layer-23 query / key weight gradients 0.27 / 0.25 off the fp32 reference,
+// profiles/r05_c5_delta_probe.txt).  This pre-pass forms the same number the exact way, sum_k P_qk dP_qk in fp32 (the dQ kernel's S
+// and dP chains without the dQ half: 16 of its 24 MFMAs per tile), into `delta`; the dQ and dK/dV kernels then read it instead of
+// forming rowsum(dO o O).  Costs ~60 % of the dQ kernel per launch; the fused one-kernel backward (L <= 256) is bypassed while it is on.
+template <bool DROPOUT>
+__global__ __launch_bounds__(256, 2) void attn_bwd3_delta_kernel(AttnArgs p) {
+  using namespace bwd3;
+  __shared__ __attribute__((aligned(16))) char smem[DQ_SMEM];
+  uint32_t (*s_valid)[2] = reinterpret_cast<uint32_t (*)[2]>(smem + DQ_TAB_OFF);
+  const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, lq = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int tile, h, b;
+  attn_block_coords(p, p.Lq, tile, h, b);
+  int Lq = p.Lq, L = p.Lk;
+  size_t qbase = (size_t)b * Lq, rowbase = (size_t)b * L;
+  if (p.cu) {
+    const int c0 = p.cu[b];
+    Lq = L = p.cu[b + 1] - c0;
+    qbase = rowbase = (size_t)c0;
+    if (tile * 128 >= Lq) return;
+  }
+  const int q0 = tile * 128 + wave * 32;
+  const bool active = q0 < Lq;
+  const int q = q0 + lq;
+  const int qc = q < Lq ? q : Lq - 1;
+  const uint32_t win = (uint32_t)(((size_t)(L - 1) * p.ld_kv + 64) * 2);
+  const __amdgpu_buffer_rsrc_t rsK = ia_rsrc(p.k + rowbase * p.ld_kv + h * 64, win);
+  const __amdgpu_buffer_rsrc_t rsV = ia_rsrc(p.v + rowbase * p.ld_kv + h * 64, win);
+  const uint32_t sbase = lds_addr(smem);
+  const uint32_t tile_bytes = (uint32_t)p.ld_kv * 128u, half_bytes = (uint32_t)p.ld_kv * 64u;
+  const int nkt_all = (L + 63) >> 6;
+  // lane constants: fragment read bases (stage 0) and the DMA offsets of this lane's 16 bytes inside a tile
+  uint32_t ka[4], du;
+  {
+    const uint32_t a0 = (uint32_t)(lq * 128 + ((hh ^ swz_u(lq)) << 4));
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) ka[kb] = sbase + (a0 ^ (uint32_t)(kb << 5));
+    const int r0 = tid >> 3, c = tid & 7;
+    du = (uint32_t)((r0 * p.ld_kv + (c ^ swz_u(r0)) * 8) * 2);
+  }
+  typedef __attribute__((address_space(3))) char lds_char;
+  lds_char* const lsm = (lds_char*)IA_LDS(smem);        // one flat -> LDS cast; DMA destinations are LDS-pointer arithmetic from here
+  auto stage_tile = [&](auto SLOT_T, int kt) {
+    constexpr int S = decltype(SLOT_T)::value * STAGE;
+    const uint32_t so = (uint32_t)kt * tile_bytes, so2 = so + half_bytes;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lsm + S + wave * 1024), 16, du, so, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lsm + S + 4096 + wave * 1024), 16, du, so2, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lsm + S + 8192 + wave * 1024), 16, du, so, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lsm + S + 12288 + wave * 1024), 16, du, so2, 0, 0);
+  };
+  using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>; using S2 = std::integral_constant<int, 2>;
+
+  // ---- prologue: one round trip for this wave's q / dO / o rows (q behind the ring, dO / o in stages 1 / 2), key tile 0, lse and
+  // the mask bytes
+  char* const rq = smem + DQ_ROWS_OFF + wave * 4096;
+  char* const rg = smem + STAGE + wave * 4096;
+  stage_rows32(ia_rsrc(p.q, p.q_bytes), rq, qbase + q0, Lq - q0, p.ld_q, h * 64, lane);
+  stage_rows32(ia_rsrc(p.d_o, p.o_bytes), rg, qbase + q0, Lq - q0, p.ld_o, h * 64, lane);
+  stage_tile(S0{}, 0);
+  const size_t sidx = ((size_t)b * p.nh + h) * p.Lq + qc;
+  const float lse = p.lse2[sidx];
+  build_valid_table(p, s_valid, rowbase, L, lane, wave);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  bf16x8 qf[4], gf[4];
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    const bf16x8 raw = frag_b128(rq, lq, kb * 2 + hh);
+    gf[kb] = frag_b128(rg, lq, kb * 2 + hh);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qf[kb][j] = (PRESCALE && !p.q_prescaled) ? f2bf(bf2f(raw[j]) * p.sc) : raw[j];
+  }
+  f32x16 nl, nd;                                              // C operands: -lse, 0
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { nl[r] = PRESCALE ? -lse : -lse / p.sc; nd[r] = 0.f; }
+  float dsum = 0.f;                                           // this lane's part of sum_k P dP of its query (its 16 key rows of every block)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int nkt = nkt_all;
+  uint32_t ragged = 0u;
+  for (int t = 0; t < nkt_all; ++t) {
+    const uint32_t lo = s_valid[t][0], hi = s_valid[t][1];
+    if ((lo & hi) != 0xFFFFFFFFu) ragged |= 1u << t;
+    if ((lo | hi) != 0u) nkt = t + 1;
+  }
+  nkt = __builtin_amdgcn_readfirstlane(nkt);
+  ragged = __builtin_amdgcn_readfirstlane(ragged);
+  if (nkt > 1) stage_tile(S1{}, 1);
+  const uint32_t rk = DROPOUT ? ia_rng_row(p.seed, (uint32_t)(b * p.nh + h), (uint32_t)q) : 0u;
+  const uint32_t thr1 = DROPOUT ? (p.thr16 - 1u) * 0x10001u : 0u;
+
+  auto tile_step = [&](auto SLOT_T, int t) {
+    constexpr int SB = decltype(SLOT_T)::value * STAGE;
+    using NEXT2 = std::integral_constant<int, (decltype(SLOT_T)::value + 2) % 3>;
+    const bool LAST = t + 1 >= nkt;
+    // tile t has landed for this wave (tile t+1, issued behind it, may still be in flight), then for everybody
+    if (LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < nkt) stage_tile(NEXT2{}, t + 2);
+    if (!active) return;
+    bf16x8 xk0, xk1, xv0, xv1, yk0, yk1, yv0, yv1;        // K / V fragments of even / odd k-steps
+    auto rd = [&](auto KB, bf16x8& k0, bf16x8& k1, bf16x8& v0, bf16x8& v1) {
+      constexpr int kb = decltype(KB)::value;
+      k0 = lds_read_b128<SB>(ka[kb]); k1 = lds_read_b128<SB + 4096>(ka[kb]);
+      v0 = lds_read_b128<SB + 8192>(ka[kb]); v1 = lds_read_b128<SB + 12288>(ka[kb]);
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    rd(I0{}, xk0, xk1, xv0, xv1);
+    rd(I1{}, yk0, yk1, yv0, yv1);
+    f32x16 s0, s1, dp0, dp1;
+    const bool plain = !((ragged >> t) & 1u);
+    frag_wait4<4>(xk0, xk1, xv0, xv1);
+    s0 = mfma(xk0, qf[0], nl); s1 = mfma(xk1, qf[0], nl);
+    dp0 = mfma(xv0, gf[0], nd); dp1 = mfma(xv1, gf[0], nd);
+    if (!plain) {
+      // masked keys: one more accumulate step adds -1e30 to their rows (A = the penalty in k-slot 0 of the key's row, B = 1.0 in
+      // k-slot 0 of every query).  The fragment registers of the reads in flight are not touched in here: a wait that sat on the
+      // far side of a branch from its read once had the register allocator copy a fragment before its data had arrived
+      // (tools/lint_asm_waits.py checks the compiled kernels for exactly that).
+      const uint32_t v_lo = __builtin_amdgcn_readfirstlane(s_valid[t][0]), v_hi = __builtin_amdgcn_readfirstlane(s_valid[t][1]);
+      const uint32_t low = hh ? 0u : 1u;
+      const uint32_t bad0 = ((~v_lo) >> lq) & low, bad1 = ((~v_hi) >> lq) & low;
+      const u32x4 a0 = {bad0 * NEG_BIG_BF16, 0u, 0u, 0u}, a1 = {bad1 * NEG_BIG_BF16, 0u, 0u, 0u}, bw = {low * 0x3F80u, 0u, 0u, 0u};
+      s0 = mfma(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, bw), s0);
+      s1 = mfma(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, bw), s1);
+    }
+    rd(I2{}, xk0, xk1, xv0, xv1);
+    frag_wait4<4>(yk0, yk1, yv0, yv1);
+    s0 = mfma(yk0, qf[1], s0); s1 = mfma(yk1, qf[1], s1); dp0 = mfma(yv0, gf[1], dp0); dp1 = mfma(yv1, gf[1], dp1);
+    rd(I3{}, yk0, yk1, yv0, yv1);
+    frag_wait4<4>(xk0, xk1, xv0, xv1);
+    s0 = mfma(xk0, qf[2], s0); s1 = mfma(xk1, qf[2], s1); dp0 = mfma(xv0, gf[2], dp0); dp1 = mfma(xv1, gf[2], dp1);
+    frag_wait4<0>(yk0, yk1, yv0, yv1);
+    s0 = mfma(yk0, qf[3], s0); s1 = mfma(yk1, qf[3], s1); dp0 = mfma(yv0, gf[3], dp0); dp1 = mfma(yv1, gf[3], dp1);
+    // sum_k P dP (dropout: the kept entries of dP, scaled by 1 / keep -- what the forward's O = sum P M / keep V contracts with dO)
+    if (DROPOUT) {
+      const uint32_t tile_c = (uint32_t)(t * 32) * IA_RNG_PAIR_C + (uint32_t)(2 * hh) * IA_RNG_PAIR_C;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        constexpr uint32_t C = IA_RNG_PAIR_C;
+        const uint32_t imm = (uint32_t)(((r & 3) >> 1) + 4 * (r >> 2)) * C;
+        float a_lo, a_hi, b_lo, b_hi;
+        keep_pair(ia_rng_pair(rk, tile_c + imm), thr1, a_lo, a_hi);
+        keep_pair(ia_rng_pair(rk, tile_c + imm + 16u * C), thr1, b_lo, b_hi);
+        dsum += __builtin_amdgcn_exp2f(PRESCALE ? s0[r] : s0[r] * p.sc) * (dp0[r] * a_lo * p.inv_keep);
+        dsum += __builtin_amdgcn_exp2f(PRESCALE ? s0[r + 1] : s0[r + 1] * p.sc) * (dp0[r + 1] * a_hi * p.inv_keep);
+        dsum += __builtin_amdgcn_exp2f(PRESCALE ? s1[r] : s1[r] * p.sc) * (dp1[r] * b_lo * p.inv_keep);
+        dsum += __builtin_amdgcn_exp2f(PRESCALE ? s1[r + 1] : s1[r + 1] * p.sc) * (dp1[r + 1] * b_hi * p.inv_keep);
+      }
+    } else {
+      float u0 = 0.f, u1 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        u0 += __builtin_amdgcn_exp2f(PRESCALE ? s0[r] : s0[r] * p.sc) * dp0[r];
+        u1 += __builtin_amdgcn_exp2f(PRESCALE ? s1[r] : s1[r] * p.sc) * dp1[r];
+      }
+      dsum += u0 + u1;
+    }
+  };
+  {
+    int t = 0;
+    for (;;) {
+      tile_step(S0{}, t); if (++t >= nkt) break;
+      tile_step(S1{}, t); if (++t >= nkt) break;
+      tile_step(S2{}, t); if (++t >= nkt) break;
+    }
+  }
+  dsum += swap32(dsum);                                   // the partner lane holds the other half of every block's key rows
+  if (active && hh == 0 && q < Lq) p.delta[sidx] = dsum;
 }
 
 // ---------------------------------------------------------------------------------- backward: dK, dV
@@ -2118,8 +2298,25 @@ template <bool D> void launch_dq(const AttnArgs& a, dim3 grid, hipStream_t st) {
   if ((bwd_version() & 1) || a.q_prescaled) hipLaunchKernelGGL(attn_bwd3_dq_kernel<D>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, grid, dim3(256), 0, st, a);
 }
+// read on every call (a test / a fine-tuning script may switch it inside one process)
+bool exact_delta_on() { const char* e = getenv("IA_ATTN_EXACT_DELTA"); return e && atoi(e) != 0; }
 // The fused backward serves plain self-attention (one length for queries and keys, padded rows) of 33 .. 256 tokens
-bool fused_applies(const AttnArgs& a) { return (bwd_version() & 4) && a.cu == nullptr && a.Lq == a.Lk && a.Lq > 32 && a.Lq <= 256 && a.delta != nullptr; }
+bool fused_applies(const AttnArgs& a) {
+  return (bwd_version() & 4) && !a.exact_delta && a.cu == nullptr && a.Lq == a.Lk && a.Lq > 32 && a.Lq <= 256 && a.delta != nullptr;
+}
+// dQ then dK/dV (the pair of kernels behind every backward entry point that is not served by the fused kernel)
+void launch_pair(AttnArgs& a, dim3 gq, dim3 gk, hipStream_t st) {
+  if (a.exact_delta) {
+    if (a.thr16) hipLaunchKernelGGL(attn_bwd3_delta_kernel<true>, gq, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(attn_bwd3_delta_kernel<false>, gq, dim3(256), 0, st, a);
+    // (the round-3 kernels only: the round-2 dQ kernel knows nothing of the flag)
+    if (a.thr16) { hipLaunchKernelGGL(attn_bwd3_dq_kernel<true>, gq, dim3(256), 0, st, a); hipLaunchKernelGGL(attn_bwd3_dkv_kernel<true>, gk, dim3(256), 0, st, a); }
+    else { hipLaunchKernelGGL(attn_bwd3_dq_kernel<false>, gq, dim3(256), 0, st, a); hipLaunchKernelGGL(attn_bwd3_dkv_kernel<false>, gk, dim3(256), 0, st, a); }
+    return;
+  }
+  if (a.thr16) { launch_dq<true>(a, gq, st); launch_dkv<true>(a, gk, st); }
+  else { launch_dq<false>(a, gq, st); launch_dkv<false>(a, gk, st); }
+}
 void launch_fused(const AttnArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(attn_key_bits_kernel, dim3(a.B), dim3(64), 0, st, a.mask, reinterpret_cast<uint32_t*>(a.delta), a.Lk);
   const int per_x = (a.B * a.nh + 7) / 8;
@@ -2194,15 +2391,9 @@ extern "C" int ia_attn_bwd_x(const void* q, int ld_q, const void* k, const void*
   a.mask = key_mask; a.lse2 = const_cast<float*>(lse2); a.delta = delta;
   a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.ld_dq = ld_dq; a.ld_dkv = ld_dkv;
   dim3 gq(((Lq + 127) / 128) * nh * B), gk(((Lk + 127) / 128) * nh * B), blk(256);
-  if (fused_applies(a)) {
-    launch_fused(a, stream);
-  } else if (a.thr16) {
-    launch_dq<true>(a, gq, stream);
-    launch_dkv<true>(a, gk, stream);
-  } else {
-    launch_dq<false>(a, gq, stream);
-    launch_dkv<false>(a, gk, stream);
-  }
+  a.exact_delta = exact_delta_on() ? 1 : 0;
+  if (fused_applies(a)) launch_fused(a, stream);
+  else launch_pair(a, gq, gk, stream);
   return ia_check_launch();
 }
 
@@ -2254,15 +2445,9 @@ static int attn_bwd_bias_impl(int q_prescaled, const void* q, const void* k, con
   if (q_prescaled && !fwd3::PRESCALE) return IA_ERR_ARG;
   a.q_prescaled = q_prescaled;
   dim3 grid(((L + 127) / 128) * nh * B), blk(256);
-  if (fused_applies(a)) {
-    launch_fused(a, stream);
-  } else if (a.thr16) {
-    launch_dq<true>(a, grid, stream);
-    launch_dkv<true>(a, grid, stream);
-  } else {
-    launch_dq<false>(a, grid, stream);
-    launch_dkv<false>(a, grid, stream);
-  }
+  a.exact_delta = exact_delta_on() ? 1 : 0;
+  if (fused_applies(a)) launch_fused(a, stream);
+  else launch_pair(a, grid, grid, stream);
   rc = ia_check_launch();
   if (rc) return rc;
   return ia_sum_rows_f32((const float*)workspace, B * ((L + 127) / 128), 3 * nh * 64, dbias, 1, stream);
@@ -2329,13 +2514,8 @@ static int attn_bwd_varlen_impl(int q_prescaled, const void* q, const void* k, c
   if (q_prescaled && !fwd3::PRESCALE) return IA_ERR_ARG;
   a.q_prescaled = q_prescaled;
   dim3 grid(((Lmax + 127) / 128) * nh * B), blk(256);
-  if (a.thr16) {
-    launch_dq<true>(a, grid, stream);
-    launch_dkv<true>(a, grid, stream);
-  } else {
-    launch_dq<false>(a, grid, stream);
-    launch_dkv<false>(a, grid, stream);
-  }
+  a.exact_delta = exact_delta_on() ? 1 : 0;
+  launch_pair(a, grid, grid, stream);
   return ia_check_launch();
 }
 extern "C" int ia_attn_bwd_varlen(const void* q, const void* k, const void* v, int ld_qkv, const int* cu_seqlens, int total_tokens,

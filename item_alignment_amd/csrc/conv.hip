@@ -351,18 +351,25 @@ __global__ __launch_bounds__(256) void eca_pool_linear_kernel(const float* __res
 }
 
 // out = x * gate[b, c] * coef + shortcut      (attn_gain * ECA(x) * alpha + shortcut, timm NormFreeBlock.forward tail)
+// ACT: also act = silu(out) * act_scale, the activation the NEXT block opens with (timm NormFreeBlock.forward: act1(x) * beta), taken from
+// the ROUNDED out -- bit for bit what silu_fwd_kernel makes of the stored tensor -- so that tensor is not read back by a pass of its own
+template <bool ACT>
 __global__ __launch_bounds__(256) void scale_residual_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ gate,
-                                                                 const bf16* __restrict__ shortcut, bf16* __restrict__ out, int HW, int C,
-                                                                 float coef, size_t total) {
+                                                                 const bf16* __restrict__ shortcut, bf16* __restrict__ out, bf16* __restrict__ act,
+                                                                 int HW, int C, float coef, float act_scale, size_t total) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const int c8n = C >> 3, c = (int)(idx % c8n) * 8;
   const size_t b = idx / ((size_t)c8n * HW);
   const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + idx * 8), sc = *reinterpret_cast<const bf16x8*>(shortcut + idx * 8);
-  bf16x8 o;
+  bf16x8 o, a;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(v[j]) * gate[b * C + c + j] * coef + bf2f(sc[j]));
+  for (int j = 0; j < 8; ++j) {
+    o[j] = f2bf(bf2f(v[j]) * gate[b * C + c + j] * coef + bf2f(sc[j]));
+    if (ACT) { const float r = bf2f(o[j]); a[j] = f2bf(r / (1.f + __expf(-r)) * act_scale); }
+  }
   *reinterpret_cast<bf16x8*>(out + idx * 8) = o;
+  if (ACT) *reinterpret_cast<bf16x8*>(act + idx * 8) = a;
 }
 
 // dx = dout * gate * coef + dpooled[b, c] / HW
@@ -648,8 +655,8 @@ extern "C" int ia_eca_fwd(const void* x, const float* conv_w, int k, const void*
   if (rc) return rc;
   hipLaunchKernelGGL(eca_gate_fwd_kernel, dim3((B * C + 255) / 256), dim3(256), 0, stream, (const float*)pooled, conv_w, gate, C, k, B * C);
   const size_t total = (size_t)B * HW * (C >> 3);
-  hipLaunchKernelGGL(scale_residual_fwd_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)x, (const float*)gate,
-                     (const bf16*)shortcut, (bf16*)out, HW, C, coef, total);
+  hipLaunchKernelGGL(scale_residual_fwd_kernel<false>, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)x, (const float*)gate,
+                     (const bf16*)shortcut, (bf16*)out, (bf16*)nullptr, HW, C, coef, 1.f, total);
   return ia_check_launch();
 }
 
@@ -660,9 +667,10 @@ extern "C" int ia_eca_fwd(const void* x, const float* conv_w, int k, const void*
 extern "C" size_t ia_eca_fwd_linear_workspace_bytes(int B, int HW, int Cmid) {
   return ia_gap_workspace_bytes(B, HW, Cmid) + (size_t)B * Cmid * sizeof(float);
 }
+// act_out (may be NULL): silu(out) * act_scale, the next block's opening activation, written by the same pass that writes out.
 extern "C" int ia_eca_fwd_linear(const void* x, const void* a, const void* what, const float* bias, int Cmid, const float* conv_w, int k,
-                                 const void* shortcut, void* out, float* pooled, float* gate, int B, int HW, int C, float coef, void* workspace,
-                                 size_t workspace_bytes, hipStream_t stream) {
+                                 const void* shortcut, void* out, void* act_out, float act_scale, float* pooled, float* gate, int B, int HW, int C,
+                                 float coef, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   (void)hipGetLastError();
   if (!x || !a || !what || !conv_w || !shortcut || !out || !pooled || !gate || k <= 0 || k > 16 || !(k & 1) || Cmid <= 0 || (Cmid & 7) || (C & 7))
     return IA_ERR_ARG;
@@ -674,8 +682,12 @@ extern "C" int ia_eca_fwd_linear(const void* x, const void* a, const void* what,
                      C, Cmid, B * C);
   hipLaunchKernelGGL(eca_gate_fwd_kernel, dim3((B * C + 255) / 256), dim3(256), 0, stream, (const float*)pooled, conv_w, gate, C, k, B * C);
   const size_t total = (size_t)B * HW * (C >> 3);
-  hipLaunchKernelGGL(scale_residual_fwd_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)x, (const float*)gate,
-                     (const bf16*)shortcut, (bf16*)out, HW, C, coef, total);
+  if (act_out)
+    hipLaunchKernelGGL(scale_residual_fwd_kernel<true>, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)x, (const float*)gate,
+                       (const bf16*)shortcut, (bf16*)out, (bf16*)act_out, HW, C, coef, act_scale, total);
+  else
+    hipLaunchKernelGGL(scale_residual_fwd_kernel<false>, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)x, (const float*)gate,
+                       (const bf16*)shortcut, (bf16*)out, (bf16*)nullptr, HW, C, coef, 1.f, total);
   return ia_check_launch();
 }
 

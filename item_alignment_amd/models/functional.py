@@ -7,6 +7,8 @@ return None for parameter inputs: autograd only carries activation gradients bet
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from .. import _lib
@@ -432,6 +434,9 @@ class PatchEmbedFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------ CoCa multimodal layers (cross_attn ensemble)
+_TRANSPOSED = os.environ.get("IA_TRANSPOSED_SHADOWS", "1") != "0"      # (models/base.py reads the same switch for the encoder layers)
+
+
 def _gemm(lib, a, a_ks, lda, b, b_ks, ldb, c, c_f32, ldc, M, N, K, epi=0, aux=None, ldaux=0, accumulate=0, what="ia_gemm_bf16"):
     ws_bytes = lib.ia_gemm_workspace_bytes(M, N, K, int(c_f32))
     ws = torch.empty(ws_bytes, device=c.device, dtype=torch.uint8) if ws_bytes else None
@@ -462,6 +467,9 @@ class LinearBf16Fn(torch.autograd.Function):
         _gemm(lib, x, 0, K, w, 0, K, y, False, N, M, N, K, epi=3 if add is not None else 0, aux=add, ldaux=N if add is not None else 0)
         ctx.weight, ctx.owner = weight, owner
         ctx.x, ctx.swiglu_src, ctx.x_shape = (None, swiglu_src, (M, K)) if swiglu_src is not None else (x, None, (M, K))
+        # W^T image for the data gradient (k-contiguous NT form: x 1.02-1.16 per launch over the k-strided form, profiles/r05_nn_vs_nt.txt;
+        # the encoder layers have had theirs since round 5).  No extra memory: shadow_t spans the whole arena once anybody registers.
+        ctx.wt = owner.arena.register_transposed(weight) if (_TRANSPOSED and ctx.needs_input_grad[0] and M >= 1024) else None
         ctx.need_dx, ctx.has_add = ctx.needs_input_grad[0], add is not None
         return y
 
@@ -479,9 +487,13 @@ class LinearBf16Fn(torch.autograd.Function):
         N = weight.shape[0]
         dx = None
         if ctx.need_dx:
-            dx = torch.empty_like(x)
-            w = ctx.owner.arena.shadow_of(weight)
-            _gemm(lib, dy, 0, N, w, 1, K, dx, False, K, M, K, N, what="ia_gemm_bf16[dgrad]")
+            dx = torch.empty((M, K), device=dy.device, dtype=BF16)
+            if ctx.wt is not None:
+                ctx.owner.arena.transposed_ready()
+                _gemm(lib, dy, 0, N, ctx.wt, 0, N, dx, False, K, M, K, N, what="ia_gemm_bf16[dgrad, W^T]")
+            else:
+                w = ctx.owner.arena.shadow_of(weight)
+                _gemm(lib, dy, 0, N, w, 1, K, dx, False, K, M, K, N, what="ia_gemm_bf16[dgrad]")
         if weight.requires_grad:
             _gemm(lib, dy, 1, N, x, 1, K, weight.grad, True, K, N, K, M, accumulate=1, what="ia_gemm_bf16[wgrad]")
             _notify([weight])

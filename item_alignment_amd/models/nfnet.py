@@ -23,6 +23,7 @@ NONLIN_GAMMA_SILU = 1.7881293296813965          # timm nfnet.py _nonlin_gamma['s
 # stride-1 grouped 3x3 convolutions run as shifted-view GEMMs over a zero-bordered tensor; IA_CONV_PATCH_MATRIX=1 keeps the
 # gathered patch matrix for them too (A/B measurement switch, tools/config_bench.py)
 PADDED_CONV = os.environ.get("IA_CONV_PATCH_MATRIX", "0") != "1"
+FUSE_TAIL_ACT = os.environ.get("IA_NFNET_FUSE_TAIL", "1") != "0"   # a block's tail pass also writes the next block's opening activation (EcaResidualFn)
 ECA_LINEAR = os.environ.get("IA_ECA_LINEAR", "1") != "0"      # ECA pooling from conv3's input (EcaResidualFn); 0: the reduction over conv3's output
 
 NFNET_CONFIGS = {   # timm nfnet.py model_cfgs (_nfnet_cfg): depths, channels, feat_mult
@@ -261,13 +262,18 @@ class AvgPool2Fn(torch.autograd.Function):
 
 
 class EcaResidualFn(torch.autograd.Function):
-    """out = x * sigmoid(conv1d(mean_HW x)) * (attn_gain * alpha) + shortcut  (timm EcaModule + NormFreeBlock.forward tail)."""
+    """out = x * sigmoid(conv1d(mean_HW x)) * (attn_gain * alpha) + shortcut  (timm EcaModule + NormFreeBlock.forward tail).
+
+    pre = (a, what, bias): x = a what^T + bias is the output of a 1x1 convolution (conv3): the ECA pooling mean_HW(x) is then taken as
+    (mean_HW a) what^T + bias -- exact, the mean commutes with the per-pixel linear map -- from the 4 x narrower tensor a
+    (ia_eca_fwd_linear, round 6; IA_ECA_LINEAR=0 keeps the reduction over x for A/B runs).
+    act_mode 1 / 2 (with pre): the same pass also writes act = silu(out) * act_scale, the activation the NEXT block opens with
+    (act1(x) * beta; mode 2 hands it out twice: a downsampling block feeds it to conv1 and to the projected shortcut), so `out` is not
+    read back by a SiLU pass of its own; the gradient that arrives through act is folded into out's by ia_silu_bwd(_sum) here -- the
+    same kernels SiluFn.backward ran, the same arithmetic."""
 
     @staticmethod
-    def forward(ctx, x, shortcut, conv_w, eca, B, HW, coef, pre=None):
-        # pre = (a, what, bias): x = a what^T + bias is the output of a 1x1 convolution (conv3): the ECA pooling mean_HW(x) is then taken
-        # as (mean_HW a) what^T + bias -- exact, the mean commutes with the per-pixel linear map -- from the 4 x narrower tensor a
-        # (ia_eca_fwd_linear, round 6; IA_ECA_LINEAR=0 keeps the reduction over x for A/B runs).  Backward is the same either way.
+    def forward(ctx, x, shortcut, conv_w, eca, B, HW, coef, pre=None, act_scale=1.0, act_mode=0):
         lib = _lib.load()
         x, shortcut = x.contiguous(), shortcut.contiguous()
         C, k = x.shape[1], conv_w.shape[-1]
@@ -275,28 +281,54 @@ class EcaResidualFn(torch.autograd.Function):
         out = torch.empty_like(x)
         pooled = torch.empty((B, C), device=dev, dtype=F32)
         gate = torch.empty((B, C), device=dev, dtype=F32)
+        act = None
         if pre is not None and ECA_LINEAR:
             a, what, bias = pre
             Cmid = a.shape[1]
             wsb = lib.ia_eca_fwd_linear_workspace_bytes(B, HW, Cmid)
             ws = _ws(dev, wsb)
+            if act_mode:
+                act = torch.empty_like(x)
             check(lib.ia_eca_fwd_linear(x.data_ptr(), a.data_ptr(), what.data_ptr(), ptr(bias), Cmid, conv_w.data_ptr(), k, shortcut.data_ptr(),
-                                        out.data_ptr(), pooled.data_ptr(), gate.data_ptr(), B, HW, C, coef, ws.data_ptr(), wsb, stream_ptr()),
-                  "ia_eca_fwd_linear")
+                                        out.data_ptr(), ptr(act), act_scale, pooled.data_ptr(), gate.data_ptr(), B, HW, C, coef, ws.data_ptr(), wsb,
+                                        stream_ptr()), "ia_eca_fwd_linear")
         else:
             wsb = lib.ia_gap_workspace_bytes(B, HW, C)
             ws = _ws(dev, wsb)
             check(lib.ia_eca_fwd(x.data_ptr(), conv_w.data_ptr(), k, shortcut.data_ptr(), out.data_ptr(), pooled.data_ptr(), gate.data_ptr(), B, HW, C,
                                  coef, ws.data_ptr(), wsb, stream_ptr()), "ia_eca_fwd")
         ctx.eca, ctx.saved, ctx.dims = eca, (x, pooled, gate), (B, HW, C, k, coef)
-        return out
+        ctx.act_scale, ctx.out = act_scale, (out if act is not None else None)
+        if act is None:
+            return out
+        ctx.set_materialize_grads(False)
+        return (out, act, act.view_as(act)) if act_mode == 2 else (out, act)
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dact=None, dact2=None):
         lib = _lib.load()
         x, pooled, gate = ctx.saved
         B, HW, C, k, coef = ctx.dims
         w = ctx.eca.conv.weight
+        if ctx.out is not None:
+            # out's whole gradient = what arrives at `out` itself (the next block's identity shortcut; nothing for a downsampling block)
+            # + (dact [+ dact2]) * act_scale * silu'(out)
+            g1, g2 = (dact, dact2) if dact is not None else (dact2, None)
+            if g1 is not None:
+                out = ctx.out
+                dtot = torch.empty_like(out)
+                dadd = None if dout is None else dout.contiguous()
+                if g2 is None:
+                    check(lib.ia_silu_bwd(g1.contiguous().data_ptr(), out.data_ptr(), ptr(dadd), dtot.data_ptr(), out.numel(), ctx.act_scale,
+                                          stream_ptr()), "ia_silu_bwd")
+                else:
+                    check(lib.ia_silu_bwd_sum(g1.contiguous().data_ptr(), g2.contiguous().data_ptr(), out.data_ptr(), ptr(dadd), dtot.data_ptr(),
+                                              out.numel(), ctx.act_scale, stream_ptr()), "ia_silu_bwd_sum")
+                dout = dtot
+            ctx.out = None
+        if dout is None:
+            ctx.saved = None
+            return (None,) * 10
         dout = dout.contiguous()
         dx = torch.empty_like(x)
         wsb = lib.ia_eca_bwd_workspace_bytes(B, HW, C)
@@ -305,7 +337,7 @@ class EcaResidualFn(torch.autograd.Function):
                              w.grad.data_ptr() if w.requires_grad else None, B, HW, C, coef, ws.data_ptr(), wsb, stream_ptr()), "ia_eca_bwd")
         Fn._notify([w])
         ctx.saved = None
-        return dx, dout, None, None, None, None, None, None
+        return dx, dout, None, None, None, None, None, None, None, None
 
 
 class GapFn(torch.autograd.Function):
@@ -335,10 +367,11 @@ class GapFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------- modules
 class FeatureMap:
     """NHWC feature map handed between the tower's modules: rows [B*H*W, C] bf16 + its geometry."""
-    __slots__ = ("t", "B", "H", "W")
+    __slots__ = ("t", "B", "H", "W", "act")
 
-    def __init__(self, t, B, H, W):
+    def __init__(self, t, B, H, W, act=None):
         self.t, self.B, self.H, self.W = t, B, H, W
+        self.act = act          # (tensors) the next block's opening activation silu(t) * beta, when the producing block tail wrote it already
 
     @property
     def shape(self):
@@ -417,14 +450,16 @@ class NormFreeBlock(nn.Module):
         self.conv3 = ScaledStdConv2d(mid_chs, out_chs, 1, gain_init=0.0)       # timm: gain_init = 1 if skipinit else 0
         self.attn_last = EcaModule(out_chs)
 
-    def forward(self, f):
+    def forward(self, f, next_block=None):
+        """next_block: the NormFreeBlock that consumes this block's output (None: something else does, e.g. final_conv) -- its opening
+        activation silu(out) * beta' is then written by this block's tail pass (EcaResidualFn) and travels as FeatureMap.act"""
         act = lambda g: FeatureMap(SiluFn.apply(g.t, 1.0, False), g.B, g.H, g.W)
         if self.downsample is not None:
-            ya, yb = SiluFn.apply(f.t, self.beta, 2)
+            ya, yb = f.act if f.act is not None else SiluFn.apply(f.t, self.beta, 2)
             out = FeatureMap(ya, f.B, f.H, f.W)
             shortcut = self.downsample(FeatureMap(yb, f.B, f.H, f.W)).t
         else:
-            o, shortcut = SiluFn.apply(f.t, self.beta, True)
+            o, shortcut = (f.act[0], f.t) if f.act is not None else SiluFn.apply(f.t, self.beta, True)
             out = FeatureMap(o, f.B, f.H, f.W)
         out = self.conv1(out)
         B, H, W = out.B, out.H, out.W
@@ -448,7 +483,12 @@ class NormFreeBlock(nn.Module):
         a = out.t                                                 # conv3's input [B*H*W, mid] (contiguous: every producer above allocates it)
         out = self.conv3(out)
         pre = (a, self.conv3.__dict__.pop("_last_what"), self.conv3.bias) if a.is_contiguous() else None
-        y = EcaResidualFn.apply(out.t, shortcut, self.attn_last.conv.weight, self.attn_last, out.B, out.H * out.W, self.attn_gain * self.alpha, pre)
+        fuse = next_block is not None and pre is not None and ECA_LINEAR and FUSE_TAIL_ACT
+        mode = 0 if not fuse else (2 if next_block.downsample is not None else 1)
+        y = EcaResidualFn.apply(out.t, shortcut, self.attn_last.conv.weight, self.attn_last, out.B, out.H * out.W, self.attn_gain * self.alpha, pre,
+                                next_block.beta if fuse else 1.0, mode)
+        if mode:
+            return FeatureMap(y[0], out.B, out.H, out.W, act=tuple(y[1:]))
         return FeatureMap(y, out.B, out.H, out.W)
 
 
@@ -532,9 +572,9 @@ class NormFreeNet(HipModule):
                     f = FeatureMap(SiluFn.apply(f.t, 1.0, False), f.B, f.H, f.W)
                 padded = to_padded
             i += 1
-        for stage in self.stages:
-            for blk in stage:
-                f = blk(f)
+        blocks = [blk for stage in self.stages for blk in stage]
+        for i, blk in enumerate(blocks):
+            f = blk(f, blocks[i + 1] if i + 1 < len(blocks) else None)
         f = self.final_conv(f)
         return FeatureMap(SiluFn.apply(f.t, 1.0, False), f.B, f.H, f.W)
 

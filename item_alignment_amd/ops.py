@@ -125,8 +125,10 @@ def attn_fwd(qkv, B, L, nh, *, key_mask=None, scale=0.125, drop_p=0.0, seed=0, q
     return out, lse
 
 
-def attn_bwd(qkv, ctx, d_ctx, lse, B, L, nh, *, key_mask=None, scale=0.125, drop_p=0.0, seed=0, dbias=None, q_prescaled=False):
-    """dbias (fp32 [3H], optional): += column sums of dqkv, i.e. the bias gradient of the fused QKV projection, out of the same launches"""
+def attn_bwd(qkv, ctx, d_ctx, lse, B, L, nh, *, key_mask=None, scale=0.125, drop_p=0.0, seed=0, dbias=None, q_prescaled=False, return_delta=False):
+    """dbias (fp32 [3H], optional): += column sums of dqkv, i.e. the bias gradient of the fused QKV projection, out of the same launches.
+    return_delta: also hand back the [B, nh, L] scratch (the softmax-gradient delta where the dQ / dK,dV kernel pair ran: L > 256 or
+    IA_ATTN_EXACT_DELTA=1; the fused backward keeps its key bits there)"""
     lib = _lib.load()
     _need(qkv, BF16, "qkv"); _need(ctx, BF16, "ctx"); _need(d_ctx, BF16, "d_ctx"); _need(lse, F32, "lse")
     H = nh * 64
@@ -142,11 +144,11 @@ def attn_bwd(qkv, ctx, d_ctx, lse, B, L, nh, *, key_mask=None, scale=0.125, drop
         check(fn(base, base + 2 * H, base + 4 * H, 3 * H, ptr(key_mask), ctx.data_ptr(), d_ctx.data_ptr(), H, lse.data_ptr(),
                                    delta.data_ptr(), dbase, dbase + 2 * H, dbase + 4 * H, 3 * H, dbias.data_ptr(), ws.data_ptr(), ws.numel(),
                                    B, nh, L, scale, drop_p, seed, stream_ptr()), "ia_attn_bwd_bias")
-        return dqkv
+        return (dqkv, delta) if return_delta else dqkv
     check(lib.ia_attn_bwd(base, base + 2 * H, base + 4 * H, 3 * H, ptr(key_mask), ctx.data_ptr(), d_ctx.data_ptr(), H, lse.data_ptr(),
                           delta.data_ptr(), dbase, dbase + 2 * H, dbase + 4 * H, 3 * H, B, nh, L, scale, drop_p, seed, stream_ptr()),
           "ia_attn_bwd")
-    return dqkv
+    return (dqkv, delta) if return_delta else dqkv
 
 
 def cast_to_bf16(src, dst=None):

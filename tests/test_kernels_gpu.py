@@ -205,6 +205,60 @@ def test_attention_fwd_bwd(gpu, B, L, nh, masked):
         assert rel_err(got, want) < 3e-2, name
 
 
+@pytest.mark.parametrize("B,L,nh,masked,drop", [(2, 255, 4, True, 0.0), (2, 577, 3, False, 0.0), (2, 130, 2, True, 0.1), (1, 510, 2, True, 0.0),
+                                                (3, 20, 1, True, 0.0), (2, 255, 16, True, 0.1)])
+def test_attention_exact_delta_opt_in(gpu, monkeypatch, B, L, nh, masked, drop):
+    """IA_ATTN_EXACT_DELTA=1 (round 6): a pre-pass forms the softmax-gradient delta_q = sum_k P_qk dP_qk in fp32 and the dQ / dK,dV kernels
+    read it, instead of the flash-style rowsum(dO o O) taken from the bf16-ROUNDED context (reference: torch autograd of
+    transformers' RobertaSelfAttention, src/models/text.py:1241, differentiates softmax exactly).  Checked: the delta it leaves equals
+    rowsum(dO o O_fp32) of the fp32 reference; the gradients keep the common bar; on an operand set built to make dP - delta a small
+    difference of large numbers (near-uniform P, value rows that differ little -- the shape of the C5 last-layer case)
+    the exact form is several times closer to fp32 than the default; with dropout the results stay finite and within bf16 of the
+    default's; switching the variable off again restores the default bit for bit."""
+    from item_alignment_amd import ops
+    H = nh * 64
+    qkv = rnd((B * L, 3 * H), gpu, 1.0, 54)
+    dctx = rnd((B * L, H), gpu, 1.0, 55)
+    mask = None
+    if masked:
+        lens = torch.tensor([L - 3 * (i + 1) for i in range(B)])
+        mask = (torch.arange(L)[None, :] < lens[:, None]).to(torch.uint8).to(gpu)
+    ctx, lse = ops.attn_fwd(qkv, B, L, nh, key_mask=mask, drop_p=drop, seed=9)
+    flash = ops.attn_bwd(qkv, ctx, dctx, lse, B, L, nh, key_mask=mask, drop_p=drop, seed=9)
+    monkeypatch.setenv("IA_ATTN_EXACT_DELTA", "1")
+    exact, delta = ops.attn_bwd(qkv, ctx, dctx, lse, B, L, nh, key_mask=mask, drop_p=drop, seed=9, return_delta=True)
+    exact_b = ops.attn_bwd(qkv, ctx, dctx, lse, B, L, nh, key_mask=mask, drop_p=drop, seed=9, dbias=torch.zeros(3 * H, device=gpu))
+    assert torch.equal(exact, exact_b)                              # both entry points take the same route
+    assert torch.isfinite(exact).all() and torch.isfinite(delta).all()
+    assert rel_err(exact, flash) < 3e-2
+    if drop == 0.0:
+        ref, dref = attn_ref(qkv, B, L, nh, mask, dctx)
+        want = (dctx.float() * ref).view(B, L, nh, 64).sum(-1).permute(0, 2, 1)      # rowsum(dO o O) with the fp32 context = sum_k P dP
+        assert rel_err(delta, want) < 1e-2
+        for i, name in enumerate("qkv"):
+            assert rel_err(exact.view(B * L, 3, H)[:, i], dref.view(B * L, 3, H)[:, i]) < 3e-2, name
+        # the adverse case: P near uniform, dP nearly the same for every key
+        g = torch.Generator(device="cpu").manual_seed(77)
+        t = torch.randn((B * L, 3, nh, 64), generator=g)
+        t[:, 0] *= 0.05
+        t[:, 2] = torch.randn((1, nh, 64), generator=g) + 0.02 * t[:, 2]
+        qkv2 = t.reshape(B * L, 3 * H).to(gpu).to(torch.bfloat16)
+        ctx2, lse2 = ops.attn_fwd(qkv2, B, L, nh, key_mask=mask)
+        ref2, dref2 = attn_ref(qkv2, B, L, nh, mask, dctx)
+        e2 = ops.attn_bwd(qkv2, ctx2, dctx, lse2, B, L, nh, key_mask=mask)
+        monkeypatch.setenv("IA_ATTN_EXACT_DELTA", "0")
+        f2 = ops.attn_bwd(qkv2, ctx2, dctx, lse2, B, L, nh, key_mask=mask)
+        want_q, want_k = dref2.view(B * L, 3, H)[:, 0], dref2.view(B * L, 3, H)[:, 1]
+        err = {n: (rel_err(x.view(B * L, 3, H)[:, 0], want_q), rel_err(x.view(B * L, 3, H)[:, 1], want_k)) for n, x in (("exact", e2), ("flash", f2))}
+        print("adverse case, (dq, dk) error against fp32:", err)
+        # measured on an MI355X: flash 0.13-0.24 / 0.05-0.11, exact 0.013-0.050 / 0.005-0.030 (the largest at L = 20, where a row's 20
+        # rounded probabilities are the noise floor for either form)
+        assert err["exact"][0] < 6e-2 and err["exact"][1] < 4e-2, err
+        assert err["exact"][0] < 0.5 * err["flash"][0] and err["exact"][1] < 0.5 * err["flash"][1], err
+    monkeypatch.setenv("IA_ATTN_EXACT_DELTA", "0")
+    assert torch.equal(flash, ops.attn_bwd(qkv, ctx, dctx, lse, B, L, nh, key_mask=mask, drop_p=drop, seed=9))
+
+
 @pytest.mark.parametrize("B,L,nh,masked,drop", [(3, 255, 4, True, 0.0), (2, 577, 3, False, 0.0), (2, 130, 2, True, 0.1), (1, 64, 1, False, 0.0)])
 def test_attention_bwd_bias_gradient(gpu, B, L, nh, masked, drop):
     """ia_attn_bwd_bias: the QKV bias gradient out of the attention backward epilogues = column sums of the dqkv it stores (exactly the
@@ -696,12 +750,21 @@ def test_eca_block_tail_pools_through_the_1x1_convolution(gpu, B, HW, Cmid, C):
     wsb = lib.ia_eca_fwd_linear_workspace_bytes(B, HW, Cmid)
     ws = torch.empty(wsb, device=gpu, dtype=torch.uint8)
     check(lib.ia_eca_fwd_linear(x.data_ptr(), a.data_ptr(), what.data_ptr(), bias.data_ptr(), Cmid, conv_w.data_ptr(), k, shortcut.data_ptr(),
-                                out.data_ptr(), pooled.data_ptr(), gate.data_ptr(), B, HW, C, coef, ws.data_ptr(), wsb, stream_ptr()), "ia_eca_fwd_linear")
+                                out.data_ptr(), None, 1.0, pooled.data_ptr(), gate.data_ptr(), B, HW, C, coef, ws.data_ptr(), wsb, stream_ptr()),
+          "ia_eca_fwd_linear")
     assert rel_err(pooled, pooled_ref) < 1e-4
     assert rel_err(gate, gate_ref) < 1e-4
     assert rel_err(out.view(B, HW, C), out_ref) < 1e-2
     assert lib.ia_eca_fwd_linear(x.data_ptr(), a.data_ptr(), what.data_ptr(), bias.data_ptr(), Cmid, conv_w.data_ptr(), k, shortcut.data_ptr(),
-                                 out.data_ptr(), pooled.data_ptr(), gate.data_ptr(), B, HW, C, coef, ws.data_ptr(), wsb - 1, stream_ptr()) != 0
+                                 out.data_ptr(), None, 1.0, pooled.data_ptr(), gate.data_ptr(), B, HW, C, coef, ws.data_ptr(), wsb - 1, stream_ptr()) != 0
+    # the next block's opening activation out of the same pass: bit-identical to ia_silu_fwd on the stored out, and out itself unchanged
+    out_a, act = torch.empty_like(x), torch.empty_like(x)
+    check(lib.ia_eca_fwd_linear(x.data_ptr(), a.data_ptr(), what.data_ptr(), bias.data_ptr(), Cmid, conv_w.data_ptr(), k, shortcut.data_ptr(),
+                                out_a.data_ptr(), act.data_ptr(), 0.93, pooled.data_ptr(), gate.data_ptr(), B, HW, C, coef, ws.data_ptr(), wsb,
+                                stream_ptr()), "ia_eca_fwd_linear[act]")
+    want_act = torch.empty_like(x)
+    check(lib.ia_silu_fwd(out.data_ptr(), want_act.data_ptr(), out.numel(), 0.93, stream_ptr()), "ia_silu_fwd")
+    assert torch.equal(out_a, out) and torch.equal(act, want_act)
     out2, pooled2, gate2 = torch.empty_like(x), torch.empty_like(pooled), torch.empty_like(gate)
     wsb2 = lib.ia_gap_workspace_bytes(B, HW, C)
     ws2 = torch.empty(wsb2, device=gpu, dtype=torch.uint8)

@@ -102,7 +102,7 @@ def c2(pairs=128):
         pairs, 1.001e12, which="c2")
 
 
-def c3(pairs=32, S=800):      # 32 pairs/step since round 5 (profiles/r05_c3_batch_sweep.txt: 16 -> 425, 32 -> 467 pairs/s; 49.6 GiB)
+def c3(pairs=64, S=800):      # 64 pairs/step since round 6 (profiles/r05_c3_batch_sweep.txt: 16 -> 431, 32 -> 470, 64 -> 484 pairs/s; 98.6 GiB)
     from types import SimpleNamespace
     cfg = SimpleNamespace(num_labels=2, hidden_dropout_prob=0.1, loss_type="ce", loss_margin=0.0, classification_method="cls", hidden_size=2304)
     g = torch.Generator().manual_seed(0)
