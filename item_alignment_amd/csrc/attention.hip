@@ -1837,8 +1837,16 @@ constexpr int NW = 8, RING = 4;
 constexpr int SL_Q = 0, SL_G = 4096, SL_O = 8192, SL_LSE = 12288, SL_DLT = SL_LSE + 256, SL_RK = SL_LSE + 384, SLOT = SL_LSE + 512;
 constexpr int DLT_F = (SL_DLT - SL_LSE) / 4;          // delta's offset from lse in floats
 constexpr int KST = 0, VST = 32768, RING_OFF = 65536, X_OFF = RING_OFF + RING * SLOT;
-constexpr int XP = 72, XT = 32 * XP;                 // exchange tile [32 keys][32 queries] bf16, 72-byte rows (conflict-free b64 writes)
-static_assert(2 * XT == EPI_SLOT, "a wave's two exchange tiles double as its epilogue staging slot");
+// Exchange tile [32 keys][32 queries] bf16.  Round 6 layout: DENSE 64-byte rows, the 8-byte chunk c of row r stored at chunk position
+// c ^ xkey(r), xkey(r) = ((r >> 2) & 1) << 2 | (r >> 3) & 3 -- conflict-free for BOTH access forms: a 32-lane pass of the part-A b64 writes
+// is 32 rows x one chunk (the eight rows that share r mod 4, i.e. a 16-bank group, differ in (r >> 2): xkey is a bijection of those
+// three bits), a 32-lane pass of the part-C transpose reads is 8 rows x 32 bytes (rows r and r + 4 share a bank group and take
+// different 32-byte halves: xkey's bit 2 = bit 2 of r).  Rounds 4-5 used 72-byte rows: conflict-free writes, but rows r and r + 7 of a
+// read pass overlapped in six banks -- every read a two-way conflict (26 % of the kernel's LDS-active cycles in SQ_LDS_BANK_CONFLICT).
+// The tile keeps its 2304-byte slot (2 x XT = the epilogue staging slot of store_block_rows).
+constexpr int XP = 64, XT = 2304;
+IA_DEV int xkey(int r) { return (((r >> 2) & 1) << 2) | ((r >> 3) & 3); }
+static_assert(2 * XT == EPI_SLOT && 32 * XP <= XT && XT % 64 == 0, "a wave's two exchange tiles double as its epilogue staging slot");
 constexpr int CS_OFF = X_OFF + NW * 2 * XT;          // column sums: 8 x (dk[64] | dv[64]) + 8 x dq tile[16] floats
 constexpr int MSK_OFF = CS_OFF + NW * 128 * 4 + NW * 16 * 4;      // the next item's attendable-key bits: 8 words (one per key block), 256 B reserved
 constexpr int DUMMY_OFF = MSK_OFF + 256;             // 8 x 256 B: targets of the count-equalising out-of-range DMA pieces
@@ -1897,8 +1905,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnArgs p) {
   // transpose-read bases for MFMA 16x16x32 operands: 16-lane group g4 reads rows 4 g4 .. +3 (second read: + 16 rows) of 16 columns
   const uint32_t ktb = sbase + KST + (uint32_t)((4 * g4 + (p16 >> 2)) * 128 + ((((16 * dqt + 4 * (p16 & 3)) >> 3) ^ swz_u(4 * g4 + (p16 >> 2))) << 4) +
                                                 ((4 * (p16 & 3)) & 7) * 2);
-  const uint32_t xrb = sbase + X_OFF + (uint32_t)((4 * g4 + (p16 >> 2)) * XP + (16 * qh + 4 * (p16 & 3)) * 2);
-  const int xwo = X_OFF + wave * 2 * XT + lk * XP + hh * 8;      // this lane's row of the wave's exchange tile
+  // part C: rows 4 g4 + (p16 >> 2) (second read: + 16 rows, whose key differs in bit 1: address ^ 16, + 16 rows), chunk 4 qh + (p16 & 3)
+  const uint32_t xrb = sbase + X_OFF + (uint32_t)((4 * g4 + (p16 >> 2)) * XP + (((4 * qh + (p16 & 3)) ^ xkey(4 * g4 + (p16 >> 2))) << 3));
+  // part A: this lane's row of the wave's exchange tile, at its chunk hh; its chunks hh + 2 j (j = 0 .. 3) sit at this address ^ (j << 4)
+  // (hh + 2 j = hh ^ 2 j, the row base is a multiple of 64 and the XOR stays inside the row)
+  const int xwo = X_OFF + wave * 2 * XT + lk * XP + ((hh ^ xkey(lk)) << 3);
   const int r8 = lane >> 3, c8 = lane & 7;                // DMA piece: 8 rows x 8 chunks of 16 bytes
   // ---- DMA issue.  Every tensor keeps ONE descriptor base; per item only its size field moves: "up to the end of the item's last
   // row of this head", so rows >= L and the pieces of items past the end read as zeros without per-lane selects, the item / block /
@@ -2124,10 +2135,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnArgs p) {
               sf[hf][rr] = f2bf(nds);
             }
             // -dS^T to the exchange slot: row = key (this lane), two groups of 4 consecutive queries
-            char* const xw = smem + xwo + par * XT + hf * 32;
+            const int xa = xwo + par * XT;
             if (!(ABL & 8)) {
-            *reinterpret_cast<bf16x4*>(xw) = bf16x4{sf[hf][0], sf[hf][1], sf[hf][2], sf[hf][3]};
-            *reinterpret_cast<bf16x4*>(xw + 16) = bf16x4{sf[hf][4], sf[hf][5], sf[hf][6], sf[hf][7]};
+            *reinterpret_cast<bf16x4*>(smem + (xa ^ (hf * 32))) = bf16x4{sf[hf][0], sf[hf][1], sf[hf][2], sf[hf][3]};
+            *reinterpret_cast<bf16x4*>(smem + (xa ^ (hf * 32 + 16))) = bf16x4{sf[hf][4], sf[hf][5], sf[hf][6], sf[hf][7]};
             }
           };
           half(std::integral_constant<int, 0>{});
@@ -2161,12 +2172,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnArgs p) {
       }
       if (g == 0) return;
       {
-        const uint32_t xr = xrb + ((g - 1) & 1) * XT;
+        const uint32_t xr = xrb + ((g - 1) & 1) * XT, xr2 = xr ^ 16u;      // rows + 16: the swizzle key differs in bit 1
         s16x4 lo[8], hi[8];
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (!(ABL & 1)) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { lo[k] = tr_read<0>(xr + k * 2 * XT); hi[k] = tr_read<16 * XP>(xr + k * 2 * XT); }
+        for (int k = 0; k < 8; ++k) { lo[k] = tr_read<0>(xr + k * 2 * XT); hi[k] = tr_read<16 * XP>(xr2 + k * 2 * XT); }
 #define IA_DQ_STEP(k, n)                                                                                   \
         wait2<n>(lo[k], hi[k]);                                                                            \
         if ((vbits >> k) & 1u) acc = mfma16(KT[k], join(lo[k], hi[k]), acc);

@@ -467,3 +467,52 @@ def test_unsupported_image_tower_is_a_usage_error_at_argparse_time():
                         "--data_version", "v0", "--model_name", "resnetv2_50x1_bitm"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 2, (r.returncode, r.stderr[-500:])
     assert "has no HIP tower" in r.stderr and "resnetv2_50" in r.stderr and "usage:" in r.stderr
+
+
+def test_fused_backward_exchange_layout_is_conflict_free():
+    """The dS exchange tile of the one-kernel attention backward (csrc/attention.hip, bwdf: [32 keys][32 queries] bf16, dense 64-byte rows,
+    8-byte chunk c of row r at chunk position c ^ xkey(r)) under the LDS bank model of the guide (64 banks x 4 bytes, a b64 access served
+    in passes of 32 lanes): every pass of the part-A writes (32 key rows x one chunk) and of the part-C transpose reads (8 rows x 32
+    bytes) touches 64 distinct banks, both sides address the same bytes for the same (key, query), and the layout rounds 4-5 used
+    (72-byte rows, no XOR) fails the read test -- the two-way conflicts behind 26 % of that kernel's LDS-active cycles."""
+    def xkey(r):
+        return (((r >> 2) & 1) << 2) | ((r >> 3) & 3)
+
+    def addr_new(row, chunk):
+        return row * 64 + ((chunk ^ xkey(row)) << 3)
+
+    def addr_old(row, chunk):
+        return row * 72 + chunk * 8
+
+    def banks(addrs):                                   # an 8-byte access covers two banks
+        return [b for a in addrs for b in ((a >> 2) & 63, ((a >> 2) + 1) & 63)]
+
+    def write_passes(addr):                             # lane (lk, hh) writes chunk hh + 4 hf + 2 s of row lk
+        for hf in (0, 1):
+            for s in (0, 1):
+                for hh in (0, 1):
+                    yield [addr(lk, hh + 4 * hf + 2 * s) for lk in range(32)]
+
+    def read_passes(addr):                              # 16-lane group g4: rows 4 g4 + (p >> 2) [+ 16], chunk 4 qh + (p & 3)
+        for qh in (0, 1):
+            for second in (0, 16):
+                for half in (0, 1):
+                    yield [addr(4 * g4 + (p >> 2) + second, 4 * qh + (p & 3)) for g4 in (2 * half, 2 * half + 1) for p in range(16)]
+
+    for p in write_passes(addr_new):
+        assert len(set(banks(p))) == 64
+    for p in read_passes(addr_new):
+        assert len(set(banks(p))) == 64
+    assert all(len(set(banks(p))) == 64 for p in write_passes(addr_old))
+    assert any(len(set(banks(p))) < 64 for p in read_passes(addr_old))
+    # a bijection of the tile's 256 chunks onto 2 KiB
+    assert sorted(addr_new(r, c) for r in range(32) for c in range(8)) == list(range(0, 2048, 8))
+    # the kernel's own address forms: part A's (row base | chunk hh) ^ (j << 4) and part C's second read (first ^ 16) + 16 rows
+    for lk in range(32):
+        for hh in (0, 1):
+            base = lk * 64 + ((hh ^ xkey(lk)) << 3)
+            for j in range(4):
+                assert base ^ (j << 4) == addr_new(lk, hh + 2 * j)
+    for row in range(16):
+        for chunk in range(8):
+            assert (addr_new(row, chunk) ^ 16) + 16 * 64 == addr_new(row + 16, chunk)

@@ -132,8 +132,13 @@ def test_optimizer_state_dict_round_trip(gpu):
     o2.load_state_dict(sd_opt)
     run(m2, o2, 2)
     torch.cuda.synchronize()
-    for (n, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):     # (atomically accumulated embedding tables: see above)
-        assert torch.allclose(p.detach(), q.detach(), rtol=0, atol=2e-6), (n, (p.detach() - q.detach()).abs().max().item())
+    # The three embedding tables' gradients are fp32 atomic adds in arrival order (embed_ln_bwd_kernel): an element whose contributions
+    # cancel to ~1e-5 of their size moves by ~1e-2 relative from run to run, which Adam's normalised update turns into ~1e-6 of weight
+    # at lr 1e-4 -- at the common bar this test failed about one full-suite run in five (round 6).  Everything else is bit-stable up
+    # to what those tables feed forward and keeps 2e-6.
+    for (n, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+        atol = 2e-5 if n.endswith("_embeddings.weight") else 2e-6
+        assert torch.allclose(p.detach(), q.detach(), rtol=0, atol=atol), (n, (p.detach() - q.detach()).abs().max().item())
 
 
 def test_optimizer_loads_a_torch_adamw_checkpoint_saved_before_its_first_step(gpu):

@@ -17,7 +17,8 @@ cd "$R" && mkdir -p gpurun_out
 sub=$1; shift
 case "$sub" in
   suite)
-    python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > gpurun_out/${TAG}_gpu_suite.txt; cat gpurun_out/${TAG}_gpu_suite.txt ;;
+    python -m pytest tests -m gpu -x -q --tb=short "$@" > gpurun_out/${TAG}_gpu_suite_full.txt 2>&1      # (the whole log: gpurun only echoes a tail)
+    grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/${TAG}_gpu_suite_full.txt | cut -c1-600 | tail -25 > gpurun_out/${TAG}_gpu_suite.txt; cat gpurun_out/${TAG}_gpu_suite.txt ;;
   tests)
     python -m pytest "$@" -q -x 2>&1 | grep -E "passed|failed|error|^E  |^FAILED" | cut -c1-300 ;;
   bench)
