@@ -132,6 +132,16 @@ int ia_attn_fwd_ps(const void* q, const void* k, const void* v, int ld_qkv, cons
 int ia_attn_bwd_bias_ps(const void* q, const void* k, const void* v, int ld_qkv, const uint8_t* key_mask, const void* out, const void* d_out,
                         int ld_o, const float* lse2, float* delta, void* dq, void* dk, void* dv, int ld_dqkv, float* dbias, void* workspace,
                         size_t workspace_bytes, int B, int nh, int L, float scale, float drop_p, uint32_t seed, ia_stream_t stream);
+/* (round 6, ABI 8) the same with flags.  IA_ATTN_MASKED_ROWS_DEAD: the caller guarantees d_out == 0 at every masked position (an
+ * encoder whose masked positions never reach the loss -- reference src/models/text.py:1241: RobertaEncoder under an attention mask,
+ * heads reading [CLS] / valid spans): the one-kernel backward (L <= 256) skips 32-query blocks that hold only masked positions;
+ * dq / dk / dv / dbias are identical to the unflagged call on such inputs. */
+#define IA_ATTN_Q_PRESCALED 1
+#define IA_ATTN_MASKED_ROWS_DEAD 2
+int ia_attn_bwd_bias_ex(int flags, const void* q, const void* k, const void* v, int ld_qkv, const uint8_t* key_mask, const void* out,
+                        const void* d_out, int ld_o, const float* lse2, float* delta, void* dq, void* dk, void* dv, int ld_dqkv, float* dbias,
+                        void* workspace, size_t workspace_bytes, int B, int nh, int L, float scale, float drop_p, uint32_t seed,
+                        ia_stream_t stream);
 
 /* General form (cross-attention and multi-query attention of the CoCa multimodal layers, src/models/multimodal.py:590-616
  * ParallelTransformerBlock and :665-706 CrossAttention): Lq queries attend to Lk keys per (sequence, head).  q / out /
@@ -228,6 +238,12 @@ size_t ia_eca_fwd_linear_workspace_bytes(int B, int HW, int Cmid);
 int ia_eca_fwd_linear(const void* x, const void* a, const void* what, const float* bias, int Cmid, const float* conv_w, int k,
                       const void* shortcut, void* out, void* act_out, float act_scale, float* pooled, float* gate, int B, int HW, int C,
                       float coef, void* workspace, size_t workspace_bytes, ia_stream_t stream);
+/* backward of a tail that wrote act_out: dtot = (dact [+ dact2]) * act_scale * silu'(out) [+ dout_direct] (= ia_silu_bwd / ia_silu_bwd_sum,
+ * bit for bit) is the whole gradient of out -- returned in dtot, it is also the shortcut's gradient -- and the gate gradient's spatial
+ * sums of dtot * x come out of the same pass; dx, dconv_w as ia_eca_bwd.  dact2 / dout_direct may be NULL (round 6, ABI 8). */
+int ia_eca_silu_bwd(const void* dact, const void* dact2, const void* out, const void* dout_direct, float act_scale, const void* x,
+                    const float* conv_w, int k, const float* pooled, const float* gate, void* dtot, void* dx, float* dconv_w, int B, int HW,
+                    int C, float coef, void* workspace, size_t workspace_bytes, ia_stream_t stream);
 size_t ia_eca_bwd_workspace_bytes(int B, int HW, int C);
 int ia_eca_bwd(const void* dout, const void* x, const float* conv_w, int k, const float* pooled, const float* gate, void* dx,
                float* dconv_w, int B, int HW, int C, float coef, void* workspace, size_t workspace_bytes, ia_stream_t stream);
@@ -433,6 +449,10 @@ typedef struct {
    * block above did that for this block's dy, so the separate column-sum pass over dy is skipped.  Zero / NULL = round-3 behaviour. */
   float* dx_colsum_out;
   int dy_colsum_done;
+  /* (ABI 8) nonzero: no output of a masked position (key_mask == 0) reaches the loss, so the gradient arriving at such rows is exactly
+   * zero in every layer -- the attention backward may skip query blocks made of masked positions only (IA_ATTN_MASKED_ROWS_DEAD).
+   * Zero = the round-5 behaviour (every row is computed). */
+  int masked_rows_dead;
 } ia_layer_cfg;
 
 /* per-layer activation stash (saved by forward, read by backward) and shared backward scratch */

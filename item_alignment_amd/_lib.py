@@ -26,7 +26,7 @@ class LayerGrads(C.Structure):
 class LayerCfg(C.Structure):
     _fields_ = [("B", i32), ("L", i32), ("H", i32), ("I", i32), ("nh", i32), ("pre_ln", i32), ("eps", f32),
                 ("hidden_drop", f32), ("attn_drop", f32), ("seed", u32), ("layer_id", u32), ("cu_seqlens", vp), ("total_tokens", i32),
-                ("dx_colsum_out", vp), ("dy_colsum_done", i32)]
+                ("dx_colsum_out", vp), ("dy_colsum_done", i32), ("masked_rows_dead", i32)]
 
 
 # name -> (restype, argtypes); must list every symbol include/itemalign.h declares
@@ -53,6 +53,7 @@ SIGNATURES = {
     "ia_attn_bwd_bias": (i32, [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, sz, i32, i32, i32, f32, f32, u32, vp]),
     "ia_attn_fwd_ps": (i32, [vp, vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, f32, f32, u32, vp]),
     "ia_attn_bwd_bias_ps": (i32, [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, sz, i32, i32, i32, f32, f32, u32, vp]),
+    "ia_attn_bwd_bias_ex": (i32, [i32, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, sz, i32, i32, i32, f32, f32, u32, vp]),
     "ia_gemm_bf16_qscale": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, i32, f32, vp]),
     "ia_attn_fwd_x": (i32, [vp, i32, vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, f32, f32, u32, vp]),
     "ia_attn_bwd_x": (i32, [vp, i32, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, f32, f32, u32, vp]),
@@ -84,6 +85,7 @@ SIGNATURES = {
     "ia_eca_fwd": (i32, [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, sz, vp]),
     "ia_eca_fwd_linear_workspace_bytes": (sz, [i32, i32, i32]),
     "ia_eca_fwd_linear": (i32, [vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, f32, vp, vp, i32, i32, i32, f32, vp, sz, vp]),
+    "ia_eca_silu_bwd": (i32, [vp, vp, vp, vp, f32, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, sz, vp]),
     "ia_eca_bwd_workspace_bytes": (sz, [i32, i32, i32]),
     "ia_eca_bwd": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, sz, vp]),
     "ia_conv3x3_padded_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),

@@ -20,6 +20,10 @@
 #include <type_traits>
 #include <cstdlib>
 
+// flag bits of ia_attn_bwd_bias_ex (include/itemalign.h; this file does not include the public header)
+#define IA_ATTN_Q_PRESCALED 1
+#define IA_ATTN_MASKED_ROWS_DEAD 2
+
 namespace {
 
 constexpr uint32_t OOB = 0xFFFFFFF0u;
@@ -46,6 +50,8 @@ struct AttnArgs {
   float* cs_part;                                 // backward, optional: [b*ntile + tile][3*nh*64] fp32 column sums of this workgroup's
                                                   // dq | dk | dv rows (the QKV bias gradient, summed over rows by ia_sum_rows_f32); null = off
   int exact_delta;                                // backward, IA_ATTN_EXACT_DELTA=1: `delta` already holds sum_k P dP in fp32 (attn_bwd3_delta_kernel)
+  int dead_queries;                               // backward (fused kernel): the caller guarantees d_o == 0 at every masked position, so a 32-query
+                                                  // block whose positions are all masked contributes nothing: it is skipped, its dq rows are zeros
 };
 
 // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): renumber them so that consecutive
@@ -1101,6 +1107,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_dq_kernel(AttnArgs p) {
     if ((lo & hi) != 0xFFFFFFFFu) ragged |= 1u << t;
     if ((lo | hi) != 0u) nkt = t + 1;
   }
+  // AttnArgs::dead_queries (round 6): a wave whose 32 query positions are all masked has dO == 0 there (the caller's guarantee), hence
+  // dS == 0 and dQ == 0: it keeps its share of the staging and skips the arithmetic; a workgroup without any live query walks one key
+  // tile instead of all of them.  Self-attention (Lq == Lk): the validity words of the keys are those of the query positions.
+  bool work = active;
+  if (p.dead_queries && p.cu == nullptr && p.Lq == p.Lk) {
+    const uint32_t mine = active ? s_valid[q0 >> 6][(q0 >> 5) & 1] : 0u;
+    const int t128 = tile * 2;                                      // this workgroup's 128 positions = tiles t128, t128 + 1 of the table
+    uint32_t any = s_valid[t128][0] | s_valid[t128][1];
+    if (t128 + 1 < nkt_all) any |= s_valid[t128 + 1][0] | s_valid[t128 + 1][1];
+    work = active && __builtin_amdgcn_readfirstlane(mine) != 0u;
+    if (__builtin_amdgcn_readfirstlane(any) == 0u) nkt = 1;
+  }
   nkt = __builtin_amdgcn_readfirstlane(nkt);
   ragged = __builtin_amdgcn_readfirstlane(ragged);
   if (nkt > 1) stage_tile(S1{}, 1);
@@ -1117,7 +1135,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_dq_kernel(AttnArgs p) {
     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (t + 2 < nkt) stage_tile(NEXT2{}, t + 2);
-    if (!active) return;
+    if (!work) return;
     bf16x8 xk0, xk1, xv0, xv1, yk0, yk1, yv0, yv1;        // K / V fragments of even / odd k-steps
     auto rd = [&](auto KB, bf16x8& k0, bf16x8& k1, bf16x8& v0, bf16x8& v1) {
       constexpr int kb = decltype(KB)::value;
@@ -1206,7 +1224,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_dq_kernel(AttnArgs p) {
   __builtin_amdgcn_s_barrier();                           // the epilogue rows are staged in the ring
   float* cs_lds = p.cs_part ? reinterpret_cast<float*>(smem + 4 * EPI_SLOT) + wave * 64 : nullptr;      // behind the four store slots
   if (!active && !cs_lds) return;
-  if (active) store_block_rows(smem + wave * EPI_SLOT, dq0, dq1, p.scale, false, p.dq + (qbase + q0) * p.ld_dq + h * 64, p.ld_dq, Lq - q0, lane, cs_lds);
+  if (active) store_block_rows(smem + wave * EPI_SLOT, dq0, dq1, p.scale, !work, p.dq + (qbase + q0) * p.ld_dq + h * 64, p.ld_dq, Lq - q0, lane, cs_lds);
   else zero_cs_row(cs_lds, lane);
   if (cs_lds) {           // workgroup-uniform: one row of the partial-sum matrix per workgroup
     __syncthreads();
@@ -1564,7 +1582,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
 // A masked key's outputs are stored as zero (its P is not bounded by the saved log-sum-exp; the garbage stays in its own column).
 namespace bwd3 {
 constexpr int KV_STAGE = 16384 + 512;                // Q | dO (unified layout: b128 and transpose reads) | lse[64] | delta[64]
-constexpr int KV_SMEM = 3 * KV_STAGE + 1024 + 512;   // + under dropout: 64 row keys (ia_rng_row) of the current query tile per wave; + 2 spare DMA slots
+constexpr int KV_SMEM = 3 * KV_STAGE + 1024 + 512 + 16;   // + under dropout: 64 row keys (ia_rng_row) of the current query tile per wave; + 2 spare DMA slots; + 4 words (round 6: last live query per wave)
 }
 
 template <bool DROPOUT>
@@ -1594,7 +1612,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_dkv_kernel(AttnArgs p) {
   const __amdgpu_buffer_rsrc_t rsD = ia_rsrc(p.delta + ((size_t)b * p.nh + h) * p.Lq, (uint32_t)Lq * 4u);
   const uint32_t sbase = lds_addr(smem);
   const uint32_t q_tile = (uint32_t)p.ld_q * 128u, q_half = (uint32_t)p.ld_q * 64u, g_tile = (uint32_t)p.ld_o * 128u, g_half = (uint32_t)p.ld_o * 64u;
-  const int nqt = (Lq + 63) >> 6;
+  int nqt = (Lq + 63) >> 6;
   // lane constants
   uint32_t ka[4], t0, t1, t0x, t1x, dqu, dgu;
   {
@@ -1657,8 +1675,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_dkv_kernel(AttnArgs p) {
       *qp = v;
     }
   }
+  // AttnArgs::dead_queries (round 6): the query tiles behind the last unmasked position bring dO == 0 (the caller's guarantee) -- nothing
+  // for dK / dV -- so the query loop ends with that position's tile (right-padded batches: ~45 % of the tiles at the bench's lengths).
+  // Each wave scans a quarter of the positions with ballots; the four maxima meet in LDS across the prologue's barrier.
+  int* const s_last = reinterpret_cast<int*>(smem + 3 * KV_STAGE + 1024 + 512);
+  const bool trim = p.dead_queries && p.mask != nullptr && p.cu == nullptr && p.Lq == p.Lk;
+  if (trim) {
+    int last = -1;
+    for (int base = wave * 64; base < Lq; base += 256) {
+      const int pos = base + lane;
+      const bool ok = pos < Lq && p.mask[rowbase + pos] != 0;
+      const uint64_t bal = __ballot(ok);
+      if (bal) last = base + 63 - __builtin_clzll(bal);
+    }
+    if (lane == 0) s_last[wave] = last;
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                           // the K / V row slots (stages 1-2) are free for query tiles
+  if (trim) {
+    const int last = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
+    const int live = __builtin_amdgcn_readfirstlane(last < 0 ? 1 : (last >> 6) + 1);
+    if (live < nqt) nqt = live;
+  }
   if (nqt > 1) stage_tile(S1{}, 1);
   f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
 
@@ -2030,7 +2068,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnArgs p) {
   for (int g = 0;; ++g) {
     const bool haveA = g < G;
     const bool first = cj == 0, last = cj == nb - 1;
-    auto part_a = [&](int ga, bool first_a) {
+    // blk: the query block of step ga inside its item.  Round 6: with AttnArgs::dead_queries a block whose 32 positions are all masked
+    // (right padding: 115 of 255 positions on the bench's ragged batches) is skipped -- its dO rows are exactly zero (the caller's
+    // guarantee: no output of a masked position reaches the loss, the position is masked as a key in every layer), hence dS = 0: nothing
+    // for dK / dV, and part C stores zeros for its dQ rows.  The step keeps its barrier, its DMA and its place in the ring.
+    auto part_a = [&](int ga, bool first_a, int blk) {
       {
         const int slot = ga & (RING - 1), par = ga & 1;
         if (first_a) {
@@ -2070,7 +2112,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnArgs p) {
           csq = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         // ---- part A of step g
-        if (mine) {
+        if (mine && (!p.dead_queries || ((vbits >> blk) & 1u))) {
           const uint32_t so = (uint32_t)(slot * SLOT);
           f32x16 s, dp;
           const float* const sL = reinterpret_cast<const float*>(smem + RING_OFF + slot * SLOT + SL_LSE) + 4 * hh;
@@ -2175,7 +2217,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnArgs p) {
         const uint32_t xr = xrb + ((g - 1) & 1) * XT, xr2 = xr ^ 16u;      // rows + 16: the swizzle key differs in bit 1
         s16x4 lo[8], hi[8];
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if (!(ABL & 1)) {
+        // (vbits still belongs to the item of step g-1 here: a new item's part A runs behind this part C)
+        if (!(ABL & 1) && (!p.dead_queries || ((vbits >> pcj) & 1u))) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) { lo[k] = tr_read<0>(xr + k * 2 * XT); hi[k] = tr_read<16 * XP>(xr2 + k * 2 * XT); }
 #define IA_DQ_STEP(k, n)                                                                                   \
@@ -2238,7 +2281,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnArgs p) {
     };
     part_c();
     if (!haveA) break;
-    if (!IA_FUSED_SWAP || grp == 0 || first) part_a(g, first);
+    if (!IA_FUSED_SWAP || grp == 0 || first) part_a(g, first, cj);
     // ---- the next block: wait for this wave's pieces of it, prepare it, publish everything with the step's barrier
     {
       // pieces issued after the ones waited for: the ring pieces of this and the previous interval (4), plus the 9 stage pieces when
@@ -2254,7 +2297,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnArgs p) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (!(ABL & 32)) __builtin_amdgcn_s_barrier();
-    if (IA_FUSED_SWAP && grp != 0 && !last) part_a(g + 1, false);      // group 1 runs one part A ahead inside an item
+    if (IA_FUSED_SWAP && grp != 0 && !last) part_a(g + 1, false, cj + 1);      // group 1 runs one part A ahead inside an item
     prev = cons; pcj = cj;
     if (++cj == nb) { cj = 0; adv(cons); }
   }
@@ -2438,7 +2481,7 @@ extern "C" size_t ia_attn_bwd_bias_workspace_bytes(int B, int nh, int L) {
   return (size_t)B * ((L + 127) / 128) * 3 * nh * 64 * sizeof(float);
 }
 
-static int attn_bwd_bias_impl(int q_prescaled, const void* q, const void* k, const void* v, int ld_qkv, const uint8_t* key_mask, const void* out,
+static int attn_bwd_bias_impl(int flags, const void* q, const void* k, const void* v, int ld_qkv, const uint8_t* key_mask, const void* out,
                               const void* d_out, int ld_o, const float* lse2, float* delta, void* dq, void* dk, void* dv, int ld_dqkv,
                               float* dbias, void* workspace, size_t workspace_bytes, int B, int nh, int L, float scale, float drop_p,
                               uint32_t seed, hipStream_t stream) {
@@ -2453,8 +2496,10 @@ static int attn_bwd_bias_impl(int q_prescaled, const void* q, const void* k, con
   a.mask = key_mask; a.lse2 = const_cast<float*>(lse2); a.delta = delta;
   a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.ld_dq = ld_dqkv; a.ld_dkv = ld_dqkv;
   a.cs_part = (float*)workspace;
+  const int q_prescaled = flags & IA_ATTN_Q_PRESCALED;
   if (q_prescaled && !fwd3::PRESCALE) return IA_ERR_ARG;
-  a.q_prescaled = q_prescaled;
+  a.q_prescaled = q_prescaled ? 1 : 0;
+  a.dead_queries = ((flags & IA_ATTN_MASKED_ROWS_DEAD) && key_mask) ? 1 : 0;
   dim3 grid(((L + 127) / 128) * nh * B), blk(256);
   a.exact_delta = exact_delta_on() ? 1 : 0;
   if (fused_applies(a)) launch_fused(a, stream);
@@ -2477,7 +2522,18 @@ extern "C" int ia_attn_bwd_bias_ps(const void* q, const void* k, const void* v, 
                                    const void* d_out, int ld_o, const float* lse2, float* delta, void* dq, void* dk, void* dv, int ld_dqkv,
                                    float* dbias, void* workspace, size_t workspace_bytes, int B, int nh, int L, float scale, float drop_p,
                                    uint32_t seed, hipStream_t stream) {
-  return attn_bwd_bias_impl(1, q, k, v, ld_qkv, key_mask, out, d_out, ld_o, lse2, delta, dq, dk, dv, ld_dqkv, dbias, workspace, workspace_bytes,
+  return attn_bwd_bias_impl(IA_ATTN_Q_PRESCALED, q, k, v, ld_qkv, key_mask, out, d_out, ld_o, lse2, delta, dq, dk, dv, ld_dqkv, dbias, workspace,
+                            workspace_bytes, B, nh, L, scale, drop_p, seed, stream);
+}
+// ia_attn_bwd_bias with flags (IA_ATTN_*): IA_ATTN_Q_PRESCALED = the _ps form; IA_ATTN_MASKED_ROWS_DEAD = the caller guarantees that d_out is
+// zero at every masked position (an encoder whose masked positions never reach the loss: they are masked as keys in every layer and no
+// head reads them) -- the one-kernel backward then skips the 32-query blocks that hold only masked positions; results are identical.
+extern "C" int ia_attn_bwd_bias_ex(int flags, const void* q, const void* k, const void* v, int ld_qkv, const uint8_t* key_mask, const void* out,
+                                   const void* d_out, int ld_o, const float* lse2, float* delta, void* dq, void* dk, void* dv, int ld_dqkv,
+                                   float* dbias, void* workspace, size_t workspace_bytes, int B, int nh, int L, float scale, float drop_p,
+                                   uint32_t seed, hipStream_t stream) {
+  if (flags & ~(IA_ATTN_Q_PRESCALED | IA_ATTN_MASKED_ROWS_DEAD)) return IA_ERR_ARG;
+  return attn_bwd_bias_impl(flags, q, k, v, ld_qkv, key_mask, out, d_out, ld_o, lse2, delta, dq, dk, dv, ld_dqkv, dbias, workspace, workspace_bytes,
                             B, nh, L, scale, drop_p, seed, stream);
 }
 

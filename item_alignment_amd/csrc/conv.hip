@@ -258,6 +258,59 @@ __global__ __launch_bounds__(256) void spatial_sum_kernel(const bf16* __restrict
   }
 }
 
+// The NormFreeBlock tail's backward meets the next block's opening activation (round 6): dtot = (dy [+ dy2]) * scale * silu'(o) [+ dadd]
+// -- silu_bwd_kernel's arithmetic: the whole gradient of the block output o -- written out AND, in the same pass, part[b][s][c] = sum over
+// the s-th slice of HW of dtot * x (x = the conv3 output the ECA gate scaled: the gate's gradient), which spatial_sum_kernel otherwise
+// takes by reading dtot and x again.  The products use the ROUNDED dtot, i.e. exactly what the two-kernel form multiplies.  Same
+// thread layout and fixed fold order as spatial_sum_kernel.
+__global__ __launch_bounds__(256) void silu_bwd_dot_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ dy2, const bf16* __restrict__ o,
+                                                           const bf16* __restrict__ dadd, const bf16* __restrict__ x, bf16* __restrict__ dtot,
+                                                           float* __restrict__ part, int HW, int C, int nsplit, float scale) {
+  __shared__ float red[256 * 8];
+  const int b = blockIdx.y, s = blockIdx.x;
+  const int per = (HW + nsplit - 1) / nsplit, h0 = s * per, h1 = min(HW, h0 + per);
+  const int c8n = C >> 3;
+  const int ncol = c8n < 256 ? c8n : 256, nlane = 256 / ncol;
+  const int col = threadIdx.x % ncol, lane = threadIdx.x / ncol;
+  for (int c0 = 0; c0 < c8n; c0 += ncol) {
+    const int c = (c0 + col) * 8;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    if (lane < nlane && c0 + col < c8n)
+      for (int hw = h0 + lane; hw < h1; hw += nlane) {
+        const size_t at = ((size_t)b * HW + hw) * C + c;
+        const bf16x8 g = *reinterpret_cast<const bf16x8*>(dy + at), v = *reinterpret_cast<const bf16x8*>(o + at);
+        const bf16x8 u = *reinterpret_cast<const bf16x8*>(x + at);
+        bf16x8 e, g2;
+        if (dadd) e = *reinterpret_cast<const bf16x8*>(dadd + at);
+        if (dy2) g2 = *reinterpret_cast<const bf16x8*>(dy2 + at);
+        bf16x8 t;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float a = bf2f(v[j]), sg = 1.f / (1.f + __expf(-a));
+          const float gy = bf2f(g[j]) + (dy2 ? bf2f(g2[j]) : 0.f);
+          t[j] = f2bf(gy * scale * sg * (1.f + a * (1.f - sg)) + (dadd ? bf2f(e[j]) : 0.f));
+          acc[j] += bf2f(t[j]) * bf2f(u[j]);
+        }
+        *reinterpret_cast<bf16x8*>(dtot + at) = t;
+      }
+    if (nlane > 1) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = acc[j];
+      __syncthreads();
+      if (lane == 0)
+        for (int l = 1; l < nlane; ++l)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += red[(l * ncol + col) * 8 + j];
+    }
+    if (lane == 0 && c0 + col < c8n)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) part[((size_t)b * nsplit + s) * C + c + j] = acc[j];
+  }
+}
+
 __global__ __launch_bounds__(256) void spatial_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int C, int nsplit,
                                                              float scale, int total) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -693,16 +746,42 @@ extern "C" int ia_eca_fwd_linear(const void* x, const void* a, const void* what,
 
 // dx (gradient of x); the shortcut's gradient is dout itself.  dconv_w [k] +=.  scratch: 2*B*C floats after the gap workspace.
 extern "C" size_t ia_eca_bwd_workspace_bytes(int B, int HW, int C) { return ia_gap_workspace_bytes(B, HW, C) + (size_t)2 * B * C * sizeof(float); }
+// everything behind the spatial partial sums of dout * x (part, in the workspace): gate gradient, conv1d weight gradient, dx
+static int eca_bwd_tail(const void* dout, const float* conv_w, int k, const float* pooled, const float* gate, void* dx, float* dconv_w, int B,
+                        int HW, int C, float coef, void* workspace, hipStream_t stream);
+
 extern "C" int ia_eca_bwd(const void* dout, const void* x, const float* conv_w, int k, const float* pooled, const float* gate, void* dx,
                           float* dconv_w, int B, int HW, int C, float coef, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   (void)hipGetLastError();
   if (!dout || !x || !conv_w || !pooled || !gate || !dx || k <= 0 || k > 16 || !(k & 1) || (C & 7)) return IA_ERR_ARG;
   if (!workspace || workspace_bytes < ia_eca_bwd_workspace_bytes(B, HW, C)) return IA_ERR_WORKSPACE;
   const int ns = nsplit_of(HW);
+  hipLaunchKernelGGL(spatial_sum_kernel, dim3(ns, B), dim3(256), 0, stream, (const bf16*)dout, (const bf16*)x, (float*)workspace, HW, C, ns);
+  return eca_bwd_tail(dout, conv_w, k, pooled, gate, dx, dconv_w, B, HW, C, coef, workspace, stream);
+}
+
+// ia_eca_bwd for a block tail that also wrote the next block's opening activation act = silu(out) * act_scale (ia_eca_fwd_linear's act_out):
+// dtot = (dact [+ dact2]) * act_scale * silu'(out) [+ dout_direct] is out's whole gradient (ia_silu_bwd / ia_silu_bwd_sum's arithmetic,
+// bit for bit), written to dtot -- the shortcut's gradient -- and the gate gradient's spatial sums come out of the same pass; dx, dconv_w
+// as ia_eca_bwd.  dact2 / dout_direct may be NULL.  Workspace: ia_eca_bwd_workspace_bytes.
+extern "C" int ia_eca_silu_bwd(const void* dact, const void* dact2, const void* out, const void* dout_direct, float act_scale, const void* x,
+                               const float* conv_w, int k, const float* pooled, const float* gate, void* dtot, void* dx, float* dconv_w, int B,
+                               int HW, int C, float coef, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dact || !out || !x || !conv_w || !pooled || !gate || !dtot || !dx || k <= 0 || k > 16 || !(k & 1) || (C & 7)) return IA_ERR_ARG;
+  if (!workspace || workspace_bytes < ia_eca_bwd_workspace_bytes(B, HW, C)) return IA_ERR_WORKSPACE;
+  const int ns = nsplit_of(HW);
+  hipLaunchKernelGGL(silu_bwd_dot_kernel, dim3(ns, B), dim3(256), 0, stream, (const bf16*)dact, (const bf16*)dact2, (const bf16*)out,
+                     (const bf16*)dout_direct, (const bf16*)x, (bf16*)dtot, (float*)workspace, HW, C, ns, act_scale);
+  return eca_bwd_tail(dtot, conv_w, k, pooled, gate, dx, dconv_w, B, HW, C, coef, workspace, stream);
+}
+
+static int eca_bwd_tail(const void* dout, const float* conv_w, int k, const float* pooled, const float* gate, void* dx, float* dconv_w, int B,
+                        int HW, int C, float coef, void* workspace, hipStream_t stream) {
+  const int ns = nsplit_of(HW);
   float* part = (float*)workspace;
   float* dgate = part + (size_t)B * ns * C;
   float* dpooled = dgate + (size_t)B * C;
-  hipLaunchKernelGGL(spatial_sum_kernel, dim3(ns, B), dim3(256), 0, stream, (const bf16*)dout, (const bf16*)x, part, HW, C, ns);
   hipLaunchKernelGGL(spatial_finish_kernel, dim3((B * C + 255) / 256), dim3(256), 0, stream, (const float*)part, dgate, C, ns, coef, B * C);
   hipLaunchKernelGGL(eca_gate_bwd_kernel, dim3((B * C + 255) / 256), dim3(256), 0, stream, (const float*)dgate, gate, conv_w, dpooled, C, k, B * C);
   if (dconv_w) hipLaunchKernelGGL(eca_gate_wgrad_kernel, dim3(k), dim3(1024), 0, stream, (const float*)dgate, gate, pooled, dconv_w, B, C, k);

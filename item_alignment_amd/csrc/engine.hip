@@ -115,8 +115,9 @@ int attn_bwd(const ia_layer_cfg* c, const char* qkv, const uint8_t* key_mask, co
                                 gqkv, gqkv + (size_t)H * 2, gqkv + (size_t)2 * H * 2, 3 * H, c->B, c->nh, c->L, scale, drop, seed, st);
     return rc ? rc : ia_colsum(gqkv, 3 * H, (int)rows_of(c), 3 * H, db_qkv, 1, ws, ws_bytes, st);
   }
-  return (ps ? ia_attn_bwd_bias_ps : ia_attn_bwd_bias)(qkv, qkv + (size_t)H * 2, qkv + (size_t)2 * H * 2, 3 * H, key_mask, ctx, dctx, H, lse, delta, gqkv,
-                          gqkv + (size_t)H * 2, gqkv + (size_t)2 * H * 2, 3 * H, db_qkv, ws, ws_bytes, c->B, c->nh, c->L, scale, drop, seed, st);
+  const int flags = (ps ? IA_ATTN_Q_PRESCALED : 0) | (c->masked_rows_dead ? IA_ATTN_MASKED_ROWS_DEAD : 0);
+  return ia_attn_bwd_bias_ex(flags, qkv, qkv + (size_t)H * 2, qkv + (size_t)2 * H * 2, 3 * H, key_mask, ctx, dctx, H, lse, delta, gqkv,
+                             gqkv + (size_t)H * 2, gqkv + (size_t)2 * H * 2, 3 * H, db_qkv, ws, ws_bytes, c->B, c->nh, c->L, scale, drop, seed, st);
 }
 
 }  // namespace

@@ -21,6 +21,9 @@ ACT_NONE, ACT_TANH = 0, 1
 # backward's data-gradient GEMMs run in the k-contiguous form; IA_TRANSPOSED_SHADOWS=0 keeps the k-strided form (no extra copy)
 import os as _os
 TRANSPOSED_SHADOWS = _os.environ.get("IA_TRANSPOSED_SHADOWS", "1") != "0"
+# padded text towers: the attention backward skips query blocks that hold only masked positions when the model reads none of them
+# (RobertaEncoder.forward(masked_rows_dead=True), set by RobertaModel under the same condition that allows IA_UNPAD); 0 = compute every row
+MASKED_ROWS_DEAD = _os.environ.get("IA_MASKED_ROWS_DEAD", "1") != "0"
 
 
 class SequenceClassifierOutput(OrderedDict):
@@ -364,6 +367,7 @@ class _EngineStack:
         c.attn_drop = self.attn_drop if training else 0.0
         c.seed = seed
         c.layer_id = self.layer_id_base + i
+        c.masked_rows_dead = int(self.__dict__.get("_masked_rows_dead", False))
         return c
 
 
@@ -399,11 +403,14 @@ class RobertaEncoder(nn.Module, _EngineStack):
                     w_fc2=l.output.dense.weight, b_fc2=l.output.dense.bias,
                     ln2_g=l.output.LayerNorm.weight, ln2_b=l.output.LayerNorm.bias)
 
-    def forward(self, hidden_states, attention_mask=None):
+    def forward(self, hidden_states, attention_mask=None, masked_rows_dead=False):
+        """masked_rows_dead: the caller reads no hidden state of a masked position (heads on [CLS] / valid spans) -- the gradient arriving
+        at such rows is then exactly zero in every layer and the attention backward may skip query blocks made of them (ia_layer_cfg)."""
         B, L, H = hidden_states.shape
         km = None
         if attention_mask is not None:
             km = (attention_mask != 0).to(torch.uint8).contiguous()
+        self.__dict__["_masked_rows_dead"] = bool(masked_rows_dead and km is not None and MASKED_ROWS_DEAD)
         outs = Fn.EncoderStackFn.apply(hidden_states.reshape(B * L, H), self.anchor, self, km, B, L, torch.is_grad_enabled(), None)
         return (hidden_states,) + tuple(o.view(B, L, H) for o in outs)
 

@@ -24,6 +24,7 @@ NONLIN_GAMMA_SILU = 1.7881293296813965          # timm nfnet.py _nonlin_gamma['s
 # gathered patch matrix for them too (A/B measurement switch, tools/config_bench.py)
 PADDED_CONV = os.environ.get("IA_CONV_PATCH_MATRIX", "0") != "1"
 FUSE_TAIL_ACT = os.environ.get("IA_NFNET_FUSE_TAIL", "1") != "0"   # a block's tail pass also writes the next block's opening activation (EcaResidualFn)
+FUSE_TAIL_BWD = os.environ.get("IA_NFNET_FUSE_TAIL", "1") == "1"   # ... and its backward folds SiLU' and the gate gradient's spatial sums into one pass
 ECA_LINEAR = os.environ.get("IA_ECA_LINEAR", "1") != "0"      # ECA pooling from conv3's input (EcaResidualFn); 0: the reduction over conv3's output
 
 NFNET_CONFIGS = {   # timm nfnet.py model_cfgs (_nfnet_cfg): depths, channels, feat_mult
@@ -312,20 +313,33 @@ class EcaResidualFn(torch.autograd.Function):
         w = ctx.eca.conv.weight
         if ctx.out is not None:
             # out's whole gradient = what arrives at `out` itself (the next block's identity shortcut; nothing for a downsampling block)
-            # + (dact [+ dact2]) * act_scale * silu'(out)
+            # + (dact [+ dact2]) * act_scale * silu'(out): formed by ia_eca_silu_bwd in the pass that also takes the gate gradient's spatial
+            # sums (IA_NFNET_FUSE_TAIL=2: by ia_silu_bwd(_sum) first, then the plain ia_eca_bwd -- the two-kernel form, for A/B runs)
             g1, g2 = (dact, dact2) if dact is not None else (dact2, None)
+            out, ctx.out = ctx.out, None
             if g1 is not None:
-                out = ctx.out
                 dtot = torch.empty_like(out)
                 dadd = None if dout is None else dout.contiguous()
+                g1 = g1.contiguous()
+                g2 = None if g2 is None else g2.contiguous()
+                if FUSE_TAIL_BWD:
+                    dx = torch.empty_like(x)
+                    wsb = lib.ia_eca_bwd_workspace_bytes(B, HW, C)
+                    ws = _ws(dtot.device, wsb)
+                    check(lib.ia_eca_silu_bwd(g1.data_ptr(), ptr(g2), out.data_ptr(), ptr(dadd), ctx.act_scale, x.data_ptr(), w.data_ptr(), k,
+                                              pooled.data_ptr(), gate.data_ptr(), dtot.data_ptr(), dx.data_ptr(),
+                                              w.grad.data_ptr() if w.requires_grad else None, B, HW, C, coef, ws.data_ptr(), wsb, stream_ptr()),
+                          "ia_eca_silu_bwd")
+                    Fn._notify([w])
+                    ctx.saved = None
+                    return dx, dtot, None, None, None, None, None, None, None, None
                 if g2 is None:
-                    check(lib.ia_silu_bwd(g1.contiguous().data_ptr(), out.data_ptr(), ptr(dadd), dtot.data_ptr(), out.numel(), ctx.act_scale,
-                                          stream_ptr()), "ia_silu_bwd")
+                    check(lib.ia_silu_bwd(g1.data_ptr(), out.data_ptr(), ptr(dadd), dtot.data_ptr(), out.numel(), ctx.act_scale, stream_ptr()),
+                          "ia_silu_bwd")
                 else:
-                    check(lib.ia_silu_bwd_sum(g1.contiguous().data_ptr(), g2.contiguous().data_ptr(), out.data_ptr(), ptr(dadd), dtot.data_ptr(),
-                                              out.numel(), ctx.act_scale, stream_ptr()), "ia_silu_bwd_sum")
+                    check(lib.ia_silu_bwd_sum(g1.data_ptr(), g2.data_ptr(), out.data_ptr(), ptr(dadd), dtot.data_ptr(), out.numel(), ctx.act_scale,
+                                              stream_ptr()), "ia_silu_bwd_sum")
                 dout = dtot
-            ctx.out = None
         if dout is None:
             ctx.saved = None
             return (None,) * 10

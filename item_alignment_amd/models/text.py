@@ -131,7 +131,10 @@ class RobertaModel(HipModule, PretrainedMixin):
             if hs is not None:
                 return BaseModelOutput(last_hidden_state=hs[-1], hidden_states=hs)
         e = self.embeddings(input_ids=input_ids, position_ids=position_ids, token_type_ids=token_type_ids, cate_ids=cate_ids)
-        hs = self.encoder(e, attention_mask)
+        # allow_unpad = "nothing the caller reads depends on the padded rows" (every head of the reference reads [CLS] or valid spans; the
+        # cross_attn multimodal layers, which attend over ALL text positions, pass False): the padded run may then at least skip what is
+        # provably zero in its backward
+        hs = self.encoder(e, attention_mask, masked_rows_dead=allow_unpad and cate_ids is None and not output_hidden_states)
         return BaseModelOutput(last_hidden_state=hs[-1], hidden_states=hs)
 
     def _forward_unpadded(self, input_ids, attention_mask, token_type_ids, position_ids):
@@ -250,8 +253,11 @@ class RobertaOneTower(_PairTowerBase):
         return RobertaModel(config, add_pooling_layer=False)
 
     def _backbone(self, input_ids, attention_mask, token_type_ids, position_ids, cate_ids, inputs_embeds, image_indices):
+        # the auxiliary attribute-pair task averages hidden states over caller-given spans (reference text.py:66-102), which may reach
+        # into padded positions (the reference computes those rows like any other; the golden fixture's third sample does exactly that):
+        # with it, the padded rows matter -- no unpadded run, no skipped query blocks in the attention backward
         return self.roberta(input_ids, attention_mask=attention_mask, token_type_ids=token_type_ids, position_ids=position_ids,
-                            cate_ids=cate_ids)
+                            cate_ids=cate_ids, allow_unpad=not hasattr(self, "auxiliary_task"))
 
     def _tgt_index(self):
         return self.max_seq_len

@@ -125,7 +125,8 @@ def attn_fwd(qkv, B, L, nh, *, key_mask=None, scale=0.125, drop_p=0.0, seed=0, q
     return out, lse
 
 
-def attn_bwd(qkv, ctx, d_ctx, lse, B, L, nh, *, key_mask=None, scale=0.125, drop_p=0.0, seed=0, dbias=None, q_prescaled=False, return_delta=False):
+def attn_bwd(qkv, ctx, d_ctx, lse, B, L, nh, *, key_mask=None, scale=0.125, drop_p=0.0, seed=0, dbias=None, q_prescaled=False, return_delta=False,
+             masked_rows_dead=False):
     """dbias (fp32 [3H], optional): += column sums of dqkv, i.e. the bias gradient of the fused QKV projection, out of the same launches.
     return_delta: also hand back the [B, nh, L] scratch (the softmax-gradient delta where the dQ / dK,dV kernel pair ran: L > 256 or
     IA_ATTN_EXACT_DELTA=1; the fused backward keeps its key bits there)"""
@@ -135,8 +136,14 @@ def attn_bwd(qkv, ctx, d_ctx, lse, B, L, nh, *, key_mask=None, scale=0.125, drop
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, nh, L), device=qkv.device, dtype=F32)
     base, dbase = qkv.data_ptr(), dqkv.data_ptr()
-    if q_prescaled and dbias is None:
+    if (q_prescaled or masked_rows_dead) and dbias is None:
         dbias = torch.zeros(3 * H, device=qkv.device, dtype=F32)
+    if masked_rows_dead:          # (ia_attn_bwd_bias_ex: d_ctx must be zero at every masked position)
+        ws = torch.empty(lib.ia_attn_bwd_bias_workspace_bytes(B, nh, L), device=qkv.device, dtype=torch.uint8)
+        check(lib.ia_attn_bwd_bias_ex((1 if q_prescaled else 0) | 2, base, base + 2 * H, base + 4 * H, 3 * H, ptr(key_mask), ctx.data_ptr(),
+                                      d_ctx.data_ptr(), H, lse.data_ptr(), delta.data_ptr(), dbase, dbase + 2 * H, dbase + 4 * H, 3 * H,
+                                      dbias.data_ptr(), ws.data_ptr(), ws.numel(), B, nh, L, scale, drop_p, seed, stream_ptr()), "ia_attn_bwd_bias_ex")
+        return (dqkv, delta) if return_delta else dqkv
     if dbias is not None:
         _need(dbias, F32, "dbias")
         ws = torch.empty(lib.ia_attn_bwd_bias_workspace_bytes(B, nh, L), device=qkv.device, dtype=torch.uint8)

@@ -259,6 +259,35 @@ def test_attention_exact_delta_opt_in(gpu, monkeypatch, B, L, nh, masked, drop):
     assert torch.equal(flash, ops.attn_bwd(qkv, ctx, dctx, lse, B, L, nh, key_mask=mask, drop_p=drop, seed=9))
 
 
+@pytest.mark.parametrize("B,L,nh,drop", [(6, 255, 4, 0.0), (5, 255, 16, 0.1), (4, 130, 2, 0.0), (3, 64, 1, 0.1), (2, 510, 2, 0.0), (4, 510, 3, 0.1),
+                                         (3, 385, 2, 0.0), (5, 577, 1, 0.0)])
+def test_attention_backward_skips_query_blocks_of_masked_positions(gpu, B, L, nh, drop):
+    """ia_attn_bwd_bias_ex(IA_ATTN_MASKED_ROWS_DEAD) (round 6): where the gradient arriving at every masked position is zero -- an encoder
+    whose heads read [CLS] / valid spans only; reference src/models/text.py:1241 under its attention mask -- the one-kernel backward
+    leaves out the 32-query blocks that hold only masked positions.  On such inputs dqkv and the bias gradient equal the unflagged call's
+    (exactly: what is skipped multiplies zeros), with ragged lengths from one valid block to a full sequence, a hole in the mask,
+    dropout on and off; L > 256 runs the dQ / dK,dV kernel pair: a wave of the dQ kernel whose 32 queries are masked skips its arithmetic,
+    a workgroup without a live query walks one key tile, the dK/dV kernel's query loop ends at the last unmasked position."""
+    from item_alignment_amd import ops
+    H = nh * 64
+    qkv = rnd((B * L, 3 * H), gpu, 1.0, 64)
+    lens = torch.tensor([max(1, (L * (i + 1)) // (B + 1) - 5 * i) for i in range(B - 1)] + [L])
+    mask = (torch.arange(L)[None, :] < lens[:, None]).to(torch.uint8).to(gpu)
+    if L > 40:
+        mask[-1, 33:70] = 0                                        # a hole that swallows a whole 32-position block of a full-length sequence
+    dctx = rnd((B * L, H), gpu, 1.0, 65) * mask.view(B * L, 1).to(torch.bfloat16)      # zero at every masked position
+    ctx, lse = ops.attn_fwd(qkv, B, L, nh, key_mask=mask, drop_p=drop, seed=3)
+    db0 = torch.zeros(3 * H, device=gpu)
+    full = ops.attn_bwd(qkv, ctx, dctx, lse, B, L, nh, key_mask=mask, drop_p=drop, seed=3, dbias=db0)
+    db1 = torch.zeros(3 * H, device=gpu)
+    skip = ops.attn_bwd(qkv, ctx, dctx, lse, B, L, nh, key_mask=mask, drop_p=drop, seed=3, dbias=db1, masked_rows_dead=True)
+    assert torch.isfinite(skip).all()
+    assert torch.equal(full, skip) and torch.equal(db0, db1)
+    # and the rows of masked positions carry no gradient at all (q: zero rows; k, v: masked keys get P = 0)
+    dead = (mask.view(B * L) == 0)
+    assert (skip[dead].float().abs().max().item() if dead.any() else 0.0) == 0.0
+
+
 @pytest.mark.parametrize("B,L,nh,masked,drop", [(3, 255, 4, True, 0.0), (2, 577, 3, False, 0.0), (2, 130, 2, True, 0.1), (1, 64, 1, False, 0.0)])
 def test_attention_bwd_bias_gradient(gpu, B, L, nh, masked, drop):
     """ia_attn_bwd_bias: the QKV bias gradient out of the attention backward epilogues = column sums of the dqkv it stores (exactly the
@@ -772,6 +801,60 @@ def test_eca_block_tail_pools_through_the_1x1_convolution(gpu, B, HW, Cmid, C):
                          ws2.data_ptr(), wsb2, stream_ptr()), "ia_eca_fwd")
     assert rel_err(pooled, pooled2) < 2e-3 and rel_err(gate, gate2) < 2e-3          # the old path sums the ROUNDED x: bf16 noise, averaged over HW
     assert rel_err(out.view(B, HW, C), out2.view(B, HW, C)) < 1e-2
+
+
+@pytest.mark.parametrize("B,HW,C,two,direct", [(3, 625, 1536, False, True), (2, 2500, 512, True, False), (5, 49, 256, False, False), (2, 10000, 256, True, True)])
+def test_eca_block_tail_backward_folds_the_next_activation(gpu, B, HW, C, two, direct):
+    """ia_eca_silu_bwd (round 6): the backward of a NormFreeBlock tail that also wrote the next block's opening activation -- out's whole
+    gradient dtot = (dact [+ dact2]) * act_scale * silu'(out) [+ dout_direct] and the ECA gate gradient's spatial sums of dtot * x in ONE pass
+    -- is bit-identical to the two-kernel form it replaces (ia_silu_bwd / ia_silu_bwd_sum, then ia_eca_bwd on its result): dtot, dx and
+    the conv1d weight gradient; and matches torch autograd of the tail in fp32 (reference src/models/image.py:253-257 -> timm
+    NormFreeBlock.forward: out = attn_last(x) * alpha + shortcut, next block: act1(out) * beta)."""
+    from item_alignment_amd import _lib
+    from item_alignment_amd.ops import check, stream_ptr
+    lib = _lib.load()
+    k, coef, beta = 5, 0.4, 0.93
+    x = rnd((B * HW, C), gpu, 1.0, 41)
+    shortcut = rnd((B * HW, C), gpu, 1.0, 42)
+    conv_w = torch.randn(k, device=gpu) * 0.5
+    dact, dact2, ddir = rnd((B * HW, C), gpu, 1.0, 43), rnd((B * HW, C), gpu, 1.0, 44), rnd((B * HW, C), gpu, 1.0, 45)
+    out, pooled, gate = torch.empty_like(x), torch.empty((B, C), device=gpu), torch.empty((B, C), device=gpu)
+    wsf = lib.ia_gap_workspace_bytes(B, HW, C)
+    ws = torch.empty(wsf, device=gpu, dtype=torch.uint8)
+    check(lib.ia_eca_fwd(x.data_ptr(), conv_w.data_ptr(), k, shortcut.data_ptr(), out.data_ptr(), pooled.data_ptr(), gate.data_ptr(), B, HW, C, coef,
+                         ws.data_ptr(), wsf, stream_ptr()), "ia_eca_fwd")
+    p2 = dact2.data_ptr() if two else None
+    pd = ddir.data_ptr() if direct else None
+    wsb = lib.ia_eca_bwd_workspace_bytes(B, HW, C)
+    wsb_t = torch.empty(wsb, device=gpu, dtype=torch.uint8)
+    # the two-kernel form
+    dtot_a = torch.empty_like(x)
+    if two:
+        check(lib.ia_silu_bwd_sum(dact.data_ptr(), p2, out.data_ptr(), pd, dtot_a.data_ptr(), out.numel(), beta, stream_ptr()), "ia_silu_bwd_sum")
+    else:
+        check(lib.ia_silu_bwd(dact.data_ptr(), out.data_ptr(), pd, dtot_a.data_ptr(), out.numel(), beta, stream_ptr()), "ia_silu_bwd")
+    dx_a, dw_a = torch.empty_like(x), torch.zeros(k, device=gpu)
+    check(lib.ia_eca_bwd(dtot_a.data_ptr(), x.data_ptr(), conv_w.data_ptr(), k, pooled.data_ptr(), gate.data_ptr(), dx_a.data_ptr(), dw_a.data_ptr(),
+                         B, HW, C, coef, wsb_t.data_ptr(), wsb, stream_ptr()), "ia_eca_bwd")
+    # the fused form
+    dtot_b, dx_b, dw_b = torch.full_like(x, float("nan")), torch.full_like(x, float("nan")), torch.zeros(k, device=gpu)
+    check(lib.ia_eca_silu_bwd(dact.data_ptr(), p2, out.data_ptr(), pd, beta, x.data_ptr(), conv_w.data_ptr(), k, pooled.data_ptr(), gate.data_ptr(),
+                              dtot_b.data_ptr(), dx_b.data_ptr(), dw_b.data_ptr(), B, HW, C, coef, wsb_t.data_ptr(), wsb, stream_ptr()), "ia_eca_silu_bwd")
+    assert torch.equal(dtot_a, dtot_b) and torch.equal(dx_a, dx_b) and torch.equal(dw_a, dw_b)
+    # torch autograd of the same function in fp32
+    xr, sr, wr = x.float().view(B, HW, C).requires_grad_(True), shortcut.float().view(B, HW, C).requires_grad_(True), conv_w.clone().requires_grad_(True)
+    g_ = torch.sigmoid(torch.nn.functional.conv1d(xr.mean(1).view(B, 1, C), wr.view(1, 1, k), padding=(k - 1) // 2).view(B, C))
+    o_ = xr * g_[:, None, :] * coef + sr
+    a_ = torch.nn.functional.silu(o_) * beta
+    loss = (a_ * dact.float().view(B, HW, C)).sum()
+    if two:
+        loss = loss + (a_ * dact2.float().view(B, HW, C)).sum()
+    if direct:
+        loss = loss + (o_ * ddir.float().view(B, HW, C)).sum()
+    loss.backward()
+    assert rel_err(dtot_b.view(B, HW, C), sr.grad) < 2e-2
+    assert rel_err(dx_b.view(B, HW, C), xr.grad) < 2e-2
+    assert rel_err(dw_b, wr.grad) < 2e-2
 
 
 def test_silu_between_padded_and_compact_layouts(gpu):
