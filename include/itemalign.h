@@ -101,6 +101,13 @@ int ia_ln_bwd(const void* dy, const void* dres, const void* z, const float* mean
 int ia_ln_bwd2(const void* dy, const void* dy2, const void* dres, const void* z, const float* mean, const float* rstd, const float* gamma,
                void* dz, void* dx, float* dgamma, float* dbeta, float* dbias, int M, int H, float drop_p, uint32_t seed, uint32_t stream_id,
                void* workspace, size_t workspace_bytes, int accumulate, ia_stream_t stream);
+/* (round 6, ABI 8) ia_ln_bwd2 with a row filter: row_live [M] uint8 or NULL; row_live[m] == 0 = the caller guarantees that dy, dy2 and dres
+ * are zero in row m (a masked position of an encoder whose heads read no masked position, ia_layer_cfg::masked_rows_dead): the row's inputs
+ * are not fetched, its dz / dx rows are written as zeros.  Identical results on such inputs; NULL = ia_ln_bwd2. */
+int ia_ln_bwd2_rows(const void* dy, const void* dy2, const void* dres, const void* z, const float* mean, const float* rstd,
+                    const float* gamma, void* dz, void* dx, float* dgamma, float* dbeta, float* dbias, int M, int H, float drop_p,
+                    uint32_t seed, uint32_t stream_id, const uint8_t* row_live, void* workspace, size_t workspace_bytes, int accumulate,
+                    ia_stream_t stream);
 size_t ia_colsum_workspace_bytes(int M, int N);
 int ia_colsum(const void* x, int ld, int M, int N, float* out, int accumulate, void* workspace, size_t workspace_bytes,
               ia_stream_t stream);

@@ -45,6 +45,7 @@ SIGNATURES = {
     "ia_ln_bwd_workspace_bytes": (sz, [i32, i32]),
     "ia_ln_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, u32, u32, vp, sz, i32, vp]),
     "ia_ln_bwd2": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, u32, u32, vp, sz, i32, vp]),
+    "ia_ln_bwd2_rows": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, u32, u32, vp, vp, sz, i32, vp]),
     "ia_colsum_workspace_bytes": (sz, [i32, i32]),
     "ia_colsum": (i32, [vp, i32, i32, i32, vp, i32, vp, sz, vp]),
     "ia_attn_fwd": (i32, [vp, vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, f32, f32, u32, vp]),

@@ -6,6 +6,7 @@
 //   pre-LN   ViT block           (timm vision_transformer.Block, called at src/models/multimodal.py:811,
 //            src/models/image.py:459)
 #include "common.h"
+#include <cstdlib>
 #include "../../include/itemalign.h"
 
 namespace {
@@ -250,11 +251,15 @@ extern "C" int ia_layer_bwd2(const ia_layer_cfg* c, const ia_layer_weights* w, c
   const uint32_t attn_seed = c->seed * 2654435761u + c->layer_id * 97u + 17u;
   const bool drop = c->hidden_drop > 0.f;
   if (!c->pre_ln) {
+    // masked_rows_dead: every gradient row of a masked position is exactly zero (ia_layer_cfg): the LayerNorm backward kernels skip them
+    // (IA_LN_ROWS=0: the LayerNorm part off, for A/B runs)
+    static const bool ln_rows = [] { const char* e = getenv("IA_LN_ROWS"); return !e || atoi(e) != 0; }();
+    const uint8_t* const live = (c->masked_rows_dead && !c->cu_seqlens && ln_rows) ? key_mask : nullptr;
     // The two residual additions of a post-LN layer make each LayerNorm output's gradient a sum of two terms; both LayerNorm
     // backward kernels take the two terms (ia_ln_bwd2), so the GEMMs in front of them keep the plain epilogue.
     // LN2 backward: d(output) = dy (+ dy2) -> dz2 in g0, masked branch gradient -> g1 (or g0 when p == 0)
-    IA_TRY(ia_ln_bwd2(dy, dy2, nullptr, s.t2, s.mean2, s.rstd2, w->ln2_g, k.g0, drop ? k.g1 : nullptr, g->ln2_g, g->ln2_b, g->b_fc2, M, H,
-                      c->hidden_drop, c->seed, c->layer_id * 4u + 1u, k.ws, k.ws_bytes, 1, st));
+    IA_TRY(ia_ln_bwd2_rows(dy, dy2, nullptr, s.t2, s.mean2, s.rstd2, w->ln2_g, k.g0, drop ? k.g1 : nullptr, g->ln2_g, g->ln2_b, g->b_fc2, M, H,
+                           c->hidden_drop, c->seed, c->layer_id * 4u + 1u, live, k.ws, k.ws_bytes, 1, st));
     const char* d_ffn = drop ? k.g1 : k.g0;
     IA_TRY(ia_gemm_bf16(d_ffn, 1, H, s.hact, 1, I, g->w_fc2, 1, I, H, I, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
     // d(pre-activation) = (d_ffn W2) * gelu'(pre), and its column sums (the fc1 bias gradient) out of the same epilogue
@@ -264,8 +269,8 @@ extern "C" int ia_layer_bwd2(const ia_layer_cfg* c, const ia_layer_weights* w, c
     // LN1 backward: d(y1) = g2 (through fc1) + g0 (residual into LN2) -> dz1 (the layer input's residual-path gradient) in
     // dz1buf: the caller's dx2 when the split form is wanted, else g0 (in place over the term just consumed)
     char* dz1buf = dx2 ? (char*)dx2 : k.g0;
-    IA_TRY(ia_ln_bwd2(k.g2, k.g0, nullptr, s.t0, s.mean1, s.rstd1, w->ln1_g, dz1buf, drop ? k.g1 : nullptr, g->ln1_g, g->ln1_b, g->b_o, M, H,
-                      c->hidden_drop, c->seed, c->layer_id * 4u + 0u, k.ws, k.ws_bytes, 1, st));
+    IA_TRY(ia_ln_bwd2_rows(k.g2, k.g0, nullptr, s.t0, s.mean1, s.rstd1, w->ln1_g, dz1buf, drop ? k.g1 : nullptr, g->ln1_g, g->ln1_b, g->b_o, M, H,
+                           c->hidden_drop, c->seed, c->layer_id * 4u + 0u, live, k.ws, k.ws_bytes, 1, st));
     const char* d_att = drop ? k.g1 : dz1buf;
     IA_TRY(ia_gemm_bf16(d_att, 1, H, s.ctx, 1, H, g->w_o, 1, H, H, H, M, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 1, k.gws, k.gws_bytes, st));
     IA_TRY(dgrad(d_att, H, w->w_o, w->wt_o, H, k.g2, M, IA_EPI_NONE, nullptr, 0, nullptr, nullptr, 0, st));

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                      bf16* dz, bf16* __restrict__ dx, float* __restrict__ part,
                                                      int M, int H, uint32_t thr16, float inv_keep, uint32_t seed,
-                                                     uint32_t stream) {
+                                                     uint32_t stream, const uint8_t* __restrict__ live) {
   __shared__ float red[3][4][512];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float ag[NV][8], ab[NV][8], ax[NV][8];
@@ -129,7 +129,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
   const int row0 = blockIdx.x * 4 + wave, rstep = gridDim.x * 4;
   bf16x8 dv[NV], zv[NV], rv[NV];
   float mu = 0.f, rs = 0.f;
-  auto fetch = [&](int row, bf16x8 (&d)[NV], bf16x8 (&z_)[NV], bf16x8 (&r)[NV], float& m_, float& s_) {
+  // live (round 6, may be null): live[row] == 0 marks a row whose incoming gradients are exactly zero by the caller's guarantee (a
+  // masked position of an encoder whose heads read none of them, ia_layer_cfg::masked_rows_dead): its outputs are zero rows and it adds
+  // nothing to the column sums, so none of its four input streams is read -- the kernel is HBM-bound and 45 % of the bench's rows are
+  // padding.  The row's zeros are still written (the GEMMs behind read them).
+  bool dead = false;
+  auto fetch = [&](int row, bf16x8 (&d)[NV], bf16x8 (&z_)[NV], bf16x8 (&r)[NV], float& m_, float& s_, bool& dd) {
+    dd = live != nullptr && live[row] == 0;               // wave-uniform: one row per wave
+    if (dd) return;
     m_ = mean[row]; s_ = rstd[row];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -146,11 +153,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
       }
     }
   };
-  if (row0 < M) fetch(row0, dv, zv, rv, mu, rs);
+  if (row0 < M) fetch(row0, dv, zv, rv, mu, rs, dead);
   for (int row = row0; row < M; row += rstep) {
     bf16x8 ndv[NV], nzv[NV], nrv[NV];
     float nmu = 0.f, nrs = 0.f;
-    if (row + rstep < M) fetch(row + rstep, ndv, nzv, nrv, nmu, nrs);
+    bool ndead = false;
+    if (row + rstep < M) fetch(row + rstep, ndv, nzv, nrv, nmu, nrs, ndead);
+    if (dead) {
+      bf16x8 zero;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) zero[j] = f2bf(0.f);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int col = i * 512 + lane * 8;
+        if (col < H) {
+          *reinterpret_cast<bf16x8*>(dz + (size_t)row * H + col) = zero;
+          if (thr16) *reinterpret_cast<bf16x8*>(dx + (size_t)row * H + col) = zero;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NV; ++i) { dv[i] = ndv[i]; zv[i] = nzv[i]; rv[i] = nrv[i]; }
+      mu = nmu; rs = nrs; dead = ndead;
+      continue;
+    }
     float g[NV][8], xh[NV][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -210,7 +235,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) { dv[i] = ndv[i]; zv[i] = nzv[i]; rv[i] = nrv[i]; }
-    mu = nmu; rs = nrs;
+    mu = nmu; rs = nrs; dead = ndead;
   }
   // cross-wave reduction, 512 columns at a time
 #pragma unroll
@@ -317,6 +342,11 @@ extern "C" int ia_ln_fwd(const void* x, const float* bias, const void* residual,
 
 extern "C" size_t ia_ln_bwd_workspace_bytes(int M, int H) { return (size_t)ln_blocks(M) * 3 * H * sizeof(float); }
 
+extern "C" int ia_ln_bwd2_rows(const void* dy, const void* dy2, const void* dres, const void* z, const float* mean, const float* rstd,
+                               const float* gamma, void* dz, void* dx, float* dgamma, float* dbeta, float* dbias, int M, int H,
+                               float drop_p, uint32_t seed, uint32_t stream_id, const uint8_t* row_live, void* workspace,
+                               size_t workspace_bytes, int accumulate, hipStream_t stream);
+
 extern "C" int ia_ln_bwd2(const void* dy, const void* dy2, const void* dres, const void* z, const float* mean, const float* rstd,
                           const float* gamma, void* dz, void* dx, float* dgamma, float* dbeta, float* dbias, int M, int H,
                           float drop_p, uint32_t seed, uint32_t stream_id, void* workspace, size_t workspace_bytes,
@@ -339,6 +369,17 @@ extern "C" int ia_ln_bwd2(const void* dy, const void* dy2, const void* dres, con
                           const float* gamma, void* dz, void* dx, float* dgamma, float* dbeta, float* dbias, int M, int H,
                           float drop_p, uint32_t seed, uint32_t stream_id, void* workspace, size_t workspace_bytes,
                           int accumulate, hipStream_t stream) {
+  return ia_ln_bwd2_rows(dy, dy2, dres, z, mean, rstd, gamma, dz, dx, dgamma, dbeta, dbias, M, H, drop_p, seed, stream_id, nullptr, workspace,
+                         workspace_bytes, accumulate, stream);
+}
+
+// ia_ln_bwd2 with a row filter (round 6): row_live [M] uint8 or NULL; row_live[m] == 0 = the caller guarantees dy, dy2 and dres are zero
+// in row m (a masked position whose hidden state no head reads): the row's inputs are not fetched, its dz / dx rows are written as
+// zeros, it adds nothing to dgamma / dbeta / dbias.  Identical results on such inputs.
+extern "C" int ia_ln_bwd2_rows(const void* dy, const void* dy2, const void* dres, const void* z, const float* mean, const float* rstd,
+                               const float* gamma, void* dz, void* dx, float* dgamma, float* dbeta, float* dbias, int M, int H,
+                               float drop_p, uint32_t seed, uint32_t stream_id, const uint8_t* row_live, void* workspace,
+                               size_t workspace_bytes, int accumulate, hipStream_t stream) {
   (void)hipGetLastError();  // drop stale status left by unrelated runtime calls (e.g. hipEventQuery -> NotReady)
   if (!dy || !z || !mean || !rstd || !gamma || !dz || M <= 0 || (H & 7) || H > 512 * MAXV) return IA_ERR_ARG;
   if (workspace_bytes < ia_ln_bwd_workspace_bytes(M, H) || !workspace) return IA_ERR_WORKSPACE;
@@ -349,7 +390,7 @@ extern "C" int ia_ln_bwd2(const void* dy, const void* dy2, const void* dres, con
   float* part = (float*)workspace;
   dim3 grid(nb), blk(256);
 #define IA_LN_BWD(NV) hipLaunchKernelGGL((ln_bwd_kernel<NV>), grid, blk, 0, stream, (const bf16*)dy, (const bf16*)dy2, (const bf16*)dres, (const bf16*)z, \
-    mean, rstd, gamma, (bf16*)dz, (bf16*)dx, part, M, H, thr16, inv_keep, seed, stream_id)
+    mean, rstd, gamma, (bf16*)dz, (bf16*)dx, part, M, H, thr16, inv_keep, seed, stream_id, row_live)
   switch (nv) {
     case 1: IA_LN_BWD(1); break;
     case 2: IA_LN_BWD(2); break;

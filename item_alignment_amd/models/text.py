@@ -256,8 +256,12 @@ class RobertaOneTower(_PairTowerBase):
         # the auxiliary attribute-pair task averages hidden states over caller-given spans (reference text.py:66-102), which may reach
         # into padded positions (the reference computes those rows like any other; the golden fixture's third sample does exactly that):
         # with it, the padded rows matter -- no unpadded run, no skipped query blocks in the attention backward
+        # ... and so they do under vec_sim: the target embedding is read at the FIXED position max_seq_len (reference text.py:1463), which is a
+        # padded position whenever a sequence is shorter than that (the eight-sample golden fixtures hold two such sequences: the row-wise
+        # LayerNorm filter of round 6 caught it -- the 32-position attention blocks had not)
+        rows_matter = hasattr(self, "auxiliary_task") or self.config.classification_method == "vec_sim"
         return self.roberta(input_ids, attention_mask=attention_mask, token_type_ids=token_type_ids, position_ids=position_ids,
-                            cate_ids=cate_ids, allow_unpad=not hasattr(self, "auxiliary_task"))
+                            cate_ids=cate_ids, allow_unpad=not rows_matter)
 
     def _tgt_index(self):
         return self.max_seq_len

@@ -138,3 +138,24 @@ def test_layer_fwd_bwd(gpu, B, L, nh, pre_ln, masked):
         assert torch.isfinite(G[k]).all(), k
         assert cos(G[k], want) > 0.995, (k, cos(G[k], want))
         assert rel(G[k], want) < 5e-2, (k, rel(G[k], want))
+    if masked and not pre_ln:
+        # ia_layer_cfg::masked_rows_dead (round 6): with the output gradient zero at every masked position -- what an encoder whose heads
+        # read no masked position hands down -- the backward that skips those rows (attention query blocks, LayerNorm rows) returns the
+        # same input gradient and the same parameter gradients, bit for bit, and zero rows at the masked positions
+        dyz = (dy.view(M, H) * valid[:, None].to(dy.dtype)).contiguous()
+        res = []
+        for flag in (0, 1):
+            cf = LayerCfg(B=B, L=L, H=H, I=I, nh=nh, pre_ln=0, eps=eps, hidden_drop=0.0, attn_drop=0.0, seed=1, layer_id=0, masked_rows_dead=flag)
+            Gf = {k: torch.zeros_like(v) for k, v in P32.items()}
+            gf = LayerGrads()
+            for k in P32:
+                setattr(gf, k, Gf[k].data_ptr())
+            dxf = dyz.clone()
+            _lib.check(lib.ia_layer_bwd(C.byref(cf), C.byref(w), C.byref(gf), x.data_ptr(), _lib.ptr(mask), y.data_ptr(), stash.data_ptr(),
+                                        dxf.data_ptr(), dxf.data_ptr(), scratch.data_ptr(), scratch.numel(), st), f"bwd (masked_rows_dead={flag})")
+            torch.cuda.synchronize()
+            res.append((dxf, Gf))
+        assert torch.equal(res[0][0], res[1][0])
+        assert res[1][0][~valid].float().abs().max().item() == 0.0
+        for k in P32:
+            assert torch.equal(res[0][1][k], res[1][1][k]), k
