@@ -469,6 +469,8 @@ def main():
                 "mean_tokens": round(lens.mean().item(), 1), "padded_len": L,
                 "executed_key_share_fwd": round((torch.ceil(lens / 64) * 64).clamp(max=L).mean().item() / L, 4),
                 "executed_key_share_bwd": round((torch.ceil(lens / 32) * 32).clamp(max=L).mean().item() / L, 4),
+                # the fused backward also leaves out 32-query blocks of padding (ia_layer_cfg::masked_rows_dead): live keys x live queries
+                "executed_share_bwd_keys_x_queries": round((((torch.ceil(lens / 32) * 32).clamp(max=L) / L) ** 2).mean().item(), 4),
                 "dense_flops_per_launch_fwd": 4.0 * 2 * B * 16 * L * L * 64, "dense_flops_per_launch_bwd": 10.0 * 2 * B * 16 * L * L * 64,
                 "note": "per-kernel TFLOP/s on EXECUTED work = dense_flops_per_launch x executed_key_share / the kernel's launch time "
                         "(profiles/*_kernel_stats_summary.txt); the ViT kernels (no padding mask) execute 19 of their 20 32-key blocks"}

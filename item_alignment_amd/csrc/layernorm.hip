@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
 }
 
 // partial layout: part[blk][3][H] : 0 = dgamma, 1 = dbeta, 2 = dbias (gradient of the GEMM branch)
-template <int NV>
+template <int NV, bool FILTER>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* dy2, const bf16* __restrict__ dres,
                                                      const bf16* __restrict__ z, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
@@ -133,10 +133,28 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
   // masked position of an encoder whose heads read none of them, ia_layer_cfg::masked_rows_dead): its outputs are zero rows and it adds
   // nothing to the column sums, so none of its four input streams is read -- the kernel is HBM-bound and 45 % of the bench's rows are
   // padding.  The row's zeros are still written (the GEMMs behind read them).
+  // (FILTER is a template parameter: with the test compiled into the unfiltered kernel every launch -- the ViT's too -- ran 7 % slower;
+  // the flags of the wave's next 64 rows are fetched by ONE load, lane i holding the flag of its i-th row ahead, and balloted into a
+  // scalar mask: a per-row flag load in front of the row's own loads put a global-memory round trip into every iteration)
   bool dead = false;
+  uint64_t live_bits = ~0ull;
+  int bits_left = 0;
+  const int lane_ = threadIdx.x & 63;
+  auto next_dead = [&](int row) -> bool {
+    if constexpr (!FILTER) return false;
+    if (bits_left == 0) {
+      const long r = (long)row + (long)lane_ * rstep;
+      const bool lv = r < M ? live[r] != 0 : true;
+      live_bits = __ballot(lv);
+      bits_left = 64;
+    }
+    const bool dd = (live_bits & 1ull) == 0ull;
+    live_bits >>= 1; --bits_left;
+    return dd;
+  };
   auto fetch = [&](int row, bf16x8 (&d)[NV], bf16x8 (&z_)[NV], bf16x8 (&r)[NV], float& m_, float& s_, bool& dd) {
-    dd = live != nullptr && live[row] == 0;               // wave-uniform: one row per wave
-    if (dd) return;
+    dd = next_dead(row);                                  // wave-uniform: one row per wave
+    if (FILTER && dd) return;
     m_ = mean[row]; s_ = rstd[row];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -159,7 +177,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
     float nmu = 0.f, nrs = 0.f;
     bool ndead = false;
     if (row + rstep < M) fetch(row + rstep, ndv, nzv, nrv, nmu, nrs, ndead);
-    if (dead) {
+    if (FILTER && dead) {
       bf16x8 zero;
 #pragma unroll
       for (int j = 0; j < 8; ++j) zero[j] = f2bf(0.f);
@@ -389,8 +407,9 @@ extern "C" int ia_ln_bwd2_rows(const void* dy, const void* dy2, const void* dres
   const int nv = (H + 511) / 512, nb = ln_blocks(M);
   float* part = (float*)workspace;
   dim3 grid(nb), blk(256);
-#define IA_LN_BWD(NV) hipLaunchKernelGGL((ln_bwd_kernel<NV>), grid, blk, 0, stream, (const bf16*)dy, (const bf16*)dy2, (const bf16*)dres, (const bf16*)z, \
+#define IA_LN_BWD_(NV, F) hipLaunchKernelGGL((ln_bwd_kernel<NV, F>), grid, blk, 0, stream, (const bf16*)dy, (const bf16*)dy2, (const bf16*)dres, (const bf16*)z, \
     mean, rstd, gamma, (bf16*)dz, (bf16*)dx, part, M, H, thr16, inv_keep, seed, stream_id, row_live)
+#define IA_LN_BWD(NV) do { if (row_live) IA_LN_BWD_(NV, true); else IA_LN_BWD_(NV, false); } while (0)
   switch (nv) {
     case 1: IA_LN_BWD(1); break;
     case 2: IA_LN_BWD(2); break;
@@ -399,6 +418,7 @@ extern "C" int ia_ln_bwd2_rows(const void* dy, const void* dy2, const void* dres
     default: IA_LN_BWD(8); break;
   }
 #undef IA_LN_BWD
+#undef IA_LN_BWD_
   int rc = ia_check_launch();
   if (rc) return rc;
   ReduceOuts outs{{dgamma, dbeta, dbias}};

@@ -366,12 +366,14 @@ class RobertaPKGMModel(HipModule, PretrainedMixin):
         self.pooler = None
         init_bert_weights(self, getattr(config, "initializer_range", 0.02))
 
-    def forward(self, input_ids, attention_mask, token_type_ids, position_ids, inputs_embeds=None, head_mask=None, **unused):
+    def forward(self, input_ids, attention_mask, token_type_ids, position_ids, inputs_embeds=None, head_mask=None, masked_rows_dead=False,
+                **unused):
+        """masked_rows_dead: the caller reads no hidden state of a masked position (RobertaEncoder.forward)"""
         (self._root if "_root" in self.__dict__ else self).ensure_arena()
         if input_ids is None or attention_mask is None or token_type_ids is None or position_ids is None:
             raise ValueError("You have to specify input_ids, attention_mask, token_type_ids and position_ids")
         e = self.embeddings(input_ids=input_ids, position_ids=position_ids, token_type_ids=token_type_ids)
-        hs = self.encoder(e, attention_mask)
+        hs = self.encoder(e, attention_mask, masked_rows_dead=masked_rows_dead)
         return BaseModelOutput(last_hidden_state=hs[-1], hidden_states=hs)
 
 
@@ -392,7 +394,9 @@ class PKGMOneTower(RobertaOneTower):
         return RobertaPKGMModel(config, add_pooling_layer=False)
 
     def _backbone(self, input_ids, attention_mask, token_type_ids, position_ids, cate_ids, inputs_embeds, image_indices):
-        return self.roberta(input_ids, attention_mask=attention_mask, token_type_ids=token_type_ids, position_ids=position_ids)
+        # the cls head reads position 0 of the last layer only; vec_sim reads a fixed second position (RobertaOneTower._backbone)
+        return self.roberta(input_ids, attention_mask=attention_mask, token_type_ids=token_type_ids, position_ids=position_ids,
+                            masked_rows_dead=self.config.classification_method != "vec_sim")
 
     def _tgt_index(self):
         return self.config.max_seq_len + 2 * self.config.max_pvs
