@@ -1680,6 +1680,194 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 
 
 
+// ============================================================================== T256LA (round 6): T256W with a k pipeline that never drains
+// Plain NT form only (k-contiguous A and B, bf16 output, no bias / aux operand), static tile order, one workgroup per CU.  T256W ends
+// every tile with an empty pipeline: the last two trips of its k loop fetch past the end, the next tile starts with a burst of 28 DMA
+// pieces (~41 cycles of blocked issue each), a wait, a workgroup barrier and the exposed latency of its first fragment reads.  Here the
+// last two trips fetch the NEXT tile's k-tiles 0 and 1 (a second descriptor pair, chosen by scalar selects), so when a tile's last trip
+// ends the next tile's k-tile 0 sits in LDS, its first fragment set is already requested (what T256W reads as "dead" look-ahead), and
+// k-tile 1 is in flight: the drain runs, and the next tile's first trip starts where a steady-state trip would -- no prologue burst, no
+// prologue wait, no barrier, no exposed read.  The loop-carried pipeline state is the fragment set a0 / b0 (32 VGPRs, live across the
+// drain: the plain kernel has ~100 to spare there) and the LDS buffer parity.  One tile boundary = drain only.
+#ifndef IA_T256LA
+#define IA_T256LA 1
+#endif
+namespace t256la {
+using namespace t256w;
+
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane0 = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nk_all = (p.K + BK - 1) / BK;             // >= 2 (the host sends shorter K to T256W)
+  const int total_tiles = p.tiles_m * p.tiles_n;
+  const int n_tiles = nk_all;
+  auto coords = [&](int tile, int& bm, int& bn) { tile_of_index(p, tile, total_tiles, bm, bn); };
+  // a tile's operand windows; a tile index past the end gives empty windows: every piece of it reads zeros
+  auto window_a = [&](int tile) {
+    int bm = 0, bn = 0;
+    if (tile < total_tiles) coords(tile, bm, bn);
+    return tile < total_tiles ? rsrc_at(p.A, p.a_bytes, (uint64_t)bm * BM * p.lda) : ia_rsrc(p.A, 0u);
+  };
+  auto window_b = [&](int tile) {
+    int bm = 0, bn = 0;
+    if (tile < total_tiles) coords(tile, bm, bn);
+    return tile < total_tiles ? rsrc_at(p.B, p.b_bytes, (uint64_t)bn * BN * p.ldb) : ia_rsrc(p.B, 0u);
+  };
+
+  int lane = lane0;
+  asm volatile("" : "+v"(lane));
+  const int li = lane & 31;
+  const int gt = wave * 64 + lane;
+  // ---- DMA lane constants (t256w::main_loop): 8 pieces per operand and k-tile, one lane offset per operand
+  const int rowd = gt >> 3;
+  const uint32_t voffA = (uint32_t)((rowd * p.lda + (((gt & 7) ^ ((rowd >> 1) & 7)) * 8)) * 2), stepA = (uint32_t)(32 * p.lda * 2);
+  const uint32_t voffB = (uint32_t)((rowd * p.ldb + (((gt & 7) ^ ((rowd >> 1) & 7)) * 8)) * 2), stepB = (uint32_t)(32 * p.ldb * 2);
+  const int kl = ((gt & 7) ^ (((gt >> 3) >> 1) & 7)) * 8;          // the k index of this lane's 16 bytes inside a k-tile
+  char* const my_part = smem + wave * 1024;
+  // ---- fragment addresses
+  const int nperm = ((li >> 2) & 1) * 16 + (li >> 3) * 4 + (li & 3);
+  uint32_t baseA[4], baseB[4];
+  const uint32_t smem_addr = ia_lds_addr(smem);
+  frag_bases<false>(baseA, smem_addr, wm * 128, lane, li);
+  frag_bases<false>(baseB, smem_addr + TILE_BYTES, wn * 128, lane, nperm);
+
+  int tile = blockIdx.x;
+  __amdgpu_buffer_rsrc_t rsA = window_a(tile), rsB = window_b(tile);
+  __amdgpu_buffer_rsrc_t rsAn = window_a(tile + (int)gridDim.x), rsBn = window_b(tile + (int)gridDim.x);
+
+  // k-tile v of the CURRENT tile (v >= n_tiles: k-tile v - n_tiles of the NEXT tile) -> lane offset of its pieces, or out of range
+  auto off_of = [&](int v) -> uint32_t {
+    const int kt = v >= n_tiles ? v - n_tiles : v;
+    return kl < p.K - kt * BK ? 1u : 0u;                 // (1 = in range; the operand's own lane offset is selected by the caller)
+  };
+  // piece i (0..7: A, 8..15: B) of k-tile v into the buffer at byte offset `buf`
+  auto dma = [&](int v, int i, uint32_t ok, uint32_t buf) {
+    const bool isB = i >= 8, nx = v >= n_tiles;
+    const int j = i & 7, kt = nx ? v - n_tiles : v;
+    char* dst = my_part + (isB ? TILE_BYTES : 0) + buf + j * 4096;
+    const uint32_t soff = (uint32_t)kt * (uint32_t)(BK * 2) + (uint32_t)j * (isB ? stepB : stepA);
+    const uint32_t off = ok ? (isB ? voffB : voffA) : OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(isB ? (nx ? rsBn : rsB) : (nx ? rsAn : rsA), IA_LDS(dst), 16, off, (int)soff, 0, 0);
+  };
+
+  // ---- the first tile's prologue: k-tiles 0 and 1 whole, landed (once per launch), first set.  Every tile's first trip then finds the
+  // same state: k-tile 1 requested in full BEFORE anything else that is in flight (below).
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dma(0, i, off_of(0), 0u);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dma(1, i, off_of(1), (uint32_t)(2 * TILE_BYTES));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  Op<false> a0, a1, a2, a3, b0, b1, b2, b3;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) read_frag<0>(a0, j, baseA, 0u);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) read_frag<0>(b0, j, baseB, 0u);
+  uint32_t bo = 0;                                       // LDS byte offset of the buffer that holds the coming trip's k-tile
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto step = [&](const Op<false>& fa, const Op<false>& fb, auto&& filler, auto FRESH_T) {
+    constexpr bool FRESH = decltype(FRESH_T)::value;
+    bf16x8 va[4], vb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { va[j] = frag_of(fa, j); vb[j] = frag_of(fb, j); }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        if constexpr (FRESH) {
+          const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb[ni], va[mi], z, 0, 0, 0);
+        } else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb[ni], va[mi], acc[mi][ni], 0, 0, 0);
+        filler(mi * 4 + ni);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+  };
+  using Acc = std::false_type;
+
+  const f32x4 no_bias[4][4] = {};
+  while (true) {
+    int bm, bn;
+    coords(tile, bm, bn);
+    const int m0_pre = bm * BM + wm * 128, n0_pre = bn * BN + wn * 128;
+    int u = 0;
+    uint32_t okA = 0u, okB = off_of(1);
+    // one trip = one k-tile (t256w::main_loop, ROUND schedule, with the look-ahead reaching into the next tile)
+    // A tile's FIRST trip: the last four pieces of its k-tile 1 went out in front of the previous tile's drain (or in the launch
+    // prologue), so the counted wait of this trip -- "k-tile 1 has landed" -- can leave the drain's 32 output stores in flight with the 8
+    // pieces it has just issued: vmcnt(40).  VMEM retires in order: with those four pieces issued BEHIND the stores (T256W's order) the
+    // wait was for the stores' completion, i.e. for the whole drain of 128 KiB at the ~18 B per clock a CU's stores sustain.
+    auto trip = [&](auto FIRST_T) {
+      constexpr bool FIRST = decltype(FIRST_T)::value;
+      const uint32_t bn_ = bo ^ (uint32_t)(2 * TILE_BYTES);
+      tie2<0>(a0, b0);
+      step(a0, b0, [&](int i) {
+        if (i < 4) { read_frag<1>(a1, i, baseA, bo); read_frag<1>(b1, i, baseB, bo); }
+        else if (i < 8) { read_frag<2>(a2, i - 4, baseA, bo); read_frag<2>(b2, i - 4, baseB, bo); }
+        else if (i < 12) { read_frag<3>(a3, i - 8, baseA, bo); read_frag<3>(b3, i - 8, baseB, bo); }
+        if (!FIRST && i % 4 == 3) dma(u + 1, 12 + i / 4, okB, bn_);       // the last four pieces of k-tile u+1 (into the other buffer)
+        if (i == 12) okA = off_of(u + 2);
+      }, FIRST_T);
+      tie6<0>(a1, b1, a2, b2, a3, b3);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      step(a1, b1, [&](int i) {
+        if (i % 4 == 1) dma(u + 2, i / 4, okA, bo);
+      }, Acc{});
+      step(a2, b2, [&](int i) {
+        if (i % 4 == 1) dma(u + 2, 4 + i / 4, okA, bo);
+        if (i == 14) okB = off_of(u + 2);
+      }, Acc{});
+      if constexpr (FIRST) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");      // 8 pieces + the previous tile's 32 stores
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      step(a3, b3, [&](int i) {
+        if (i < 4) read_frag<0>(a0, i, baseA, bn_);
+        else if (i < 8) read_frag<0>(b0, i - 4, baseB, bn_);
+        if (i % 4 == 3) dma(u + 2, 8 + i / 4, okB, bo);
+      }, Acc{});
+      bo = bn_;
+      ++u;
+    };
+    trip(std::true_type{});
+    do { trip(Acc{}); } while (u < n_tiles);
+    // the next tile's k-tile 1: its last four pieces in front of the drain's stores (see trip)
+    {
+      const uint32_t ok1 = off_of(n_tiles + 1), b1_ = bo ^ (uint32_t)(2 * TILE_BYTES);
+#pragma unroll
+      for (int i = 12; i < 16; ++i) dma(n_tiles + 1, i, ok1, b1_);
+    }
+
+    // ---- drain (t256w's plain epilogue); the pipeline stays loaded: a0 / b0 requested, k-tile 1 of the next tile in flight
+    int lane_e = lane0;
+    asm volatile("" : "+v"(lane_e));
+    int m0 = m0_pre, n0 = n0_pre;
+    asm volatile("" : "+s"(m0), "+s"(n0));
+    char* stg = smem + 2 * 2 * TILE_BYTES + wave * 2 * STAGE_BYTES;
+    drain_half_plain<false, 0, false>(p, acc, m0, n0, stg, lane_e, no_bias);
+    drain_half_plain<false, 1, false>(p, acc, m0, n0 + 64, stg, lane_e, no_bias);
+    tile += (int)gridDim.x;
+    if (tile >= total_tiles) break;
+    rsA = rsAn; rsB = rsBn;
+    rsAn = window_a(tile + (int)gridDim.x); rsBn = window_b(tile + (int)gridDim.x);
+  }
+  tie2<0>(a0, b0);                                        // dead, but in flight
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the look-ahead pieces of the tile that does not exist target this workgroup's LDS
+}
+}  // namespace t256la
+
 // Optional per-launch timing of ONE kernel instantiation with HIP events on the launch stream
 // (bench.py's roofline leg): variant id = AKS*1000 + BKS*100 + EPI*10 + OUTF32.
 struct GemmProf {
@@ -1840,6 +2028,27 @@ int launch(GemmArgs a, bool big, hipStream_t st) {
     const int gx = a.splits > 1 ? ntile * a.splits : (ntile < 256 ? ntile : 256);
     // persistent launches with more than one tile per workgroup claim their tiles dynamically (IA_GEMM_DYNAMIC=0: the static order)
     a.tile_ctr = (a.splits == 1 && ntile > gx) ? next_ctr_slot() : nullptr;
+    // plain NT form, several tiles per workgroup, static order: the look-ahead kernel (t256la; IA_GEMM_LA=0 keeps t256w)
+    int la = IA_T256LA;
+    { const char* e = getenv("IA_GEMM_LA"); if (e) la = atoi(e); }       // (read per launch: tests and A/B runs switch it in one process)
+    if constexpr (!AKS && !BKS && EPI == EPI_NONE && !OUTF32) {
+      if (la && a.splits == 1 && ntile > gx && !a.tile_ctr && a.K >= 2 * BK && !(IA_DBG(a))) {
+        static bool attr_set_la = false;
+        if (!attr_set_la) {
+          if (hipFuncSetAttribute((const void*)t256la::gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, t256::LDS_BYTES) != hipSuccess)
+            return IA_ERR_LAUNCH;
+          attr_set_la = true;
+        }
+        hipLaunchKernelGGL(t256la::gemm_kernel, dim3(gx), dim3(256), t256::LDS_BYTES, st, a);
+        if (rec) {
+          (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st);
+          g_prof.flops += 2.0 * a.M * a.N * a.K;
+          g_prof.bytes += 2.0 * ((double)a.M * a.K + (double)a.N * a.K) + 2.0 * a.M * a.N;
+          ++g_prof.n;
+        }
+        return ia_check_launch();
+      }
+    }
     hipLaunchKernelGGL(kern, dim3(gx), dim3(256), t256::LDS_BYTES, st, a);
   } else if (big) {
     a.tiles_m = (a.M + t256::BM - 1) / t256::BM; a.tiles_n = (a.N + t256::BN - 1) / t256::BN;

@@ -38,6 +38,30 @@ def test_gemm_nt_epilogues(gpu, M, N, K):
     assert rel_err(ops.gemm(a, w, out_f32=True), ref) < 2e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(70000, 1024, 1024), (65280, 1024, 4096), (66000, 768, 1088), (40000, 2304, 128), (33000, 4096, 200),
+                                   (130560, 1024, 1024)])
+def test_gemm_lookahead_kernel_matches_the_draining_one(gpu, monkeypatch, M, N, K):
+    """t256la (round 6): the plain NT GEMM whose k pipeline runs on across tile boundaries -- the last two trips of a tile fetch the NEXT
+    tile's first k-tiles through a second descriptor pair -- against t256w, which drains and refills per tile (IA_GEMM_LA=0): the same
+    MFMAs on the same operands in the same order, so the outputs must be bit-identical; and against torch fp32.  Shapes with several
+    tiles per workgroup (otherwise the dispatcher keeps t256w), ragged M (clipped last tile row), ragged K (partial last k-tile), K = 128
+    (two k-tiles: the whole loop is look-ahead), a tile count that is no multiple of the grid."""
+    from item_alignment_amd import ops
+    a, w = rnd((M, K), gpu, 1.0, 81), rnd((N, K), gpu, 0.05, 82)
+    monkeypatch.setenv("IA_GEMM_LA", "1")
+    y1 = ops.gemm(a, w).clone()
+    y1b = ops.gemm(a, w).clone()
+    monkeypatch.setenv("IA_GEMM_LA", "0")
+    y0 = ops.gemm(a, w).clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(y1.float()).all()
+    assert torch.equal(y1, y1b)
+    assert torch.equal(y1, y0)
+    rows = torch.cat((torch.arange(0, 512), torch.arange(M // 2, M // 2 + 512), torch.arange(M - 512, M))).to(gpu)
+    ref = a[rows].float() @ w.float().t()
+    assert rel_err(y1[rows], ref) < 2e-2
+
+
 @pytest.mark.parametrize("M,N", [(256, 256), (512, 128), (77, 64)])
 def test_gemm_gelu_epilogue_accuracy(gpu, M, N):
     """The FFN1 epilogue's GELU pair against the exact erf form (reference hidden_act = "gelu") at chosen pre-activations.  The GEMM is
