@@ -1,0 +1,141 @@
+#!/bin/bash
+# Every GPU command list of round 6 other than the final collection (r06_final.sh), in the order they ran: `r06_calls.sh <name>` runs one
+# (through gpu.sh -> gpurun, from the repository root on the box).  One file instead of one script per call (round 5 left 21 of those).
+cd ${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
+case "$1" in
+  baseline)
+    bash tools/runs/run.sh suite
+    bash tools/runs/run.sh bench
+    ;;
+  call2)
+    bash tools/runs/run.sh tests tests/test_models_gpu.py -k dropout_on -s
+    bash tools/runs/run.sh suite
+    ;;
+  call3)
+    IA_DROPOUT_SEEDS=256 python -m pytest tests/test_models_gpu.py -k dropout_on -s -q 2>&1 | grep -E "dropout z|passed|failed"
+    IA_DROPOUT_SEEDS=64 python -m pytest tests/test_models_gpu.py -k dropout_on -s -q 2>&1 | grep -E "dropout z|passed|failed"
+    python tools/c5x_mem_probe.py 16 2>&1 | grep -v "Warning\|amdgpu.ids\|getattr" | tee gpurun_out/r06_c5x_mem_probe16.txt
+    PROF_STEPS=11 bash tools/runs/run.sh prof c5x python3 tools/config_bench.py c5x
+    ;;
+  call4)
+    O=gpurun_out/r06_call4.txt; : > $O
+    python -m pytest tests/test_models_gpu.py -k "coca" -q 2>&1 | tail -3 >> $O
+    for n in 16 32 64 96; do IA_CB_PAIRS=$n python tools/config_bench.py c5x 2>&1 | grep -E "pairs/s|Error|error" >> $O; done
+    IA_DROPOUT_SEEDS=256 python -m pytest tests/test_models_gpu.py -k dropout_on -s -q 2>&1 | grep -E "dropout z|passed|failed" >> $O
+    IA_DROPOUT_SEEDS=64 python -m pytest tests/test_models_gpu.py -k dropout_on -s -q 2>&1 | grep -E "dropout z|passed|failed" >> $O
+    cat $O
+    ;;
+  c5x)
+    # C5x (--ensemble cross_attn, coca_large): where the memory goes + a kernel profile at the round-5 batch (verdict r5 item 4)
+    python tools/c5x_mem_probe.py 4 2>&1 | grep -v Warning | tee gpurun_out/r06_c5x_mem_probe.txt
+    PROF_STEPS=11 bash tools/runs/run.sh prof c5x python3 tools/config_bench.py c5x
+    ;;
+  call5)
+    O=gpurun_out/r06_call5.txt; : > $O
+    python -m pytest tests/test_kernels_gpu.py -k "eca or conv3x3" -q -x 2>&1 | tail -4 >> $O
+    python -m pytest tests/test_models_gpu.py -k "nfnet or dropout_on or resnet" -q -x 2>&1 | tail -4 >> $O
+    python -m pytest tests/test_baseline_shapes_gpu.py -k "c3 or c5" -q -x 2>&1 | tail -4 >> $O
+    python -m pytest tests/test_optim_gpu.py -q -x 2>&1 | tail -3 >> $O
+    for v in 1 0 1 0; do echo "IA_ECA_LINEAR=$v" >> $O; IA_ECA_LINEAR=$v python tools/config_bench.py c3 2>&1 | grep -E "pairs/s" >> $O; done
+    PROF_STEPS=11 bash tools/runs/run.sh prof c5x64 python3 tools/config_bench.py c5x > /dev/null 2>&1
+    PROF_STEPS=11 bash tools/runs/run.sh prof c3 python3 tools/config_bench.py c3 > /dev/null 2>&1
+    cat $O
+    ;;
+  call6)
+    O=gpurun_out/r06_call6.txt; : > $O
+    python -m pytest tests/test_kernels_gpu.py -k "exact_delta" -q -x -s 2>&1 | grep -E "adverse|passed|failed|Error|assert" | cut -c1-400 >> $O
+    python -m pytest tests -m gpu -x -q 2>&1 | tail -12 >> $O
+    cat $O
+    ;;
+  call7)
+    O=gpurun_out/r06_call7.txt; : > $O
+    python -m pytest tests -m gpu -x -q 2>&1 | tail -12 >> $O
+    for v in 1 0 1 0; do echo "IA_NFNET_FUSE_TAIL=$v (32 pairs)" >> $O; IA_CB_PAIRS=32 IA_NFNET_FUSE_TAIL=$v python tools/config_bench.py c3 2>&1 | grep -E "pairs/s" >> $O; done
+    python tools/config_bench.py c3 2>&1 | grep -E "pairs/s" >> $O
+    bash tools/runs/run.sh quick >> $O 2>&1
+    cat $O
+    ;;
+  call8)
+    O=gpurun_out/r06_call8.txt; : > $O
+    for i in 1 2 3; do python -m pytest tests/test_optim_gpu.py -q -x 2>&1 | grep -E "^E  .*(AssertionError|assert|\(')|passed|failed" | cut -c1-400 | head -8 >> $O; done
+    cat $O
+    ;;
+  call9)
+    bash tools/runs/run.sh suite
+    O=gpurun_out/r06_ab_fused_exchange.txt; : > $O
+    echo "attn_bwd_fused_kernel<true> at 512 x 255 x 16, dropout 0.1 (tools/attn_one.py under rocprofv3): this commit's exchange layout (dense rows + XOR key)" >> $O
+    echo "against the previous one (72-byte rows), two libraries on one box, interleaved" >> $O
+    cp item_alignment_amd/libitemalign_hip.so /tmp/lib_default.so
+    for rep in 1 2; do
+      for which in default prev; do
+        if [ $which = prev ]; then cp tools/abl/lib_prev_exchange.so item_alignment_amd/libitemalign_hip.so; else cp /tmp/lib_default.so item_alignment_amd/libitemalign_hip.so; fi
+        TAG=r06tmp bash tools/runs/run.sh prof bwdf_$which python3 tools/attn_one.py 512 255 16 0.1 > /dev/null 2>&1
+        echo "$which (rep $rep): $(grep -E 'attn_bwd_fused' gpurun_out/r06tmp_bwdf_${which}_kernel_stats_summary.txt)" >> $O
+      done
+    done
+    cp /tmp/lib_default.so item_alignment_amd/libitemalign_hip.so
+    cat $O
+    bash tools/runs/run.sh quick
+    ;;
+  call11)
+    O=gpurun_out/r06_call11.txt; : > $O
+    python -m pytest tests/test_kernels_gpu.py -k "skips_query or eca_block or attention_fwd_bwd or bwd_bias or dropout_mask or bench_shapes or first_launch" -q -x --tb=short 2>&1 | grep -E "^E  |passed|failed" | cut -c1-400 | tail -6 >> $O
+    python -m pytest tests/test_models_gpu.py tests/test_engine_gpu.py -q -x --tb=short 2>&1 | grep -E "^E  |passed|failed|^FAILED" | cut -c1-400 | tail -6 >> $O
+    python -m pytest tests/test_baseline_shapes_gpu.py -q -x --tb=short 2>&1 | grep -E "^E  |passed|failed|^FAILED" | cut -c1-400 | tail -6 >> $O
+    for v in 1 0 1 0; do echo "IA_MASKED_ROWS_DEAD=$v" >> $O; IA_MASKED_ROWS_DEAD=$v bash tools/runs/run.sh quick >> $O 2>&1; done
+    for v in 1 2 1 2; do echo "IA_NFNET_FUSE_TAIL=$v (32 pairs)" >> $O; IA_CB_PAIRS=32 IA_NFNET_FUSE_TAIL=$v python tools/config_bench.py c3 2>&1 | grep -E "pairs/s" >> $O; done
+    cat $O
+    ;;
+  call12)
+    O=gpurun_out/r06_call12.txt; : > $O
+    python -m pytest tests/test_models_gpu.py tests/test_engine_gpu.py tests/test_cli_gpu.py tests/test_dp_gpu.py tests/test_optim_gpu.py -q -x --tb=short 2>&1 | grep -E "^E  |passed|failed|^FAILED" | cut -c1-400 | tail -8 >> $O
+    cat $O
+    ;;
+  call13)
+    O=gpurun_out/r06_call13.txt; : > $O
+    python -m pytest tests/test_kernels_gpu.py -k "skips_query or attention" -q -x --tb=short 2>&1 | grep -E "^E  |passed|failed|^FAILED" | cut -c1-400 | tail -6 >> $O
+    bash tools/runs/run.sh suite >> $O 2>&1
+    for v in 1 0 1 0; do echo "IA_MASKED_ROWS_DEAD=$v" >> $O; IA_MASKED_ROWS_DEAD=$v python tools/config_bench.py c2 2>&1 | grep -E "pairs/s" >> $O; done
+    for v in 1 0; do echo "IA_MASKED_ROWS_DEAD=$v" >> $O; IA_MASKED_ROWS_DEAD=$v bash tools/runs/run.sh quick >> $O 2>&1; done
+    cat $O
+    ;;
+  call14)
+    O=gpurun_out/r06_call14.txt; : > $O
+    python -m pytest tests/test_engine_gpu.py tests/test_models_gpu.py -q -x --tb=short 2>&1 | grep -E "^E  |passed|failed|^FAILED" | cut -c1-400 | tail -6 >> $O
+    for v in 1 0 1 0; do echo "IA_LN_ROWS=$v: $(IA_LN_ROWS=$v bash tools/runs/run.sh quick 2>&1 | tail -1)" >> $O; done
+    cat $O
+    ;;
+  call15)
+    bash tools/runs/run.sh suite
+    ;;
+  call17)
+    O=gpurun_out/r06_call17.txt; : > $O
+    python tools/abl/ln_rows_bench.py >> $O 2>&1
+    python -m pytest tests/test_models_gpu.py -q -x --tb=short -k "pkgm" 2>&1 | grep -E "^E  |passed|failed|^FAILED" | cut -c1-300 | tail -4 >> $O
+    for v in 1 0; do
+      IA_LN_ROWS=$v TAG=r06tmp bash tools/runs/run.sh prof lnrows$v python3 bench.py --single-stream --steps 3 --warmup 2 --no-cpu-baseline --no-pmc --no-variants > /dev/null 2>&1
+      echo "IA_LN_ROWS=$v: $(grep -E 'ln_bwd_kernel' gpurun_out/r06tmp_lnrows${v}_kernel_stats_summary.txt)" >> $O
+    done
+    for v in 1 0; do echo "IA_MASKED_ROWS_DEAD=$v" >> $O; IA_MASKED_ROWS_DEAD=$v python tools/config_bench.py c4 2>&1 | grep -E "pairs/s" >> $O; done
+    cat $O
+    ;;
+  call18)
+    O=gpurun_out/r06_call18.txt; : > $O
+    python tools/abl/ln_rows_bench.py 2>&1 | grep -v amdgpu.ids >> $O
+    python -m pytest tests/test_engine_gpu.py tests/test_models_gpu.py tests/test_kernels_gpu.py -q -x --tb=short 2>&1 | grep -E "^E  |passed|failed|^FAILED" | cut -c1-300 | tail -4 >> $O
+    for v in 1 0; do
+      IA_LN_ROWS=$v TAG=r06tmp bash tools/runs/run.sh prof lnrows$v python3 bench.py --single-stream --steps 3 --warmup 2 --no-cpu-baseline --no-pmc --no-variants > /dev/null 2>&1
+      echo "IA_LN_ROWS=$v: $(grep -E 'ln_bwd_kernel' gpurun_out/r06tmp_lnrows${v}_kernel_stats_summary.txt)" >> $O
+    done
+    for v in 1 0 1 0; do echo "IA_LN_ROWS=$v: $(IA_LN_ROWS=$v bash tools/runs/run.sh quick 2>&1 | tail -1)" >> $O; done
+    cat $O
+    ;;
+  call20)
+    O=gpurun_out/r06_call20.txt; : > $O
+    timeout 600 python -m pytest tests/test_kernels_gpu.py -k "lookahead or gemm" -q -x --tb=short 2>&1 | grep -E "^E  |passed|failed|^FAILED" | cut -c1-300 | tail -6 >> $O
+    timeout 600 python tools/abl/gemm_la_ab.py 2>&1 | grep -v amdgpu.ids >> $O
+    for v in 1 0 1 0; do echo "IA_GEMM_LA=$v: $(IA_GEMM_LA=$v timeout 600 bash tools/runs/run.sh quick 2>&1 | tail -1)" >> $O; done
+    cat $O
+    ;;
+  *) echo "usage: $0 <" $(grep -oE '^  [a-z0-9_]+\)' "$0" | tr -d ' )') ">" >&2; exit 2 ;;
+esac
