@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Image-only two-tower pair matching (ViT / ECA-NFNet / ResNetV2 through `create_model`): CLI-compatible with
-the reference's finetune_image.py (flags :17-74, dispatch :192-218, loop :310-348).  The ViT family, eca_nfnet_l0/l1/l2
-and resnetv2_50/101/152 (BatchNorm) have HIP encoders; any other name (the BiT resnetv2_*_bitm variants among them) is a usage error at
-argparse time that lists the supported towers."""
+the reference's finetune_image.py (flags :17-74, dispatch :192-218, loop :310-348).  The ViT family, eca_nfnet_l0/l1/l2,
+resnetv2_50/101/152 (BatchNorm) and the BiT resnetv2_*_bitm[_in21k] towers (GroupNorm + StdConv2d: the two names of the reference's
+--model_name help text, :23) have HIP encoders; any other name is a usage error at argparse time that lists the supported towers."""
 import argparse
 import json
 import os

@@ -37,7 +37,7 @@ const char* ia_strerror(int code);
 /* Bumped whenever an entry point is added or the meaning of an argument / output changes (round 2 changed what IA_EPI_BIAS_GELU
  * stores in C2 and what IA_EPI_DGELU expects in aux): a caller built against another header must not run on this library.
  * item_alignment_amd/_lib.py refuses to load a library whose version differs from the one it was written for. */
-#define IA_ABI_VERSION 8
+#define IA_ABI_VERSION 9
 int ia_abi_version(void);
 
 /* ---- GEMM: torch.nn.Linear forward / dgrad / wgrad (src/models/text.py:1241 -> RobertaLayer dense
@@ -300,11 +300,25 @@ int ia_bn_act_fwd(const void* x, const float* gamma, const float* beta, float* r
 int ia_bn_act_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
                   const void* extra, void* dx, float* dgamma, float* dbeta, int rows, int C, int segments, int training, int relu,
                   void* workspace, size_t workspace_bytes, ia_stream_t stream);
+/* GroupNorm(groups, C, eps) + ReLU: the norm layer of the BiT towers (`--model_name resnetv2_50x3_bitm_in21k`, named by the help text
+ * of finetune_image.py:23 and handed to timm at :191; timm 0.6.5 resnetv2.py norm_layer=GroupNormAct(num_groups=32)).  x: `images`
+ * images of rows / images pixels each; biased statistics per (image, group of C / groups consecutive channels), the same in training
+ * and eval mode.  mean / rstd [images][C] fp32 (the group's value once per channel) are saved for the backward call. */
+size_t ia_gn_act_workspace_bytes(int rows, int C, int images);
+int ia_gn_act_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int rows, int C, int images,
+                  int groups, float eps, int relu, void* workspace, size_t workspace_bytes, ia_stream_t stream);
+/* dx (+ extra [rows, C] bf16 when not NULL), dgamma / dbeta [C] accumulated (NULL allowed) */
+int ia_gn_act_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                  const void* extra, void* dx, float* dgamma, float* dbeta, int rows, int C, int images, int groups, int relu,
+                  void* workspace, size_t workspace_bytes, ia_stream_t stream);
 /* cols [B*Ho*Wo, Kp] bf16: patch matrix of a k x k / stride / pad convolution read from NCHW fp32 images; column
  * (ky*k + kx)*C + c, columns >= k*k*C zero, Kp % 8 == 0 (the 7x7 stem, timm resnetv2.py create_resnetv2_stem) */
 int ia_patches_nchw(const float* images, void* cols, int B, int C, int H, int W, int k, int stride, int pad, int Kp, ia_stream_t stream);
 /* MaxPool2d(3, stride 2, padding 1): y [B*Ho*Wo, C] bf16, arg [B*Ho*Wo, C] u8 = window position of the first maximum */
 int ia_maxpool3s2_fwd(const void* x, void* y, uint8_t* arg, int B, int H, int W, int C, ia_stream_t stream);
+/* pad_zero != 0: window positions outside the image count as zeros -- ConstantPad2d(1, 0.) + MaxPool2d(3, 2, padding 0), the 'fixed'
+ * stem of the BiT towers (timm resnetv2.py create_resnetv2_stem); ia_maxpool3s2_bwd serves both forms */
+int ia_maxpool3s2_fwd_ex(const void* x, void* y, uint8_t* arg, int B, int H, int W, int C, int pad_zero, ia_stream_t stream);
 int ia_maxpool3s2_bwd(const void* dy, const uint8_t* arg, void* dx, int B, int H, int W, int C, ia_stream_t stream);
 /* rows read by a strided 1x1 convolution: y [B*Ho*Wo, C] = x[b, oy*stride, ox*stride, :]; the backward call writes
  * dx = base (NULL = zeros; may alias dx) + dy scattered onto the stride grid */

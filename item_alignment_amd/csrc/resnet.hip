@@ -186,6 +186,9 @@ __global__ __launch_bounds__(256) void bn_finish_bwd_kernel(const float* __restr
 
 // dx = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat))  [training]   or   gamma * rstd * g  [eval: statistics are constants]
 // (+ extra: a second gradient reaching x, e.g. the identity shortcut of a pre-activation block)
+// GN (GroupNorm): mean / rstd are per (image, channel) copies of the group statistics and sums holds the GROUP means
+// M1 = mean over the group of gamma * g, M2 = mean of gamma * g * xhat:  dx = rstd * (gamma * g - M1 - xhat * M2)
+template <bool GN>
 __global__ __launch_bounds__(256) void bn_dx_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x, const float* __restrict__ mean,
                                                     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     const float* __restrict__ sums, const bf16* __restrict__ extra, bf16* __restrict__ dx,
@@ -202,8 +205,10 @@ __global__ __launch_bounds__(256) void bn_dx_kernel(const bf16* __restrict__ dy,
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       k1[j] = ga[j] * rs[j];
-      k2[j] = training ? k2[j] * inv_n : 0.f;          // mean(g)
-      k3[j] = training ? k3[j] * inv_n : 0.f;          // mean(g * xhat)
+      if (!GN) {
+        k2[j] = training ? k2[j] * inv_n : 0.f;          // mean(g)
+        k3[j] = training ? k3[j] * inv_n : 0.f;          // mean(g * xhat)
+      }
     }
     for (int r = t.r0 + t.lane; r < t.r1; r += t.nlane) {
       const size_t off = (t.base + r) * C + c;
@@ -217,13 +222,67 @@ __global__ __launch_bounds__(256) void bn_dx_kernel(const bf16* __restrict__ dy,
         const float xh = (bf2f(v[j]) - mu[j]) * rs[j];
         float g = bf2f(g8[j]);
         if (relu && xh * ga[j] + be[j] <= 0.f) g = 0.f;
-        float d = k1[j] * (g - k2[j] - xh * k3[j]);
+        float d = GN ? k1[j] * g - rs[j] * (k2[j] + xh * k3[j]) : k1[j] * (g - k2[j] - xh * k3[j]);
         if (extra) d += bf2f(e8[j]);
         o[j] = f2bf(d);
       }
       *reinterpret_cast<bf16x8*>(dx + off) = o;
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------- GroupNorm (BiT towers)
+// GroupNormAct (timm layers/norm_act.py: nn.GroupNorm(32, C) + ReLU) on NHWC rows: every image is one "segment" of the BatchNorm
+// passes above, so bn_partial_kernel delivers per (image, slice, channel) sums; the kernels below fold them over the slices and then
+// over the channels of a group.  Everything here touches [images][C] floats: a few microseconds; fixed orders (deterministic).
+__global__ __launch_bounds__(256) void gn_fold_kernel(const float* __restrict__ part, float* __restrict__ sums, int C, int nsplit, size_t plane,
+                                                      int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int seg = idx / C, c = idx - seg * C;
+  float s = 0.f, q = 0.f;
+  for (int i = 0; i < nsplit; ++i) { s += part[((size_t)seg * nsplit + i) * C + c]; q += part[plane + ((size_t)seg * nsplit + i) * C + c]; }
+  sums[((size_t)seg * 2) * C + c] = s;
+  sums[((size_t)seg * 2 + 1) * C + c] = q;
+}
+
+// forward: mean / rstd of (image, group) from sums = (sum x, sum x^2) per (image, channel), written once per channel of the group
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ sums, float* __restrict__ mean, float* __restrict__ rstd, int C,
+                                                       int groups, int rows_per_seg, float eps, int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int seg = idx / groups, g = idx - seg * groups, cg = C / groups, c0 = g * cg;
+  float s = 0.f, q = 0.f;
+  for (int c = c0; c < c0 + cg; ++c) { s += sums[((size_t)seg * 2) * C + c]; q += sums[((size_t)seg * 2 + 1) * C + c]; }
+  const float n = (float)cg * (float)rows_per_seg, mu = s / n;
+  float var = q / n - mu * mu;
+  var = var < 0.f ? 0.f : var;
+  const float rs = rsqrtf(var + eps);
+  for (int c = c0; c < c0 + cg; ++c) { mean[(size_t)seg * C + c] = mu; rstd[(size_t)seg * C + c] = rs; }
+}
+
+// backward: gmean[image][0][c] = M1, [1][c] = M2 of the channel's group from sums = (sum g, sum g * xhat) per (image, channel)
+__global__ __launch_bounds__(256) void gn_bwd_group_kernel(const float* __restrict__ sums, const float* __restrict__ gamma, float* __restrict__ gmean,
+                                                           int C, int groups, int rows_per_seg, int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int seg = idx / groups, g = idx - seg * groups, cg = C / groups, c0 = g * cg;
+  float m1 = 0.f, m2 = 0.f;
+  for (int c = c0; c < c0 + cg; ++c) { m1 += gamma[c] * sums[((size_t)seg * 2) * C + c]; m2 += gamma[c] * sums[((size_t)seg * 2 + 1) * C + c]; }
+  const float inv_n = 1.f / ((float)cg * (float)rows_per_seg);
+  m1 *= inv_n; m2 *= inv_n;
+  for (int c = c0; c < c0 + cg; ++c) { gmean[((size_t)seg * 2) * C + c] = m1; gmean[((size_t)seg * 2 + 1) * C + c] = m2; }
+}
+
+// dgamma[c] += sum over the images of sum g * xhat, dbeta[c] += sum g
+__global__ __launch_bounds__(256) void gn_dparam_kernel(const float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int C,
+                                                        int segments) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float db = 0.f, dg = 0.f;
+  for (int seg = 0; seg < segments; ++seg) { db += sums[((size_t)seg * 2) * C + c]; dg += sums[((size_t)seg * 2 + 1) * C + c]; }
+  if (dgamma) dgamma[c] += dg;
+  if (dbeta) dbeta[c] += db;
 }
 
 // ------------------------------------------------------------------------------------------ stem patch gather
@@ -291,8 +350,10 @@ __global__ __launch_bounds__(256) void patches_stem7_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------- MaxPool 3x3 / 2 / pad 1
 // y[b, oy, ox, c] = max over the 3x3 window at (2oy-1, 2ox-1); arg = window position (ky*3+kx) of the FIRST maximum in scan
 // order (the element PyTorch's max_pool2d backward routes the gradient to)
+// pad_zero: the window positions outside the image count as ZEROS (timm's 'fixed' stem of the BiT towers: ConstantPad2d(1, 0.) in
+// front of MaxPool2d(3, 2, padding 0)); a recorded maximum that is such a zero has no pixel, so its gradient goes nowhere
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, uint8_t* __restrict__ arg, int H, int W,
-                                                          int C, int Ho, int Wo, size_t total) {
+                                                          int C, int Ho, int Wo, int pad_zero, size_t total) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const int c8n = C >> 3, c = (int)(idx % c8n) * 8;
@@ -306,11 +367,13 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16* __restrict
   bool first = true;
   for (int t = 0; t < 9; ++t) {
     const int iy = 2 * oy + t / 3 - 1, ix = 2 * ox + t % 3 - 1;
-    if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + ((b * H + iy) * W + ix) * C + c);
+    const bool inside = iy >= 0 && iy < H && ix >= 0 && ix < W;
+    if (!inside && !pad_zero) continue;
+    bf16x8 v;
+    if (inside) v = *reinterpret_cast<const bf16x8*>(x + ((b * H + iy) * W + ix) * C + c);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float f = bf2f(v[j]);
+      const float f = inside ? bf2f(v[j]) : 0.f;
       if (first || f > best[j] || f != f) { best[j] = f; at[j] = t; }
     }
     first = false;
@@ -478,8 +541,67 @@ extern "C" int ia_bn_act_bwd(const void* dy, const void* x, const float* gamma, 
   hipLaunchKernelGGL(bn_finish_bwd_kernel, dim3((C + 15) / 16), dim3(256), 0, stream, (const float*)workspace, sums, dgamma, dbeta, C, ns, segments,
                      plane);
   const int per = slab_rows(C);
-  hipLaunchKernelGGL(bn_dx_kernel, dim3((rps + per - 1) / per, segments), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)x, mean, rstd, gamma,
+  hipLaunchKernelGGL(bn_dx_kernel<false>, dim3((rps + per - 1) / per, segments), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)x, mean, rstd, gamma,
                      beta, (const float*)sums, (const bf16*)extra, (bf16*)dx, rps, C, relu, training, per);
+  return ia_check_launch();
+}
+
+// workspace of ia_gn_act_fwd / ia_gn_act_bwd: two planes of [images][nsplit][C] partial sums + [images][2][C] folded sums + [images][2][C]
+// group means
+extern "C" size_t ia_gn_act_workspace_bytes(int rows, int C, int images) {
+  if (rows <= 0 || C <= 0 || images <= 0 || rows % images) return 0;
+  const int ns = bn_nsplit(rows / images);
+  return ((size_t)2 * images * ns * C + (size_t)4 * images * C) * sizeof(float);
+}
+
+// GroupNormAct (timm layers/norm_act.py GroupNormAct: nn.GroupNorm(groups, C, eps) followed by ReLU -- the norm layer of the BiT
+// `resnetv2_*_bit*` towers, timm resnetv2.py) over NHWC rows x [rows, C] bf16 of `images` images (rows / images pixels each): biased
+// statistics per (image, group of C / groups channels); the same arithmetic in training and eval mode.  mean / rstd [images][C] fp32
+// (the group's value repeated for each of its channels) are written for the backward.  C % 8 == 0, C % groups == 0.
+extern "C" int ia_gn_act_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int rows, int C, int images,
+                             int groups, float eps, int relu, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || C <= 0 || (C & 7) || images <= 0 || images > 65535 || rows % images ||
+      groups <= 0 || C % groups)
+    return IA_ERR_ARG;
+  if (!workspace || workspace_bytes < ia_gn_act_workspace_bytes(rows, C, images)) return IA_ERR_WORKSPACE;
+  const int rps = rows / images, ns = bn_nsplit(rps);
+  const size_t plane = (size_t)images * ns * C;
+  float* sums = (float*)workspace + 2 * plane;
+  hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(ns, images), dim3(256), 0, stream, (const bf16*)x, (const bf16*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)workspace, rps, C, ns, 0, plane);
+  hipLaunchKernelGGL(gn_fold_kernel, dim3(blocks_of((size_t)images * C)), dim3(256), 0, stream, (const float*)workspace, sums, C, ns, plane, images * C);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(blocks_of((size_t)images * groups)), dim3(256), 0, stream, (const float*)sums, mean, rstd, C, groups, rps, eps,
+                     images * groups);
+  const int per = slab_rows(C);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((rps + per - 1) / per, images), dim3(256), 0, stream, (const bf16*)x, (const float*)mean,
+                     (const float*)rstd, gamma, beta, (bf16*)y, rps, C, relu, per);
+  return ia_check_launch();
+}
+
+// dx [rows, C] bf16 (+ extra [rows, C] bf16 if not NULL), dgamma / dbeta [C] fp32 accumulated (either may be NULL)
+extern "C" int ia_gn_act_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                             const void* extra, void* dx, float* dgamma, float* dbeta, int rows, int C, int images, int groups, int relu,
+                             void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dy || !x || !gamma || !beta || !mean || !rstd || !dx || rows <= 0 || C <= 0 || (C & 7) || images <= 0 || images > 65535 || rows % images ||
+      groups <= 0 || C % groups)
+    return IA_ERR_ARG;
+  if (!workspace || workspace_bytes < ia_gn_act_workspace_bytes(rows, C, images)) return IA_ERR_WORKSPACE;
+  const int rps = rows / images, ns = bn_nsplit(rps);
+  const size_t plane = (size_t)images * ns * C;
+  float* sums = (float*)workspace + 2 * plane;
+  float* gmean = sums + (size_t)2 * images * C;
+  hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(ns, images), dim3(256), 0, stream, (const bf16*)x, (const bf16*)dy, mean, rstd, gamma, beta,
+                     (float*)workspace, rps, C, ns, relu, plane);
+  hipLaunchKernelGGL(gn_fold_kernel, dim3(blocks_of((size_t)images * C)), dim3(256), 0, stream, (const float*)workspace, sums, C, ns, plane, images * C);
+  hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(blocks_of((size_t)images * groups)), dim3(256), 0, stream, (const float*)sums, gamma, gmean, C, groups, rps,
+                     images * groups);
+  if (dgamma || dbeta)
+    hipLaunchKernelGGL(gn_dparam_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)sums, dgamma, dbeta, C, images);
+  const int per = slab_rows(C);
+  hipLaunchKernelGGL(bn_dx_kernel<true>, dim3((rps + per - 1) / per, images), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)x, mean, rstd, gamma,
+                     beta, (const float*)gmean, (const bf16*)extra, (bf16*)dx, rps, C, relu, 1, per);
   return ia_check_launch();
 }
 
@@ -501,13 +623,16 @@ extern "C" int ia_patches_nchw(const float* images, void* cols, int B, int C, in
 }
 
 // MaxPool2d(3, stride 2, padding 1) on NHWC rows: y [B*Ho*Wo, C] bf16, arg [B*Ho*Wo, C] u8 (window position of the maximum)
-extern "C" int ia_maxpool3s2_fwd(const void* x, void* y, uint8_t* arg, int B, int H, int W, int C, hipStream_t stream) {
+extern "C" int ia_maxpool3s2_fwd_ex(const void* x, void* y, uint8_t* arg, int B, int H, int W, int C, int pad_zero, hipStream_t stream) {
   (void)hipGetLastError();
   if (!x || !y || !arg || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7)) return IA_ERR_ARG;
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const size_t total = (size_t)B * Ho * Wo * (C >> 3);
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, arg, H, W, C, Ho, Wo, total);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, arg, H, W, C, Ho, Wo, pad_zero, total);
   return ia_check_launch();
+}
+extern "C" int ia_maxpool3s2_fwd(const void* x, void* y, uint8_t* arg, int B, int H, int W, int C, hipStream_t stream) {
+  return ia_maxpool3s2_fwd_ex(x, y, arg, B, H, W, C, 0, stream);
 }
 
 extern "C" int ia_maxpool3s2_bwd(const void* dy, const uint8_t* arg, void* dx, int B, int H, int W, int C, hipStream_t stream) {

@@ -123,8 +123,8 @@ def create_model(model_name, pretrained=False, **kwargs):
     from .nfnet import NFNET_CONFIGS, create_nfnet
     if model_name in NFNET_CONFIGS:
         return create_nfnet(model_name, **kwargs)
-    from .resnetv2 import RESNETV2_CONFIGS, create_resnetv2
-    if model_name in RESNETV2_CONFIGS:
+    from .resnetv2 import BIT_CONFIGS, RESNETV2_CONFIGS, create_resnetv2
+    if model_name in RESNETV2_CONFIGS or model_name in BIT_CONFIGS:
         return create_resnetv2(model_name, **kwargs)
     raise ValueError(unsupported_encoder_message(model_name))
 
@@ -132,13 +132,13 @@ def create_model(model_name, pretrained=False, **kwargs):
 def supported_image_encoders():
     """every name `create_model` builds on the HIP engine (the reference hands any name to timm, finetune_image.py:191)"""
     from .nfnet import NFNET_CONFIGS
-    from .resnetv2 import RESNETV2_CONFIGS
-    return sorted(VIT_CONFIGS) + sorted(NFNET_CONFIGS) + sorted(RESNETV2_CONFIGS)
+    from .resnetv2 import BIT_CONFIGS, RESNETV2_CONFIGS
+    return sorted(VIT_CONFIGS) + sorted(NFNET_CONFIGS) + sorted(RESNETV2_CONFIGS) + sorted(BIT_CONFIGS)
 
 
 def unsupported_encoder_message(model_name):
-    extra = (" (the BiT `resnetv2_*_bitm` variants -- GroupNorm + StdConv -- are not built: use the BatchNorm resnetv2_50 / 101 / 152)"
-             if "bit" in model_name else "")
+    extra = (" (of timm's ResNetV2 family the BatchNorm resnetv2_50 / 101 / 152 and the BiT resnetv2_*_bit* towers are built; the"
+             " 'd' / 't' stems and the EvoNorm / FilterResponseNorm variants are not)" if "resnetv2" in model_name else "")
     return f"image encoder {model_name!r} has no HIP tower{extra}; supported: {', '.join(supported_image_encoders())}"
 
 

@@ -12,6 +12,13 @@ row subsampling are csrc/resnet.hip.  Module / parameter / buffer names are timm
 BatchNorm statistics are per forward call in the reference, and ResNetTwoTower calls the encoder once per tower
 (image.py:337-341).  The HIP two-tower wrapper runs both towers as one 2B batch, so the encoder normalises in
 `bn_segments` = 2 runs of B images and updates the running statistics run by run — the same numbers as two calls.
+
+The BiT variants (`resnetv2_50x3_bitm_in21k` is one of the two names the help text of finetune_image.py:23 gives; timm resnetv2.py
+`_create_resnetv2_bit`: stem_type='fixed', conv_layer=StdConv2d(eps=1e-8), norm_layer=GroupNormAct(num_groups=32), channels and
+stem scaled by `width_factor`) are the same graph with three pieces exchanged: the weights are standardised per output channel
+before every convolution (ia_ws_conv_weight_*, the kernel of the NF-Net tower with gain 1 and scale 1), the norm is per (image,
+group) (ia_gn_act_*: no batch statistics, so nothing to segment), and the stem pads its 7x7/2 output with a ring of ZEROS in front
+of an unpadded 3x3/2 MaxPool (ia_maxpool3s2_fwd_ex).
 """
 import torch
 from torch import nn
@@ -29,6 +36,16 @@ RESNETV2_CONFIGS = {   # timm resnetv2.py: the BatchNorm (non-BiT) variants
     "resnetv2_101": (3, 4, 23, 3),
     "resnetv2_152": (3, 8, 36, 3),
 }
+_BIT_GEOMETRY = {"50x1": ((3, 4, 6, 3), 1), "50x3": ((3, 4, 6, 3), 3), "101x1": ((3, 4, 23, 3), 1), "101x3": ((3, 4, 23, 3), 3),
+                 "152x2": ((3, 8, 36, 3), 2), "152x4": ((3, 8, 36, 3), 4)}
+BIT_CONFIGS = {}        # timm resnetv2.py: name -> (layers, width_factor, num_classes of the (unused) head)
+for _g, (_layers, _wf) in _BIT_GEOMETRY.items():
+    BIT_CONFIGS[f"resnetv2_{_g}_bitm"] = (_layers, _wf, 1000)
+    BIT_CONFIGS[f"resnetv2_{_g}_bitm_in21k"] = (_layers, _wf, 21843)
+BIT_CONFIGS["resnetv2_50x1_bit_distilled"] = ((3, 4, 6, 3), 1, 1000)
+BIT_CONFIGS["resnetv2_152x2_bit_teacher"] = ((3, 8, 36, 3), 2, 1000)
+BIT_CONFIGS["resnetv2_152x2_bit_teacher_384"] = ((3, 8, 36, 3), 2, 1000)
+BIT_STD_EPS, GN_GROUPS = 1e-8, 32
 
 
 # ---------------------------------------------------------------------------------------------- autograd functions
@@ -82,12 +99,80 @@ class BnActFn(torch.autograd.Function):
         return dx, None, None, None, None, None
 
 
+class GnActFn(torch.autograd.Function):
+    """GroupNormAct (timm layers/norm_act.py: nn.GroupNorm + ReLU) on NHWC rows of `images` images; `passthrough` as in BnActFn."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gn, images, passthrough):
+        lib = _lib.load()
+        Fn._need_gpu(x, "feature map")
+        x = x.contiguous()
+        rows, C = x.shape
+        dev = x.device
+        if rows % images:
+            raise ValueError(f"GroupNorm: {rows} rows are not {images} images of equal size")
+        y = torch.empty_like(x)
+        mean = torch.empty((images, C), device=dev, dtype=F32)
+        rstd = torch.empty((images, C), device=dev, dtype=F32)
+        wsb = lib.ia_gn_act_workspace_bytes(rows, C, images)
+        ws = _ws(dev, wsb)
+        check(lib.ia_gn_act_fwd(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, C, images,
+                                gn.num_groups, gn.eps, 1, ws.data_ptr(), wsb, stream_ptr()), "ia_gn_act_fwd")
+        ctx.gn, ctx.saved, ctx.args = gn, (x, mean, rstd), (rows, C, images)
+        ctx.set_materialize_grads(False)
+        return (y, x.view_as(x)) if passthrough else y
+
+    @staticmethod
+    def backward(ctx, dy, dpass=None):
+        lib = _lib.load()
+        gn = ctx.gn
+        x, mean, rstd = ctx.saved
+        rows, C, images = ctx.args
+        if dy is None:
+            return dpass, None, None, None, None, None
+        dy = dy.contiguous()
+        dp = None if dpass is None else dpass.contiguous()
+        dx = torch.empty_like(x)
+        wsb = lib.ia_gn_act_workspace_bytes(rows, C, images)
+        ws = _ws(dy.device, wsb)
+        wg = gn.weight.grad.data_ptr() if gn.weight.requires_grad else None
+        bg = gn.bias.grad.data_ptr() if gn.bias.requires_grad else None
+        check(lib.ia_gn_act_bwd(dy.data_ptr(), x.data_ptr(), gn.weight.data_ptr(), gn.bias.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ptr(dp),
+                                dx.data_ptr(), wg, bg, rows, C, images, gn.num_groups, 1, ws.data_ptr(), wsb, stream_ptr()), "ia_gn_act_bwd")
+        Fn._notify([gn.weight, gn.bias])
+        ctx.saved = None
+        return dx, None, None, None, None, None
+
+
+_ONES = {}
+
+
+def _ones(dev, n):
+    """the gain of a plain StdConv2d (ia_ws_conv_weight_* are the ScaledStdConv2d kernels of the NF-Net tower: gain[o] * scale)"""
+    key = (str(dev), n)
+    if key not in _ONES:
+        _ONES[key] = torch.ones(n, device=dev, dtype=F32)
+    return _ONES[key]
+
+
 def _packed_weight(conv, Cgp, ldw):
+    """the bf16 GEMM operand [Cout, ldw] (tap-major) of the convolution's weight -- standardised first when the module is a StdConv2d"""
     lib = _lib.load()
     w = conv.weight
     Cout, Cg, k, _ = w.shape
-    what = torch.empty((Cout, ldw), device=w.device, dtype=BF16)
-    check(lib.ia_conv_weight_pack(w.data_ptr(), what.data_ptr(), Cout, Cg, k * k, Cgp, ldw, stream_ptr()), "ia_conv_weight_pack")
+    std_eps = getattr(conv, "std_eps", None)
+    if std_eps is None:
+        what = torch.empty((Cout, ldw), device=w.device, dtype=BF16)
+        check(lib.ia_conv_weight_pack(w.data_ptr(), what.data_ptr(), Cout, Cg, k * k, Cgp, ldw, stream_ptr()), "ia_conv_weight_pack")
+        return what
+    what = torch.empty((Cout, k * k * Cgp), device=w.device, dtype=BF16)
+    mean = torch.empty(Cout, device=w.device, dtype=F32)
+    rstd = torch.empty(Cout, device=w.device, dtype=F32)
+    check(lib.ia_ws_conv_weight_fwd(w.data_ptr(), _ones(w.device, Cout).data_ptr(), what.data_ptr(), mean.data_ptr(), rstd.data_ptr(), Cout, Cg, k * k,
+                                    Cgp, 1.0, std_eps, stream_ptr()), "ia_ws_conv_weight_fwd")
+    conv.__dict__["_ws_stats"] = (mean, rstd)      # of the weights as they are now: the same for every call until the optimiser steps
+    if ldw > k * k * Cgp:                           # (the stem's 147 columns padded to the GEMM's 8-column granule)
+        what = torch.nn.functional.pad(what, (0, ldw - k * k * Cgp))
     return what
 
 
@@ -95,7 +180,14 @@ def _weight_grad(conv, dwhat, Cgp, ldw):
     lib = _lib.load()
     w = conv.weight
     Cout, Cg, k, _ = w.shape
-    check(lib.ia_conv_weight_unpack_grad(dwhat.data_ptr(), w.grad.data_ptr(), Cout, Cg, k * k, Cgp, ldw, stream_ptr()), "ia_conv_weight_unpack_grad")
+    if getattr(conv, "std_eps", None) is None:
+        check(lib.ia_conv_weight_unpack_grad(dwhat.data_ptr(), w.grad.data_ptr(), Cout, Cg, k * k, Cgp, ldw, stream_ptr()), "ia_conv_weight_unpack_grad")
+    else:
+        mean, rstd = conv.__dict__["_ws_stats"]
+        if ldw > k * k * Cgp:
+            dwhat = dwhat[:, :k * k * Cgp].contiguous()
+        check(lib.ia_ws_conv_weight_bwd(dwhat.data_ptr(), w.data_ptr(), _ones(w.device, Cout).data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                        w.grad.data_ptr(), None, Cout, Cg, k * k, Cgp, 1.0, stream_ptr()), "ia_ws_conv_weight_bwd")
     Fn._notify([w])
 
 
@@ -257,17 +349,17 @@ class StemConvFn(torch.autograd.Function):
 
 
 class MaxPoolFn(torch.autograd.Function):
-    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1) on NHWC rows."""
+    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1) on NHWC rows; pad_zero: ConstantPad2d(1, 0.) + MaxPool2d(3, 2, padding 0)."""
 
     @staticmethod
-    def forward(ctx, x, B, H, W):
+    def forward(ctx, x, B, H, W, pad_zero=False):
         lib = _lib.load()
         x = x.contiguous()
         C = x.shape[1]
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         y = torch.empty((B * Ho * Wo, C), device=x.device, dtype=BF16)
         arg = torch.empty((B * Ho * Wo, C), device=x.device, dtype=torch.uint8)
-        check(lib.ia_maxpool3s2_fwd(x.data_ptr(), y.data_ptr(), arg.data_ptr(), B, H, W, C, stream_ptr()), "ia_maxpool3s2_fwd")
+        check(lib.ia_maxpool3s2_fwd_ex(x.data_ptr(), y.data_ptr(), arg.data_ptr(), B, H, W, C, int(pad_zero), stream_ptr()), "ia_maxpool3s2_fwd_ex")
         ctx.arg, ctx.dims = arg, (B, H, W, C)
         return y
 
@@ -278,12 +370,14 @@ class MaxPoolFn(torch.autograd.Function):
         dx = torch.empty((B * H * W, C), device=dy.device, dtype=BF16)
         check(lib.ia_maxpool3s2_bwd(dy.contiguous().data_ptr(), ctx.arg.data_ptr(), dx.data_ptr(), B, H, W, C, stream_ptr()), "ia_maxpool3s2_bwd")
         ctx.arg = None
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------- modules
 class Conv2d(nn.Module):
     """timm create_conv2d(in, out, k, stride=..) = nn.Conv2d(bias=False, symmetric padding) holding only the weight"""
+
+    std_eps = None
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1):
         super().__init__()
@@ -300,6 +394,25 @@ class Conv2d(nn.Module):
         return FeatureMap(y, f.B, (f.H - 1) // s + 1, (f.W - 1) // s + 1)
 
 
+class StdConv2d(Conv2d):
+    """timm layers/std_conv.py StdConv2d(eps=1e-8) as the BiT towers configure it: the weight is standardised per output channel
+    (F.batch_norm over its fan-in: biased variance, eps inside the root) in front of every convolution"""
+    std_eps = BIT_STD_EPS
+
+
+class GroupNormAct(nn.GroupNorm):
+    """timm layers/norm_act.py GroupNormAct (GroupNorm(32, C, eps 1e-5) + ReLU); statistics are per image: `segments` is unused"""
+
+    def __init__(self, num_channels, num_groups=GN_GROUPS):
+        super().__init__(num_groups, num_channels, eps=1e-5, affine=True)
+
+    def forward(self, f, segments=1, passthrough=False):
+        out = GnActFn.apply(f.t, self.weight, self.bias, self, f.B, passthrough)
+        if passthrough:
+            return FeatureMap(out[0], f.B, f.H, f.W), out[1]
+        return FeatureMap(out, f.B, f.H, f.W)
+
+
 class BatchNormAct2d(nn.BatchNorm2d):
     """timm layers/norm_act.py BatchNormAct2d (BatchNorm2d + ReLU, eps 1e-5, momentum 0.1); `segments` as in the module doc"""
 
@@ -313,9 +426,9 @@ class BatchNormAct2d(nn.BatchNorm2d):
 class DownsampleConv(nn.Module):
     """timm resnetv2.py DownsampleConv with preact=True: a strided 1x1 convolution, no norm"""
 
-    def __init__(self, in_chs, out_chs, stride=1):
+    def __init__(self, in_chs, out_chs, stride=1, conv_layer=Conv2d):
         super().__init__()
-        self.conv = Conv2d(in_chs, out_chs, 1, stride=stride)
+        self.conv = conv_layer(in_chs, out_chs, 1, stride=stride)
         self.norm = nn.Identity()
 
     def forward(self, f):
@@ -326,16 +439,16 @@ class PreActBottleneck(nn.Module):
     """timm resnetv2.py PreActBottleneck: norm1 -> (shortcut = downsample(preact) | x) -> conv1 -> norm2 -> conv2 (3x3, stride)
     -> norm3 -> conv3 -> + shortcut"""
 
-    def __init__(self, in_chs, out_chs, bottle_ratio=0.25, stride=1, downsample=False):
+    def __init__(self, in_chs, out_chs, bottle_ratio=0.25, stride=1, downsample=False, conv_layer=Conv2d, norm_layer=BatchNormAct2d):
         super().__init__()
         mid_chs = make_divisible(out_chs * bottle_ratio)
-        self.downsample = DownsampleConv(in_chs, out_chs, stride=stride) if downsample else None
-        self.norm1 = BatchNormAct2d(in_chs)
-        self.conv1 = Conv2d(in_chs, mid_chs, 1)
-        self.norm2 = BatchNormAct2d(mid_chs)
-        self.conv2 = Conv2d(mid_chs, mid_chs, 3, stride=stride)
-        self.norm3 = BatchNormAct2d(mid_chs)
-        self.conv3 = Conv2d(mid_chs, out_chs, 1)
+        self.downsample = DownsampleConv(in_chs, out_chs, stride=stride, conv_layer=conv_layer) if downsample else None
+        self.norm1 = norm_layer(in_chs)
+        self.conv1 = conv_layer(in_chs, mid_chs, 1)
+        self.norm2 = norm_layer(mid_chs)
+        self.conv2 = conv_layer(mid_chs, mid_chs, 3, stride=stride)
+        self.norm3 = norm_layer(mid_chs)
+        self.conv3 = conv_layer(mid_chs, out_chs, 1)
 
     def forward(self, f, segments=1):
         if self.downsample is not None:
@@ -349,20 +462,27 @@ class PreActBottleneck(nn.Module):
 
 
 class ResNetStage(nn.Module):
-    def __init__(self, in_chs, out_chs, stride, depth, bottle_ratio=0.25):
+    def __init__(self, in_chs, out_chs, stride, depth, bottle_ratio=0.25, conv_layer=Conv2d, norm_layer=BatchNormAct2d):
         super().__init__()
         blocks, prev = [], in_chs
         for bi in range(depth):
-            blocks.append(PreActBottleneck(prev, out_chs, bottle_ratio, stride=stride if bi == 0 else 1, downsample=bi == 0))
+            blocks.append(PreActBottleneck(prev, out_chs, bottle_ratio, stride=stride if bi == 0 else 1, downsample=bi == 0,
+                                           conv_layer=conv_layer, norm_layer=norm_layer))
             prev = out_chs
         self.blocks = nn.Sequential(*blocks)
 
 
 class _Stem(nn.Module):
-    def __init__(self, in_chans, stem_chs):
+    """timm resnetv2.py create_resnetv2_stem(preact=True): stem_type '' = conv 7x7/2 + MaxPool2d(3, 2, padding 1); 'fixed' (BiT) =
+    conv 7x7/2 + ConstantPad2d(1, 0.) + MaxPool2d(3, 2, padding 0)"""
+
+    def __init__(self, in_chans, stem_chs, conv_layer=Conv2d, fixed=False):
         super().__init__()
-        self.conv = Conv2d(in_chans, stem_chs, 7, stride=2)
-        self.pool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.conv = conv_layer(in_chans, stem_chs, 7, stride=2)
+        if fixed:
+            self.pad = nn.ConstantPad2d(1, 0.0)
+        self.pool = nn.MaxPool2d(kernel_size=3, stride=2, padding=0 if fixed else 1)
+        self.fixed = fixed
 
 
 class _GlobalPool(nn.Module):
@@ -383,16 +503,20 @@ class _Head(nn.Module):
 class ResNetV2(HipModule):
     """forward_features(images [B,3,S,S] fp32) -> FeatureMap [B, S/32, S/32, 2048] NHWC bf16; head.global_pool(map) -> [B, 2048]"""
 
-    def __init__(self, layers, channels=(256, 512, 1024, 2048), num_classes=1000, in_chans=3, stem_chs=64, bottle_ratio=0.25):
+    def __init__(self, layers, channels=(256, 512, 1024, 2048), num_classes=1000, in_chans=3, stem_chs=64, bottle_ratio=0.25, width_factor=1,
+                 bit=False):
         super().__init__()
-        self.stem = _Stem(in_chans, stem_chs)
+        conv_layer, norm_layer = (StdConv2d, GroupNormAct) if bit else (Conv2d, BatchNormAct2d)
+        stem_chs = make_divisible(stem_chs * width_factor)
+        self.stem = _Stem(in_chans, stem_chs, conv_layer, fixed=bit)
         stages, prev = [], stem_chs
         for si, (d, c) in enumerate(zip(layers, channels)):
-            stages.append(ResNetStage(prev, c, 1 if si == 0 else 2, d, bottle_ratio))
+            c = make_divisible(c * width_factor)
+            stages.append(ResNetStage(prev, c, 1 if si == 0 else 2, d, bottle_ratio, conv_layer, norm_layer))
             prev = c
         self.stages = nn.Sequential(*stages)
         self.num_features = prev
-        self.norm = BatchNormAct2d(prev)
+        self.norm = norm_layer(prev)
         self.head = _Head(prev, num_classes)
         for p in self.head.parameters():
             p.requires_grad = False            # never reached by the pair step
@@ -409,7 +533,7 @@ class ResNetV2(HipModule):
         k, s = conv.kernel_size, conv.stride
         pad = ((s - 1) + (k - 1)) // 2
         H, W = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
-        f = FeatureMap(MaxPoolFn.apply(y, B, H, W), B, (H - 1) // 2 + 1, (W - 1) // 2 + 1)
+        f = FeatureMap(MaxPoolFn.apply(y, B, H, W, self.stem.fixed), B, (H - 1) // 2 + 1, (W - 1) // 2 + 1)
         for stage in self.stages:
             for blk in stage.blocks:
                 f = blk(f, seg)
@@ -420,4 +544,7 @@ class ResNetV2(HipModule):
 
 
 def create_resnetv2(model_name, **kwargs):
+    if model_name in BIT_CONFIGS:
+        layers, wf, num_classes = BIT_CONFIGS[model_name]
+        return ResNetV2(layers, num_classes=num_classes, width_factor=wf, bit=True)
     return ResNetV2(RESNETV2_CONFIGS[model_name])

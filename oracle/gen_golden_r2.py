@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE — second set of golden vectors (round 2), kept apart from gen_golden.py so that the first set's random
 draws (and therefore its committed fixtures) stay bit-identical.  Build container only (needs /root/reference, read-only).
 
-    python oracle/gen_golden_r2.py [wrappers] [vit_hf] [deep]
+    python oracle/gen_golden_r2.py [wrappers] [vit_hf] [deep] [bit_hf] [bit_wrapper]      (default: the first three)
 
 wrappers  the reference's OWN image two-tower classes — NFNetTwoTower (src/models/image.py:212-294), ResNetTwoTower (:298-378),
           VitTwoTower (:418-499) — instantiated with an encoder module that evaluates the oracle's restatement of the timm tower
@@ -11,6 +11,8 @@ wrappers  the reference's OWN image two-tower classes — NFNetTwoTower (src/mod
 vit_hf    cross-check of the oracle's ViT restatement against an independent third-party implementation that IS installed:
           transformers.ViTModel (eager attention, layer_norm_eps 1e-6) with the same seeded weights under HF's key names.
           A cross-check between two restatements of the same public architecture, not a pin by the reference.
+bit_hf / bit_wrapper   (round 6) the same two kinds of evidence for the BiT ResNetV2 towers (GroupNorm + StdConv2d + 'fixed' stem):
+          transformers.BitModel as the independent implementation, the reference's ResNetTwoTower as the wrapper.
 deep      roberta_large.json geometry with all 24 layers through the reference's RobertaModel, B = 2, L = 510 (config C2
           shapes): strided subsamples of the hidden states after layers 1, 6, 12, 18, 24, so the bf16 engine's drift over depth
           is bounded against the fp32 reference.
@@ -175,6 +177,92 @@ def vit_hf():
     print("wrote vit_hf_crosscheck.npz")
 
 
+NARROW_BIT = SimpleNamespace(layers=(1, 2, 1, 1), channels=(128, 256, 256, 512), stem_chs=32, bottle_ratio=0.25, eps=1e-5, momentum=0.1,
+                             num_features=512, bit=True, std_eps=1e-8, groups=32)
+
+
+def bit_hf():
+    """the oracle's BiT restatement (timm resnetv2.py `_create_resnetv2_bit` layout and key names) against transformers.BitModel -- an
+    independent implementation of the same published architecture -- with the same seeded weights: features, pooled output and the
+    gradients of a weighted sum of the pooled output"""
+    from transformers import BitConfig, BitModel
+    c = NARROW_BIT
+    spec = O.resnetv2_state_spec(c, prefix="e")
+    sd = seeded_state_dict(spec, 83, scale=0.08)
+    hf_cfg = BitConfig(num_channels=3, embedding_size=c.stem_chs, hidden_sizes=list(c.channels), depths=list(c.layers), layer_type="preactivation",
+                       hidden_act="relu", global_padding=None, num_groups=c.groups, drop_path_rate=0.0, embedding_dynamic_padding=False,
+                       output_stride=32, width_factor=1)
+    hf = BitModel(hf_cfg).eval()
+    m = {"embedder.convolution.weight": sd["e.stem.conv.weight"], "norm.weight": sd["e.norm.weight"], "norm.bias": sd["e.norm.bias"]}
+    for k, v in sd.items():
+        if k.startswith("e.stages."):
+            _, _, si, _, bi, rest = k.split(".", 5)
+            m[f"encoder.stages.{si}.layers.{bi}.{rest}"] = v
+    missing, unexpected = hf.load_state_dict(m, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    rs = np.random.RandomState(84)
+    images = rs.standard_normal((3, 3, 96, 96)).astype(np.float32)
+    wts = rs.standard_normal((3, c.num_features)).astype(np.float32)
+    gnames = ["stem.conv.weight", "stages.0.blocks.0.downsample.conv.weight", "stages.0.blocks.0.norm1.weight", "stages.1.blocks.0.conv2.weight",
+              "stages.1.blocks.1.norm2.bias", "stages.2.blocks.0.conv1.weight", "stages.3.blocks.0.conv3.weight", "norm.weight", "norm.bias"]
+    hf_params = dict(hf.named_parameters())
+    out = hf(pixel_values=torch.from_numpy(images))
+    (out.pooler_output.flatten(1) * torch.from_numpy(wts)).sum().backward()
+    want_feat, want_pool = out.last_hidden_state.detach(), out.pooler_output.flatten(1).detach()
+    hf_key = lambda k: ("embedder.convolution.weight" if k == "stem.conv.weight" else k if k.startswith("norm.") else
+                        "encoder.stages.{}.layers.{}.{}".format(*(lambda q: (q[1], q[3], q[4]))(k.split(".", 4))))
+    want_grads = {k: hf_params[hf_key(k)].grad.detach() for k in gnames}
+    ref = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    feat = O.resnetv2_forward_features(ref, "e", c, torch.from_numpy(images))
+    (feat.mean((2, 3)) * torch.from_numpy(wts)).sum().backward()
+    err = (feat.detach() - want_feat).abs().max().item() / want_feat.abs().max().item()
+    print(f"bit_hf_crosscheck: oracle vs transformers.BitModel max |diff| / max |.| = {err:.2e}")
+    assert err < 1e-4
+    for k in gnames:
+        g, w = ref["e." + k].grad, want_grads[k]
+        e = (g - w).norm().item() / w.norm().item()
+        print(f"  grad {k}: rel {e:.2e}")
+        assert e < 1e-3, k
+    import json
+    meta = dict(case="bit_hf_crosscheck", seed=83, seed_scale=0.08, config=dict(vars(c)), spec=[[k, list(s)] for k, s in spec],
+                transformers=__import__("transformers").__version__)
+    arrays = dict(in_images=images, in_wts=wts, out_features=want_feat.numpy(), out_pooled=want_pool.numpy(),
+                  extra_seed_scale=np.array(0.08, dtype=np.float32))
+    arrays.update({"grad_" + k: v.numpy() for k, v in want_grads.items()})
+    np.savez_compressed(os.path.join(GOLDEN, "bit_hf_crosscheck.npz"), meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), **arrays)
+    print("wrote bit_hf_crosscheck.npz")
+
+
+def bit_wrapper(M):
+    """the reference's OWN ResNetTwoTower (src/models/image.py:298-378) around the oracle's BiT restatement -- the `resnetv2_*_bitm` names
+    take the same `"resnet" in args.model_name` branch of finetune_image.py:215-216 as resnetv2_50.  Own random stream: the fixtures of
+    wrappers() stay bit-identical."""
+    rs = np.random.RandomState(4343)
+    B, size, nf, seed, scale = 3, 96, NARROW_BIT.num_features, 53, 0.08
+    spec = O.resnetv2_state_spec(NARROW_BIT, prefix="e")
+    cfg = reference_config(hidden_size=nf, num_labels=2, hidden_dropout_prob=0.1, interaction_type="two_tower", loss_type="ce", loss_margin=0.3)
+    enc = OracleEncoder("resnet", NARROW_BIT, spec, nf, None)
+    model = M.ResNetTwoTower(cfg, enc).eval()
+    full_spec = [("img_encoder." + k[2:], s) for k, s in spec] + [("classifier.out_proj.weight", (2, 2 * nf)), ("classifier.out_proj.bias", (2,))]
+    sd = seeded_state_dict(full_spec, seed, scale=scale)
+    with torch.no_grad():
+        for k, v in sd.items():
+            if k.startswith("img_encoder."):
+                enc.params[k[len("img_encoder."):].replace(".", "__")].copy_(v)
+        model.classifier.out_proj.weight.copy_(sd["classifier.out_proj.weight"])
+        model.classifier.out_proj.bias.copy_(sd["classifier.out_proj.bias"])
+    im1 = rs.standard_normal((B, 3, size, size)).astype(np.float32)
+    im2 = (rs.standard_normal((B, 3, size, size)) * 1.3 + 0.2).astype(np.float32)
+    labels = np.array([0, 1, 1], dtype=np.int64)
+    out = model(t(im1), t(im2), t(labels))
+    out.loss.backward()
+    grads = {"classifier.out_proj.weight": model.classifier.out_proj.weight.grad}
+    for g in ["stem.conv.weight", "stages.1.blocks.1.conv2.weight", "stages.3.blocks.0.conv3.weight", "norm.weight"]:
+        grads["img_encoder." + g] = enc.params[g.replace(".", "__")].grad
+    save("resnet_bit_two_tower", cfg, seed, full_spec, dict(images_1=im1, images_2=im2, labels=labels), out, grads,
+         extra=dict(seed_scale=np.array(scale, dtype=np.float32)))
+
+
 def deep(M):
     """24 layers of roberta_large geometry through the reference's RobertaModel (C2 shapes, B = 2, L = 510)"""
     rs = np.random.RandomState(7171)
@@ -203,10 +291,14 @@ def deep(M):
 if __name__ == "__main__":
     which = sys.argv[1:] or ["wrappers", "vit_hf", "deep"]
     os.makedirs(GOLDEN, exist_ok=True)
-    M = load_reference() if ("wrappers" in which or "deep" in which) else None
+    M = load_reference() if ("wrappers" in which or "deep" in which or "bit_wrapper" in which) else None
     if "wrappers" in which:
         wrappers(M)
     if "vit_hf" in which:
         vit_hf()
+    if "bit_hf" in which:
+        bit_hf()
+    if "bit_wrapper" in which:
+        bit_wrapper(M)
     if "deep" in which:
         deep(M)

@@ -739,9 +739,24 @@ def nfnet_two_tower(sd, cfg, ncfg, images_1, images_2, labels=None, training=Fal
 # the reference at finetune_image.py:191,215-216 and image.py:337-341.
 
 
+# The BiT variants (`resnetv2_{50x1,50x3,101x1,101x3,152x2,152x4}_bitm[_in21k]`; finetune_image.py:23 names resnetv2_50x3_bitm_in21k) are
+# timm resnetv2.py `_create_resnetv2_bit`: the same ResNetV2 class with stem_type='fixed', conv_layer=partial(StdConv2d, eps=1e-8),
+# norm_layer=partial(GroupNormAct, num_groups=32) and every width (stem included) multiplied by width_factor.  cfg.bit selects them here.
+# Cross-checked against an independent implementation of the same published architecture that IS installed (transformers.BitModel):
+# oracle/gen_golden_r2.py bit_hf -> tests/golden/bit_hf_crosscheck.npz.
+
+
 def resnetv2_cfg(name="resnetv2_50"):
     from types import SimpleNamespace
-    layers = {"resnetv2_50": (3, 4, 6, 3), "resnetv2_101": (3, 4, 23, 3), "resnetv2_152": (3, 8, 36, 3)}[name]
+    depth = {"50": (3, 4, 6, 3), "101": (3, 4, 23, 3), "152": (3, 8, 36, 3)}
+    if "_bit" in name:
+        geo = name.split("_")[1]                      # "50x3"
+        d, wf = geo.split("x")
+        wf = int(wf)
+        ch = tuple(make_divisible(c * wf) for c in (256, 512, 1024, 2048))
+        return SimpleNamespace(layers=depth[d], channels=ch, stem_chs=make_divisible(64 * wf), bottle_ratio=0.25, eps=1e-5, momentum=0.1,
+                               num_features=ch[-1], bit=True, std_eps=1e-8, groups=32, num_classes=21843 if name.endswith("in21k") else 1000)
+    layers = depth[name.split("_")[1]]
     return SimpleNamespace(layers=layers, channels=(256, 512, 1024, 2048), stem_chs=64, bottle_ratio=0.25, eps=1e-5, momentum=0.1,
                            num_features=2048)
 
@@ -767,30 +782,54 @@ def bn_act(x, sd, p, cfg, training, stats=None):
     if training:
         rm = stats[p + ".running_mean"] if stats is not None else None
         rv = stats[p + ".running_var"] if stats is not None else None
-        return F.relu(F.batch_norm(x, rm, rv, w, b, True, cfg.momentum, cfg.eps))
-    return F.relu(F.batch_norm(x, stats[p + ".running_mean"], stats[p + ".running_var"], w, b, False, cfg.momentum, cfg.eps))
+        return _r(F.relu(F.batch_norm(x, rm, rv, w, b, True, cfg.momentum, cfg.eps)))
+    return _r(F.relu(F.batch_norm(x, stats[p + ".running_mean"], stats[p + ".running_var"], w, b, False, cfg.momentum, cfg.eps)))
+
+
+def gn_act(x, sd, p, cfg):
+    """timm layers/norm_act.py GroupNormAct = nn.GroupNorm(32, C, eps 1e-5) + ReLU (per image: no batch statistics, no buffers)"""
+    return _r(F.relu(F.group_norm(x, cfg.groups, sd[p + ".weight"], sd[p + ".bias"], cfg.eps)))
+
+
+def _norm_act(x, sd, p, cfg, training, stats):
+    return gn_act(x, sd, p, cfg) if getattr(cfg, "bit", False) else bn_act(x, sd, p, cfg, training, stats)
+
+
+def _conv_weight(sd, key, cfg):
+    """timm layers/std_conv.py StdConv2d.forward for the BiT towers: F.batch_norm over the weight viewed as [1, Cout, fan_in] in training
+    mode without affine terms = (w - mean) / sqrt(biased var + eps) per output channel; the BatchNorm variants use the weight as it is"""
+    w = sd[key]
+    if not getattr(cfg, "bit", False):
+        return _r(w)
+    return _r(F.batch_norm(w.reshape(1, w.shape[0], -1), None, None, training=True, momentum=0.0, eps=cfg.std_eps).reshape_as(w))
 
 
 def preact_bottleneck(x, sd, p, blk, cfg, training, stats):
     """timm resnetv2.py PreActBottleneck.forward"""
-    pre = bn_act(x, sd, p + ".norm1", cfg, training, stats)
+    pre = _norm_act(x, sd, p + ".norm1", cfg, training, stats)
     shortcut = x
     if blk["downsample"]:
-        shortcut = F.conv2d(pre, sd[p + ".downsample.conv.weight"], None, stride=blk["stride"])
-    out = F.conv2d(pre, sd[p + ".conv1.weight"])
-    out = F.conv2d(bn_act(out, sd, p + ".norm2", cfg, training, stats), sd[p + ".conv2.weight"], None, stride=blk["stride"], padding=1)
-    out = F.conv2d(bn_act(out, sd, p + ".norm3", cfg, training, stats), sd[p + ".conv3.weight"])
-    return out + shortcut
+        shortcut = _r(F.conv2d(pre, _conv_weight(sd, p + ".downsample.conv.weight", cfg), None, stride=blk["stride"]))
+    out = _r(F.conv2d(pre, _conv_weight(sd, p + ".conv1.weight", cfg)))
+    out = _r(F.conv2d(_norm_act(out, sd, p + ".norm2", cfg, training, stats), _conv_weight(sd, p + ".conv2.weight", cfg), None, stride=blk["stride"],
+                      padding=1))
+    out = F.conv2d(_norm_act(out, sd, p + ".norm3", cfg, training, stats), _conv_weight(sd, p + ".conv3.weight", cfg))
+    return _r(out + shortcut)           # (the engine adds the shortcut in the GEMM epilogue: one rounding)
 
 
 def resnetv2_forward_features(sd, p, cfg, images, training=True, stats=None):
-    """ResNetV2.forward_features: stem (7x7/2 conv, MaxPool 3/2/1), stages, final BatchNormAct2d."""
-    x = F.conv2d(images, sd[p + ".stem.conv.weight"], None, stride=2, padding=3)
-    x = F.max_pool2d(x, 3, 2, 1)
+    """ResNetV2.forward_features: stem, stages, final norm.  Stem (timm create_resnetv2_stem, preact=True -> no norm): 7x7/2 conv then
+    MaxPool2d(3, 2, padding 1) for stem_type '' / ConstantPad2d(1, 0.) + MaxPool2d(3, 2, padding 0) for the BiT towers' 'fixed'."""
+    # (_r: the storage-rounding mode of the text towers, `with rounding(torch.bfloat16)`, covers this tower as well -- identity otherwise)
+    x = _r(F.conv2d(_r(images), _conv_weight(sd, p + ".stem.conv.weight", cfg), None, stride=2, padding=3))
+    if getattr(cfg, "bit", False):
+        x = F.max_pool2d(F.pad(x, (1, 1, 1, 1), value=0.0), 3, 2, 0)
+    else:
+        x = F.max_pool2d(x, 3, 2, 1)
     for si, blocks in enumerate(resnetv2_plan(cfg)):
         for bi, blk in enumerate(blocks):
             x = preact_bottleneck(x, sd, f"{p}.stages.{si}.blocks.{bi}", blk, cfg, training, stats)
-    return bn_act(x, sd, p + ".norm", cfg, training, stats)
+    return _norm_act(x, sd, p + ".norm", cfg, training, stats)
 
 
 def resnetv2_state_spec(cfg, prefix="img_encoder"):

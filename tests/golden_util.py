@@ -31,6 +31,8 @@ NARROW_NFNET = SimpleNamespace(depths=(1, 2, 1, 1), channels=(256, 512, 512, 512
                                num_features=512, alpha=0.2, attn_gain=2.0, eps=1e-5, ch_div=8)
 NARROW_RESNET = SimpleNamespace(layers=(1, 2, 1, 1), channels=(64, 128, 256, 256), stem_chs=32, bottle_ratio=0.25, eps=1e-5, momentum=0.1,
                                 num_features=256)
+NARROW_BIT = SimpleNamespace(layers=(1, 2, 1, 1), channels=(128, 256, 256, 512), stem_chs=32, bottle_ratio=0.25, eps=1e-5, momentum=0.1,
+                             num_features=512, bit=True, std_eps=1e-8, groups=32)
 TINY_VIT = SimpleNamespace(embed_dim=128, depth=2, num_heads=2, patch_size=16, eps=1e-6, image_size=64)
 
 
@@ -84,6 +86,8 @@ def run_oracle(case, sd, training=False):
         return O.textcnn_two_tower(sd, cfg, i["input_ids_1"], i["input_ids_2"], i["labels"], training)
     if n.startswith("nfnet_two_tower"):
         return O.nfnet_two_tower(sd, cfg, NARROW_NFNET, i["images_1"], i["images_2"], i["labels"], training)
+    if n.startswith("resnet_bit_two_tower"):
+        return O.resnetv2_two_tower(sd, cfg, NARROW_BIT, i["images_1"], i["images_2"], i["labels"], training, None)
     if n.startswith("resnet_two_tower"):
         stats = O.resnetv2_running_stats(NARROW_RESNET, "img_encoder")
         return O.resnetv2_two_tower(sd, cfg, NARROW_RESNET, i["images_1"], i["images_2"], i["labels"], training, stats)

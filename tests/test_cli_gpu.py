@@ -61,7 +61,7 @@ def test_finetune_multimodal_coca_gpu(gpu, tmp_path):
     assert "f1=" in r.stderr and "loss:" in r.stderr
 
 
-@pytest.mark.parametrize("model_name,size", [("eca_nfnet_l0", 64), ("vit_base_patch16_224", 224), ("resnetv2_50", 64)])
+@pytest.mark.parametrize("model_name,size", [("eca_nfnet_l0", 64), ("vit_base_patch16_224", 224), ("resnetv2_50", 64), ("resnetv2_50x1_bitm", 64)])
 def test_finetune_image_gpu(gpu, tmp_path, model_name, size):
     root = str(tmp_path)
     rs = np.random.RandomState(1)

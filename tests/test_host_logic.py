@@ -175,6 +175,30 @@ def test_resnetv2_structure_and_timm_names():
     assert tuple(y.shape) == (2, 2048, 2, 2) and torch.isfinite(y).all()
 
 
+def test_bit_towers_have_timm_names_and_shapes():
+    """`create_model("resnetv2_50x1_bitm")` (a BiT name: finetune_image.py:23 lists resnetv2_50x3_bitm_in21k) builds the GroupNorm +
+    StdConv2d tower with timm's state_dict keys and shapes -- no BatchNorm buffers -- and the head of the named variant; the x3 width
+    scales the stem and every stage (the model is built on the meta device: 217 M parameters are not allocated here)."""
+    import torch
+    from item_alignment_amd.models import create_model
+    from item_alignment_amd.models.resnetv2 import GroupNormAct, StdConv2d
+    from oracle import ref_models as O
+    cfg = O.resnetv2_cfg("resnetv2_50x1_bitm")
+    spec = O.resnetv2_state_spec(cfg)
+    net = create_model("resnetv2_50x1_bitm")
+    want = {k[len("img_encoder."):]: tuple(s) for k, s in spec}
+    have = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert set(want) <= set(have) and all(have[k] == s for k, s in want.items())
+    assert set(have) - set(want) == {"head.fc.weight", "head.fc.bias"} and have["head.fc.weight"] == (1000, 2048, 1, 1)
+    assert isinstance(net.stem.conv, StdConv2d) and net.stem.conv.std_eps == 1e-8 and net.stem.fixed
+    assert isinstance(net.norm, GroupNormAct) and net.norm.num_groups == 32 and net.norm.eps == 1e-5
+    assert all(isinstance(m, (StdConv2d, torch.nn.Conv2d)) for m in net.modules() if hasattr(m, "kernel_size") and not isinstance(m, torch.nn.MaxPool2d))
+    with torch.device("meta"):
+        big = create_model("resnetv2_50x3_bitm_in21k")
+    assert big.num_features == 6144 and big.stem.conv.out_channels == 192 and tuple(big.head.fc.weight.shape) == (21843, 6144, 1, 1)
+    assert sum(p.numel() for p in big.parameters()) == 345399315          # timm lists 217.32 M with 1000 classes (345.40 M with 21 843)
+
+
 def test_resize_tables_reproduce_pillow_bit_exact():
     """The host-built resampling tables (data/gpu_preproc.py: Pillow Resample.c precompute_coeffs + normalize_coeffs_8bpc) and
     the 8.22 fixed-point two-pass arithmetic the GPU kernels implement reproduce PIL Image.resize(..., BICUBIC / BILINEAR) bit for
@@ -451,9 +475,9 @@ def test_direct_convolution_swizzle_keys_are_the_best_of_their_family():
 
 
 def test_unsupported_image_tower_is_a_usage_error_at_argparse_time():
-    """`finetune_image.py --model_name resnetv2_50x1_bitm` (a name the reference hands to timm, finetune_image.py:191,215) has no HIP
-    tower: the run ends in argparse with the supported set named, not with a NotImplementedError in the middle of model construction;
-    `create_model` itself raises a ValueError with the same text."""
+    """`finetune_image.py --model_name resnetv2_50d_evos` (any name goes to timm in the reference, finetune_image.py:191,215) has no HIP
+    tower: the run ends in argparse with the supported set named, not with an error in the middle of model construction; `create_model`
+    itself raises a ValueError with the same text.  The BiT names of the reference's help text (finetune_image.py:23) ARE built."""
     import os
     import subprocess
     import sys
@@ -461,10 +485,11 @@ def test_unsupported_image_tower_is_a_usage_error_at_argparse_time():
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     names = supported_image_encoders()
     assert "vit_base_patch16_384" in names and "eca_nfnet_l0" in names and "resnetv2_50" in names
-    with pytest.raises(ValueError, match="resnetv2_50x1_bitm.*BiT.*supported: .*eca_nfnet_l0"):
-        create_model("resnetv2_50x1_bitm")
+    assert "resnetv2_50x3_bitm_in21k" in names and "resnetv2_50x1_bitm" in names and "resnetv2_152x4_bitm" in names
+    with pytest.raises(ValueError, match="resnetv2_50d_evos.*EvoNorm.*supported: .*eca_nfnet_l0"):
+        create_model("resnetv2_50d_evos")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "finetune_image.py"), "--data_dir", "/nonexistent", "--output_dir", "/nonexistent",
-                        "--data_version", "v0", "--model_name", "resnetv2_50x1_bitm"], capture_output=True, text=True, timeout=300)
+                        "--data_version", "v0", "--model_name", "resnetv2_50d_evos"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 2, (r.returncode, r.stderr[-500:])
     assert "has no HIP tower" in r.stderr and "resnetv2_50" in r.stderr and "usage:" in r.stderr
 

@@ -963,6 +963,85 @@ def test_batchnorm_relu_fwd_bwd(gpu, rows, C, segments):
     assert rel_err(y, ref_ev) < 1e-2
 
 
+@pytest.mark.parametrize("images,hw,C,groups", [(3, 49, 192, 32), (2, 56 * 56, 768, 32), (4, 100, 32, 32), (2, 333, 64, 8), (1, 9, 6144, 32)])
+def test_groupnorm_relu_fwd_bwd(gpu, images, hw, C, groups):
+    """ia_gn_act_* (GroupNorm + ReLU on NHWC rows: the norm layer of the BiT towers; statistics per (image, group), groups of 6 / 24 / 1 /
+    8 / 192 channels -- narrower and wider than a thread's eight) against torch group_norm in fp32 on the same bf16-rounded input:
+    output, dx (with a second gradient added, the identity shortcut of a pre-activation block), dgamma, dbeta; the saved statistics are
+    the group's, repeated per channel."""
+    from item_alignment_amd import _lib
+    from item_alignment_amd.ops import check, stream_ptr
+    lib = _lib.load()
+    rows = images * hw
+    x = rnd((rows, C), gpu, 1.5, 71) * torch.linspace(0.3, 2.0, C, device=gpu).bfloat16() + 0.4
+    dy = rnd((rows, C), gpu, 1.0, 72)
+    extra = rnd((rows, C), gpu, 1.0, 73)
+    gg = torch.Generator().manual_seed(74)
+    gamma = (1 + 0.2 * torch.randn(C, generator=gg)).to(gpu).contiguous()
+    beta = (0.1 * torch.randn(C, generator=gg)).to(gpu).contiguous()
+    xr = x.float().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    nchw = xr.view(images, hw, C).permute(0, 2, 1)                                        # [images, C, hw]
+    ref = torch.relu(torch.nn.functional.group_norm(nchw, groups, gr, br, 1e-5)).permute(0, 2, 1).reshape(rows, C)
+    ref.backward(dy.float())
+
+    y = torch.empty_like(x)
+    mean, rstd = torch.empty((images, C), device=gpu), torch.empty((images, C), device=gpu)
+    wsb = lib.ia_gn_act_workspace_bytes(rows, C, images)
+    ws = torch.empty(wsb, device=gpu, dtype=torch.uint8)
+    check(lib.ia_gn_act_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, C, images, groups,
+                            1e-5, 1, ws.data_ptr(), wsb, stream_ptr()), "gn_fwd")
+    assert rel_err(y, ref) < 1e-2
+    xg = x.float().view(images, hw, groups, C // groups)
+    mu_ref = xg.mean((1, 3))
+    rs_ref = torch.rsqrt(xg.var((1, 3), unbiased=False) + 1e-5)
+    assert rel_err(mean.view(images, groups, C // groups), mu_ref[:, :, None].expand(-1, -1, C // groups)) < 1e-4
+    assert rel_err(rstd.view(images, groups, C // groups), rs_ref[:, :, None].expand(-1, -1, C // groups)) < 1e-4
+    dx = torch.empty_like(x)
+    dg, db = torch.full((C,), 0.5, device=gpu), torch.full((C,), -0.25, device=gpu)           # accumulated into
+    check(lib.ia_gn_act_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(), extra.data_ptr(),
+                            dx.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, C, images, groups, 1, ws.data_ptr(), wsb, stream_ptr()), "gn_bwd")
+    assert rel_err(dx, xr.grad + extra.float()) < 2e-2
+    assert rel_err(dg - 0.5, gr.grad) < 1e-2 and rel_err(db + 0.25, br.grad) < 1e-2
+    # without the second gradient, and deterministic
+    dx2, dx3 = torch.empty_like(x), torch.empty_like(x)
+    for out in (dx2, dx3):
+        check(lib.ia_gn_act_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(), None, out.data_ptr(),
+                                None, None, rows, C, images, groups, 1, ws.data_ptr(), wsb, stream_ptr()), "gn_bwd")
+    assert rel_err(dx2, xr.grad) < 2e-2 and torch.equal(dx2, dx3)
+    # argument checks: channels that do not split into the groups, a short workspace
+    assert lib.ia_gn_act_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, C, images, 7, 1e-5, 1,
+                             ws.data_ptr(), wsb, stream_ptr()) != 0
+    assert lib.ia_gn_act_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, C, images, groups,
+                             1e-5, 1, ws.data_ptr(), 16, stream_ptr()) != 0
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 9, 12, 16), (1, 32, 32, 64), (2, 7, 7, 8)])
+def test_maxpool_with_a_ring_of_zeros(gpu, B, H, W, C):
+    """The BiT stem (timm create_resnetv2_stem 'fixed'): ConstantPad2d(1, 0.) + MaxPool2d(3, 2, padding 0) -- the ring counts as zeros, so
+    a border window of negative values yields 0 and routes no gradient.  Bit-exact forward, torch's gradient routing (ties included)."""
+    from item_alignment_amd import _lib
+    from item_alignment_amd.ops import check, stream_ptr
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(13)
+    x = (torch.randint(-5, 3, (B, H, W, C), generator=g).float() * 0.5).to(gpu).bfloat16()      # mostly negative, coarse: zero ties and wins
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    ref = torch.nn.functional.max_pool2d(torch.nn.functional.pad(xr, (1, 1, 1, 1), value=0.0), 3, 2, 0)
+    assert tuple(ref.shape[2:]) == (Ho, Wo)
+    dy = rnd((B, Ho, Wo, C), gpu, 1.0, 15)
+    ref.backward(dy.float().permute(0, 3, 1, 2))
+    y = torch.empty((B, Ho, Wo, C), device=gpu, dtype=torch.bfloat16)
+    arg = torch.empty((B, Ho, Wo, C), device=gpu, dtype=torch.uint8)
+    check(lib.ia_maxpool3s2_fwd_ex(x.data_ptr(), y.data_ptr(), arg.data_ptr(), B, H, W, C, 1, stream_ptr()), "maxpool_fwd_ex")
+    assert torch.equal(y.float(), ref.detach().permute(0, 2, 3, 1))
+    plain = torch.nn.functional.max_pool2d(x.float().permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    assert not torch.equal(y.float(), plain)                                                # the ring did win somewhere
+    dx = torch.empty_like(x)
+    check(lib.ia_maxpool3s2_bwd(dy.data_ptr(), arg.data_ptr(), dx.data_ptr(), B, H, W, C, stream_ptr()), "maxpool_bwd")
+    assert rel_err(dx, xr.grad.permute(0, 2, 3, 1)) < 1e-2
+
+
 @pytest.mark.parametrize("B,H,W,C", [(2, 9, 12, 16), (1, 32, 32, 64), (2, 7, 7, 8)])
 def test_maxpool_stem_patches_and_subsample(gpu, B, H, W, C):
     """MaxPool 3/2/1 (ties go to the first maximum, as PyTorch routes the gradient), the strided-row gather of a 1x1/2

@@ -25,11 +25,15 @@ COS_EXCEPTIONS = {}
 # (tools/parity_report.py -> profiles/r04_parity_report.txt) and bounded at 1.25 x that value.
 GRAD_REL = 5e-2
 REL_EXCEPTIONS = {
-    # conv towers: the rounding mode does not cover convolutions; BatchNorm batch statistics over 3 images / ReLU gates in bf16
-    ("resnet_two_tower", "img_encoder.stem.conv.weight"): 0.191,
-    ("resnet_two_tower", "img_encoder.stages.3.blocks.0.conv3.weight"): 0.072,
     # (round 6: the roberta_one_tower_* and roberta_image_two_tower_begin fixtures hold eight samples too -- the six exceptions their
-    # three-sample batches needed, head / embedding-table gradients that were sums over a handful of tokens, are gone)
+    # three-sample batches needed, head / embedding-table gradients that were sums over a handful of tokens, are gone; and the rounding
+    # mode covers the ResNetV2 towers now: the BatchNorm tower's two tensors -- 0.19 / 0.072 from the fp32 gradients -- sit at 0.040 /
+    # 0.038 from the same-precision oracle's and need no entry.)
+    # The BiT tower (StdConv2d: every layer at full gain -> the ReLU gates that bf16 rounding flips are not the same ones in two bf16
+    # implementations with different summation orders): distance to the same-precision oracle, 0.32-0.36 to the fp32 reference
+    ("resnet_bit_two_tower", "img_encoder.stem.conv.weight"): 0.102,
+    ("resnet_bit_two_tower", "img_encoder.stages.1.blocks.1.conv2.weight"): 0.30,
+    ("resnet_bit_two_tower", "img_encoder.stages.3.blocks.0.conv3.weight"): 0.30,
 }
 EXCEPTION_HEADROOM = 1.25
 MEASURED = []            # (case, kind, key, value) of everything check() compared: printed by tools/parity_report.py
@@ -240,19 +244,23 @@ def test_coca_cross_attn(gpu):
     check(case, out, model)
 
 
-@pytest.mark.parametrize("name", ["nfnet_two_tower", "resnet_two_tower", "vit_two_tower"])
+@pytest.mark.parametrize("name", ["nfnet_two_tower", "resnet_two_tower", "resnet_bit_two_tower", "vit_two_tower"])
 def test_image_two_tower_wrappers_vs_reference(gpu, name):
     """NFNetTwoTower / ResNetTwoTower / VitTwoTower against golden vectors captured from the REFERENCE's own wrapper classes
     (src/models/image.py:212-294, :298-378, :418-499; oracle/gen_golden_r2.py wrappers).  The encoder handed to the reference class
     evaluates the oracle's restatement of the timm tower, so the wrapper logic (pooling calls, pair head, probs[:, 0] / probs[:, 1] as
     embeds, loss) is pinned by the reference while the tower arithmetic stays parity-unpinned (timm is absent offline)."""
     import item_alignment_amd.models as M
-    from golden_util import NARROW_NFNET, NARROW_RESNET, TINY_VIT
+    from golden_util import NARROW_BIT, NARROW_NFNET, NARROW_RESNET, TINY_VIT
     case = load_case(name)
     cfg = cfg_of(case)
     if name.startswith("nfnet"):
         from item_alignment_amd.models.nfnet import NormFreeNet
         model = M.NFNetTwoTower(cfg, NormFreeNet(NARROW_NFNET.depths, NARROW_NFNET.channels, 1.0))
+    elif name.startswith("resnet_bit"):
+        # the BiT names (resnetv2_*_bitm) take the same `"resnet" in args.model_name` branch of finetune_image.py:215-216
+        from item_alignment_amd.models.resnetv2 import ResNetV2
+        model = M.ResNetTwoTower(cfg, ResNetV2(NARROW_BIT.layers, NARROW_BIT.channels, stem_chs=NARROW_BIT.stem_chs, bit=True))
     elif name.startswith("resnet"):
         from item_alignment_amd.models.resnetv2 import ResNetV2
         model = M.ResNetTwoTower(cfg, ResNetV2(NARROW_RESNET.layers, NARROW_RESNET.channels, stem_chs=NARROW_RESNET.stem_chs))
@@ -265,8 +273,10 @@ def test_image_two_tower_wrappers_vs_reference(gpu, name):
     assert all((".head." in k or "running_" in k or "num_batches" in k) for k in missing), missing
     model = model.cuda().eval()
     out = model(g(case, "images_1"), g(case, "images_2"), g(case, "labels"))
-    # ReLU towers in bf16 flip gates near zero: direction of deep-layer gradients is looser there
-    check(case, out, model, cos_min=0.97 if name.startswith("resnet") else None)
+    # ReLU towers in bf16 flip gates near zero: direction of deep-layer gradients is looser there -- and looser
+    # still in the BiT tower, whose standardised weights give every layer full gain whatever the scale of the seeded weights (the CPU
+    # oracle's own gradients move to cosine 0.93 when it rounds its activations to bf16: tests/test_oracle_golden.py)
+    check(case, out, model, cos_min=0.90 if name.startswith("resnet_bit") else 0.97 if name.startswith("resnet") else None)
 
 
 def test_vit_tokens_vs_transformers_vit(gpu):
@@ -499,6 +509,65 @@ def test_resnetv2_tower_vs_oracle(gpu):
         ev = net(images.cuda())
     ref_ev = O.resnetv2_forward_features(sd, "e", rcfg, images, False, stats).mean((2, 3))
     assert rel(ev, ref_ev) < TOL, rel(ev, ref_ev)
+
+
+def test_bit_tower_vs_oracle_and_transformers_bit(gpu):
+    """The BiT ResNetV2 tower (`--model_name resnetv2_50x3_bitm_in21k` of finetune_image.py:23; timm resnetv2.py `_create_resnetv2_bit`:
+    StdConv2d eps 1e-8 + GroupNormAct(32) + the zero-ring stem) on a narrow instance of the architecture, against (a) the features, the
+    pooled output and nine parameter gradients of transformers.BitModel on the same seeded weights (tests/golden/bit_hf_crosscheck.npz,
+    an independent implementation of the published architecture; the CPU oracle reproduces it to fp32 round-off,
+    test_oracle_golden.py) and (b) eval mode = training mode (GroupNorm keeps no batch statistics).  bf16 bar 5e-2 on the outputs;
+    gradients by direction and norm: >= 0.97 in the last stage / >= 0.90 further down against the fp32 gradients (the oracle's own
+    gradients under bf16 storage rounding sit at 0.93: test_oracle_golden.py), and >= 0.97 everywhere against that same-precision
+    oracle (measured 0.981-1.000)."""
+    from item_alignment_amd.models.resnetv2 import ResNetV2
+    case = load_case("bit_hf_crosscheck")
+    c = case.cfg
+    sd = weights(case)
+    net = ResNetV2(tuple(c.layers), tuple(c.channels), stem_chs=c.stem_chs, bit=True)
+    missing, unexpected = net.load_state_dict({k[2:]: v for k, v in sd.items()}, strict=False)
+    assert not unexpected and all(k.startswith("head.fc") for k in missing), (missing, unexpected)
+    assert not any("running_" in k for k in net.state_dict())
+    net = net.cuda().train()
+    images, wts = g(case, "images"), g(case, "wts")
+    fmap = net.forward_features(images)
+    feat = fmap.t.view(fmap.B, fmap.H, fmap.W, -1).permute(0, 3, 1, 2)
+    r = rel(feat.detach(), case.outs["features"])
+    MEASURED.append((case.name, "out rel", "features", r))
+    assert r < TOL, r
+    out = net(images)
+    r = rel(out.detach(), case.outs["pooled"])
+    MEASURED.append((case.name, "out rel", "pooled", r))
+    assert tuple(out.shape) == (3, c.num_features) and r < TOL, r
+    net.param_arena.zero_grad()
+    (out * wts).sum().backward()
+    torch.cuda.synchronize()
+    params = dict(net.named_parameters())
+    # the same-precision yardstick: the CPU oracle rounding to bf16 where the engine stores bf16 (oracle.ref_models.rounding)
+    from oracle import ref_models as O
+    sd16 = weights(case, requires_grad=True)
+    with O.rounding(torch.bfloat16):
+        f16 = O.resnetv2_forward_features(sd16, "e", c, case.inputs["images"])
+        (f16.mean((2, 3)) * case.inputs["wts"]).sum().backward()
+    for k, want in case.grads.items():
+        got = params[k].grad.float().cpu().flatten()
+        want = want.flatten()
+        assert torch.isfinite(got).all(), k
+        cos = (torch.dot(got, want) / (got.norm() * want.norm() + 1e-30)).item()
+        g16 = sd16["e." + k].grad.flatten()
+        cos16 = (torch.dot(got, g16) / (got.norm() * g16.norm() + 1e-30)).item()
+        MEASURED.append((case.name, "grad cos", k, cos))
+        MEASURED.append((case.name, "grad rel", k, rel(got, want)))
+        MEASURED.append((case.name, "grad cos-bf16-oracle", k, cos16))
+        MEASURED.append((case.name, "grad rel-bf16-oracle", k, ((got - g16).abs().max() / (want.abs().max() + 1e-6)).item()))
+        last = k.startswith("stages.3") or k.startswith("norm")
+        assert cos > (0.97 if last else 0.90), ("grad cosine", k, cos)
+        assert cos16 > 0.97, ("grad cosine against the bf16-rounding oracle", k, cos16)          # measured 0.981 .. 1.000
+        assert 0.8 < (got.norm() / want.norm()).item() < 1.25, ("grad norm", k)
+    net.eval()
+    with torch.no_grad():
+        ev = net(images)
+    assert torch.equal(ev, out.detach())
 
 
 def test_resnet_two_tower_normalises_each_tower_separately(gpu):

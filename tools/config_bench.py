@@ -1,7 +1,7 @@
 """Train-step throughput of the other BASELINE.json configurations on one MI355X (synthetic inputs, dropout on, fused
 AdamW; SURVEY.md §8(d) shapes and FLOP counts).  bench.py stays the headline C5 measurement; this fills DESIGN.md §7.
 
-usage: python tools/config_bench.py [--pmc] [c2] [c3] [c3r] [c4] [c5x]
+usage: python tools/config_bench.py [--pmc] [c2] [c3] [c3r] [c3b] [c3b3] [c4] [c5x]
   --pmc  also re-run each configuration (1 warm-up + 2 steps) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes)
          and print the HBM bytes per step, the achieved HBM GB/s at the measured step time and its fraction of the 8 TB/s peak
   c2  roberta_large one_tower cls/ce, L = 510          c3  eca_nfnet_l0 two_tower, 800x800
@@ -121,6 +121,32 @@ def c3r(pairs=32, S=800):
     labels = torch.randint(0, 2, (pairs,), generator=g).to(dev)
     torch.manual_seed(2345)
     run(f"C3r resnetv2_50 two_tower {S}x{S}", M.ResNetTwoTower(cfg, M.create_model("resnetv2_50")), lambda m: m(im1, im2, labels), pairs, 6.28e11, which="c3r")
+
+
+def c3b(pairs=32, S=800):
+    """resnetv2_50x1_bitm two_tower (a BiT name; finetune_image.py:23 lists resnetv2_50x3_bitm_in21k): the resnetv2_50 graph with StdConv2d and
+    GroupNormAct -- 4.1 GMAC @224 -> 52.3 GMAC / image @800, like c3r"""
+    from types import SimpleNamespace
+    cfg = SimpleNamespace(num_labels=2, hidden_dropout_prob=0.1, loss_type="ce", loss_margin=0.0, classification_method="cls", hidden_size=2048)
+    g = torch.Generator().manual_seed(0)
+    im1, im2 = torch.randn((pairs, 3, S, S), generator=g).to(dev), torch.randn((pairs, 3, S, S), generator=g).to(dev)
+    labels = torch.randint(0, 2, (pairs,), generator=g).to(dev)
+    torch.manual_seed(2345)
+    run(f"C3b resnetv2_50x1_bitm two_tower {S}x{S}", M.ResNetTwoTower(cfg, M.create_model("resnetv2_50x1_bitm")), lambda m: m(im1, im2, labels), pairs,
+        6.28e11, which="c3b")
+
+
+def c3b3(pairs=16, S=800):
+    """resnetv2_50x3_bitm_in21k two_tower -- the BiT name finetune_image.py:23 gives: every width x 3 (6144 features; 37.1 GMAC @224 in timm's
+    model table -> 473 GMAC / image @800).  Its 192 / 384 / 768 / 1536-channel 3x3 convolutions are not powers of two: patch-matrix path."""
+    from types import SimpleNamespace
+    cfg = SimpleNamespace(num_labels=2, hidden_dropout_prob=0.1, loss_type="ce", loss_margin=0.0, classification_method="cls", hidden_size=6144)
+    g = torch.Generator().manual_seed(0)
+    im1, im2 = torch.randn((pairs, 3, S, S), generator=g).to(dev), torch.randn((pairs, 3, S, S), generator=g).to(dev)
+    labels = torch.randint(0, 2, (pairs,), generator=g).to(dev)
+    torch.manual_seed(2345)
+    run(f"C3b3 resnetv2_50x3_bitm_in21k two_tower {S}x{S}", M.ResNetTwoTower(cfg, M.create_model("resnetv2_50x3_bitm_in21k")),
+        lambda m: m(im1, im2, labels), pairs, 5.68e12, which="c3b3")
 
 
 def c4(pairs=256):

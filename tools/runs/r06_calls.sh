@@ -137,5 +137,15 @@ case "$1" in
     for v in 1 0 1 0; do echo "IA_GEMM_LA=$v: $(IA_GEMM_LA=$v timeout 600 bash tools/runs/run.sh quick 2>&1 | tail -1)" >> $O; done
     cat $O
     ;;
+  bit)          # the BiT towers: kernel + model + CLI tests, parity numbers, throughput beside resnetv2_50
+    O=gpurun_out/r06_bit.txt; : > $O
+    timeout 900 python -m pytest tests/test_kernels_gpu.py -k "groupnorm or ring_of_zeros or maxpool or batchnorm" -q -x --tb=short 2>&1 | grep -E "^E  |passed|failed|^FAILED" | cut -c1-400 | tail -8 >> $O
+    timeout 900 python -m pytest tests/test_cli_gpu.py -k "finetune_image" -q -x --tb=short 2>&1 | grep -E "^E  |passed|failed|^FAILED" | cut -c1-400 | tail -8 >> $O
+    timeout 1500 python tools/parity_report.py > gpurun_out/r06_parity_report.txt 2>&1
+    grep -E "^E  |passed|failed|^FAILED|bit|pytest exit" gpurun_out/r06_parity_report.txt | cut -c1-400 | tail -60 >> $O
+    timeout 900 python tools/config_bench.py c3r c3b 2>&1 | grep -E "pairs/s|GiB|Error|error" >> $O
+    timeout 900 python tools/config_bench.py c3b3 2>&1 | grep -E "pairs/s|GiB|Error|error" >> $O
+    cat $O
+    ;;
   *) echo "usage: $0 <" $(grep -oE '^  [a-z0-9_]+\)' "$0" | tr -d ' )') ">" >&2; exit 2 ;;
 esac
