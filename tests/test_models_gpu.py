@@ -30,10 +30,11 @@ REL_EXCEPTIONS = {
     # mode covers the ResNetV2 towers now: the BatchNorm tower's two tensors -- 0.19 / 0.072 from the fp32 gradients -- sit at 0.040 /
     # 0.038 from the same-precision oracle's and need no entry.)
     # The BiT tower (StdConv2d: every layer at full gain -> the ReLU gates that bf16 rounding flips are not the same ones in two bf16
-    # implementations with different summation orders): distance to the same-precision oracle, 0.32-0.36 to the fp32 reference
+    # implementations with different summation orders): distance to the same-precision oracle, 0.34-0.38 to the fp32 reference
+    # (profiles/r06_parity_report.txt; direction against the fp32 reference 0.934 / 0.952 / 0.988)
     ("resnet_bit_two_tower", "img_encoder.stem.conv.weight"): 0.102,
-    ("resnet_bit_two_tower", "img_encoder.stages.1.blocks.1.conv2.weight"): 0.30,
-    ("resnet_bit_two_tower", "img_encoder.stages.3.blocks.0.conv3.weight"): 0.30,
+    ("resnet_bit_two_tower", "img_encoder.stages.1.blocks.1.conv2.weight"): 0.130,
+    ("resnet_bit_two_tower", "img_encoder.stages.3.blocks.0.conv3.weight"): 0.256,
 }
 EXCEPTION_HEADROOM = 1.25
 MEASURED = []            # (case, kind, key, value) of everything check() compared: printed by tools/parity_report.py

@@ -137,6 +137,12 @@ case "$1" in
     for v in 1 0 1 0; do echo "IA_GEMM_LA=$v: $(IA_GEMM_LA=$v timeout 600 bash tools/runs/run.sh quick 2>&1 | tail -1)" >> $O; done
     cat $O
     ;;
+  final)        # GroupNorm kernel tests on the final library, then the round's collection (tools/runs/r06_final.sh)
+    O=gpurun_out/r06_final_head.txt; : > $O
+    timeout 900 python -m pytest tests/test_kernels_gpu.py -k "groupnorm or ring_of_zeros or batchnorm" -q -x --tb=short 2>&1 | grep -E "^E  |passed|failed|^FAILED" | cut -c1-400 | tail -8 >> $O
+    cat $O
+    bash tools/runs/r06_final.sh
+    ;;
   bit)          # the BiT towers: kernel + model + CLI tests, parity numbers, throughput beside resnetv2_50
     O=gpurun_out/r06_bit.txt; : > $O
     timeout 900 python -m pytest tests/test_kernels_gpu.py -k "groupnorm or ring_of_zeros or maxpool or batchnorm" -q -x --tb=short 2>&1 | grep -E "^E  |passed|failed|^FAILED" | cut -c1-400 | tail -8 >> $O

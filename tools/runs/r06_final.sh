@@ -4,7 +4,10 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/profiles
 bash tools/collect_profiles.sh r06 > gpurun_out/r06_collect.log 2>&1
 python tools/config_bench.py c2 c4 c5x 2>&1 | grep -E "pairs/s" > gpurun_out/profiles/r06_config_bench_other.txt
-cat gpurun_out/profiles/r06_config_bench_other.txt
+python tools/config_bench.py c3r c3b c3b3 2>&1 | grep -E "pairs/s" > gpurun_out/profiles/r06_config_bench_resnets.txt
+cat gpurun_out/profiles/r06_config_bench_other.txt gpurun_out/profiles/r06_config_bench_resnets.txt
+python tools/parity_report.py > gpurun_out/profiles/r06_parity_report.txt 2>&1
+grep -E "passed|failed|pytest exit|gradient cosine:|output relative" gpurun_out/profiles/r06_parity_report.txt
 python bench.py > gpurun_out/profiles/r06_bench_line.json 2> gpurun_out/r06_bench_line.err
 python -c "
 import json; d=json.load(open('gpurun_out/profiles/r06_bench_line.json'))
