@@ -37,7 +37,7 @@ const char* ia_strerror(int code);
 /* Bumped whenever an entry point is added or the meaning of an argument / output changes (round 2 changed what IA_EPI_BIAS_GELU
  * stores in C2 and what IA_EPI_DGELU expects in aux): a caller built against another header must not run on this library.
  * item_alignment_amd/_lib.py refuses to load a library whose version differs from the one it was written for. */
-#define IA_ABI_VERSION 9
+#define IA_ABI_VERSION 10
 int ia_abi_version(void);
 
 /* ---- GEMM: torch.nn.Linear forward / dgrad / wgrad (src/models/text.py:1241 -> RobertaLayer dense
@@ -279,6 +279,21 @@ int ia_conv3x3_padded_bwd_data_t(const void* dyp, const void* what_t, void* dxp,
 size_t ia_conv3x3_padded_workspace_bytes(int B, int H, int W, int Cin, int Cout, int groups);
 int ia_conv3x3_padded_bwd_weight(const void* xp, const void* dyp, float* dwhat, float* dbias, int B, int H, int W, int Cin, int Cout,
                                  int groups, void* workspace, size_t workspace_bytes, ia_stream_t stream);
+/* 3x3 / stride 2 / padding 1 between bordered layouts: xp [B, H+2, W+2, Cin] (zero border) -> yp [B, Ho+2, Wo+2, Cout], Ho = (H-1)/2 + 1
+ * (border of yp not written).  The strided convolutions of timm's NormFreeNet (nfnet.py: conv2 of the first block of stages 2-4,
+ * 64 channels per group; stem conv4, 64 -> 128) behind reference src/models/image.py:254-257, without a patch matrix: forward = one
+ * kernel over the four parity views of x, weight gradient = the direct weight-gradient kernel on those views, data gradient = GEMM +
+ * gather between the bordered layouts.  ia_conv3x3_s2_supported: 1 for Cin = Cout = 64 * groups, or groups = 1, Cin = 64, Cout = 64 n
+ * (0 also when IA_CONV_S2_DIRECT=0): other shapes go through ia_conv_nhwc_*.  One workspace size serves both gradient calls. */
+int ia_conv3x3_s2_supported(int Cin, int Cout, int groups);
+size_t ia_conv3x3_s2_padded_workspace_bytes(int B, int H, int W, int Cin, int Cout, int groups);
+/* y_compact != 0: yp / dyp are [B, Ho, Wo, Cout] without a border (the stem's last convolution feeds compact consumers) */
+int ia_conv3x3_s2_padded_fwd(const void* xp, const void* what, const float* bias, void* yp, int B, int H, int W, int Cin, int Cout,
+                             int groups, int y_compact, ia_stream_t stream);
+int ia_conv3x3_s2_padded_bwd_data(const void* dyp, const void* what, void* dxp, int B, int H, int W, int Cin, int Cout, int groups,
+                                  int y_compact, void* workspace, size_t workspace_bytes, ia_stream_t stream);
+int ia_conv3x3_s2_padded_bwd_weight(const void* xp, const void* dyp, float* dwhat, float* dbias, int B, int H, int W, int Cin, int Cout,
+                                    int groups, int y_compact, void* workspace, size_t workspace_bytes, ia_stream_t stream);
 /* y = silu(x) * scale between the compact [B,H,W,C] and the zero-bordered [B,H+2,W+2,C] layouts (one flag per side); the
  * backward call produces dx in x's layout from dy in y's layout */
 int ia_silu_pad_fwd(const void* x, void* y, int B, int H, int W, int C, float scale, int in_padded, int out_padded, ia_stream_t stream);

@@ -103,6 +103,11 @@ SIGNATURES = {
     "ia_bn_act_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, i32, i32, vp, sz, vp]),
     "ia_bn_act_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]),
     "ia_patches_nchw": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "ia_conv3x3_s2_supported": (i32, [i32, i32, i32]),
+    "ia_conv3x3_s2_padded_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
+    "ia_conv3x3_s2_padded_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "ia_conv3x3_s2_padded_bwd_data": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "ia_conv3x3_s2_padded_bwd_weight": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "ia_gn_act_workspace_bytes": (sz, [i32, i32, i32]),
     "ia_gn_act_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, sz, vp]),
     "ia_gn_act_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]),
@@ -157,7 +162,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 9      # = IA_ABI_VERSION of include/itemalign.h (tests/test_cabi_symbols.py keeps the two in step)
+ABI_VERSION = 10      # = IA_ABI_VERSION of include/itemalign.h (tests/test_cabi_symbols.py keeps the two in step)
 
 
 class ItemAlignError(RuntimeError):

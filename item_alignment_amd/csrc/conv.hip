@@ -85,6 +85,38 @@ __global__ __launch_bounds__(256) void col2im3_kernel(const bf16* __restrict__ d
   *reinterpret_cast<bf16x8*>(dx + pix * C + c) = o;
 }
 
+// the same gather between BORDERED layouts (stride 2): dcols rows are the pixels of [B, Ho + 2, Wo + 2], dx is [B, H + 2, W + 2, C]; only the
+// interior of dx is written (its reader, the SiLU backward in front, looks at nothing else)
+__global__ __launch_bounds__(256) void col2im3_s2_padded_kernel(const bf16* __restrict__ dcols, bf16* __restrict__ dx, int H, int W, int C, int Cg,
+                                                                int Ho, int Wo, int y_compact, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c8n = C >> 3;
+  const int c = (int)(idx % c8n) * 8;
+  const size_t pix = idx / c8n;
+  const int ix = (int)(pix % W), iy = (int)((pix / W) % H);
+  const size_t b = pix / ((size_t)W * H);
+  const int g = c / Cg, cg = c % Cg;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int ny = iy + 1 - t / 3, nx = ix + 1 - t % 3;
+    if (ny < 0 || nx < 0 || (ny & 1) || (nx & 1)) continue;
+    const int oy = ny >> 1, ox = nx >> 1;
+    if (oy >= Ho || ox >= Wo) continue;
+    const size_t orow = y_compact ? (b * Ho + oy) * Wo + ox : (b * (Ho + 2) + oy + 1) * (Wo + 2) + ox + 1;
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(dcols + orow * (size_t)(9 * C) + (size_t)g * 9 * Cg + t * Cg + cg);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += bf2f(v[j]);
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = f2bf(acc[j]);
+  *reinterpret_cast<bf16x8*>(dx + ((b * (H + 2) + iy + 1) * (size_t)(W + 2) + ix + 1) * C + c) = o;
+}
+
 // ------------------------------------------------------------------------------ weight standardisation
 // ScaledStdConv2d: what[o][t*Cgp + c] = (w[o][c][t] - mean_o) * rstd_o * gain[o] * scale, statistics over the real fan-in
 // (Cg*kk, biased variance, eps inside the sqrt); channels c >= Cg (padding of the 3-channel stem) are zero.  One wave per o.
@@ -1010,6 +1042,169 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(Args p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------- stride-2 forward (round 6)
+// y[oy][ox] = sum over taps of w[dy][dx] . x[2 oy + dy][2 ox + dx] (bordered input coordinates).  Rows and columns of the input split
+// by parity: the EVEN bordered rows 2 i serve the taps dy = 0 (i = oy) and dy = 2 (i = oy + 1), the ODD rows 2 i + 1 serve dy = 1 (i = oy)
+// -- likewise the columns.  So the convolution is the sum of four STRIDE-1 pieces over four views of x, each a dense (8 + 1) x (30 + 1)
+// pixel tile once it sits in LDS: view (even, even) with the four corner taps at shifts {0, 1}^2, (even, odd) / (odd, even) with two
+// taps each, (odd, odd) with the centre tap.  The kernel is the stride-1 one with the work list (tile, view): the LDS-DMA gathers a
+// view's tile with a pixel stride of two (16-byte lanes, 128 contiguous bytes per pixel and group: full sectors), the k loop runs that
+// view's taps out of the resident filter bank, the accumulators stay over the four views and the tile is stored after the last.  Every
+// input byte is fetched once (+ halo) and no patch matrix exists: 1.6 units of traffic instead of 5.75.  64 channels per
+// group in, CO out; `in_gstride` = 0 lets several output groups share one input slice (the stem's 64 -> 128: two output halves).
+struct S2Args {
+  const bf16* xp; const bf16* w; const float* bias; bf16* yp;
+  int B, H, W;                 // OUTPUT height / width
+  int XH, XW;                  // input height / width (H = (XH - 1) / 2 + 1)
+  int Cin, Cout, groups, in_gstride;
+  int tiles_x, tiles_y;
+  int out_compact;             // yp is [B, H, W, Cout] without a border (the stem's last convolution feeds compact consumers)
+};
+
+template <int CO>
+__global__ __launch_bounds__(256) void conv3x3_s2_kernel(S2Args p) {
+  constexpr int CI = 64;
+  using G = Geo<CI, CO>;
+  constexpr int PB = G::PB, NC = G::NC, PPP = G::PPP, NI = G::NI, IN_BYTES = G::IN_BYTES, W_BYTES = G::W_BYTES;
+  constexpr int IN_PIECES = G::IN_PIECES, W_PIECES = G::W_PIECES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int grp = blockIdx.x % p.groups, slot = blockIdx.x / p.groups, nslots = gridDim.x / p.groups;
+  const int ntiles = p.B * p.tiles_y * p.tiles_x;
+  if (slot >= ntiles) return;
+  const int PW = p.W + 2, PH = p.H + 2, XPW = p.XW + 2, XPH = p.XH + 2;
+  typedef __attribute__((address_space(3))) char lds_char;
+  lds_char* const lsm = (lds_char*)IA_LDS(smem);
+  const uint32_t sbase = ia_lds_addr(smem);
+  {   // the filter bank, as in the stride-1 kernel: k-step s = tap s / 2, channels 32 (s & 1) ..
+    const bf16* wg = p.w + (size_t)grp * CO * 9 * CI;
+    const __amdgpu_buffer_rsrc_t rsW = ia_rsrc(wg, (uint32_t)(CO * 9 * CI * 2));
+#pragma unroll 1
+    for (int pc = wave; pc < W_PIECES; pc += 4) {
+      const int s = pc / (CO / 16), r16 = pc - s * (CO / 16);
+      const int row = r16 * 16 + (lane >> 2);
+      const int chunk = (lane & 3) ^ bkey<CO>(row);
+      const int k = (s >> 1) * 64 + (s & 1) * 32 + chunk * 8;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, lsm + pc * 1024, 16, (uint32_t)((row * 9 * CI + k) * 2), 0, 0, 0);
+    }
+  }
+  int a_p0[4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    int q = wave * 64 + mi * 16 + li;
+    q = q < TILE_PX ? q : TILE_PX - 1;
+    const int y = q / TW, x = q - y * TW;
+    a_p0[mi] = y * TWP + x;
+  }
+  int b_off[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int row = (li >> 2) * (CO / 4) + ni * 4 + (li & 3);
+    b_off[ni] = row * 64 + ((g ^ bkey<CO>(row)) << 4);
+  }
+  f32x4 bv[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+    bv[ni] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + grp * CO + g * (CO / 4) + ni * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  // DMA piece of a view: pixel lane / NC of the piece lies 2 (lane / NC) input pixels further
+  const uint32_t lane_in = (uint32_t)(((lane / NC) * 2 * p.Cin + (((lane % NC) ^ akey<CI>(lane / NC)) * 8)) * 2);
+  const size_t total_in = (size_t)p.B * XPH * XPW * p.Cin;
+
+  auto tile_of = [&](int t, int& b, int& y0, int& x0) {
+    const int tx = t % p.tiles_x, r = t / p.tiles_x;
+    const int ty = r % p.tiles_y;
+    b = r / p.tiles_y; y0 = 1 + ty * TH; x0 = 1 + tx * TW;      // first OUTPUT pixel of the tile, bordered output coordinates
+  };
+  // view v = 2 (rows odd) + (columns odd) of tile t -> buffer: view pixel (r, c) = bordered input pixel (2 (y0 - 1 + r) + rows odd,
+  // 2 (x0 - 1 + c) + columns odd); rows 0 .. 8 (the tenth row of the stride-1 tile has no reader)
+  auto stage = [&](int t, int v, int buf) {
+    int b, y0, x0;
+    tile_of(t, b, y0, x0);
+    const size_t org = (((size_t)b * XPH + 2 * (y0 - 1) + (v >> 1)) * XPW + 2 * (x0 - 1) + (v & 1)) * p.Cin + (size_t)grp * p.in_gstride;
+    const size_t rem = org < total_in ? (total_in - org) * 2 : 0;
+    const __amdgpu_buffer_rsrc_t rs = ia_rsrc(p.xp + (rem ? org : 0), (uint32_t)(rem < 0x7FFFFFF0ull ? rem : 0x7FFFFFF0ull));
+#pragma unroll
+    for (int i = 0; i < (IN_PIECES + 3) / 4; ++i) {
+      const int pc = wave + 4 * i;
+      const int r = pc / (TWP / PPP), c = pc - r * (TWP / PPP);
+      if (pc < IN_PIECES && r <= TH) {
+        const uint32_t adv = (uint32_t)((r * 2 * XPW + c * PPP * 2) * p.Cin * 2);      // (in the lane offset: range-checked, see the stride-1 kernel)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lsm + W_BYTES + buf * IN_BYTES + pc * 1024, 16, lane_in + adv, 0, 0, 0);
+      }
+    }
+  };
+
+  stage(slot, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int buf = 0;
+#pragma unroll 1
+  for (int t = slot; t < ntiles; t += nslots) {
+    f32x4 acc[4][NI];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      if (v < 3) stage(t, v + 1, buf ^ 1);
+      else if (t + nslots < ntiles) stage(t + nslots, 0, buf ^ 1);
+      const uint32_t in = sbase + W_BYTES + buf * IN_BYTES;
+      // the view's taps: rows even -> dy in {0, 2} at row shifts {0, 1}; rows odd -> dy = 1 at shift 0; the same for the columns
+      const int nry = (v >> 1) ? 1 : 2, nrx = (v & 1) ? 1 : 2, NK = nry * nrx * 2;
+      bf16x8 af[2][4], bfr[2][NI];
+      auto load = [&](int i, int slot2) {                       // i-th k-step of the view: (row tap, column tap, channel half)
+        const int half = i & 1, ix = (i >> 1) % nrx, iy = (i >> 1) / nrx;
+        const int dy = (v >> 1) ? 1 : 2 * iy, dx = (v & 1) ? 1 : 2 * ix;
+        const int sy = (v >> 1) ? 0 : iy, sx = (v & 1) ? 0 : ix;
+        const int s = (dy * 3 + dx) * 2 + half, off = sy * TWP + sx, chunk = half * 4 + g;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          const int P = a_p0[mi] + off;
+          lds_read128(af[slot2][mi], in + (uint32_t)(P * PB + ((chunk ^ akey<CI>(P)) << 4)));
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) lds_read128(bfr[slot2][ni], sbase + (uint32_t)(s * (CO * 64) + b_off[ni]));
+      };
+      load(0, 0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (i < NK) {
+          if (i + 1 < NK) { load(i + 1, (i + 1) & 1); wait_frags<4 + NI, NI>(af[i & 1], bfr[i & 1]); }
+          else wait_frags<0, NI>(af[i & 1], bfr[i & 1]);
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[i & 1][ni], af[i & 1][mi], acc[mi][ni], 0, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the next view has landed; everybody is through with `in`
+      __syncthreads();
+      buf ^= 1;
+    }
+    int b, y0, x0;
+    tile_of(t, b, y0, x0);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int q = wave * 64 + mi * 16 + li;
+      const int y = q / TW, x = q - y * TW;
+      if (q >= TILE_PX || y0 + y > p.H || x0 + x > p.W) continue;
+      const size_t orow = p.out_compact ? ((size_t)b * p.H + (y0 + y - 1)) * p.W + (x0 + x - 1) : ((size_t)b * PH + (y0 + y)) * PW + (x0 + x);
+      bf16* const dst = p.yp + orow * p.Cout + (size_t)grp * CO + g * (CO / 4);
+#pragma unroll
+      for (int h = 0; h < NI / 2; ++h) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[j] = f2bf(acc[mi][2 * h][j] + bv[2 * h][j]); o[4 + j] = f2bf(acc[mi][2 * h + 1][j] + bv[2 * h + 1][j]); }
+        *reinterpret_cast<bf16x8*>(dst + 8 * h) = o;
+      }
+    }
+  }
+}
+
 // wt[g][ci][(8 - tap) * CO + co] = w[g][co][tap * CI + ci]: the filter bank of the data gradient (a correlation with the flipped taps)
 __global__ __launch_bounds__(256) void flip_weights_kernel(const bf16* __restrict__ w, bf16* __restrict__ wt, int CI, int CO, int total) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -1099,8 +1294,12 @@ IA_DEV bf16x8 tr_pair(uint32_t base, int P, int ch) {
 
 struct WArgs {
   const bf16* xp; const bf16* dyp; float* part;      // part: [workgroups][CO * 9 * CI + CO] fp32 partial banks (+ bias sums)
-  int B, H, W, Cin, Cout, groups;
+  int B, H, W, Cin, Cout, groups;                    // H, W: height / width of dy
   int tiles_x, tiles_y;
+  // x as a strided view (the stride-2 convolution's weight gradient, below): bordered x pixel of view pixel (r, c) = (xs r + offy, xs c + offx)
+  // in a tensor of XH x XW interior pixels; group g reads channels g * in_gstride ..  Stride 1: xs = 1, off = 0, XH = H, XW = W, in_gstride = CI.
+  int XH, XW, xs, offy, offx, in_gstride;
+  int dy_compact;              // dyp is [B, H, W, Cout] without a border
 };
 
 template <int CI, int CO>
@@ -1120,23 +1319,25 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WArgs p) {
   typedef __attribute__((address_space(3))) char lds_char;
   lds_char* const lsm = (lds_char*)IA_LDS(smem);
   const uint32_t sbase = ia_lds_addr(smem);
-  const size_t total_x = (size_t)p.B * PH * PW * p.Cin, total_y = (size_t)p.B * PH * PW * p.Cout;
+  const int XPW = p.XW + 2, XPH = p.XH + 2;
+  const int YW = p.dy_compact ? p.W : PW, YH = p.dy_compact ? p.H : PH, yo = p.dy_compact ? 1 : 0;      // dy's own row pitch / origin shift
+  const size_t total_x = (size_t)p.B * XPH * XPW * p.Cin, total_y = (size_t)p.B * YH * YW * p.Cout;
 
   auto tile_of = [&](int t, int& b, int& y0, int& x0) {
     const int tx = t % p.tiles_x, r = t / p.tiles_x;
     const int ty = r % p.tiles_y;
     b = r / p.tiles_y; y0 = 1 + ty * TH; x0 = 1 + tx * TW;
   };
-  const uint32_t lane_x = (uint32_t)(((lane / XNC) * p.Cin + (((lane % XNC) ^ tkey<CI>(lane / XNC)) * 8)) * 2);
+  const uint32_t lane_x = (uint32_t)(((lane / XNC) * p.xs * p.Cin + (((lane % XNC) ^ tkey<CI>(lane / XNC)) * 8)) * 2);
   const int ypix = lane / YNC;                               // pixel of this lane inside a dy piece
   const uint32_t lane_y = (uint32_t)((ypix * p.Cout + (((lane % YNC) ^ tkey<CO>(ypix)) * 8)) * 2);
   auto stage = [&](int t, int buf) {
     int b, y0, x0;
     tile_of(t, b, y0, x0);
     {   // x tile: rows y0 - 1 .. y0 + 8, pixels x0 - 1 .. x0 + 30 (as the forward kernel)
-      const size_t org = (((size_t)b * PH + (y0 - 1)) * PW + (x0 - 1)) * p.Cin + (size_t)grp * CI;
-      const size_t rem = (total_x - org) * 2;
-      const __amdgpu_buffer_rsrc_t rs = ia_rsrc(p.xp + org, (uint32_t)(rem < 0x7FFFFFF0ull ? rem : 0x7FFFFFF0ull));
+      const size_t org = (((size_t)b * XPH + p.xs * (y0 - 1) + p.offy) * XPW + p.xs * (x0 - 1) + p.offx) * p.Cin + (size_t)grp * p.in_gstride;
+      const size_t rem = org < total_x ? (total_x - org) * 2 : 0;
+      const __amdgpu_buffer_rsrc_t rs = ia_rsrc(p.xp + (rem ? org : 0), (uint32_t)(rem < 0x7FFFFFF0ull ? rem : 0x7FFFFFF0ull));
       constexpr int PPP = 64 / XNC;
 #pragma unroll
       for (int i = 0; i < (X_PIECES + 3) / 4; ++i) {
@@ -1145,13 +1346,13 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WArgs p) {
           const int r = pc / (TWP / PPP), c = pc - r * (TWP / PPP);
           // whole address in the lane offset (range-checked; see the forward kernel): x past the end of the tensor arrives as zeros --
           // read through the scalar offset it was whatever lies behind the allocation, and 0 (masked dy) x NaN = NaN in dW
-          const uint32_t adv = (uint32_t)((r * PW + c * PPP) * p.Cin * 2);
+          const uint32_t adv = (uint32_t)((r * XPW + c * PPP) * p.xs * p.Cin * 2);
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lsm + buf * STAGE + pc * 1024, 16, lane_x + adv, 0, 0, 0);
         }
       }
     }
     {   // dy tile: rows y0 .. y0 + 7, pixels x0 .. x0 + 31; pixels 30, 31 of a row, pixels right of the image and rows below it -> zeros
-      const size_t org = (((size_t)b * PH + y0) * PW + x0) * p.Cout + (size_t)grp * CO;
+      const size_t org = (((size_t)b * YH + (y0 - yo)) * YW + (x0 - yo)) * p.Cout + (size_t)grp * CO;
       const size_t rem = (total_y - org) * 2;
       const __amdgpu_buffer_rsrc_t rs = ia_rsrc(p.dyp + org, (uint32_t)(rem < 0x7FFFFFF0ull ? rem : 0x7FFFFFF0ull));
       constexpr int PPP = 64 / YNC;
@@ -1162,7 +1363,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WArgs p) {
           const int r = pc / (TWP / PPP), c = pc - r * (TWP / PPP);
           const int col = c * PPP + ypix;
           const bool ok = col < TW && x0 + col <= p.W && y0 + r <= p.H;
-          const uint32_t voff = ok ? lane_y + (uint32_t)((r * PW + c * PPP) * p.Cout * 2) : 0xFFFFFFF0u;
+          const uint32_t voff = ok ? lane_y + (uint32_t)((r * YW + c * PPP) * p.Cout * 2) : 0xFFFFFFF0u;
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lsm + buf * STAGE + X_BYTES + pc * 1024, 16, voff, 0, 0, 0);
         }
       }
@@ -1260,6 +1461,29 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(const float* __restrict
   else if (dbias) dbias[grp * (bank - wsize) + (e - wsize)] += sum;
 }
 
+// the stride-2 form: four launches of the weight-gradient kernel, one per parity view of x (view v = 2 (rows odd) + (columns odd)), each with
+// its own region of `part`; tap (dy, dx) of the convolution is kernel tap (ty, tx) of one view -- dy = 0 -> (rows even, ty = 0), dy = 1 ->
+// (rows odd, ty = 0), dy = 2 -> (rows even, ty = 1), the same for the columns -- the other 27 tap sums the four launches produce are dropped
+__global__ __launch_bounds__(256) void wgrad_fold_s2_kernel(const float* __restrict__ part, float* __restrict__ dwhat, float* __restrict__ dbias, int groups,
+                                                            int per_group, int bank, int wsize, int CI, size_t region) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;      // element of [groups][bank]
+  if (idx >= groups * bank) return;
+  const int grp = idx / bank, e = idx - grp * bank;
+  int v = 0, src = e;
+  if (e < wsize) {
+    const int co = e / (9 * CI), rest = e - co * (9 * CI), tap = rest / CI, ci = rest - tap * CI;
+    const int dy = tap / 3, dx = tap - dy * 3;
+    v = ((dy == 1) << 1) | (dx == 1);
+    const int tk = (dy == 2 ? 3 : 0) + (dx == 2 ? 1 : 0);
+    src = co * (9 * CI) + tk * CI + ci;
+  }
+  const float* pv = part + (size_t)v * region;
+  float sum = 0.f;
+  for (int s = 0; s < per_group; ++s) sum += pv[(size_t)(s * groups + grp) * bank + src];
+  if (e < wsize) dwhat[(size_t)grp * wsize + e] = sum;
+  else if (dbias) dbias[grp * (bank - wsize) + (e - wsize)] += sum;
+}
+
 template <int CI, int CO>
 static int wgrad_t(WArgs a, float* dwhat, float* dbias, hipStream_t stream) {
   using G = WGeo<CI, CO>;
@@ -1274,8 +1498,19 @@ static int wgrad_t(WArgs a, float* dwhat, float* dbias, hipStream_t stream) {
   long per_group = (256L * per_cu) / a.groups;
   if (per_group > ntiles) per_group = ntiles;
   if (per_group < 1) per_group = 1;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(per_group * a.groups)), dim3(256), G::LDS_BYTES, stream, a);
   const int wsize = CO * 9 * CI, bank = wsize + CO;
+  if (a.xs == 2) {
+    const size_t region = (size_t)per_group * a.groups * bank;
+    float* const part = a.part;
+    for (int v = 0; v < 4; ++v) {
+      a.offy = v >> 1; a.offx = v & 1; a.part = part + (size_t)v * region;
+      hipLaunchKernelGGL(kern, dim3((unsigned)(per_group * a.groups)), dim3(256), G::LDS_BYTES, stream, a);
+    }
+    hipLaunchKernelGGL(wgrad_fold_s2_kernel, dim3((a.groups * bank + 255) / 256), dim3(256), 0, stream, part, dwhat, dbias, a.groups, (int)per_group, bank,
+                       wsize, CI, region);
+    return ia_check_launch();
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(per_group * a.groups)), dim3(256), G::LDS_BYTES, stream, a);
   hipLaunchKernelGGL(wgrad_fold_kernel, dim3((a.groups * bank + 255) / 256), dim3(256), 0, stream, a.part, dwhat, dbias, a.groups, (int)per_group, bank, wsize);
   return ia_check_launch();
 }
@@ -1288,10 +1523,47 @@ static int wgrad(const void* xp, const void* dyp, float* dwhat, float* dbias, in
   a.xp = (const bf16*)xp; a.dyp = (const bf16*)dyp; a.part = (float*)ws;
   a.B = B; a.H = H; a.W = W; a.Cin = groups * ci; a.Cout = groups * co; a.groups = groups;
   a.tiles_x = (W + TW - 1) / TW; a.tiles_y = (H + TH - 1) / TH;
+  a.XH = H; a.XW = W; a.xs = 1; a.offy = a.offx = 0; a.in_gstride = ci; a.dy_compact = 0;
   if (ci == 64 && co == 64) return wgrad_t<64, 64>(a, dwhat, dbias, stream);
   if (ci == 16 && co == 32) return wgrad_t<16, 32>(a, dwhat, dbias, stream);
   if (ci == 32 && co == 64) return wgrad_t<32, 64>(a, dwhat, dbias, stream);
   return IA_ERR_UNSUPPORTED;
+}
+// stride 2, 64 -> 64 channels per group: x [B, XH + 2, XW + 2, Cin] bordered, dy [B, H + 2, W + 2, Cout] bordered (H = (XH - 1) / 2 + 1);
+// shared_input: every output group reads input channels 0 .. 63 (Cin = 64)
+static int wgrad_s2(const void* xp, const void* dyp, float* dwhat, float* dbias, int B, int XH, int XW, int Cin, int Cout, int groups, int shared_input,
+                    int dy_compact, void* ws, hipStream_t stream) {
+  WArgs a;
+  a.xp = (const bf16*)xp; a.dyp = (const bf16*)dyp; a.part = (float*)ws;
+  a.H = (XH - 1) / 2 + 1; a.W = (XW - 1) / 2 + 1;
+  a.B = B; a.Cin = Cin; a.Cout = Cout; a.groups = groups;
+  a.tiles_x = (a.W + TW - 1) / TW; a.tiles_y = (a.H + TH - 1) / TH;
+  a.XH = XH; a.XW = XW; a.xs = 2; a.offy = a.offx = 0; a.in_gstride = shared_input ? 0 : 64; a.dy_compact = dy_compact;
+  return wgrad_t<64, 64>(a, dwhat, dbias, stream);
+}
+static size_t wgrad_s2_workspace(int groups) { return 4 * wgrad_workspace(64, 64, groups); }
+
+// launcher of the stride-2 forward kernel
+static int launch_s2(const void* xp, const void* w, const float* bias, void* yp, int B, int XH, int XW, int Cin, int Cout, int groups, int shared_input,
+                     int out_compact, hipStream_t stream) {
+  S2Args a;
+  a.xp = (const bf16*)xp; a.w = (const bf16*)w; a.bias = bias; a.yp = (bf16*)yp;
+  a.B = B; a.XH = XH; a.XW = XW; a.H = (XH - 1) / 2 + 1; a.W = (XW - 1) / 2 + 1;
+  a.Cin = Cin; a.Cout = Cout; a.groups = groups; a.in_gstride = shared_input ? 0 : 64; a.out_compact = out_compact;
+  a.tiles_x = (a.W + TW - 1) / TW; a.tiles_y = (a.H + TH - 1) / TH;
+  using G = Geo<64, 64>;
+  auto kern = conv3x3_s2_kernel<64>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) return IA_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const long ntiles = (long)a.B * a.tiles_x * a.tiles_y;
+  long per_group = 256L / groups;
+  if (per_group > ntiles) per_group = ntiles;
+  if (per_group < 1) per_group = 1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(per_group * groups)), dim3(256), G::LDS_BYTES, stream, a);
+  return ia_check_launch();
 }
 static bool wgrad_ok(int ci, int co) { return (ci == 64 && co == 64) || (ci == 16 && co == 32) || (ci == 32 && co == 64); }
 }  // namespace dconv
@@ -1398,6 +1670,83 @@ extern "C" int ia_conv3x3_padded_bwd_weight(const void* xp, const void* dyp, flo
 }
 
 // y = silu(x) * scale moving between the compact [B,H,W,C] and the zero-bordered [B,H+2,W+2,C] layouts (flags per side)
+// ---------------------------------------------------------------------------------------------- 3x3 / stride 2 on the bordered domain
+// xp [B, H + 2, W + 2, Cin] (zero border) -> yp [B, Ho + 2, Wo + 2, Cout] (border not written; y_compact: [B, Ho, Wo, Cout], and so
+// is dyp), Ho = (H - 1) / 2 + 1: the strided
+// convolutions of the NF-Net stage transitions (64 -> 64 channels per group) and of its stem (64 -> 128: output halves over one shared input
+// slice) without a patch matrix -- forward by dconv::conv3x3_s2_kernel, weight gradient by four launches of the direct weight-gradient
+// kernel on the parity views of x; the data gradient keeps the GEMM + gather form, between bordered layouts.  IA_CONV_S2_DIRECT=0 reports
+// every shape as unsupported (callers fall back to ia_conv_nhwc_*).
+static bool s2_enabled() {
+  const char* e = getenv("IA_CONV_S2_DIRECT");
+  return !e || atoi(e) != 0;
+}
+// virtual groups of 64 output channels; *shared = every one of them reads input channels 0 .. 63
+static int s2_groups(int Cin, int Cout, int groups, int* shared) {
+  *shared = 0;
+  if (groups >= 1 && groups <= 64 && Cin == 64 * groups && Cout == 64 * groups) return groups;
+  if (groups == 1 && Cin == 64 && Cout > 64 && Cout % 64 == 0 && Cout <= 64 * 64) { *shared = 1; return Cout / 64; }
+  return 0;
+}
+extern "C" int ia_conv3x3_s2_supported(int Cin, int Cout, int groups) {
+  int shared;
+  return dconv::enabled() && dconv::wgrad_enabled() && s2_enabled() && s2_groups(Cin, Cout, groups, &shared) > 0;
+}
+static int s2_ok(int B, int H, int W, int Cin, int Cout, int groups, int* vg, int* shared) {
+  if (B <= 0 || H <= 0 || W <= 0 || groups <= 0 || Cin <= 0 || Cout <= 0) return IA_ERR_ARG;
+  *vg = s2_groups(Cin, Cout, groups, shared);
+  if (!*vg) return IA_ERR_UNSUPPORTED;
+  if ((size_t)B * (H + 2) * (W + 2) >= 0x7FFFFFFFull) return IA_ERR_ARG;
+  return IA_OK;
+}
+extern "C" size_t ia_conv3x3_s2_padded_workspace_bytes(int B, int H, int W, int Cin, int Cout, int groups) {
+  int vg, shared;
+  if (s2_ok(B, H, W, Cin, Cout, groups, &vg, &shared)) return 0;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const size_t dcols = (size_t)B * (Ho + 2) * (Wo + 2) * 9 * Cin * 2, wg = dconv::wgrad_s2_workspace(vg);
+  return dcols > wg ? dcols : wg;
+}
+extern "C" int ia_conv3x3_s2_padded_fwd(const void* xp, const void* what, const float* bias, void* yp, int B, int H, int W, int Cin, int Cout,
+                                        int groups, int y_compact, hipStream_t stream) {
+  (void)hipGetLastError();
+  int vg, shared;
+  const int rc = s2_ok(B, H, W, Cin, Cout, groups, &vg, &shared);
+  if (rc) return rc;
+  if (!xp || !what || !yp) return IA_ERR_ARG;
+  return dconv::launch_s2(xp, what, bias, yp, B, H, W, Cin, Cout, vg, shared, y_compact, stream);
+}
+// dwhat [Cout][9 * Cin / groups] fp32 (overwritten), dbias [Cout] (+=, may be NULL); dyp needs no particular border
+extern "C" int ia_conv3x3_s2_padded_bwd_weight(const void* xp, const void* dyp, float* dwhat, float* dbias, int B, int H, int W, int Cin, int Cout,
+                                               int groups, int y_compact, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  (void)hipGetLastError();
+  int vg, shared;
+  const int rc = s2_ok(B, H, W, Cin, Cout, groups, &vg, &shared);
+  if (rc) return rc;
+  if (!xp || !dyp || !dwhat) return IA_ERR_ARG;
+  if (!workspace || workspace_bytes < dconv::wgrad_s2_workspace(vg)) return IA_ERR_WORKSPACE;
+  return dconv::wgrad_s2(xp, dyp, dwhat, dbias, B, H, W, Cin, Cout, vg, shared, y_compact, workspace, stream);
+}
+// dxp [B, H + 2, W + 2, Cin] (interior written) from dyp [B, Ho + 2, Wo + 2, Cout] (border rows may hold anything finite)
+extern "C" int ia_conv3x3_s2_padded_bwd_data(const void* dyp, const void* what, void* dxp, int B, int H, int W, int Cin, int Cout, int groups,
+                                             int y_compact, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  (void)hipGetLastError();
+  int vg, shared;
+  int rc = s2_ok(B, H, W, Cin, Cout, groups, &vg, &shared);
+  if (rc) return rc;
+  if (!dyp || !what || !dxp) return IA_ERR_ARG;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, Cg = Cin / groups, Ng = Cout / groups, K = 9 * Cg;
+  const size_t Mp = y_compact ? (size_t)B * Ho * Wo : (size_t)B * (Ho + 2) * (Wo + 2);
+  if (!workspace || workspace_bytes < Mp * 9 * Cin * 2) return IA_ERR_WORKSPACE;
+  bf16* dcols = (bf16*)workspace;
+  for (int gi = 0; gi < groups && !rc; ++gi)
+    rc = ia_gemm_bf16((const bf16*)dyp + gi * Ng, 0, Cout, (const bf16*)what + (size_t)gi * Ng * K, 1, K, dcols + (size_t)gi * K, 0, 9 * Cin, (int)Mp, K,
+                      Ng, IA_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, stream);
+  if (rc) return rc;
+  const size_t total = (size_t)B * H * W * (Cin >> 3);
+  hipLaunchKernelGGL(col2im3_s2_padded_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, dcols, (bf16*)dxp, H, W, Cin, Cg, Ho, Wo, y_compact, total);
+  return ia_check_launch();
+}
+
 extern "C" int ia_silu_pad_fwd(const void* x, void* y, int B, int H, int W, int C, float scale, int in_padded, int out_padded, hipStream_t stream) {
   (void)hipGetLastError();
   if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7)) return IA_ERR_ARG;

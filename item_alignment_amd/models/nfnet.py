@@ -169,6 +169,61 @@ class PaddedStdConvFn(torch.autograd.Function):
         return dxp, None, None, None, None, None
 
 
+class PaddedS2ConvFn(torch.autograd.Function):
+    """ScaledStdConv2d, 3x3 / stride 2 (64 channels per group, or the stem's 64 -> 128), from the zero-bordered domain at H x W to the
+    bordered -- or, `y_compact`, the compact -- domain at ceil(H/2) x ceil(W/2) without a patch matrix (ia_conv3x3_s2_padded_*: forward over
+    the four parity views of x, weight gradient = the direct kernel on those views, data gradient = GEMM + gather).  Borders as for
+    PaddedStdConvFn: the input's must be zero, the output's is garbage, the incoming gradient's is not read."""
+
+    @staticmethod
+    def forward(ctx, xp, weight, conv, B, H, W, y_compact):
+        lib = _lib.load()
+        Fn._need_gpu(xp, "feature map")
+        Cin, Cout, g = conv.in_channels, conv.out_channels, conv.groups
+        ci = Cin // g
+        dev = xp.device
+        what = torch.empty((Cout, 9 * ci), device=dev, dtype=BF16)
+        mean = torch.empty(Cout, device=dev, dtype=F32)
+        rstd = torch.empty(Cout, device=dev, dtype=F32)
+        check(lib.ia_ws_conv_weight_fwd(conv.weight.data_ptr(), conv.gain.data_ptr(), what.data_ptr(), mean.data_ptr(), rstd.data_ptr(), Cout, ci, 9,
+                                        ci, conv.scale, conv.eps, stream_ptr()), "ia_ws_conv_weight_fwd")
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        rows = B * Ho * Wo if y_compact else B * (Ho + 2) * (Wo + 2)
+        yp = torch.empty((rows, Cout), device=dev, dtype=BF16)
+        check(lib.ia_conv3x3_s2_padded_fwd(xp.data_ptr(), what.data_ptr(), ptr(conv.bias), yp.data_ptr(), B, H, W, Cin, Cout, g, int(y_compact),
+                                           stream_ptr()), "ia_conv3x3_s2_padded_fwd")
+        ctx.conv, ctx.saved, ctx.dims = conv, (xp, what, mean, rstd), (B, H, W, Cin, Cout, g, ci, int(y_compact))
+        ctx.need_dx = ctx.needs_input_grad[0]
+        return yp
+
+    @staticmethod
+    def backward(ctx, dyp):
+        lib = _lib.load()
+        conv = ctx.conv
+        xp, what, mean, rstd = ctx.saved
+        B, H, W, Cin, Cout, g, ci, yc = ctx.dims
+        dyp = dyp.contiguous()
+        dev = dyp.device
+        wsb = lib.ia_conv3x3_s2_padded_workspace_bytes(B, H, W, Cin, Cout, g)
+        ws = _ws(dev, wsb)
+        dxp = None
+        if ctx.need_dx:
+            dxp = torch.empty_like(xp)
+            check(lib.ia_conv3x3_s2_padded_bwd_data(dyp.data_ptr(), what.data_ptr(), dxp.data_ptr(), B, H, W, Cin, Cout, g, yc, ws.data_ptr(), wsb,
+                                                    stream_ptr()), "ia_conv3x3_s2_padded_bwd_data")
+        if conv.weight.requires_grad:
+            dwhat = torch.empty((Cout, 9 * ci), device=dev, dtype=F32)
+            bg = conv.bias.grad.data_ptr() if conv.bias is not None and conv.bias.requires_grad else None
+            check(lib.ia_conv3x3_s2_padded_bwd_weight(xp.data_ptr(), dyp.data_ptr(), dwhat.data_ptr(), bg, B, H, W, Cin, Cout, g, yc, ws.data_ptr(), wsb,
+                                                      stream_ptr()), "ia_conv3x3_s2_padded_bwd_weight")
+            check(lib.ia_ws_conv_weight_bwd(dwhat.data_ptr(), conv.weight.data_ptr(), conv.gain.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                            conv.weight.grad.data_ptr(), conv.gain.grad.data_ptr(), Cout, ci, 9, ci, conv.scale, stream_ptr()),
+                  "ia_ws_conv_weight_bwd")
+            Fn._notify([p for p in (conv.weight, conv.bias, conv.gain) if p is not None])
+        ctx.saved = None
+        return dxp, None, None, None, None, None, None
+
+
 class SiluPadFn(torch.autograd.Function):
     """y = silu(x) * scale while moving between the compact [B*H*W, C] rows and the zero-bordered [B*(H+2)*(W+2), C] rows
     that PaddedStdConvFn works on (one flag per side; ia_silu_pad_*).  A padded output gets its border written as zero, a
@@ -412,6 +467,12 @@ class ScaledStdConv2d(nn.Module):
         ci, co = self.in_channels // self.groups, self.out_channels // self.groups
         return (PADDED_CONV and self.kernel_size == 3 and self.stride == 1 and ci >= 8 and co >= 8 and not (ci & (ci - 1)) and not (co & (co - 1)))
 
+    @property
+    def strided_direct(self):
+        """3x3 / stride 2 with a shape the patch-matrix-free strided kernels take (64 channels per group; the stem's 64 -> 128)"""
+        return (PADDED_CONV and self.kernel_size == 3 and self.stride == 2
+                and bool(_lib.load().ia_conv3x3_s2_supported(self.in_channels, self.out_channels, self.groups)))
+
     def fits_padded(self, B, H, W):
         """row indices of the padded tensor are 32-bit ints (its byte size is not limited)"""
         return B * (H + 2) * (W + 2) < 0x7FFFFFFF
@@ -482,6 +543,14 @@ class NormFreeBlock(nn.Module):
             # conv1 -> [silu -> padded] conv2 [silu, padded -> padded] conv2b [silu -> compact] -> conv3
             t = SiluPadFn.apply(out.t, 1.0, B, H, W, False, True)
             t = PaddedStdConvFn.apply(t, self.conv2.weight, self.conv2, B, H, W)
+            t = SiluPadFn.apply(t, 1.0, B, H, W, True, True)
+            t = PaddedStdConvFn.apply(t, self.conv2b.weight, self.conv2b, B, H, W)
+            out = FeatureMap(SiluPadFn.apply(t, 1.0, B, H, W, True, False), B, H, W)
+        elif self.conv2.strided_direct and self.conv2b.shifted_views and fits:
+            # the same chain through a stage transition: conv2 reads the bordered map at H x W and writes the bordered map at half size
+            t = SiluPadFn.apply(out.t, 1.0, B, H, W, False, True)
+            t = PaddedS2ConvFn.apply(t, self.conv2.weight, self.conv2, B, H, W, False)
+            H, W = (H - 1) // 2 + 1, (W - 1) // 2 + 1
             t = SiluPadFn.apply(t, 1.0, B, H, W, True, True)
             t = PaddedStdConvFn.apply(t, self.conv2b.weight, self.conv2b, B, H, W)
             out = FeatureMap(SiluPadFn.apply(t, 1.0, B, H, W, True, False), B, H, W)
@@ -573,13 +642,16 @@ class NormFreeNet(HipModule):
         while i < len(mods):
             m = mods[i]
             if isinstance(m, ScaledStdConv2d):
-                if padded:
+                if padded and m.stride == 2:                  # conv4: bordered in, compact out (the blocks read compact maps)
+                    y = PaddedS2ConvFn.apply(f.t, m.weight, m, f.B, f.H, f.W, True)
+                    f, padded = FeatureMap(y, f.B, (f.H - 1) // 2 + 1, (f.W - 1) // 2 + 1), False
+                elif padded:
                     f = FeatureMap(PaddedStdConvFn.apply(f.t, m.weight, m, f.B, f.H, f.W), f.B, f.H, f.W)
                 else:
                     f = m(f)
             else:
                 nxt = mods[i + 1] if i + 1 < len(mods) else None
-                to_padded = isinstance(nxt, ScaledStdConv2d) and nxt.shifted_views and nxt.fits_padded(f.B, f.H, f.W)
+                to_padded = (isinstance(nxt, ScaledStdConv2d) and (nxt.shifted_views or nxt.strided_direct) and nxt.fits_padded(f.B, f.H, f.W))
                 if padded or to_padded:
                     f = FeatureMap(SiluPadFn.apply(f.t, 1.0, f.B, f.H, f.W, padded, to_padded), f.B, f.H, f.W)
                 else:

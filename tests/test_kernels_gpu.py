@@ -963,6 +963,72 @@ def test_batchnorm_relu_fwd_bwd(gpu, rows, C, segments):
     assert rel_err(y, ref_ev) < 1e-2
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,groups,yc", [(2, 37, 45, 128, 128, 2, 0), (3, 16, 60, 64, 64, 1, 0), (2, 50, 31, 64, 128, 1, 1), (1, 8, 30, 384, 384, 6, 0),
+                                                      (2, 63, 64, 64, 64, 1, 1), (5, 3, 2, 64, 64, 1, 0), (2, 61, 122, 64, 128, 1, 0)])
+def test_conv3x3_stride2_without_a_patch_matrix(gpu, B, H, W, Cin, Cout, groups, yc):
+    """ia_conv3x3_s2_padded_* (the strided convolutions of the NF-Net: stage transitions with 64 channels per group, the stem's 64 -> 128 as
+    two output halves over one shared input slice) against torch conv2d / its autograd in fp32 on the same bf16 operands: odd and even
+    maps, maps smaller than a tile, several tiles per row, bordered and compact (yc) output layouts.  The border of dy is filled with NaN
+    for the weight gradient (it must not be read) and the output's border is left alone by the forward."""
+    from item_alignment_amd import _lib
+    from item_alignment_amd.ops import check, stream_ptr
+    lib = _lib.load()
+    assert lib.ia_conv3x3_s2_supported(Cin, Cout, groups) == 1 and lib.ia_conv3x3_s2_supported(96, 96, 1) == 0
+    Cg, Ho, Wo = Cin // groups, (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    x = rnd((B, H, W, Cin), gpu, 1.0, 81)
+    what = rnd((Cout, 9 * Cg), gpu, 0.05, 82)
+    bias = torch.randn(Cout, generator=torch.Generator().manual_seed(83)).to(gpu)
+    dy = rnd((B, Ho, Wo, Cout), gpu, 1.0, 84)
+    w_ref = what.float().view(Cout, 9, Cg).permute(0, 2, 1).reshape(Cout, Cg, 3, 3).requires_grad_(True)
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(xr, w_ref, br, stride=2, padding=1, groups=groups)
+    assert tuple(ref.shape) == (B, Cout, Ho, Wo)
+    ref.backward(dy.float().permute(0, 3, 1, 2))
+
+    def bordered(t, fill):
+        if yc:
+            return t.contiguous()
+        out = torch.full((B, Ho + 2, Wo + 2, Cout), fill, device=gpu, dtype=torch.bfloat16)
+        out[:, 1:-1, 1:-1] = t
+        return out
+
+    def interior(t):
+        return t if yc else t[:, 1:-1, 1:-1]
+
+    xp = torch.zeros((B, H + 2, W + 2, Cin), device=gpu, dtype=torch.bfloat16)
+    xp[:, 1:-1, 1:-1] = x
+    yp = bordered(torch.full((B, Ho, Wo, Cout), 7.0, device=gpu, dtype=torch.bfloat16), 7.0)
+    check(lib.ia_conv3x3_s2_padded_fwd(xp.data_ptr(), what.data_ptr(), bias.data_ptr(), yp.data_ptr(), B, H, W, Cin, Cout, groups, yc, stream_ptr()), "s2_fwd")
+    assert rel_err(interior(yp), ref.detach().permute(0, 2, 3, 1)) < 1e-2
+    if not yc:
+        edge = yp.clone()
+        edge[:, 1:-1, 1:-1] = 7.0
+        assert (edge == 7.0).all()                                         # the border is not written
+    wsb = lib.ia_conv3x3_s2_padded_workspace_bytes(B, H, W, Cin, Cout, groups)
+    ws = torch.empty(wsb, device=gpu, dtype=torch.uint8)
+    dyp = bordered(dy, float("nan"))
+    dwhat = torch.full((Cout, 9 * Cg), 3.0, device=gpu, dtype=torch.float32)
+    dbias = torch.full((Cout,), 0.5, device=gpu)
+    check(lib.ia_conv3x3_s2_padded_bwd_weight(xp.data_ptr(), dyp.data_ptr(), dwhat.data_ptr(), dbias.data_ptr(), B, H, W, Cin, Cout, groups, yc, ws.data_ptr(),
+                                              wsb, stream_ptr()), "s2_wgrad")
+    dw_ref = w_ref.grad.view(Cout, Cg, 9).permute(0, 2, 1).reshape(Cout, 9 * Cg)
+    assert torch.isfinite(dwhat).all()
+    assert rel_err(dwhat, dw_ref) < 2e-3 and rel_err(dbias - 0.5, br.grad) < 2e-3
+    dyz = bordered(dy, 0.0)
+    dxp = torch.full((B, H + 2, W + 2, Cin), 9.0, device=gpu, dtype=torch.bfloat16)
+    check(lib.ia_conv3x3_s2_padded_bwd_data(dyz.data_ptr(), what.data_ptr(), dxp.data_ptr(), B, H, W, Cin, Cout, groups, yc, ws.data_ptr(), wsb, stream_ptr()),
+          "s2_dgrad")
+    assert rel_err(dxp[:, 1:-1, 1:-1], xr.grad.permute(0, 2, 3, 1)) < 2e-2
+    # the same numbers as the patch-matrix path the model used until round 6 (bf16 outputs of fp32 sums in another order)
+    y_old = torch.empty((B * Ho * Wo, Cout), device=gpu, dtype=torch.bfloat16)
+    wsb2 = lib.ia_conv_nhwc_workspace_bytes(B, H, W, Cin, Cout, 3, 2, groups)
+    ws2 = torch.empty(wsb2, device=gpu, dtype=torch.uint8)
+    check(lib.ia_conv_nhwc_fwd(x.data_ptr(), what.data_ptr(), bias.data_ptr(), y_old.data_ptr(), B, H, W, Cin, Cout, 3, 2, groups, ws2.data_ptr(), wsb2,
+                               stream_ptr()), "nhwc_fwd")
+    assert rel_err(interior(yp).reshape(-1, Cout), y_old) < 1e-2
+
+
 @pytest.mark.parametrize("images,hw,C,groups", [(3, 49, 192, 32), (2, 56 * 56, 768, 32), (4, 100, 32, 32), (2, 333, 64, 8), (1, 9, 6144, 32)])
 def test_groupnorm_relu_fwd_bwd(gpu, images, hw, C, groups):
     """ia_gn_act_* (GroupNorm + ReLU on NHWC rows: the norm layer of the BiT towers; statistics per (image, group), groups of 6 / 24 / 1 /

@@ -143,6 +143,13 @@ case "$1" in
     cat $O
     bash tools/runs/r06_final.sh
     ;;
+  s2)           # the strided 3x3 convolutions without a patch matrix: kernel tests, the NF-Net model tests, C3 A/B on one box
+    O=gpurun_out/r06_s2.txt; : > $O
+    timeout 900 python -m pytest tests/test_kernels_gpu.py -k "stride2 or conv" -q -x --tb=short 2>&1 | grep -E "^E  |passed|failed|^FAILED" | cut -c1-400 | tail -8 >> $O
+    timeout 900 python -m pytest tests/test_models_gpu.py tests/test_cli_gpu.py -k "nfnet or image" -q --tb=short 2>&1 | grep -E "^E  |passed|failed|^FAILED" | cut -c1-400 | tail -8 >> $O
+    for v in 1 0 1 0; do echo "IA_CONV_S2_DIRECT=$v: $(IA_CONV_S2_DIRECT=$v timeout 600 python tools/config_bench.py c3 2>&1 | grep -E 'pairs/s')" >> $O; done
+    cat $O
+    ;;
   bit)          # the BiT towers: kernel + model + CLI tests, parity numbers, throughput beside resnetv2_50
     O=gpurun_out/r06_bit.txt; : > $O
     timeout 900 python -m pytest tests/test_kernels_gpu.py -k "groupnorm or ring_of_zeros or maxpool or batchnorm" -q -x --tb=short 2>&1 | grep -E "^E  |passed|failed|^FAILED" | cut -c1-400 | tail -8 >> $O
