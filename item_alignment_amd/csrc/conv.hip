@@ -1302,8 +1302,12 @@ struct WArgs {
   int dy_compact;              // dyp is [B, H, W, Cout] without a border
 };
 
-template <int CI, int CO>
+// TAPS: bit t = kernel tap t is wanted (a parity view of the stride-2 form needs 1, 2 or 4 of the nine).  A compile-time mask: a run-time
+// branch around the transpose reads is a merge point at which hipcc copies the fragment registers before the data has arrived
+// (tools/lint_asm_waits.py caught exactly that); with CI = 64 a wave's j-th column block IS tap j, so the mask folds away.
+template <int CI, int CO, int TAPS = 0x1FF>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WArgs p) {
+  static_assert(TAPS == 0x1FF || CI == 64, "tap masks need the block <-> tap identity of CI = 64");
   using G = WGeo<CI, CO>;
   // (every Geo constant used inside the lambdas is copied to a local first: `X_BYTES` written inside an argument of the LDS-DMA
   // builtin made hipcc drop this kernel's host launch stub -- undefined symbol at load time, tests/test_cabi_symbols.py)
@@ -1411,7 +1415,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WArgs p) {
       for (int j = 0; j < NBW; ++j) {
         const int nb = wave + 4 * j < NB ? wave + 4 * j : NB - 1;      // column block (tap, 16 input channels), wave-uniform (clamped: unused)
         const int tap = nb / (CI / 16), cb = nb - tap * (CI / 16);
-        bf[set][j] = tr_pair<CI>(xs, r * TWP + tpx + (tap / 3) * TWP + tap % 3, cb * 16 + tch);
+        if (TAPS == 0x1FF || ((TAPS >> j) & 1)) bf[set][j] = tr_pair<CI>(xs, r * TWP + tpx + (tap / 3) * TWP + tap % 3, cb * 16 + tch);
       }
     };
     load(0, 0);
@@ -1423,7 +1427,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WArgs p) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < NBW; ++j)
-        if (wave + 4 * j < NB) {
+        if (wave + 4 * j < NB && (TAPS == 0x1FF || ((TAPS >> j) & 1))) {
 #pragma unroll
           for (int mi = 0; mi < MB; ++mi) acc[mi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[r & 1][j], af[r & 1][mi], acc[mi][j], 0, 0, 0);
         }
@@ -1484,6 +1488,19 @@ __global__ __launch_bounds__(256) void wgrad_fold_s2_kernel(const float* __restr
   else if (dbias) dbias[grp * (bank - wsize) + (e - wsize)] += sum;
 }
 
+template <int TAPS>
+static int wgrad_view_launch(const WArgs& a, unsigned grid, hipStream_t stream) {
+  using G = WGeo<64, 64>;
+  auto kern = conv3x3_wgrad_kernel<64, 64, TAPS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) return IA_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G::LDS_BYTES, stream, a);
+  return IA_OK;
+}
+
 template <int CI, int CO>
 static int wgrad_t(WArgs a, float* dwhat, float* dbias, hipStream_t stream) {
   using G = WGeo<CI, CO>;
@@ -1502,9 +1519,16 @@ static int wgrad_t(WArgs a, float* dwhat, float* dbias, hipStream_t stream) {
   if (a.xs == 2) {
     const size_t region = (size_t)per_group * a.groups * bank;
     float* const part = a.part;
-    for (int v = 0; v < 4; ++v) {
-      a.offy = v >> 1; a.offx = v & 1; a.part = part + (size_t)v * region;
-      hipLaunchKernelGGL(kern, dim3((unsigned)(per_group * a.groups)), dim3(256), G::LDS_BYTES, stream, a);
+    if constexpr (CI == 64 && CO == 64) {
+      for (int v = 0; v < 4; ++v) {      // taps wanted: rows even -> ty = 0, 1, rows odd -> ty = 0; the same for the columns (tap = 3 ty + tx)
+        a.offy = v >> 1; a.offx = v & 1; a.part = part + (size_t)v * region;
+        const unsigned grid = (unsigned)(per_group * a.groups);
+        const int rc = v == 0 ? wgrad_view_launch<0x1B>(a, grid, stream) : v == 1 ? wgrad_view_launch<0x09>(a, grid, stream)
+                     : v == 2 ? wgrad_view_launch<0x03>(a, grid, stream) : wgrad_view_launch<0x01>(a, grid, stream);
+        if (rc) return rc;
+      }
+    } else {
+      return IA_ERR_UNSUPPORTED;
     }
     hipLaunchKernelGGL(wgrad_fold_s2_kernel, dim3((a.groups * bank + 255) / 256), dim3(256), 0, stream, part, dwhat, dbias, a.groups, (int)per_group, bank,
                        wsize, CI, region);

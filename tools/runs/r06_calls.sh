@@ -150,6 +150,17 @@ case "$1" in
     for v in 1 0 1 0; do echo "IA_CONV_S2_DIRECT=$v: $(IA_CONV_S2_DIRECT=$v timeout 600 python tools/config_bench.py c3 2>&1 | grep -E 'pairs/s')" >> $O; done
     cat $O
     ;;
+  c3prof)       # C3 again after the strided kernels: kernel summary, PMC traffic, A/B lines (-> profiles/r06_c3_*.txt, r06_ab_c3_strided.txt)
+    mkdir -p gpurun_out/profiles; OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles; R=$GRAFT_REPO_ROOT
+    O=$OUT/r06_ab_c3_strided.txt; : > $O
+    for v in 1 0 1 0 1 0; do echo "IA_CONV_S2_DIRECT=$v: $(IA_CONV_S2_DIRECT=$v timeout 600 python tools/config_bench.py c3 2>&1 | grep -E 'pairs/s')" >> $O; done
+    cat $O
+    (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $OUT/kt_c3 -o b --output-format csv -- python3 $R/tools/config_bench.py c3 > $OUT/c3_log.txt 2>&1)
+    python3 tools/config_bench.py --pmc c3 2>&1 | grep -E "pairs/s|HBM traffic" > $OUT/r06_c3_hbm.txt
+    python3 tools/prof_summary.py $OUT/kt_c3/b_kernel_stats.csv 11 40 > $OUT/r06_c3_kernel_stats_summary.txt
+    rm -rf $OUT/kt_c3 $OUT/c3_log.txt
+    cat $OUT/r06_c3_hbm.txt; head -12 $OUT/r06_c3_kernel_stats_summary.txt
+    ;;
   bit)          # the BiT towers: kernel + model + CLI tests, parity numbers, throughput beside resnetv2_50
     O=gpurun_out/r06_bit.txt; : > $O
     timeout 900 python -m pytest tests/test_kernels_gpu.py -k "groupnorm or ring_of_zeros or maxpool or batchnorm" -q -x --tb=short 2>&1 | grep -E "^E  |passed|failed|^FAILED" | cut -c1-400 | tail -8 >> $O
