@@ -294,6 +294,11 @@ int ia_conv3x3_s2_padded_bwd_data(const void* dyp, const void* what, void* dxp, 
                                   int y_compact, void* workspace, size_t workspace_bytes, ia_stream_t stream);
 int ia_conv3x3_s2_padded_bwd_weight(const void* xp, const void* dyp, float* dwhat, float* dbias, int B, int H, int W, int Cin, int Cout,
                                     int groups, int y_compact, void* workspace, size_t workspace_bytes, ia_stream_t stream);
+/* the data gradient as one kernel over the four parity classes of dx (Cin = Cout = 64 * groups only: ia_conv3x3_s2_dgrad_supported):
+ * what_t from ia_conv3x3_flip_weights, dyp bordered with a ZERO border, dxp bordered (interior written) */
+int ia_conv3x3_s2_dgrad_supported(int Cin, int Cout, int groups);
+int ia_conv3x3_s2_padded_bwd_data_t(const void* dyp, const void* what_t, void* dxp, int B, int H, int W, int Cin, int Cout, int groups,
+                                    ia_stream_t stream);
 /* y = silu(x) * scale between the compact [B,H,W,C] and the zero-bordered [B,H+2,W+2,C] layouts (one flag per side); the
  * backward call produces dx in x's layout from dy in y's layout */
 int ia_silu_pad_fwd(const void* x, void* y, int B, int H, int W, int C, float scale, int in_padded, int out_padded, ia_stream_t stream);

@@ -1205,6 +1205,157 @@ __global__ __launch_bounds__(256) void conv3x3_s2_kernel(S2Args p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------- stride-2 data gradient (round 6)
+// dx[2 j + py][2 i + px] (interior coordinates) = sum over the taps (dy, dx) with dy = py + 1 (mod 2), dx = px + 1 (mod 2) of
+// w[dy][dx]^T . g[(2 j + py + 1 - dy) / 2][(2 i + px + 1 - dx) / 2]: the four parity classes of dx are four stride-1 pieces over the SAME
+// (8 + 1) x (30 + 1) tile of the incoming gradient g -- class (0, 0) the centre tap at g[j][i], (0, 1) / (1, 0) two taps, (1, 1) the
+// four corner taps at g[j + a][i + b], a = (dy == 0), b = (dx == 0).  One LDS tile of g per 8 x 30 cells serves all four classes; every
+// class has its own accumulators and leaves as soon as it is done (its pixels lie two apart: 128-byte segments, the other classes fill
+// the gaps).  The filter bank is the tap-flipped, transposed one of the stride-1 data gradient (flip_weights_kernel).  g needs a ZERO
+// border (row Ho / column Wo are read for odd maps' last cells); 64 -> 64 channels per group.
+struct S2DArgs {
+  const bf16* gp; const bf16* wt; bf16* dxp;
+  int B, H, W;                 // height / width of dx (the convolution's input)
+  int Ho, Wo;                  // of g (its output)
+  int Cin, Cout, groups;       // channels of dx / of g
+  int tiles_x, tiles_y;        // over the cells (j, i): ceil(H / 2) x ceil(W / 2)
+};
+
+__global__ __launch_bounds__(256) void conv3x3_s2_dgrad_kernel(S2DArgs p) {
+  constexpr int CI = 64, CO = 64;                              // CI: contraction (channels of g), CO: channels of dx
+  using G = Geo<CI, CO>;
+  constexpr int PB = G::PB, NC = G::NC, PPP = G::PPP, NI = G::NI, IN_BYTES = G::IN_BYTES, W_BYTES = G::W_BYTES;
+  constexpr int IN_PIECES = G::IN_PIECES, W_PIECES = G::W_PIECES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int grp = blockIdx.x % p.groups, slot = blockIdx.x / p.groups, nslots = gridDim.x / p.groups;
+  const int ntiles = p.B * p.tiles_y * p.tiles_x;
+  if (slot >= ntiles) return;
+  const int GPW = p.Wo + 2, GPH = p.Ho + 2, XPW = p.W + 2, XPH = p.H + 2;
+  typedef __attribute__((address_space(3))) char lds_char;
+  lds_char* const lsm = (lds_char*)IA_LDS(smem);
+  const uint32_t sbase = ia_lds_addr(smem);
+  {
+    const bf16* wg = p.wt + (size_t)grp * CO * 9 * CI;
+    const __amdgpu_buffer_rsrc_t rsW = ia_rsrc(wg, (uint32_t)(CO * 9 * CI * 2));
+#pragma unroll 1
+    for (int pc = wave; pc < W_PIECES; pc += 4) {
+      const int s = pc / (CO / 16), r16 = pc - s * (CO / 16);
+      const int row = r16 * 16 + (lane >> 2);
+      const int chunk = (lane & 3) ^ bkey<CO>(row);
+      const int k = (s >> 1) * 64 + (s & 1) * 32 + chunk * 8;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, lsm + pc * 1024, 16, (uint32_t)((row * 9 * CI + k) * 2), 0, 0, 0);
+    }
+  }
+  int a_p0[4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    int q = wave * 64 + mi * 16 + li;
+    q = q < TILE_PX ? q : TILE_PX - 1;
+    const int y = q / TW, x = q - y * TW;
+    a_p0[mi] = y * TWP + x;
+  }
+  int b_off[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int row = (li >> 2) * (CO / 4) + ni * 4 + (li & 3);
+    b_off[ni] = row * 64 + ((g ^ bkey<CO>(row)) << 4);
+  }
+  const uint32_t lane_in = (uint32_t)(((lane / NC) * p.Cout + (((lane % NC) ^ akey<CI>(lane / NC)) * 8)) * 2);
+  const size_t total_in = (size_t)p.B * GPH * GPW * p.Cout;
+
+  auto tile_of = [&](int t, int& b, int& j0, int& i0) {
+    const int tx = t % p.tiles_x, r = t / p.tiles_x;
+    const int ty = r % p.tiles_y;
+    b = r / p.tiles_y; j0 = ty * TH; i0 = tx * TW;               // first cell of the tile
+  };
+  // g tile: LDS pixel (r, c) = g[j0 + r][i0 + c] (interior coordinates; bordered: + 1), rows 0 .. 8
+  auto stage = [&](int t, int buf) {
+    int b, j0, i0;
+    tile_of(t, b, j0, i0);
+    const size_t org = (((size_t)b * GPH + (j0 + 1)) * GPW + (i0 + 1)) * p.Cout + (size_t)grp * CI;
+    const size_t rem = org < total_in ? (total_in - org) * 2 : 0;
+    const __amdgpu_buffer_rsrc_t rs = ia_rsrc(p.gp + (rem ? org : 0), (uint32_t)(rem < 0x7FFFFFF0ull ? rem : 0x7FFFFFF0ull));
+#pragma unroll
+    for (int i = 0; i < (IN_PIECES + 3) / 4; ++i) {
+      const int pc = wave + 4 * i;
+      const int r = pc / (TWP / PPP), c = pc - r * (TWP / PPP);
+      if (pc < IN_PIECES && r <= TH) {
+        const uint32_t adv = (uint32_t)((r * GPW + c * PPP) * p.Cout * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lsm + W_BYTES + buf * IN_BYTES + pc * 1024, 16, lane_in + adv, 0, 0, 0);
+      }
+    }
+  };
+
+  stage(slot, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int buf = 0;
+#pragma unroll 1
+  for (int t = slot; t < ntiles; t += nslots, buf ^= 1) {
+    if (t + nslots < ntiles) stage(t + nslots, buf ^ 1);
+    const uint32_t in = sbase + W_BYTES + buf * IN_BYTES;
+    int b, j0, i0;
+    tile_of(t, b, j0, i0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {                                // parity class (py, px) = (v >> 1, v & 1) of dx
+      f32x4 acc[4][NI];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int nry = (v >> 1) ? 2 : 1, nrx = (v & 1) ? 2 : 1, NK = nry * nrx * 2;
+      bf16x8 af[2][4], bfr[2][NI];
+      auto load = [&](int i, int slot2) {
+        const int half = i & 1, ix = (i >> 1) % nrx, iy = (i >> 1) / nrx;
+        const int dy = (v >> 1) ? 2 * iy : 1, dx = (v & 1) ? 2 * ix : 1;      // class 1: taps 0 and 2; class 0: the middle tap
+        const int sy = dy == 0 ? 1 : 0, sx = dx == 0 ? 1 : 0;
+        const int s = (8 - (dy * 3 + dx)) * 2 + half, off = sy * TWP + sx, chunk = half * 4 + g;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          const int P = a_p0[mi] + off;
+          lds_read128(af[slot2][mi], in + (uint32_t)(P * PB + ((chunk ^ akey<CI>(P)) << 4)));
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) lds_read128(bfr[slot2][ni], sbase + (uint32_t)(s * (CO * 64) + b_off[ni]));
+      };
+      load(0, 0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (i < NK) {
+          if (i + 1 < NK) { load(i + 1, (i + 1) & 1); wait_frags<4 + NI, NI>(af[i & 1], bfr[i & 1]); }
+          else wait_frags<0, NI>(af[i & 1], bfr[i & 1]);
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[i & 1][ni], af[i & 1][mi], acc[mi][ni], 0, 0, 0);
+        }
+      }
+      // this class's pixels: cell q -> dx (2 (j0 + y) + py, 2 (i0 + x) + px), bordered + 1
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int q = wave * 64 + mi * 16 + li;
+        const int y = q / TW, x = q - y * TW;
+        const int iy = 2 * (j0 + y) + (v >> 1), ix = 2 * (i0 + x) + (v & 1);
+        if (q >= TILE_PX || iy >= p.H || ix >= p.W) continue;
+        bf16* const dst = p.dxp + (((size_t)b * XPH + (iy + 1)) * XPW + (ix + 1)) * p.Cin + (size_t)grp * CO + g * (CO / 4);
+#pragma unroll
+        for (int h = 0; h < NI / 2; ++h) {
+          bf16x8 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { o[j] = f2bf(acc[mi][2 * h][j]); o[4 + j] = f2bf(acc[mi][2 * h + 1][j]); }
+          *reinterpret_cast<bf16x8*>(dst + 8 * h) = o;
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the next tile of g has landed; everybody is through with `in`
+    __syncthreads();
+  }
+}
+
 // wt[g][ci][(8 - tap) * CO + co] = w[g][co][tap * CI + ci]: the filter bank of the data gradient (a correlation with the flipped taps)
 __global__ __launch_bounds__(256) void flip_weights_kernel(const bf16* __restrict__ w, bf16* __restrict__ wt, int CI, int CO, int total) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -1567,6 +1718,27 @@ static int wgrad_s2(const void* xp, const void* dyp, float* dwhat, float* dbias,
 }
 static size_t wgrad_s2_workspace(int groups) { return 4 * wgrad_workspace(64, 64, groups); }
 
+static int launch_s2_dgrad(const void* gp, const void* wt, void* dxp, int B, int H, int W, int Cin, int Cout, int groups, hipStream_t stream) {
+  S2DArgs a;
+  a.gp = (const bf16*)gp; a.wt = (const bf16*)wt; a.dxp = (bf16*)dxp;
+  a.B = B; a.H = H; a.W = W; a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1;
+  a.Cin = Cin; a.Cout = Cout; a.groups = groups;
+  a.tiles_x = (a.Wo + TW - 1) / TW; a.tiles_y = (a.Ho + TH - 1) / TH;      // cells: ceil(H / 2) x ceil(W / 2) = Ho x Wo
+  using G = Geo<64, 64>;
+  auto kern = conv3x3_s2_dgrad_kernel;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) return IA_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const long ntiles = (long)a.B * a.tiles_x * a.tiles_y;
+  long per_group = 256L / groups;
+  if (per_group > ntiles) per_group = ntiles;
+  if (per_group < 1) per_group = 1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(per_group * groups)), dim3(256), G::LDS_BYTES, stream, a);
+  return ia_check_launch();
+}
+
 // launcher of the stride-2 forward kernel
 static int launch_s2(const void* xp, const void* w, const float* bias, void* yp, int B, int XH, int XW, int Cin, int Cout, int groups, int shared_input,
                      int out_compact, hipStream_t stream) {
@@ -1769,6 +1941,22 @@ extern "C" int ia_conv3x3_s2_padded_bwd_data(const void* dyp, const void* what, 
   const size_t total = (size_t)B * H * W * (Cin >> 3);
   hipLaunchKernelGGL(col2im3_s2_padded_kernel, dim3(blocks_of(total)), dim3(256), 0, stream, dcols, (bf16*)dxp, H, W, Cin, Cg, Ho, Wo, y_compact, total);
   return ia_check_launch();
+}
+
+// The data gradient without the patch-matrix detour, for Cin = Cout = 64 * groups (the stage transitions; ia_conv3x3_s2_dgrad_supported):
+// what_t = the tap-flipped transposed bank of ia_conv3x3_flip_weights, dyp bordered [B, Ho + 2, Wo + 2, Cout] with a ZERO border, dxp bordered
+// [B, H + 2, W + 2, Cin] (interior written)
+extern "C" int ia_conv3x3_s2_dgrad_supported(int Cin, int Cout, int groups) {
+  static const bool on = [] { const char* e = getenv("IA_CONV_S2_DGRAD"); return !e || atoi(e) != 0; }();
+  return on && dconv::enabled() && s2_enabled() && groups >= 1 && groups <= 64 && Cin == 64 * groups && Cout == 64 * groups;
+}
+extern "C" int ia_conv3x3_s2_padded_bwd_data_t(const void* dyp, const void* what_t, void* dxp, int B, int H, int W, int Cin, int Cout, int groups,
+                                               hipStream_t stream) {
+  (void)hipGetLastError();
+  if (B <= 0 || H <= 0 || W <= 0 || groups < 1 || groups > 64 || Cin != 64 * groups || Cout != 64 * groups) return IA_ERR_UNSUPPORTED;
+  if (!dyp || !what_t || !dxp) return IA_ERR_ARG;
+  if ((size_t)B * (H + 2) * (W + 2) >= 0x7FFFFFFFull) return IA_ERR_ARG;
+  return dconv::launch_s2_dgrad(dyp, what_t, dxp, B, H, W, Cin, Cout, groups, stream);
 }
 
 extern "C" int ia_silu_pad_fwd(const void* x, void* y, int B, int H, int W, int C, float scale, int in_padded, int out_padded, hipStream_t stream) {

@@ -209,8 +209,16 @@ class PaddedS2ConvFn(torch.autograd.Function):
         dxp = None
         if ctx.need_dx:
             dxp = torch.empty_like(xp)
-            check(lib.ia_conv3x3_s2_padded_bwd_data(dyp.data_ptr(), what.data_ptr(), dxp.data_ptr(), B, H, W, Cin, Cout, g, yc, ws.data_ptr(), wsb,
-                                                    stream_ptr()), "ia_conv3x3_s2_padded_bwd_data")
+            if not yc and lib.ia_conv3x3_s2_dgrad_supported(Cin, Cout, g):
+                # one kernel over the four parity classes of dx, on the tap-flipped transposed bank (the incoming gradient's border is zero:
+                # the SiLU backward behind this convolution writes it)
+                what_t = torch.empty((Cin, 9 * (Cout // g)), device=dev, dtype=BF16)
+                check(lib.ia_conv3x3_flip_weights(what.data_ptr(), what_t.data_ptr(), Cin, Cout, g, stream_ptr()), "ia_conv3x3_flip_weights")
+                check(lib.ia_conv3x3_s2_padded_bwd_data_t(dyp.data_ptr(), what_t.data_ptr(), dxp.data_ptr(), B, H, W, Cin, Cout, g, stream_ptr()),
+                      "ia_conv3x3_s2_padded_bwd_data_t")
+            else:
+                check(lib.ia_conv3x3_s2_padded_bwd_data(dyp.data_ptr(), what.data_ptr(), dxp.data_ptr(), B, H, W, Cin, Cout, g, yc, ws.data_ptr(), wsb,
+                                                        stream_ptr()), "ia_conv3x3_s2_padded_bwd_data")
         if conv.weight.requires_grad:
             dwhat = torch.empty((Cout, 9 * ci), device=dev, dtype=F32)
             bg = conv.bias.grad.data_ptr() if conv.bias is not None and conv.bias.requires_grad else None

@@ -153,8 +153,34 @@ case "$1" in
   c3prof)       # C3 again after the strided kernels: kernel summary, PMC traffic, A/B lines (-> profiles/r06_c3_*.txt, r06_ab_c3_strided.txt)
     mkdir -p gpurun_out/profiles; OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles; R=$GRAFT_REPO_ROOT
     O=$OUT/r06_ab_c3_strided.txt; : > $O
-    for v in 1 0 1 0 1 0; do echo "IA_CONV_S2_DIRECT=$v: $(IA_CONV_S2_DIRECT=$v timeout 600 python tools/config_bench.py c3 2>&1 | grep -E 'pairs/s')" >> $O; done
+    for v in "1 1" "1 0" "0 0" "1 1" "1 0" "0 0"; do set -- $v
+      echo "IA_CONV_S2_DIRECT=$1 IA_CONV_S2_DGRAD=$2: $(IA_CONV_S2_DIRECT=$1 IA_CONV_S2_DGRAD=$2 timeout 600 python tools/config_bench.py c3 2>&1 | grep -E 'pairs/s')" >> $O; done
     cat $O
+    timeout 900 python - >> $O 2>&1 <<'PY'
+# soak: 200 C3 steps on fresh random images, the loss stays finite and falls
+import sys, torch
+sys.path.insert(0, ".")
+import item_alignment_amd.models as M
+from item_alignment_amd.optim import AdamW
+from types import SimpleNamespace
+dev = torch.device("cuda:0")
+cfg = SimpleNamespace(num_labels=2, hidden_dropout_prob=0.1, loss_type="ce", loss_margin=0.0, classification_method="cls", hidden_size=2304)
+torch.manual_seed(1)
+m = M.NFNetTwoTower(cfg, M.create_model("eca_nfnet_l0")).to(dev).train()
+opt = AdamW(m.parameters(), lr=2e-5)
+g = torch.Generator().manual_seed(0)
+im1, im2 = torch.randn((8, 3, 413, 397), generator=g).to(dev), torch.randn((8, 3, 413, 397), generator=g).to(dev)      # odd, ragged maps
+labels = torch.randint(0, 2, (8,), generator=g).to(dev)
+losses = []
+for step in range(200):
+    out = m(im1, im2, labels)
+    out.loss.backward()
+    opt.step(); opt.zero_grad()
+    losses.append(float(out.loss))
+assert all(l == l and abs(l) < 1e4 for l in losses), losses[-5:]
+print(f"soak: 200 steps of eca_nfnet_l0 two_tower at 413 x 397 (odd maps through every strided kernel): loss {losses[0]:.4f} -> {losses[-1]:.4f}, all finite")
+PY
+    tail -1 $O
     (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $OUT/kt_c3 -o b --output-format csv -- python3 $R/tools/config_bench.py c3 > $OUT/c3_log.txt 2>&1)
     python3 tools/config_bench.py --pmc c3 2>&1 | grep -E "pairs/s|HBM traffic" > $OUT/r06_c3_hbm.txt
     python3 tools/prof_summary.py $OUT/kt_c3/b_kernel_stats.csv 11 40 > $OUT/r06_c3_kernel_stats_summary.txt
