@@ -1604,6 +1604,148 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WArgs p) {
   }
 }
 
+// The stride-2 form in ONE launch (64 -> 64 channels per group): work list (tile, parity view of x) as in the forward kernel -- the dy tile is
+// fetched once per tile and serves the four views, the x buffers alternate per view, and every view's taps accumulate straight into the
+// column blocks of the REAL taps (rows even: kernel tap ty -> dy = 2 ty; rows odd: ty = 0 -> dy = 1; the same for the columns), so the bank has
+// the stride-1 layout and the stride-1 fold applies.  Against four masked launches: dy read once instead of four times, one launch.
+__global__ __launch_bounds__(256) void conv3x3_wgrad_s2_kernel(WArgs p) {
+  constexpr int CI = 64, CO = 64;
+  using G = WGeo<CI, CO>;
+  constexpr int XB = G::XB, MB = G::MB, STAGE = G::STAGE, XNC = CI / 8, YNC = CO / 8;
+  constexpr int X_BYTES = G::X_BYTES, X_PIECES = G::X_PIECES, Y_PIECES = G::Y_PIECES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int grp = blockIdx.x % p.groups, slot = blockIdx.x / p.groups, nslots = gridDim.x / p.groups;
+  const int ntiles = p.B * p.tiles_y * p.tiles_x;
+  const int PW = p.W + 2, PH = p.H + 2, XPW = p.XW + 2, XPH = p.XH + 2;
+  const int YW = p.dy_compact ? p.W : PW, YH = p.dy_compact ? p.H : PH, yo = p.dy_compact ? 1 : 0;
+  typedef __attribute__((address_space(3))) char lds_char;
+  lds_char* const lsm = (lds_char*)IA_LDS(smem);
+  const uint32_t sbase = ia_lds_addr(smem);
+  const size_t total_x = (size_t)p.B * XPH * XPW * p.Cin, total_y = (size_t)p.B * YH * YW * p.Cout;
+
+  auto tile_of = [&](int t, int& b, int& y0, int& x0) {
+    const int tx = t % p.tiles_x, r = t / p.tiles_x;
+    const int ty = r % p.tiles_y;
+    b = r / p.tiles_y; y0 = 1 + ty * TH; x0 = 1 + tx * TW;
+  };
+  const uint32_t lane_x = (uint32_t)(((lane / XNC) * 2 * p.Cin + (((lane % XNC) ^ tkey<CI>(lane / XNC)) * 8)) * 2);
+  const int ypix = lane / YNC;
+  const uint32_t lane_y = (uint32_t)((ypix * p.Cout + (((lane % YNC) ^ tkey<CO>(ypix)) * 8)) * 2);
+  // x view v = 2 (rows odd) + (columns odd) of tile t -> x buffer xb: view pixel (r, c) = bordered x pixel (2 (y0 - 1 + r) + rows odd, ...)
+  auto stage_x = [&](int t, int v, int xb) {
+    int b, y0, x0;
+    tile_of(t, b, y0, x0);
+    const size_t org = (((size_t)b * XPH + 2 * (y0 - 1) + (v >> 1)) * XPW + 2 * (x0 - 1) + (v & 1)) * p.Cin + (size_t)grp * p.in_gstride;
+    const size_t rem = org < total_x ? (total_x - org) * 2 : 0;
+    const __amdgpu_buffer_rsrc_t rs = ia_rsrc(p.xp + (rem ? org : 0), (uint32_t)(rem < 0x7FFFFFF0ull ? rem : 0x7FFFFFF0ull));
+    constexpr int PPP = 64 / XNC;
+#pragma unroll
+    for (int i = 0; i < (X_PIECES + 3) / 4; ++i) {
+      const int pc = wave + 4 * i;
+      const int r = pc / (TWP / PPP), c = pc - r * (TWP / PPP);
+      if (pc < X_PIECES && r <= TH) {                           // rows 0 .. 8: the views' taps reach one row down, not two
+        const uint32_t adv = (uint32_t)((r * XPW + c * PPP) * 2 * p.Cin * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lsm + xb * STAGE + pc * 1024, 16, lane_x + adv, 0, 0, 0);
+      }
+    }
+  };
+  auto stage_y = [&](int t, int yb) {
+    int b, y0, x0;
+    tile_of(t, b, y0, x0);
+    const size_t org = (((size_t)b * YH + (y0 - yo)) * YW + (x0 - yo)) * p.Cout + (size_t)grp * CO;
+    const size_t rem = (total_y - org) * 2;
+    const __amdgpu_buffer_rsrc_t rs = ia_rsrc(p.dyp + org, (uint32_t)(rem < 0x7FFFFFF0ull ? rem : 0x7FFFFFF0ull));
+    constexpr int PPP = 64 / YNC;
+#pragma unroll
+    for (int i = 0; i < (Y_PIECES + 3) / 4; ++i) {
+      const int pc = wave + 4 * i;
+      if (pc < Y_PIECES) {
+        const int r = pc / (TWP / PPP), c = pc - r * (TWP / PPP);
+        const int col = c * PPP + ypix;
+        const bool ok = col < TW && x0 + col <= p.W && y0 + r <= p.H;
+        const uint32_t voff = ok ? lane_y + (uint32_t)((r * YW + c * PPP) * p.Cout * 2) : 0xFFFFFFF0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lsm + yb * STAGE + X_BYTES + pc * 1024, 16, voff, 0, 0, 0);
+      }
+    }
+  };
+
+  f32x4 acc[MB][9], racc[MB];
+#pragma unroll
+  for (int mi = 0; mi < MB; ++mi) {
+    racc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 9; ++j) acc[mi][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  bf16x8 ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = f2bf(1.0f);
+  const int tpx = g * 8 + (li >> 2), tch = (li & 3) * 4;
+  // the tail of both x buffers (row 9 is not fetched, shifted reads of row 8 overhang by one pixel): finite bytes, they only meet dy = 0
+  for (int i = tid; i < (X_BYTES - (TH + 1) * TWP * XB) / 4; i += 256) {
+    *reinterpret_cast<uint32_t*>(smem + (TH + 1) * TWP * XB + i * 4) = 0u;
+    *reinterpret_cast<uint32_t*>(smem + STAGE + (TH + 1) * TWP * XB + i * 4) = 0u;
+  }
+  if (slot < ntiles) {
+    stage_y(slot, 0);
+    stage_x(slot, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  int yb = 0;
+#pragma unroll 1
+  for (int t = slot; t < ntiles; t += nslots, yb ^= 1) {
+    const uint32_t ys = sbase + yb * STAGE + X_BYTES;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      if (v < 3) stage_x(t, v + 1, (v + 1) & 1);
+      else if (t + nslots < ntiles) { stage_x(t + nslots, 0, 0); stage_y(t + nslots, yb ^ 1); }
+      const uint32_t xs = sbase + (v & 1) * STAGE;
+      const int nty = (v >> 1) ? 1 : 2, ntx = (v & 1) ? 1 : 2, NT = nty * ntx;      // the view's kernel taps (ty, tx), ty < nty, tx < ntx
+      bf16x8 af[2][MB], bf[2][4];
+      auto load = [&](int r, int set) {
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi) af[set][mi] = tr_pair<CO>(ys, r * TWP + tpx, mi * 16 + tch);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k < NT) bf[set][k] = tr_pair<CI>(xs, r * TWP + tpx + (k / ntx) * TWP + k % ntx, wave * 16 + tch);
+      };
+      load(0, 0);
+#pragma unroll
+      for (int r = 0; r < TH; ++r) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (r + 1 < TH) load(r + 1, (r + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k < NT) {
+            const int ty = k / ntx, tx = k % ntx;
+            const int T = ((v >> 1) ? 1 : 2 * ty) * 3 + ((v & 1) ? 1 : 2 * tx);       // the real tap
+#pragma unroll
+            for (int mi = 0; mi < MB; ++mi) acc[mi][T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[r & 1][k], af[r & 1][mi], acc[mi][T], 0, 0, 0);
+          }
+        if (v == 0 && wave == 0) {
+#pragma unroll
+          for (int mi = 0; mi < MB; ++mi) racc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[r & 1][mi], racc[mi], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+  float* const bank = p.part + (size_t)blockIdx.x * (CO * 9 * CI + CO);
+#pragma unroll
+  for (int mi = 0; mi < MB; ++mi) {
+#pragma unroll
+    for (int j = 0; j < 9; ++j) *reinterpret_cast<f32x4*>(bank + (size_t)(mi * 16 + li) * (9 * CI) + (wave + 4 * j) * 16 + g * 4) = acc[mi][j];
+    if (wave == 0 && g == 0) bank[CO * 9 * CI + mi * 16 + li] = racc[mi][0];
+  }
+}
+
 // dwhat[g][co][9 CI] = sum over the group's workgroups of their banks (fixed order), dbias[g * CO + co] += the bias sums
 __global__ __launch_bounds__(256) void wgrad_fold_kernel(const float* __restrict__ part, float* __restrict__ dwhat, float* __restrict__ dbias, int groups,
                                                          int per_group, int bank, int wsize) {
@@ -1639,6 +1781,11 @@ __global__ __launch_bounds__(256) void wgrad_fold_s2_kernel(const float* __restr
   else if (dbias) dbias[grp * (bank - wsize) + (e - wsize)] += sum;
 }
 
+// IA_CONV_S2_WGRAD_MERGED=0: the four masked view launches instead of the one-launch kernel (read per call: A/B in one process)
+static bool wgrad_s2_merged() {
+  const char* e = getenv("IA_CONV_S2_WGRAD_MERGED");
+  return !e || atoi(e) != 0;
+}
 template <int TAPS>
 static int wgrad_view_launch(const WArgs& a, unsigned grid, hipStream_t stream) {
   using G = WGeo<64, 64>;
@@ -1667,6 +1814,21 @@ static int wgrad_t(WArgs a, float* dwhat, float* dbias, hipStream_t stream) {
   if (per_group > ntiles) per_group = ntiles;
   if (per_group < 1) per_group = 1;
   const int wsize = CO * 9 * CI, bank = wsize + CO;
+  if (a.xs == 2 && wgrad_s2_merged()) {
+    if constexpr (CI == 64 && CO == 64) {
+      auto k2 = conv3x3_wgrad_s2_kernel;
+      static bool attr2 = false;
+      if (!attr2) {
+        if (hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) return IA_ERR_LAUNCH;
+        attr2 = true;
+      }
+      hipLaunchKernelGGL(k2, dim3((unsigned)(per_group * a.groups)), dim3(256), G::LDS_BYTES, stream, a);
+      hipLaunchKernelGGL(wgrad_fold_kernel, dim3((a.groups * bank + 255) / 256), dim3(256), 0, stream, a.part, dwhat, dbias, a.groups, (int)per_group, bank, wsize);
+      return ia_check_launch();
+    } else {
+      return IA_ERR_UNSUPPORTED;
+    }
+  }
   if (a.xs == 2) {
     const size_t region = (size_t)per_group * a.groups * bank;
     float* const part = a.part;

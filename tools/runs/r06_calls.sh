@@ -187,6 +187,15 @@ PY
     rm -rf $OUT/kt_c3 $OUT/c3_log.txt
     cat $OUT/r06_c3_hbm.txt; head -12 $OUT/r06_c3_kernel_stats_summary.txt
     ;;
+  s2w)          # the one-launch weight gradient of the strided convolutions against the four masked launches
+    O=gpurun_out/r06_s2w.txt; : > $O
+    for m in 1 0; do
+      echo "IA_CONV_S2_WGRAD_MERGED=$m: $(IA_CONV_S2_WGRAD_MERGED=$m timeout 900 python -m pytest tests/test_kernels_gpu.py -k 'stride2' -q -x --tb=short 2>&1 | grep -E '^E  |passed|failed|^FAILED' | cut -c1-300 | tail -3)" >> $O
+    done
+    timeout 900 python -m pytest tests/test_models_gpu.py -k "nfnet" -q --tb=short 2>&1 | grep -E "^E  |passed|failed|^FAILED" | cut -c1-400 | tail -4 >> $O
+    for m in 1 0 1 0; do echo "IA_CONV_S2_WGRAD_MERGED=$m: $(IA_CONV_S2_WGRAD_MERGED=$m timeout 600 python tools/config_bench.py c3 2>&1 | grep -E 'pairs/s')" >> $O; done
+    cat $O
+    ;;
   bit)          # the BiT towers: kernel + model + CLI tests, parity numbers, throughput beside resnetv2_50
     O=gpurun_out/r06_bit.txt; : > $O
     timeout 900 python -m pytest tests/test_kernels_gpu.py -k "groupnorm or ring_of_zeros or maxpool or batchnorm" -q -x --tb=short 2>&1 | grep -E "^E  |passed|failed|^FAILED" | cut -c1-400 | tail -8 >> $O
