@@ -294,11 +294,13 @@ int ia_conv3x3_s2_padded_bwd_data(const void* dyp, const void* what, void* dxp, 
                                   int y_compact, void* workspace, size_t workspace_bytes, ia_stream_t stream);
 int ia_conv3x3_s2_padded_bwd_weight(const void* xp, const void* dyp, float* dwhat, float* dbias, int B, int H, int W, int Cin, int Cout,
                                     int groups, int y_compact, void* workspace, size_t workspace_bytes, ia_stream_t stream);
-/* the data gradient as one kernel over the four parity classes of dx (Cin = Cout = 64 * groups only: ia_conv3x3_s2_dgrad_supported):
- * what_t from ia_conv3x3_flip_weights, dyp bordered with a ZERO border, dxp bordered (interior written) */
+/* the data gradient as one kernel over the four parity classes of dx (ia_conv3x3_s2_dgrad_supported): what_t from
+ * ia_conv3x3_flip_weights, dyp bordered with a ZERO border (or compact: y_compact), dxp bordered (interior written).  Cin = Cout = 64 * groups;
+ * groups = 1, Cin = 64, Cout = 64 n runs as n launches over the 64-channel slices of dy that add up in dx, what_t then holds n banks
+ * (ia_conv3x3_flip_weights(what, what_t, Cout, Cout, n)) */
 int ia_conv3x3_s2_dgrad_supported(int Cin, int Cout, int groups);
 int ia_conv3x3_s2_padded_bwd_data_t(const void* dyp, const void* what_t, void* dxp, int B, int H, int W, int Cin, int Cout, int groups,
-                                    ia_stream_t stream);
+                                    int y_compact, ia_stream_t stream);
 /* y = silu(x) * scale between the compact [B,H,W,C] and the zero-bordered [B,H+2,W+2,C] layouts (one flag per side); the
  * backward call produces dx in x's layout from dy in y's layout */
 int ia_silu_pad_fwd(const void* x, void* y, int B, int H, int W, int C, float scale, int in_padded, int out_padded, ia_stream_t stream);

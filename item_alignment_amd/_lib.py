@@ -109,7 +109,7 @@ SIGNATURES = {
     "ia_conv3x3_s2_padded_bwd_data": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "ia_conv3x3_s2_padded_bwd_weight": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "ia_conv3x3_s2_dgrad_supported": (i32, [i32, i32, i32]),
-    "ia_conv3x3_s2_padded_bwd_data_t": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "ia_conv3x3_s2_padded_bwd_data_t": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "ia_gn_act_workspace_bytes": (sz, [i32, i32, i32]),
     "ia_gn_act_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, sz, vp]),
     "ia_gn_act_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]),

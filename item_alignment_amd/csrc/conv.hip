@@ -1219,6 +1219,11 @@ struct S2DArgs {
   int Ho, Wo;                  // of g (its output)
   int Cin, Cout, groups;       // channels of dx / of g
   int tiles_x, tiles_y;        // over the cells (j, i): ceil(H / 2) x ceil(W / 2)
+  // a contraction wider than 64 channels (the stem's 64 -> 128) runs as one launch per 64-channel slice of g: slice `g_choff` with its own
+  // bank, every launch after the first ADDS to dx (a bf16 read-modify-write: one rounding more per slice, as the patch-matrix path's
+  // per-tap bf16 partial sums had)
+  int g_choff, accumulate;
+  int g_compact;               // g is [B, Ho, Wo, Cout] without a border: the lanes that would read past a row / past the image fetch zeros
 };
 
 __global__ __launch_bounds__(256) void conv3x3_s2_dgrad_kernel(S2DArgs p) {
@@ -1233,7 +1238,7 @@ __global__ __launch_bounds__(256) void conv3x3_s2_dgrad_kernel(S2DArgs p) {
   const int grp = blockIdx.x % p.groups, slot = blockIdx.x / p.groups, nslots = gridDim.x / p.groups;
   const int ntiles = p.B * p.tiles_y * p.tiles_x;
   if (slot >= ntiles) return;
-  const int GPW = p.Wo + 2, GPH = p.Ho + 2, XPW = p.W + 2, XPH = p.H + 2;
+  const int GPW = p.g_compact ? p.Wo : p.Wo + 2, GPH = p.g_compact ? p.Ho : p.Ho + 2, gb = p.g_compact ? 0 : 1, XPW = p.W + 2, XPH = p.H + 2;
   typedef __attribute__((address_space(3))) char lds_char;
   lds_char* const lsm = (lds_char*)IA_LDS(smem);
   const uint32_t sbase = ia_lds_addr(smem);
@@ -1275,7 +1280,7 @@ __global__ __launch_bounds__(256) void conv3x3_s2_dgrad_kernel(S2DArgs p) {
   auto stage = [&](int t, int buf) {
     int b, j0, i0;
     tile_of(t, b, j0, i0);
-    const size_t org = (((size_t)b * GPH + (j0 + 1)) * GPW + (i0 + 1)) * p.Cout + (size_t)grp * CI;
+    const size_t org = (((size_t)b * GPH + (j0 + gb)) * GPW + (i0 + gb)) * p.Cout + (size_t)grp * CI + p.g_choff;
     const size_t rem = org < total_in ? (total_in - org) * 2 : 0;
     const __amdgpu_buffer_rsrc_t rs = ia_rsrc(p.gp + (rem ? org : 0), (uint32_t)(rem < 0x7FFFFFF0ull ? rem : 0x7FFFFFF0ull));
 #pragma unroll
@@ -1284,7 +1289,8 @@ __global__ __launch_bounds__(256) void conv3x3_s2_dgrad_kernel(S2DArgs p) {
       const int r = pc / (TWP / PPP), c = pc - r * (TWP / PPP);
       if (pc < IN_PIECES && r <= TH) {
         const uint32_t adv = (uint32_t)((r * GPW + c * PPP) * p.Cout * 2);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lsm + W_BYTES + buf * IN_BYTES + pc * 1024, 16, lane_in + adv, 0, 0, 0);
+        const bool ok = !p.g_compact || (j0 + r < p.Ho && i0 + c * PPP + lane / NC < p.Wo);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lsm + W_BYTES + buf * IN_BYTES + pc * 1024, 16, ok ? lane_in + adv : 0xFFFFFFF0u, 0, 0, 0);
       }
     }
   };
@@ -1345,8 +1351,14 @@ __global__ __launch_bounds__(256) void conv3x3_s2_dgrad_kernel(S2DArgs p) {
 #pragma unroll
         for (int h = 0; h < NI / 2; ++h) {
           bf16x8 o;
+          if (p.accumulate) {
+            const bf16x8 old = *reinterpret_cast<const bf16x8*>(dst + 8 * h);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { o[j] = f2bf(acc[mi][2 * h][j]); o[4 + j] = f2bf(acc[mi][2 * h + 1][j]); }
+            for (int j = 0; j < 4; ++j) { o[j] = f2bf(acc[mi][2 * h][j] + bf2f(old[j])); o[4 + j] = f2bf(acc[mi][2 * h + 1][j] + bf2f(old[4 + j])); }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { o[j] = f2bf(acc[mi][2 * h][j]); o[4 + j] = f2bf(acc[mi][2 * h + 1][j]); }
+          }
           *reinterpret_cast<bf16x8*>(dst + 8 * h) = o;
         }
       }
@@ -1880,11 +1892,13 @@ static int wgrad_s2(const void* xp, const void* dyp, float* dwhat, float* dbias,
 }
 static size_t wgrad_s2_workspace(int groups) { return 4 * wgrad_workspace(64, 64, groups); }
 
-static int launch_s2_dgrad(const void* gp, const void* wt, void* dxp, int B, int H, int W, int Cin, int Cout, int groups, hipStream_t stream) {
+// slices > 1: groups = 1, Cin = 64, Cout = 64 * slices; wt = `slices` banks back to back (ia_conv3x3_flip_weights with groups = slices)
+static int launch_s2_dgrad(const void* gp, const void* wt, void* dxp, int B, int H, int W, int Cin, int Cout, int groups, int slices, int g_compact,
+                           hipStream_t stream) {
   S2DArgs a;
   a.gp = (const bf16*)gp; a.wt = (const bf16*)wt; a.dxp = (bf16*)dxp;
   a.B = B; a.H = H; a.W = W; a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1;
-  a.Cin = Cin; a.Cout = Cout; a.groups = groups;
+  a.Cin = Cin; a.Cout = Cout; a.groups = groups; a.g_choff = 0; a.accumulate = 0; a.g_compact = g_compact;
   a.tiles_x = (a.Wo + TW - 1) / TW; a.tiles_y = (a.Ho + TH - 1) / TH;      // cells: ceil(H / 2) x ceil(W / 2) = Ho x Wo
   using G = Geo<64, 64>;
   auto kern = conv3x3_s2_dgrad_kernel;
@@ -1897,7 +1911,10 @@ static int launch_s2_dgrad(const void* gp, const void* wt, void* dxp, int B, int
   long per_group = 256L / groups;
   if (per_group > ntiles) per_group = ntiles;
   if (per_group < 1) per_group = 1;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(per_group * groups)), dim3(256), G::LDS_BYTES, stream, a);
+  for (int sl = 0; sl < slices; ++sl) {
+    a.g_choff = sl * 64; a.accumulate = sl > 0; a.wt = (const bf16*)wt + (size_t)sl * 64 * 9 * 64;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(per_group * groups)), dim3(256), G::LDS_BYTES, stream, a);
+  }
   return ia_check_launch();
 }
 
@@ -2105,20 +2122,27 @@ extern "C" int ia_conv3x3_s2_padded_bwd_data(const void* dyp, const void* what, 
   return ia_check_launch();
 }
 
-// The data gradient without the patch-matrix detour, for Cin = Cout = 64 * groups (the stage transitions; ia_conv3x3_s2_dgrad_supported):
-// what_t = the tap-flipped transposed bank of ia_conv3x3_flip_weights, dyp bordered [B, Ho + 2, Wo + 2, Cout] with a ZERO border, dxp bordered
+// The data gradient without the patch-matrix detour (ia_conv3x3_s2_dgrad_supported): Cin = Cout = 64 * groups (the stage transitions), and
+// groups = 1, Cin = 64, Cout = 64 n (the stem) as n launches over the 64-channel slices of dy that add up in dx -- there what_t holds n
+// banks, ia_conv3x3_flip_weights(what, what_t, Cout, Cout, n).
+// what_t = the tap-flipped transposed bank of ia_conv3x3_flip_weights, dyp compact (y_compact) or bordered [B, Ho + 2, Wo + 2, Cout] with a ZERO border, dxp bordered
 // [B, H + 2, W + 2, Cin] (interior written)
 extern "C" int ia_conv3x3_s2_dgrad_supported(int Cin, int Cout, int groups) {
-  static const bool on = [] { const char* e = getenv("IA_CONV_S2_DGRAD"); return !e || atoi(e) != 0; }();
-  return on && dconv::enabled() && s2_enabled() && groups >= 1 && groups <= 64 && Cin == 64 * groups && Cout == 64 * groups;
+  const char* e = getenv("IA_CONV_S2_DGRAD");                    // 0: off; 1: 64-channel groups only; default: the sliced 64 -> 64 n form too
+  const int mode = e ? atoi(e) : 2;
+  int shared;
+  const int vg = s2_groups(Cin, Cout, groups, &shared);
+  return mode > 0 && dconv::enabled() && s2_enabled() && vg > 0 && (!shared || mode > 1);
 }
 extern "C" int ia_conv3x3_s2_padded_bwd_data_t(const void* dyp, const void* what_t, void* dxp, int B, int H, int W, int Cin, int Cout, int groups,
-                                               hipStream_t stream) {
+                                               int y_compact, hipStream_t stream) {
   (void)hipGetLastError();
-  if (B <= 0 || H <= 0 || W <= 0 || groups < 1 || groups > 64 || Cin != 64 * groups || Cout != 64 * groups) return IA_ERR_UNSUPPORTED;
+  int vg, shared;
+  const int rc = s2_ok(B, H, W, Cin, Cout, groups, &vg, &shared);
+  if (rc) return rc;
   if (!dyp || !what_t || !dxp) return IA_ERR_ARG;
-  if ((size_t)B * (H + 2) * (W + 2) >= 0x7FFFFFFFull) return IA_ERR_ARG;
-  return dconv::launch_s2_dgrad(dyp, what_t, dxp, B, H, W, Cin, Cout, groups, stream);
+  return shared ? dconv::launch_s2_dgrad(dyp, what_t, dxp, B, H, W, Cin, Cout, 1, vg, y_compact, stream)
+                : dconv::launch_s2_dgrad(dyp, what_t, dxp, B, H, W, Cin, Cout, vg, 1, y_compact, stream);
 }
 
 extern "C" int ia_silu_pad_fwd(const void* x, void* y, int B, int H, int W, int C, float scale, int in_padded, int out_padded, hipStream_t stream) {

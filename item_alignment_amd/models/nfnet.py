@@ -209,12 +209,15 @@ class PaddedS2ConvFn(torch.autograd.Function):
         dxp = None
         if ctx.need_dx:
             dxp = torch.empty_like(xp)
-            if not yc and lib.ia_conv3x3_s2_dgrad_supported(Cin, Cout, g):
+            if lib.ia_conv3x3_s2_dgrad_supported(Cin, Cout, g):
                 # one kernel over the four parity classes of dx, on the tap-flipped transposed bank (the incoming gradient's border is zero:
                 # the SiLU backward behind this convolution writes it)
-                what_t = torch.empty((Cin, 9 * (Cout // g)), device=dev, dtype=BF16)
-                check(lib.ia_conv3x3_flip_weights(what.data_ptr(), what_t.data_ptr(), Cin, Cout, g, stream_ptr()), "ia_conv3x3_flip_weights")
-                check(lib.ia_conv3x3_s2_padded_bwd_data_t(dyp.data_ptr(), what_t.data_ptr(), dxp.data_ptr(), B, H, W, Cin, Cout, g, stream_ptr()),
+                what_t = torch.empty((Cout, 9 * ci), device=dev, dtype=BF16)
+                if Cout == Cin:
+                    check(lib.ia_conv3x3_flip_weights(what.data_ptr(), what_t.data_ptr(), Cin, Cout, g, stream_ptr()), "ia_conv3x3_flip_weights")
+                else:       # the stem's 64 -> 128: one bank per 64-channel slice of dy (the flip sees them as groups of a 128 -> 128 layout)
+                    check(lib.ia_conv3x3_flip_weights(what.data_ptr(), what_t.data_ptr(), Cout, Cout, Cout // 64, stream_ptr()), "ia_conv3x3_flip_weights")
+                check(lib.ia_conv3x3_s2_padded_bwd_data_t(dyp.data_ptr(), what_t.data_ptr(), dxp.data_ptr(), B, H, W, Cin, Cout, g, yc, stream_ptr()),
                       "ia_conv3x3_s2_padded_bwd_data_t")
             else:
                 check(lib.ia_conv3x3_s2_padded_bwd_data(dyp.data_ptr(), what.data_ptr(), dxp.data_ptr(), B, H, W, Cin, Cout, g, yc, ws.data_ptr(), wsb,

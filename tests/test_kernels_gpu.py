@@ -1020,19 +1020,20 @@ def test_conv3x3_stride2_without_a_patch_matrix(gpu, B, H, W, Cin, Cout, groups,
     check(lib.ia_conv3x3_s2_padded_bwd_data(dyz.data_ptr(), what.data_ptr(), dxp.data_ptr(), B, H, W, Cin, Cout, groups, yc, ws.data_ptr(), wsb, stream_ptr()),
           "s2_dgrad")
     assert rel_err(dxp[:, 1:-1, 1:-1], xr.grad.permute(0, 2, 3, 1)) < 2e-2
-    if not yc and Cin == Cout:
-        # the one-kernel data gradient over the four parity classes of dx (flipped bank, zero-bordered dy)
-        assert lib.ia_conv3x3_s2_dgrad_supported(Cin, Cout, groups) == 1
-        what_t = torch.empty((Cin, 9 * (Cout // groups)), device=gpu, dtype=torch.bfloat16)
+    # the one-kernel data gradient over the four parity classes of dx (flipped bank; zero-bordered or compact dy); the 64 -> 128 form runs
+    # as two launches over the 64-channel slices of dy that add up in dx (one bf16 rounding more)
+    assert lib.ia_conv3x3_s2_dgrad_supported(Cin, Cout, groups) == 1
+    what_t = torch.empty((Cout, 9 * Cg), device=gpu, dtype=torch.bfloat16)
+    if Cin == Cout:
         check(lib.ia_conv3x3_flip_weights(what.data_ptr(), what_t.data_ptr(), Cin, Cout, groups, stream_ptr()), "flip")
-        dxd = torch.full((B, H + 2, W + 2, Cin), 9.0, device=gpu, dtype=torch.bfloat16)
-        check(lib.ia_conv3x3_s2_padded_bwd_data_t(dyz.data_ptr(), what_t.data_ptr(), dxd.data_ptr(), B, H, W, Cin, Cout, groups, stream_ptr()), "s2_dgrad_t")
-        assert rel_err(dxd[:, 1:-1, 1:-1], xr.grad.permute(0, 2, 3, 1)) < 1e-2
-        edge = dxd.clone()
-        edge[:, 1:-1, 1:-1] = 9.0
-        assert (edge == 9.0).all()
     else:
-        assert lib.ia_conv3x3_s2_dgrad_supported(Cin, Cout, groups) == 0 or yc
+        check(lib.ia_conv3x3_flip_weights(what.data_ptr(), what_t.data_ptr(), Cout, Cout, Cout // 64, stream_ptr()), "flip")
+    dxd = torch.full((B, H + 2, W + 2, Cin), 9.0, device=gpu, dtype=torch.bfloat16)
+    check(lib.ia_conv3x3_s2_padded_bwd_data_t(dyz.data_ptr(), what_t.data_ptr(), dxd.data_ptr(), B, H, W, Cin, Cout, groups, yc, stream_ptr()), "s2_dgrad_t")
+    assert rel_err(dxd[:, 1:-1, 1:-1], xr.grad.permute(0, 2, 3, 1)) < (1e-2 if Cin == Cout else 1.5e-2)
+    edge = dxd.clone()
+    edge[:, 1:-1, 1:-1] = 9.0
+    assert (edge == 9.0).all()
     # the same numbers as the patch-matrix path the model used until round 6 (bf16 outputs of fp32 sums in another order)
     y_old = torch.empty((B * Ho * Wo, Cout), device=gpu, dtype=torch.bfloat16)
     wsb2 = lib.ia_conv_nhwc_workspace_bytes(B, H, W, Cin, Cout, 3, 2, groups)

@@ -153,7 +153,7 @@ case "$1" in
   c3prof)       # C3 again after the strided kernels: kernel summary, PMC traffic, A/B lines (-> profiles/r06_c3_*.txt, r06_ab_c3_strided.txt)
     mkdir -p gpurun_out/profiles; OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles; R=$GRAFT_REPO_ROOT
     O=$OUT/r06_ab_c3_strided.txt; : > $O
-    for v in "1 1" "1 0" "0 0" "1 1" "1 0" "0 0"; do set -- $v
+    for v in "1 2" "1 0" "0 0" "1 2" "1 0" "0 0"; do set -- $v
       echo "IA_CONV_S2_DIRECT=$1 IA_CONV_S2_DGRAD=$2: $(IA_CONV_S2_DIRECT=$1 IA_CONV_S2_DGRAD=$2 timeout 600 python tools/config_bench.py c3 2>&1 | grep -E 'pairs/s')" >> $O; done
     cat $O
     timeout 900 python - >> $O 2>&1 <<'PY'
@@ -186,6 +186,13 @@ PY
     python3 tools/prof_summary.py $OUT/kt_c3/b_kernel_stats.csv 11 40 > $OUT/r06_c3_kernel_stats_summary.txt
     rm -rf $OUT/kt_c3 $OUT/c3_log.txt
     cat $OUT/r06_c3_hbm.txt; head -12 $OUT/r06_c3_kernel_stats_summary.txt
+    ;;
+  s2d)          # the sliced data gradient of the stem's strided convolution: tests, then IA_CONV_S2_DGRAD=2 (with it) / 1 (without) on one box
+    O=gpurun_out/r06_s2d.txt; : > $O
+    timeout 900 python -m pytest tests/test_kernels_gpu.py -k "stride2" -q -x --tb=short 2>&1 | grep -E "^E  |passed|failed|^FAILED" | cut -c1-400 | tail -6 >> $O
+    timeout 900 python -m pytest tests/test_models_gpu.py tests/test_cli_gpu.py -k "nfnet or image" -q --tb=short 2>&1 | grep -E "^E  |passed|failed|^FAILED" | cut -c1-400 | tail -6 >> $O
+    for m in 2 1 2 1; do echo "IA_CONV_S2_DGRAD=$m: $(IA_CONV_S2_DGRAD=$m timeout 600 python tools/config_bench.py c3 2>&1 | grep -E 'pairs/s')" >> $O; done
+    cat $O
     ;;
   s2w)          # the one-launch weight gradient of the strided convolutions against the four masked launches
     O=gpurun_out/r06_s2w.txt; : > $O
