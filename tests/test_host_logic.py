@@ -175,6 +175,34 @@ def test_resnetv2_structure_and_timm_names():
     assert tuple(y.shape) == (2, 2048, 2, 2) and torch.isfinite(y).all()
 
 
+def test_strided_convolution_dispatch():
+    """Which strided 3x3 convolutions leave the patch-matrix path (host logic of csrc/conv.hip, no GPU needed): 64 channels per group in
+    and out, and one 64-channel input shared by 64 n output channels (the NF-Net stem's conv4); everything else -- the 3-channel conv1, the
+    ResNets' ungrouped 128 / 256 / 512-channel convolutions -- stays on ia_conv_nhwc_*.  eca_nfnet_l0's five strided convolutions split 4 : 1."""
+    import os
+    import subprocess
+    import sys
+    from item_alignment_amd import _lib
+    from item_alignment_amd.models import create_model
+    from item_alignment_amd.models.nfnet import ScaledStdConv2d
+    lib = _lib.load()
+    yes = [(64, 64, 1), (128, 128, 2), (384, 384, 6), (64, 128, 1), (64, 256, 1)]
+    no = [(3, 16, 1), (8, 16, 1), (128, 128, 1), (256, 256, 1), (96, 96, 1), (64, 96, 1), (128, 256, 2), (64, 64, 2)]
+    assert all(lib.ia_conv3x3_s2_supported(*a) == 1 and lib.ia_conv3x3_s2_dgrad_supported(*a) == 1 for a in yes)
+    assert all(lib.ia_conv3x3_s2_supported(*a) == 0 and lib.ia_conv3x3_s2_dgrad_supported(*a) == 0 for a in no)
+    assert lib.ia_conv3x3_s2_padded_workspace_bytes(2, 40, 40, 128, 128, 2) > 0 and lib.ia_conv3x3_s2_padded_workspace_bytes(2, 40, 40, 128, 128, 1) == 0
+    net = create_model("eca_nfnet_l0")
+    strided = [m for m in net.modules() if isinstance(m, ScaledStdConv2d) and m.kernel_size == 3 and m.stride == 2]
+    assert len(strided) == 5 and sum(m.strided_direct for m in strided) == 4 and not net.stem.conv1.strided_direct
+    # the switches (read when asked, so a fresh process): everything off / the sliced stem form off
+    code = ("from item_alignment_amd import _lib; l = _lib.load(); "
+            "print(l.ia_conv3x3_s2_supported(64, 64, 1), l.ia_conv3x3_s2_dgrad_supported(64, 64, 1), l.ia_conv3x3_s2_dgrad_supported(64, 128, 1))")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for env, want in (({"IA_CONV_S2_DIRECT": "0"}, "0 0 0"), ({"IA_CONV_S2_DGRAD": "1"}, "1 1 0"), ({"IA_CONV_S2_DGRAD": "0"}, "1 0 0"), ({}, "1 1 1")):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root, env={**os.environ, **env})
+        assert r.stdout.split("\n")[0].strip() == want, (env, r.stdout, r.stderr[-300:])
+
+
 def test_bit_towers_have_timm_names_and_shapes():
     """`create_model("resnetv2_50x1_bitm")` (a BiT name: finetune_image.py:23 lists resnetv2_50x3_bitm_in21k) builds the GroupNorm +
     StdConv2d tower with timm's state_dict keys and shapes -- no BatchNorm buffers -- and the head of the named variant; the x3 width
