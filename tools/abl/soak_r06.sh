@@ -4,6 +4,7 @@
 #   bench, 100 steps with IA_ATTN_EXACT_DELTA=1 (delta pre-pass + the dQ / dK,dV pair in every layer)
 #   C3, 200 steps (direct convolutions with lane-offset DMA, ECA pooling through conv3, fused tail activation), C3 on resnetv2_50
 #   C5x, 40 steps at 64 pairs (SwiGLU recompute, transposed shadows for the multimodal Linears)
+#   resnetv2_50x1_bitm 200 steps, resnetv2_50x3_bitm_in21k 40 steps (GroupNorm kernels, standardised weights, zero-ring stem)
 R=${GRAFT_REPO_ROOT:-.}
 cd $R
 for d in 0 1; do
@@ -15,3 +16,6 @@ import sys,json,math; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); p
 IA_CB_STEPS=200 python3 tools/config_bench.py c3 2>&1 | grep -E "pairs/s"
 IA_CB_STEPS=200 python3 tools/config_bench.py c3r 2>&1 | grep -E "pairs/s"
 IA_CB_STEPS=40 python3 tools/config_bench.py c5x 2>&1 | grep -E "pairs/s"
+# (added with the BiT towers and the strided-convolution kernels: C3 above runs through them; the BiT towers below)
+IA_CB_STEPS=200 python3 tools/config_bench.py c3b 2>&1 | grep -E "pairs/s"
+IA_CB_STEPS=40 python3 tools/config_bench.py c3b3 2>&1 | grep -E "pairs/s"
